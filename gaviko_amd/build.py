@@ -1,0 +1,74 @@
+"""In-tree build of libgaviko_hip.so (hipcc, gfx950 only).  `python -m gaviko_amd.build [--force]`.
+
+The .so is git-ignored but travels with the gpurun snapshot; nothing is JIT-compiled at run time.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libgaviko_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-ffp-contract=off"]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need ROCm with gfx950 support)")
+
+
+def _newer(src_list, target) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(HERE, "..", "include", "gaviko_hip.h")]
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    jobs = []
+    for s in srcs:
+        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
+        if force or _newer([s] + hdrs, o):
+            jobs.append((s, o))
+
+    def compile_one(job):
+        s, o = job
+        cmd = [cc, *FLAGS, "-c", s, "-o", o]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return s, r.returncode, r.stdout + r.stderr
+
+    if jobs:
+        with cf.ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            for s, rc, out in ex.map(compile_one, jobs):
+                if verbose or rc:
+                    print(f"[hipcc] {os.path.basename(s)} rc={rc}", file=sys.stderr)
+                if out.strip() and (verbose or rc):
+                    print(out, file=sys.stderr)
+                if rc:
+                    raise RuntimeError(f"hipcc failed on {s}")
+    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    if force or jobs or _newer(objs, LIB):
+        cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            print(r.stdout + r.stderr, file=sys.stderr)
+            raise RuntimeError("link of libgaviko_hip.so failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

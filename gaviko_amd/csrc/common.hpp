@@ -1,0 +1,72 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gvk {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define GVK_LDS __attribute__((address_space(3)))
+#define GVK_GLOBAL __attribute__((address_space(1)))
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const GVK_GLOBAL void*)gsrc, (GVK_LDS void*)lds_wave_base, 16, 0, 0);
+}
+
+// 4x16 transposed LDS read (ds_read_b64_tr_b16): within each 16-lane group, lane 4q+p supplies the address of
+// row q, columns 4p..4p+3; lane i receives column i of the 4 rows (row q in element q).  EXEC must be all ones.
+__device__ __forceinline__ bf16x4 lds_read_tr16(const void* p) {
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((GVK_LDS s16x4*)p);
+  return __builtin_bit_cast(bf16x4, v);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float quick_gelu(float x) { return x * sigmoidf_(1.702f * x); }
+__device__ __forceinline__ float quick_gelu_grad(float x) {
+  float s = sigmoidf_(1.702f * x);
+  return s + 1.702f * x * s * (1.0f - s);
+}
+
+}  // namespace gvk
+
+// host-side error plumbing shared by every C-ABI entry point
+extern "C" const char* gvk_last_error(void);
+namespace gvk {
+int set_error(int code, const char* fmt, ...);
+int check_launch(const char* what);
+}  // namespace gvk
+
+#define GVK_REQUIRE(cond, ...)                                  \
+  do {                                                          \
+    if (!(cond)) return gvk::set_error(-2, __VA_ARGS__);        \
+  } while (0)

@@ -1,0 +1,89 @@
+// Casts / layout kernels (HBM-bound): fp32 -> bf16, transposing cast for dgrad weights, patch im2col.
+#include "common.hpp"
+#include "../../include/gaviko_hip.h"
+
+namespace gvk {
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out, int64_t n) {
+  int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  for (; i + 3 < n; i += stride) {
+    const f32x4 v = *(const f32x4*)(in + i);
+    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *(bf16x4*)(out + i) = o;
+  }
+  if (i < n && i + 3 >= n)
+    for (int64_t j = i; j < n; ++j) out[j] = (bf16)in[j];
+}
+
+// out[c][r] = in[r][c]; 64x64 tile through LDS (+1 pad), coalesced both sides.
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ in, bf16* __restrict__ out, int rows, int cols) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) out[(size_t)c * rows + r] = (bf16)tile[tx][i];
+  }
+}
+
+// One thread = 4 consecutive kw of one (patch, kd, kh): a float4 read, an 8-byte bf16x4 write.
+// out row = patch index (b, d, h, w), column = (kd*ph + kh)*pw + kw.
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16* __restrict__ out, int B, int D, int H,
+                                                       int W, int pd, int ph, int pw) {
+  const int nd = D / pd, nh = H / ph, nw = W / pw;
+  const int K = pd * ph * pw, kq = K / 4;
+  const int64_t total = (int64_t)B * nd * nh * nw * kq;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    // order the work so that consecutive threads walk consecutive image addresses: (b, z, y, x4) over the volume
+    const int wq = W / 4;
+    int64_t t = idx;
+    const int x4 = t % wq; t /= wq;
+    const int y = t % H; t /= H;
+    const int z = t % D; const int b = t / D;
+    const int x = x4 * 4;
+    const f32x4 v = *(const f32x4*)(img + (((int64_t)b * D + z) * H + y) * W + x);
+    const int d = z / pd, kd = z - d * pd, h = y / ph, kh = y - h * ph, w = x / pw, kw = x - w * pw;
+    const int64_t row = (((int64_t)b * nd + d) * nh + h) * nw + w;
+    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *(bf16x4*)(out + row * K + (kd * ph + kh) * pw + kw) = o;
+  }
+}
+
+}  // namespace gvk
+
+extern "C" int gvk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(in && out && n >= 0, "gvk_cast_f32_bf16: null pointer");
+  if (n == 0) return 0;
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, (bf16*)out, n);
+  return check_launch("cast_f32_bf16");
+}
+
+extern "C" int gvk_transpose_cast_f32_bf16(const float* in, void* out, int rows, int cols, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(in && out && rows > 0 && cols > 0, "gvk_transpose_cast_f32_bf16: bad arguments");
+  hipLaunchKernelGGL(transpose_cast_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, in,
+                     (bf16*)out, rows, cols);
+  return check_launch("transpose_cast_f32_bf16");
+}
+
+extern "C" int gvk_patchify_bf16(const float* img, void* out, int B, int D, int H, int W, int pd, int ph, int pw, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(img && out && B > 0, "gvk_patchify_bf16: null pointer");
+  GVK_REQUIRE(D % pd == 0 && H % ph == 0 && W % pw == 0 && pw % 4 == 0 && W % 4 == 0,
+              "gvk_patchify_bf16: volume %dx%dx%d not divisible by patch %dx%dx%d (pw must be a multiple of 4)", D, H, W, pd, ph, pw);
+  const int64_t total = (int64_t)B * D * H * (W / 4);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img, (bf16*)out, B, D, H, W, pd, ph, pw);
+  return check_launch("patchify_bf16");
+}

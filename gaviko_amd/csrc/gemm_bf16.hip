@@ -1,0 +1,249 @@
+// bf16 MFMA GEMM, Y = A . W^T with fused epilogues, for gfx950.
+//
+// Structure: 256-thread workgroup = 4 waves (2x2), BMxBN output tile, BK = 64.  Both operands are K-contiguous,
+// staged global -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4), double-buffered.  An LDS tile row is
+// 64 bf16 = 128 B = eight 16-B chunks; chunk c of row r is stored at chunk position c ^ ((r>>1)&7) (the XOR is
+// applied on the per-lane SOURCE address because the DMA destination is lane-linear) so that the 16 rows a
+// ds_read_b128 lane group touches land on 16 distinct 16-B slots of the 256-B bank row.
+// MFMA: v_mfma_f32_16x16x32_bf16 with the WEIGHT fragment as the A operand and the ACTIVATION fragment as the B
+// operand, i.e. each wave computes D[n][m]; a lane then owns 4 consecutive n of one row m, which makes every
+// epilogue a 8/16-byte contiguous access of the row-major output.
+#include "common.hpp"
+#include "../../include/gaviko_hip.h"
+
+namespace gvk {
+
+struct GemmArgs {
+  const bf16* A;
+  const bf16* W;
+  void* out0;
+  void* out1;
+  const float* bias;
+  const float* res;
+  const bf16* aux;
+  const float* pos;
+  int M, N, K, lda, ldw, ldo, ldres, ldaux;
+  int rows_in, rows_out, row_off;
+  int nbm, nbn;
+};
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+  constexpr int BK = 64;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int MT = WM / 16, NT = WN / 16;
+  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // XCD-aware bijective remap: blocks b, b+8, ... share an XCD (own L2); give each XCD a contiguous run of tiles.
+  const int nwg = p.nbm * p.nbn;
+  int wg;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_m = wg / p.nbn, tile_n = wg - tile_m * p.nbn;   // n fastest: neighbours share the A panel
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int lane = lane_id();
+  const int wave = wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  const bf16* __restrict__ Ag = p.A + (size_t)m0 * p.lda;
+  const bf16* __restrict__ Wg = p.W + (size_t)n0 * p.ldw;
+
+  auto stage = [&](int buf, int kt) {
+    char* sA = smem + buf * STAGE;
+    char* sW = sA + A_BYTES;
+    const int k0 = kt * BK;
+    const int rsub = lane >> 3, slot = lane & 7;
+#pragma unroll
+    for (int r = 0; r < BM / 32; ++r) {
+      const int row = r * 32 + wave * 8 + rsub;
+      const int chunk = slot ^ ((row >> 1) & 7);
+      glds16(Ag + (size_t)row * p.lda + k0 + chunk * 8, sA + (r * 32 + wave * 8) * 128);
+    }
+#pragma unroll
+    for (int r = 0; r < BN / 32; ++r) {
+      const int row = r * 32 + wave * 8 + rsub;
+      const int chunk = slot ^ ((row >> 1) & 7);
+      glds16(Wg + (size_t)row * p.ldw + k0 + chunk * 8, sW + (r * 32 + wave * 8) * 128);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nt = p.K / BK;
+  stage(0, 0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) stage(buf ^ 1, t + 1);
+    const char* sA = smem + buf * STAGE;
+    const char* sW = sA + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 xa[MT], wb[NT];
+      const int chunk = ks * 4 + lq;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = wm * WM + i * 16 + l15;
+        xa[i] = *(const bf16x8*)(sA + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int row = wn * WN + j * 16 + l15;
+        wb[j] = *(const bf16x8*)(sW + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();   // drains the LDS-DMA of tile t+1 (vmcnt(0)) and fences reads of buf before it is restaged
+  }
+
+  // ---- epilogue: lane owns rows m (one per i) x 4 consecutive columns n (per j)
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * WM + i * 16 + l15;
+    if (m >= p.M) continue;
+    size_t orow = (size_t)m;
+    int prow = 0;
+    if constexpr (EPI == GVK_EPI_PATCH_F32) {
+      const int s = m / p.rows_in;
+      prow = m - s * p.rows_in;
+      orow = (size_t)s * p.rows_out + p.row_off + prow;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * WN + j * 16 + lq * 4;
+      f32x4 v = acc[i][j];
+      if (p.bias != nullptr) {
+        const f32x4 b = *(const f32x4*)(p.bias + n);
+        v += b;
+      }
+      if constexpr (EPI == GVK_EPI_STORE_BF16) {
+        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *(bf16x4*)((bf16*)p.out0 + (size_t)m * p.ldo + n) = o;
+      } else if constexpr (EPI == GVK_EPI_BIAS_RES_F32 || EPI == GVK_EPI_BIAS_RES_F32_BF16) {
+        const f32x4 r = *(const f32x4*)(p.res + (size_t)m * p.ldres + n);
+        v += r;
+        *(f32x4*)((float*)p.out0 + (size_t)m * p.ldo + n) = v;
+        if constexpr (EPI == GVK_EPI_BIAS_RES_F32_BF16) {
+          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *(bf16x4*)((bf16*)p.out1 + (size_t)m * p.ldo + n) = o;
+        }
+      } else if constexpr (EPI == GVK_EPI_BIAS_GELU_BF16) {
+        if (p.out0 != nullptr) {
+          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *(bf16x4*)((bf16*)p.out0 + (size_t)m * p.ldo + n) = o;
+        }
+        bf16x4 g = {(bf16)gelu_erf(v[0]), (bf16)gelu_erf(v[1]), (bf16)gelu_erf(v[2]), (bf16)gelu_erf(v[3])};
+        *(bf16x4*)((bf16*)p.out1 + (size_t)m * p.ldo + n) = g;
+      } else if constexpr (EPI == GVK_EPI_PATCH_F32) {
+        const f32x4 pe = *(const f32x4*)(p.pos + (size_t)prow * p.N + n);
+        v += pe;
+        *(f32x4*)((float*)p.out0 + orow * p.ldo + n) = v;
+        if (p.out1 != nullptr) *(f32x4*)((float*)p.out1 + (size_t)m * p.ldo + n) = v;
+      } else if constexpr (EPI == GVK_EPI_GELU_BWD_BF16) {
+        const bf16x4 a = *(const bf16x4*)(p.aux + (size_t)m * p.ldaux + n);
+        bf16x4 o = {(bf16)(v[0] * gelu_erf_grad((float)a[0])), (bf16)(v[1] * gelu_erf_grad((float)a[1])),
+                    (bf16)(v[2] * gelu_erf_grad((float)a[2])), (bf16)(v[3] * gelu_erf_grad((float)a[3]))};
+        *(bf16x4*)((bf16*)p.out0 + (size_t)m * p.ldo + n) = o;
+      } else if constexpr (EPI == GVK_EPI_STORE_F32) {
+        *(f32x4*)((float*)p.out0 + (size_t)m * p.ldo + n) = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int EPI>
+static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+  constexpr int lds = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(gemm %dx%d): %s", BM, BN, hipGetErrorString(e));
+    attr_set = true;
+  }
+  GemmArgs p = a;
+  p.nbm = (a.M + BM - 1) / BM;
+  p.nbn = a.N / BN;
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, EPI>), dim3(p.nbm * p.nbn), dim3(256), lds, stream, p);
+  return check_launch("gemm_nt_bf16");
+}
+
+template <int EPI>
+static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
+  if (tile == 0) {
+    const int bn = (a.N % 128 == 0) ? 128 : 64;
+    // fill the 256 CUs: fall back to 64-row tiles when 128-row tiles give < ~1.5 workgroups per CU
+    const long t128 = (long)((a.M + 127) / 128) * (a.N / bn);
+    const int bm = (t128 >= 384) ? 128 : 64;
+    tile = bm * 1000 + bn;
+  }
+  switch (tile) {
+    case 128128: return launch_gemm<128, 128, EPI>(a, stream);
+    case 128064: return launch_gemm<128, 64, EPI>(a, stream);
+    case 64128: return launch_gemm<64, 128, EPI>(a, stream);
+    case 64064: return launch_gemm<64, 64, EPI>(a, stream);
+    default: return set_error(-2, "gvk_gemm_nt_bf16: unsupported tile %d", tile);
+  }
+}
+
+}  // namespace gvk
+
+extern "C" int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(d != nullptr, "gvk_gemm_nt_bf16: null descriptor");
+  GVK_REQUIRE(d->a && d->w && d->M > 0 && d->N > 0 && d->K > 0, "gvk_gemm_nt_bf16: null operand or empty shape");
+  GVK_REQUIRE(d->K % 64 == 0, "gvk_gemm_nt_bf16: K=%d must be a multiple of 64", d->K);
+  GVK_REQUIRE(d->N % 64 == 0, "gvk_gemm_nt_bf16: N=%d must be a multiple of 64", d->N);
+  GVK_REQUIRE(d->lda >= d->K && d->ldw >= d->K && d->lda % 8 == 0 && d->ldw % 8 == 0,
+              "gvk_gemm_nt_bf16: lda/ldw must be >= K and multiples of 8");
+  GVK_REQUIRE(d->ldo % 4 == 0 && d->ldo >= d->N, "gvk_gemm_nt_bf16: ldo=%d must be >= N and a multiple of 4", d->ldo);
+  if (d->tile != 0) {
+    const int bn = d->tile % 1000;
+    GVK_REQUIRE(bn > 0 && d->N % bn == 0, "gvk_gemm_nt_bf16: N=%d not a multiple of the tile's BN", d->N);
+  }
+  GemmArgs a{};
+  a.A = (const bf16*)d->a; a.W = (const bf16*)d->w; a.out0 = d->out0; a.out1 = d->out1;
+  a.bias = d->bias; a.res = d->res; a.aux = (const bf16*)d->aux; a.pos = d->pos;
+  a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldw = d->ldw; a.ldo = d->ldo;
+  a.ldres = d->ldres; a.ldaux = d->ldaux; a.rows_in = d->rows_in; a.rows_out = d->rows_out; a.row_off = d->row_off;
+  hipStream_t s = (hipStream_t)stream;
+  switch (d->epilogue) {
+    case GVK_EPI_STORE_BF16:
+      GVK_REQUIRE(d->out0, "gemm STORE_BF16: out0 null");
+      return dispatch_tile<GVK_EPI_STORE_BF16>(a, d->tile, s);
+    case GVK_EPI_BIAS_RES_F32:
+      GVK_REQUIRE(d->out0 && d->res && d->ldres >= d->N && d->ldres % 4 == 0, "gemm BIAS_RES_F32: out0/res");
+      return dispatch_tile<GVK_EPI_BIAS_RES_F32>(a, d->tile, s);
+    case GVK_EPI_BIAS_RES_F32_BF16:
+      GVK_REQUIRE(d->out0 && d->out1 && d->res && d->ldres >= d->N && d->ldres % 4 == 0, "gemm BIAS_RES_F32_BF16: out0/out1/res");
+      return dispatch_tile<GVK_EPI_BIAS_RES_F32_BF16>(a, d->tile, s);
+    case GVK_EPI_BIAS_GELU_BF16:
+      GVK_REQUIRE(d->out1, "gemm BIAS_GELU_BF16: out1 null");
+      return dispatch_tile<GVK_EPI_BIAS_GELU_BF16>(a, d->tile, s);
+    case GVK_EPI_PATCH_F32:
+      GVK_REQUIRE(d->out0 && d->pos && d->rows_in > 0 && d->rows_out >= d->rows_in + d->row_off && d->ldo == d->N,
+                  "gemm PATCH_F32: out0/pos/rows_in/rows_out/row_off inconsistent (ldo must equal N)");
+      return dispatch_tile<GVK_EPI_PATCH_F32>(a, d->tile, s);
+    case GVK_EPI_GELU_BWD_BF16:
+      GVK_REQUIRE(d->out0 && d->aux && d->ldaux >= d->N && d->ldaux % 4 == 0, "gemm GELU_BWD_BF16: out0/aux");
+      return dispatch_tile<GVK_EPI_GELU_BWD_BF16>(a, d->tile, s);
+    case GVK_EPI_STORE_F32:
+      GVK_REQUIRE(d->out0, "gemm STORE_F32: out0 null");
+      return dispatch_tile<GVK_EPI_STORE_F32>(a, d->tile, s);
+    default:
+      return set_error(-2, "gvk_gemm_nt_bf16: unknown epilogue %d", d->epilogue);
+  }
+}

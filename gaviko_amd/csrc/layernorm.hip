@@ -1,0 +1,183 @@
+// LayerNorm forward / backward, one 64-lane wave per token row (HBM-bound; rows stay in registers).
+// fp32 statistics with the two-pass variance torch's CPU kernel uses (mean, then mean((x-mean)^2)).
+#include "common.hpp"
+#include "../../include/gaviko_hip.h"
+
+namespace gvk {
+
+constexpr int kMaxChunks = 4;   // C <= 1024: up to four float4 per lane
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16* __restrict__ y16, float* __restrict__ y32,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o, int M, int C, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = lane_id();
+  const float* xr = x + (size_t)row * C;
+  f32x4 v[kMaxChunks];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < kMaxChunks; ++k) {
+    const int c = k * 256 + lane * 4;
+    v[k] = (c < C) ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < kMaxChunks; ++k) {
+    const int c = k * 256 + lane * 4;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[k][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) {
+    if (mean_o) mean_o[row] = mean;
+    if (rstd_o) rstd_o[row] = rstd;
+  }
+#pragma unroll
+  for (int k = 0; k < kMaxChunks; ++k) {
+    const int c = k * 256 + lane * 4;
+    if (c < C) {
+      const f32x4 g = *(const f32x4*)(gamma + c);
+      const f32x4 b = *(const f32x4*)(beta + c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[k][e] - mean) * rstd * g[e] + b[e];
+      if (y16) {
+        bf16x4 h = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+        *(bf16x4*)(y16 + (size_t)row * C + c) = h;
+      }
+      if (y32) *(f32x4*)(y32 + (size_t)row * C + c) = o;
+    }
+  }
+}
+
+// dx = dres + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                     const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                     float* __restrict__ dx, bf16* __restrict__ dx16, int M, int C) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = lane_id();
+  const float mean = mean_i[row], rstd = rstd_i[row];
+  f32x4 xh[kMaxChunks], dh[kMaxChunks];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < kMaxChunks; ++k) {
+    const int c = k * 256 + lane * 4;
+    if (c < C) {
+      const f32x4 xv = *(const f32x4*)(x + (size_t)row * C + c);
+      const f32x4 dv = *(const f32x4*)(dy + (size_t)row * C + c);
+      const f32x4 g = *(const f32x4*)(gamma + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[k][e] = (xv[e] - mean) * rstd;
+        dh[k][e] = dv[e] * g[e];
+        s1 += dh[k][e];
+        s2 += dh[k][e] * xh[k][e];
+      }
+    } else {
+      xh[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dh[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+#pragma unroll
+  for (int k = 0; k < kMaxChunks; ++k) {
+    const int c = k * 256 + lane * 4;
+    if (c < C) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = rstd * (dh[k][e] - m1 - xh[k][e] * m2);
+      if (dres) {
+        const f32x4 r = *(const f32x4*)(dres + (size_t)row * C + c);
+        o += r;
+      }
+      *(f32x4*)(dx + (size_t)row * C + c) = o;
+      if (dx16) {
+        bf16x4 h = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+        *(bf16x4*)(dx16 + (size_t)row * C + c) = h;
+      }
+    }
+  }
+}
+
+// Affine grads, deterministic two-stage: stage 1 = 64 row-slabs x column chunks, stage 2 = sum the 64 partials.
+__global__ __launch_bounds__(256) void ln_affine_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                                float* __restrict__ scratch, int M, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int slab = blockIdx.y;                  // 0..63
+  const int rows_per = (M + 63) / 64;
+  const int r0 = slab * rows_per, r1 = min(M, r0 + rows_per);
+  float dg = 0.f, db = 0.f;
+  if (c < C) {
+    for (int r = r0; r < r1; ++r) {
+      const float d = dy[(size_t)r * C + c];
+      dg += d * (x[(size_t)r * C + c] - mean_i[r]) * rstd_i[r];
+      db += d;
+    }
+    scratch[(size_t)slab * C + c] = dg;
+    scratch[(size_t)(64 + slab) * C + c] = db;
+  }
+}
+__global__ __launch_bounds__(256) void ln_affine_final_kernel(const float* __restrict__ scratch, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int C, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float dg = 0.f, db = 0.f;
+  for (int s = 0; s < 64; ++s) {
+    dg += scratch[(size_t)s * C + c];
+    db += scratch[(size_t)(64 + s) * C + c];
+  }
+  if (accumulate) {
+    dgamma[c] += dg;
+    dbeta[c] += db;
+  } else {
+    dgamma[c] = dg;
+    dbeta[c] = db;
+  }
+}
+
+}  // namespace gvk
+
+extern "C" int gvk_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32, float* mean,
+                                 float* rstd, int M, int C, float eps, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(x && gamma && beta && (y_bf16 || y_f32), "gvk_layernorm_fwd: null pointer");
+  GVK_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 256 * kMaxChunks, "gvk_layernorm_fwd: C=%d must be a multiple of 4 and <= 1024", C);
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16*)y_bf16, y_f32, mean,
+                     rstd, M, C, eps);
+  return check_launch("layernorm_fwd");
+}
+
+extern "C" int gvk_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                 const float* dres, float* dx, void* dx_bf16, int M, int C, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(dy && x && mean && rstd && gamma && dx, "gvk_layernorm_bwd: null pointer");
+  GVK_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 256 * kMaxChunks, "gvk_layernorm_bwd: C=%d must be a multiple of 4 and <= 1024", C);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dres, dx,
+                     (bf16*)dx_bf16, M, C);
+  return check_launch("layernorm_bwd");
+}
+
+extern "C" int gvk_layernorm_bwd_affine(const float* dy, const float* x, const float* mean, const float* rstd, float* dgamma,
+                                        float* dbeta, float* scratch, int M, int C, int accumulate, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(dy && x && mean && rstd && dgamma && dbeta && scratch, "gvk_layernorm_bwd_affine: null pointer");
+  GVK_REQUIRE(M > 0 && C > 0, "gvk_layernorm_bwd_affine: empty shape");
+  hipLaunchKernelGGL(ln_affine_partial_kernel, dim3((C + 255) / 256, 64), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd,
+                     scratch, M, C);
+  int rc = check_launch("layernorm_bwd_affine/partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(ln_affine_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, dgamma, dbeta, C,
+                     accumulate);
+  return check_launch("layernorm_bwd_affine/final");
+}

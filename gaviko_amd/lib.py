@@ -1,0 +1,96 @@
+"""ctypes binding of libgaviko_hip.so (the C-ABI declared in include/gaviko_hip.h).
+
+There is no fallback: if the shared library is missing or a call fails, this raises.  torch is used only
+for device memory (tensors -> raw pointers) and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgaviko_hip.so")
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("w", C.c_void_p), ("out0", C.c_void_p), ("out1", C.c_void_p),
+        ("bias", C.c_void_p), ("res", C.c_void_p), ("aux", C.c_void_p), ("pos", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldw", C.c_int32), ("ldo", C.c_int32), ("ldres", C.c_int32), ("ldaux", C.c_int32),
+        ("epilogue", C.c_int32), ("rows_in", C.c_int32), ("rows_out", C.c_int32), ("row_off", C.c_int32),
+        ("tile", C.c_int32),
+    ]
+
+
+EPI_STORE_BF16, EPI_BIAS_RES_F32, EPI_BIAS_GELU_BF16, EPI_PATCH_F32, EPI_GELU_BWD_BF16, EPI_STORE_F32, EPI_BIAS_RES_F32_BF16 = range(7)
+
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
+# name -> argtypes (every function returns int and takes the stream last)
+SIGNATURES = {
+    "gvk_gemm_nt_bf16": [C.POINTER(GemmDesc), _P],
+    "gvk_cast_f32_bf16": [_P, _P, _L, _P],
+    "gvk_transpose_cast_f32_bf16": [_P, _P, _I, _I, _P],
+    "gvk_patchify_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "gvk_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "gvk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "gvk_layernorm_bwd_affine": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+}
+NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, []), "gvk_abi_version": (C.c_int, [])}
+
+_lib = None
+
+
+class GavikoHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the library (once).  Raises GavikoHipError with build instructions if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GavikoHipError(
+            f"{LIB_PATH} not found: build it with `python -m gaviko_amd.build` (hipcc, gfx950). "
+            "gaviko_amd has no CPU or eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in NO_STREAM.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = C.c_int, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise GavikoHipError(f"{what} failed (rc={rc}): {load().gvk_last_error().decode()}")
+
+
+_device_ok = False
+
+
+def require_device() -> None:
+    """The product path runs on gfx950 only."""
+    global _device_ok
+    if _device_ok:
+        return
+    if not torch.cuda.is_available():
+        raise GavikoHipError("no HIP device visible: gaviko_amd runs on MI355X (gfx950) only and has no CPU fallback")
+    rc = load().gvk_device_check()
+    if rc != 950:
+        raise GavikoHipError(f"gvk_device_check: {load().gvk_last_error().decode()}")
+    _device_ok = True
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,128 @@
+"""Host-side launchers: torch tensors in, C-ABI calls out (include/gaviko_hip.h).
+
+Every wrapper validates device / dtype / contiguity / row padding on the host before launching --
+a hand-written kernel never sees a shape it was not built for.  All launches go to torch's current HIP
+stream, so they are capturable into a HIP graph with torch.cuda.graph().
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .lib import (EPI_BIAS_GELU_BF16, EPI_BIAS_RES_F32, EPI_BIAS_RES_F32_BF16, EPI_GELU_BWD_BF16, EPI_PATCH_F32,  # noqa: F401
+                  EPI_STORE_BF16, EPI_STORE_F32)
+
+ROW_PAD = 128
+
+
+def pad_rows(m: int) -> int:
+    return (m + ROW_PAD - 1) // ROW_PAD * ROW_PAD
+
+
+def act_zeros(m: int, c: int, dtype, device) -> torch.Tensor:
+    """Activation matrix with rows padded to the MFMA panel height (padding rows stay finite)."""
+    return torch.zeros((pad_rows(m), c), dtype=dtype, device=device)
+
+
+def _chk(t, dtype, what, min_elems=0):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise L.GavikoHipError(f"{what}: tensor must live on the HIP device (no CPU path)")
+    if t.dtype != dtype:
+        raise L.GavikoHipError(f"{what}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise L.GavikoHipError(f"{what}: tensor must be contiguous")
+    if t.numel() < min_elems:
+        raise L.GavikoHipError(f"{what}: needs >= {min_elems} elements, has {t.numel()}")
+
+
+def gemm_nt(a, w, M, out0, *, epilogue, out1=None, bias=None, res=None, aux=None, pos=None,
+            lda=None, ldo=None, ldres=None, ldaux=None, rows_in=0, rows_out=0, row_off=0, tile=0, N=None, K=None):
+    """Y[M,N] = A[M,K] . W[N,K]^T with a fused epilogue (gvk_gemm_nt_bf16)."""
+    N = w.shape[0] if N is None else N
+    K = w.shape[1] if K is None else K
+    lda = a.shape[-1] if lda is None else lda
+    ldw = w.shape[-1]
+    ldo = N if ldo is None else ldo
+    _chk(a, torch.bfloat16, "gemm A", pad_rows(M) * lda if lda == a.shape[-1] else 0)
+    _chk(w, torch.bfloat16, "gemm W", N * ldw)
+    out_dt = torch.float32 if epilogue in (EPI_BIAS_RES_F32, EPI_PATCH_F32, EPI_STORE_F32, EPI_BIAS_RES_F32_BF16) else torch.bfloat16
+    _chk(out0, out_dt, "gemm out0")
+    if out1 is not None:
+        _chk(out1, torch.float32 if epilogue == EPI_PATCH_F32 else torch.bfloat16, "gemm out1")
+    _chk(bias, torch.float32, "gemm bias", N)
+    _chk(res, torch.float32, "gemm res")
+    _chk(aux, torch.bfloat16, "gemm aux")
+    _chk(pos, torch.float32, "gemm pos", rows_in * N)
+    d = L.GemmDesc(L.ptr(a), L.ptr(w), L.ptr(out0), L.ptr(out1), L.ptr(bias), L.ptr(res), L.ptr(aux), L.ptr(pos),
+                   M, N, K, lda, ldw, ldo, (N if ldres is None else ldres), (N if ldaux is None else ldaux),
+                   epilogue, rows_in, rows_out, row_off, tile)
+    L.check(L.load().gvk_gemm_nt_bf16(C.byref(d), L.stream_ptr()), "gvk_gemm_nt_bf16")
+
+
+def cast_bf16(x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    _chk(x, torch.float32, "cast in")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _chk(out, torch.bfloat16, "cast out", x.numel())
+    L.check(L.load().gvk_cast_f32_bf16(L.ptr(x), L.ptr(out), x.numel(), L.stream_ptr()), "gvk_cast_f32_bf16")
+    return out
+
+
+def transpose_cast_bf16(x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """x f32 [rows, cols] -> bf16 [cols, rows]."""
+    _chk(x, torch.float32, "transpose_cast in")
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((cols, rows), dtype=torch.bfloat16, device=x.device)
+    _chk(out, torch.bfloat16, "transpose_cast out", rows * cols)
+    L.check(L.load().gvk_transpose_cast_f32_bf16(L.ptr(x), L.ptr(out), rows, cols, L.stream_ptr()), "gvk_transpose_cast_f32_bf16")
+    return out
+
+
+def patchify(img: torch.Tensor, out: torch.Tensor, patch) -> None:
+    _chk(img, torch.float32, "patchify img")
+    B, ch, D, H, W = img.shape
+    if ch != 1:
+        raise L.GavikoHipError("patchify: single-channel MRI volumes only (channels=1)")
+    pd, ph, pw = patch
+    n = (D // pd) * (H // ph) * (W // pw)
+    _chk(out, torch.bfloat16, "patchify out", B * n * pd * ph * pw)
+    L.check(L.load().gvk_patchify_bf16(L.ptr(img), L.ptr(out), B, D, H, W, pd, ph, pw, L.stream_ptr()), "gvk_patchify_bf16")
+
+
+def layernorm_fwd(x, gamma, beta, M, C_, *, y16=None, y32=None, mean=None, rstd=None, eps=1e-5):
+    _chk(x, torch.float32, "ln x", M * C_)
+    _chk(gamma, torch.float32, "ln gamma", C_)
+    _chk(beta, torch.float32, "ln beta", C_)
+    _chk(y16, torch.bfloat16, "ln y16", M * C_)
+    _chk(y32, torch.float32, "ln y32", M * C_)
+    _chk(mean, torch.float32, "ln mean", M)
+    _chk(rstd, torch.float32, "ln rstd", M)
+    L.check(L.load().gvk_layernorm_fwd(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y16), L.ptr(y32), L.ptr(mean), L.ptr(rstd),
+                                       M, C_, eps, L.stream_ptr()), "gvk_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, M, C_, *, dx, dres=None, dx16=None):
+    for t, n in ((dy, "dy"), (x, "x"), (dx, "dx")):
+        _chk(t, torch.float32, "ln_bwd " + n, M * C_)
+    _chk(dres, torch.float32, "ln_bwd dres", M * C_)
+    _chk(dx16, torch.bfloat16, "ln_bwd dx16", M * C_)
+    _chk(mean, torch.float32, "ln_bwd mean", M)
+    _chk(rstd, torch.float32, "ln_bwd rstd", M)
+    _chk(gamma, torch.float32, "ln_bwd gamma", C_)
+    L.check(L.load().gvk_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dres), L.ptr(dx),
+                                       L.ptr(dx16), M, C_, L.stream_ptr()), "gvk_layernorm_bwd")
+
+
+def layernorm_bwd_affine(dy, x, mean, rstd, dgamma, dbeta, scratch, M, C_, accumulate=False):
+    for t, n in ((dy, "dy"), (x, "x")):
+        _chk(t, torch.float32, "ln_affine " + n, M * C_)
+    _chk(dgamma, torch.float32, "ln_affine dgamma", C_)
+    _chk(dbeta, torch.float32, "ln_affine dbeta", C_)
+    _chk(scratch, torch.float32, "ln_affine scratch", 128 * C_)
+    L.check(L.load().gvk_layernorm_bwd_affine(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta),
+                                              L.ptr(scratch), M, C_, int(accumulate), L.stream_ptr()), "gvk_layernorm_bwd_affine")

@@ -1,0 +1,145 @@
+"""-m gpu: each HIP kernel (through the C-ABI) against a plain fp32/fp64 torch computation on the CPU."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+def _bf16_round(x):
+    return x.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(300, 192, 192, 0), (1033, 768, 768, 128128), (1033, 768, 768, 64064),
+                                        (2066, 2304, 768, 0), (517, 576, 192, 128064), (517, 768, 3072, 64128)])
+def test_gemm_store_bf16_and_f32(dev, M, N, K, tile):
+    from gaviko_amd import ops
+    a = _bf16_round(_rand((M, K), 1))
+    w = _bf16_round(_rand((N, K), 2, 1 / math.sqrt(K)))
+    bias = _rand((N,), 3, 0.1)
+    ref = a.double() @ w.double().T
+    A = ops.act_zeros(M, K, torch.bfloat16, dev)
+    A[:M] = a.to(dev).bfloat16()
+    W = w.to(dev).bfloat16().contiguous()
+    out = torch.full((ops.pad_rows(M), N), 7.0, dtype=torch.float32, device=dev)
+    ops.gemm_nt(A, W, M, out, epilogue=ops.EPI_STORE_F32, tile=tile)
+    torch.cuda.synchronize()
+    got = out[:M].cpu().double()
+    assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+    assert (out[M:] == 7.0).all(), "rows >= M must never be stored"
+    out16 = torch.zeros((ops.pad_rows(M), N), dtype=torch.bfloat16, device=dev)
+    ops.gemm_nt(A, W, M, out16, epilogue=ops.EPI_STORE_BF16, bias=bias.to(dev), tile=tile)
+    got = out16[:M].cpu().double()
+    refb = ref + bias.double()
+    assert (got - refb).abs().max().item() < 1.5 * 2 ** -8 * refb.abs().max().item()
+
+
+def test_gemm_epilogues(dev):
+    from gaviko_amd import ops
+    M, N, K = 1033, 768, 192
+    a = _bf16_round(_rand((M, K), 11))
+    w = _bf16_round(_rand((N, K), 12, 2 / math.sqrt(K)))
+    bias = _rand((N,), 13, 0.2)
+    res = _rand((M, N), 14)
+    ref = a.double() @ w.double().T + bias.double()
+    A = ops.act_zeros(M, K, torch.bfloat16, dev)
+    A[:M] = a.to(dev).bfloat16()
+    W = w.to(dev).bfloat16().contiguous()
+    # bias + residual (in place on the residual buffer) and the bf16 twin
+    R = ops.act_zeros(M, N, torch.float32, dev)
+    R[:M] = res.to(dev)
+    O16 = ops.act_zeros(M, N, torch.bfloat16, dev)
+    ops.gemm_nt(A, W, M, R, epilogue=ops.EPI_BIAS_RES_F32_BF16, out1=O16, bias=bias.to(dev), res=R)
+    want = ref + res.double()
+    assert (R[:M].cpu().double() - want).abs().max().item() < 3e-4
+    assert (O16[:M].cpu().double() - want).abs().max().item() < 2 ** -7 * want.abs().max().item()
+    # bias + erf-GELU, saving the pre-activation
+    pre = ops.act_zeros(M, N, torch.bfloat16, dev)
+    act = ops.act_zeros(M, N, torch.bfloat16, dev)
+    ops.gemm_nt(A, W, M, pre, epilogue=ops.EPI_BIAS_GELU_BF16, out1=act, bias=bias.to(dev))
+    assert (pre[:M].cpu().double() - ref).abs().max().item() < 2 ** -7 * ref.abs().max().item()
+    g = torch.nn.functional.gelu(ref)
+    assert (act[:M].cpu().double() - g).abs().max().item() < 2 ** -7 * max(1.0, g.abs().max().item())
+    # dgrad fused with GELU'
+    ops.gemm_nt(A, W, M, act, epilogue=ops.EPI_GELU_BWD_BF16, aux=pre)
+    x = pre[:M].cpu().double().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    want = (a.double() @ w.double().T) * x.grad
+    assert (act[:M].cpu().double() - want).abs().max().item() < 2 ** -6 * want.abs().max().item()
+
+
+def test_patch_embed_path(dev):
+    """patchify + GEMM(PATCH epilogue) == conv3d + flatten/transpose + pos, scattered into [P+1 .. ] rows."""
+    from gaviko_amd import ops
+    from gaviko_amd.utils import synth
+    B, C_, P = 2, 192, 32
+    img = torch.from_numpy(synth.volumes(5, B))
+    w = _rand((C_, 1, 12, 16, 16), 21, math.sqrt(3.0 / 3072) * 1.7)
+    bias = _rand((C_,), 22, 0.05)
+    pos = _rand((1000, C_), 23, 0.3)
+    wb = _bf16_round(w)
+    ref = torch.nn.functional.conv3d(_bf16_round(img).double(), wb.double(), bias.double(), stride=(12, 16, 16))
+    ref = ref.flatten(2).transpose(1, 2) + pos.double()
+    T = P + 1 + 1000
+    cols = ops.act_zeros(B * 1000, 3072, torch.bfloat16, dev)
+    ops.patchify(img.to(dev), cols, (12, 16, 16))
+    G = torch.full((ops.pad_rows(B * T), C_), -5.0, dtype=torch.float32, device=dev)
+    Lo = torch.zeros((ops.pad_rows(B * 1000), C_), dtype=torch.float32, device=dev)
+    W = wb.reshape(C_, 3072).to(dev).bfloat16().contiguous()
+    ops.gemm_nt(cols, W, B * 1000, G, epilogue=ops.EPI_PATCH_F32, out1=Lo, bias=bias.to(dev), pos=pos.to(dev).contiguous(),
+                rows_in=1000, rows_out=T, row_off=P + 1)
+    g = G[: B * T].view(B, T, C_).cpu().double()
+    assert (g[:, P + 1:] - ref).abs().max().item() < 5e-4
+    assert (g[:, : P + 1] == -5.0).all()
+    assert (Lo[: B * 1000].view(B, 1000, C_).cpu().double() - ref).abs().max().item() < 5e-4
+
+
+@pytest.mark.parametrize("M,C_", [(1033, 768), (77, 192), (515, 1024), (9, 384)])
+def test_layernorm_fwd_bwd(dev, M, C_):
+    from gaviko_amd import ops
+    x = _rand((M, C_), 31, 2.0) + 0.3
+    gamma = 1 + _rand((C_,), 32, 0.2)
+    beta = _rand((C_,), 33, 0.1)
+    dy = _rand((M, C_), 34)
+    dres = _rand((M, C_), 35)
+    xd = x.double().requires_grad_(True)
+    gd = gamma.double().requires_grad_(True)
+    bd = beta.double().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xd, (C_,), gd, bd, 1e-5)
+    y.backward(dy.double())
+    X, Gm, Bt = x.to(dev), gamma.to(dev), beta.to(dev)
+    y16 = torch.zeros((M, C_), dtype=torch.bfloat16, device=dev)
+    y32 = torch.zeros((M, C_), dtype=torch.float32, device=dev)
+    mean = torch.zeros(M, device=dev)
+    rstd = torch.zeros(M, device=dev)
+    ops.layernorm_fwd(X, Gm, Bt, M, C_, y16=y16, y32=y32, mean=mean, rstd=rstd)
+    assert (y32.cpu().double() - y.detach()).abs().max().item() < 2e-5
+    assert (y16.cpu().double() - y.detach()).abs().max().item() < 2 ** -7 * y.abs().max().item()
+    dx = torch.zeros((M, C_), device=dev)
+    dx16 = torch.zeros((M, C_), dtype=torch.bfloat16, device=dev)
+    ops.layernorm_bwd(dy.to(dev), X, mean, rstd, Gm, M, C_, dx=dx, dres=dres.to(dev), dx16=dx16)
+    want = xd.grad + dres.double()
+    assert (dx.cpu().double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    assert (dx16.cpu().double() - want).abs().max().item() < 2 ** -7 * want.abs().max().item()
+    dg = torch.zeros(C_, device=dev)
+    db = torch.zeros(C_, device=dev)
+    scratch = torch.zeros(128 * C_, device=dev)
+    ops.layernorm_bwd_affine(dy.to(dev), X, mean, rstd, dg, db, scratch, M, C_)
+    assert (dg.cpu().double() - gd.grad).abs().max().item() < 1e-4 * max(1.0, gd.grad.abs().max().item())
+    assert (db.cpu().double() - bd.grad).abs().max().item() < 1e-4 * max(1.0, bd.grad.abs().max().item())
+
+
+def test_casts(dev):
+    from gaviko_amd import ops
+    x = _rand((771, 193), 41)
+    o = ops.cast_bf16(x.to(dev).contiguous())
+    assert torch.equal(o.cpu(), x.bfloat16())
+    t = ops.transpose_cast_bf16(x.to(dev).contiguous())
+    assert torch.equal(t.cpu(), x.t().contiguous().bfloat16())
