@@ -1,0 +1,167 @@
+// Flash-style multi-head self-attention forward for gfx950, head dim 64, bf16 operands / fp32 accumulate.
+// Replaces vision_transformer.py:63-71 (q.k^T * scale -> softmax -> .v and both einops rearranges): the [B,h,T,T]
+// score tensor is never materialised, only the per-row log-sum-exp is saved for the backward.
+//
+// One workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 queries.
+// S^T[key][query] = K.Q^T with v_mfma_f32_32x32x16_bf16 (A = K rows from LDS, B = Q kept in registers), so a lane
+// holds ONE query column: the online-softmax max/sum are lane-local plus one exchange between the two 32-lane
+// halves.  The S^T accumulator is then reused in place as the B operand of O^T[d][query] += V^T.P^T (its k order
+// is the accumulator row order; the V^T fragment is gathered in that same order with ds_read_b64_tr_b16 from the
+// row-major [key][d] V tile), so nothing is transposed through memory.
+// LDS tile rows are 64 bf16 = 128 B; 16-B chunk c of row r sits at chunk c ^ swz(r), swz(r) = bit1(r)<<2 | bits3:2(r)
+// -- conflict-free for both the ds_read_b128 row reads and the 4x16 transposed reads.
+#include "common.hpp"
+#include "../../include/gaviko_hip.h"
+
+namespace gvk {
+
+__device__ __forceinline__ int swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+constexpr int kQB = 128;   // queries per workgroup
+constexpr int kKB = 64;    // keys per tile
+constexpr int kTileBytes = kKB * 128;
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse,
+                                                       int T, int H, int ld_qkv, int ld_out, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K tile | V tile]
+  const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * kQB;
+  const int lane = lane_id(), wave = wave_id();
+  const int r31 = lane & 31, hh = lane >> 5;
+  const int inner = H * 64;
+  const bf16* base = qkv + (size_t)b * T * ld_qkv + head * 64;
+  const bf16* kbase = base + inner;
+  const bf16* vbase = base + 2 * inner;
+
+  // Q fragments: B operand, col = query (lane&31), k = d = 16*ks + 8*hh + j
+  const int qrow = min(q0 + wave * 32 + r31, T - 1);
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(base + (size_t)qrow * ld_qkv + 16 * ks + 8 * hh);
+
+  auto stage = [&](int buf, int kt) {
+    char* sK = smem + buf * 2 * kTileBytes;
+    char* sV = sK + kTileBytes;
+    const int rsub = lane >> 3, slot = lane & 7;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int row = r * 32 + wave * 8 + rsub;
+      const int key = min(kt * kKB + row, T - 1);
+      const int chunk = slot ^ swz(row);
+      glds16(kbase + (size_t)key * ld_qkv + chunk * 8, sK + (r * 32 + wave * 8) * 128);
+      glds16(vbase + (size_t)key * ld_qkv + chunk * 8, sV + (r * 32 + wave * 8) * 128);
+    }
+  };
+
+  f32x16 ot[2];
+  ot[0] = f32x16{};
+  ot[1] = f32x16{};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nkt = (T + kKB - 1) / kKB;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
+    const char* sK = smem + buf * 2 * kTileBytes;
+    const char* sV = sK + kTileBytes;
+
+    // ---- S^T = K . Q^T   (two 32-key blocks)
+    f32x16 st[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      st[kb] = f32x16{};
+      const int row = kb * 32 + r31;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int chunk = 2 * ks + hh;
+        const bf16x8 kf = *(const bf16x8*)(sK + row * 128 + ((chunk ^ swz(row)) << 4));
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
+      }
+    }
+    // ---- scale (log2 domain), mask keys >= T, running max
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * kKB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        float s = st[kb][r] * scale_log2e;
+        s = (key < T) ? s : -INFINITY;
+        st[kb][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(st[kb][r] - m_new);
+        st[kb][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[db][r] *= alpha;
+
+    // ---- O^T += V^T . P^T : P^T straight from the accumulator registers as the B operand
+    const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[kb][8 * s + j];
+        const int key0 = kb * 32 + 16 * s + 4 * (g >> 1);   // lane half hh == g>>1
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
+          const int ra = key0 + tq, rb = key0 + 8 + tq;
+          const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((chunk ^ swz(ra)) << 4) + (tp & 1) * 8);
+          const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((chunk ^ swz(rb)) << 4) + (tp & 1) * 8);
+          const bf16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+          ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[db], 0, 0, 0);
+        }
+      }
+    __syncthreads();
+  }
+
+  // ---- epilogue: O[q][d] = O^T / l ; lse = ln(sum exp(s*scale))
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + wave * 32 + r31;
+  if (q < T) {
+    bf16* orow = out + ((size_t)b * T + q) * ld_out + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 o = {(bf16)(ot[db][4 * g4 + 0] * inv), (bf16)(ot[db][4 * g4 + 1] * inv), (bf16)(ot[db][4 * g4 + 2] * inv),
+                    (bf16)(ot[db][4 * g4 + 3] * inv)};
+        *(bf16x4*)(orow + db * 32 + 8 * g4 + 4 * hh) = o;
+      }
+    if (hh == 0 && lse != nullptr) lse[((size_t)b * H + head) * T + q] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
+  }
+}
+
+}  // namespace gvk
+
+extern "C" int gvk_attention_fwd_bf16(const void* qkv, void* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale,
+                                      void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(qkv && out, "gvk_attention_fwd_bf16: null pointer");
+  GVK_REQUIRE(B > 0 && T > 0 && H > 0, "gvk_attention_fwd_bf16: empty shape");
+  GVK_REQUIRE(ld_qkv >= 3 * H * 64 && ld_qkv % 8 == 0 && ld_out >= H * 64 && ld_out % 4 == 0,
+              "gvk_attention_fwd_bf16: head dim is fixed at 64; ld_qkv=%d ld_out=%d inconsistent with H=%d", ld_qkv, ld_out, H);
+  const int lds = 2 * 2 * kTileBytes;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((T + kQB - 1) / kQB, H, B), dim3(256), lds, (hipStream_t)stream, (const bf16*)qkv,
+                     (bf16*)out, lse, T, H, ld_qkv, ld_out, scale * 1.44269504088896340736f);
+  return check_launch("attention_fwd_bf16");
+}

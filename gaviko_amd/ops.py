@@ -126,3 +126,13 @@ def layernorm_bwd_affine(dy, x, mean, rstd, dgamma, dbeta, scratch, M, C_, accum
     _chk(scratch, torch.float32, "ln_affine scratch", 128 * C_)
     L.check(L.load().gvk_layernorm_bwd_affine(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(dgamma), L.ptr(dbeta),
                                               L.ptr(scratch), M, C_, int(accumulate), L.stream_ptr()), "gvk_layernorm_bwd_affine")
+
+
+def attention_fwd(qkv, out, lse, B, T, H, scale):
+    """qkv bf16 [pad(B*T), 3*H*64] -> out bf16 [pad(B*T), H*64], lse f32 [B,H,T]."""
+    inner = H * 64
+    _chk(qkv, torch.bfloat16, "attn qkv", pad_rows(B * T) * 3 * inner)
+    _chk(out, torch.bfloat16, "attn out", B * T * inner)
+    _chk(lse, torch.float32, "attn lse", B * H * T)
+    L.check(L.load().gvk_attention_fwd_bf16(L.ptr(qkv), L.ptr(out), L.ptr(lse), B, T, H, 3 * inner, inner, scale, L.stream_ptr()),
+            "gvk_attention_fwd_bf16")

@@ -77,6 +77,13 @@ int gvk_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
 int gvk_layernorm_bwd_affine(const float* dy, const float* x, const float* mean, const float* rstd, float* dgamma,
                              float* dbeta, float* scratch, int M, int C, int accumulate, void* stream);
 
+/* ------------------------------------------------------------------ multi-head self-attention, head dim 64
+ * qkv bf16 [B*T (padded)][ld_qkv]: columns [q | k | v], each (head, 64) -- the to_qkv output as is
+ * (vision_transformer.py:62-63).  out bf16 [B*T][ld_out] in 'b n (h d)' order (vision_transformer.py:71), lse f32 [B][H][T]
+ * = log sum_j exp(scale * q.k_j) (natural log), saved for the backward.  scale = dim_head^-0.5 (vision_transformer.py:47,65). */
+int gvk_attention_fwd_bf16(const void* qkv, void* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,3 +143,45 @@ def test_casts(dev):
     assert torch.equal(o.cpu(), x.bfloat16())
     t = ops.transpose_cast_bf16(x.to(dev).contiguous())
     assert torch.equal(t.cpu(), x.t().contiguous().bfloat16())
+
+
+def _attn_ref(qkv, B, T, H):
+    q, k, v = (t.reshape(B, T, H, 64).permute(0, 2, 1, 3) for t in qkv.double().chunk(3, dim=-1))
+    s = q @ k.transpose(-1, -2) * 0.125
+    return (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B, T, H * 64), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 1033, 3), (1, 1001, 12), (3, 65, 2), (1, 393, 3), (2, 128, 1)])
+def test_attention_fwd(dev, B, T, H):
+    from gaviko_amd import ops
+    inner = H * 64
+    qkv = _bf16_round(_rand((B, T, 3 * inner), 51, 2.5))
+    ref, lse_ref = _attn_ref(qkv, B, T, H)
+    Q = ops.act_zeros(B * T, 3 * inner, torch.bfloat16, dev)
+    Q[: B * T] = qkv.reshape(B * T, -1).to(dev).bfloat16()
+    O = ops.act_zeros(B * T, inner, torch.bfloat16, dev)
+    lse = torch.zeros((B, H, T), device=dev)
+    ops.attention_fwd(Q, O, lse, B, T, H, 0.125)
+    torch.cuda.synchronize()
+    got = O[: B * T].view(B, T, inner).cpu().double()
+    assert (lse.cpu().double() - lse_ref).abs().max().item() < 2e-3
+    assert (got - ref).abs().max().item() < 1.5e-2 * max(1.0, ref.abs().max().item())
+
+
+def test_attention_fwd_forced_rescale(dev):
+    """Online-softmax rescale branch: one key per tile dominates, with the max growing tile after tile."""
+    from gaviko_amd import ops
+    B, T, H = 1, 300, 1
+    qkv = _bf16_round(_rand((B, T, 192), 52, 0.5))
+    for j, t in enumerate((10, 70, 140, 200, 299)):
+        qkv[0, t, 64:128] = qkv[0, 5, 0:64] * (4.0 + 3.0 * j)     # key t aligned with query 5, growing
+    qkv = _bf16_round(qkv)
+    ref, lse_ref = _attn_ref(qkv, B, T, H)
+    Q = ops.act_zeros(T, 192, torch.bfloat16, dev)
+    Q[:T] = qkv.reshape(T, -1).to(dev).bfloat16()
+    O = ops.act_zeros(T, 64, torch.bfloat16, dev)
+    lse = torch.zeros((1, 1, T), device=dev)
+    ops.attention_fwd(Q, O, lse, B, T, H, 0.125)
+    got = O[:T].view(1, T, 64).cpu().double()
+    assert (got - ref).abs().max().item() < 1.5e-2 * max(1.0, ref.abs().max().item())
+    assert (lse.cpu().double() - lse_ref).abs().max().item() < 5e-3
