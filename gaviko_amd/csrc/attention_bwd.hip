@@ -1,0 +1,296 @@
+// Flash-style attention backward for gfx950, head dim 64, bf16 operands / fp32 accumulate.
+// Autograd of vision_transformer.py:63-71.  P is recomputed from Q, K and the forward's log-sum-exp; nothing N x N is
+// stored.  Two passes, no atomics, bitwise reproducible:
+//   dkdv pass: workgroup = 128 keys (4 waves x 32) of one (batch, head), sweeping 32-query slices.  S[q][key] and
+//              dP[q][key] are computed with the KEY on the MFMA lane, so their accumulators are directly the B operands
+//              of dV^T += dO^T.P and dK^T += Q^T.dS (Q / dO tiles are read row-wise for S, dP and 4x16-transposed
+//              (ds_read_b64_tr_b16) for the two gradient products -- one LDS image serves both).
+//   dq pass:   workgroup = 128 queries, sweeping 64-key tiles exactly like the forward: S^T, dP^T with the QUERY on the
+//              lane, dQ^T += K^T.dS^T with K^T gathered by transposed reads of the row-major K tile.
+// The row constants (-lse/scale) are preloaded into the S accumulators, so P = exp2(c * S') needs no subtraction.
+#include "common.hpp"
+#include "../../include/gaviko_hip.h"
+
+namespace gvk {
+
+__device__ __forceinline__ int swz_b(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+
+// delta[b][h][t] = sum_d dO * O
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ d_o, float* __restrict__ delta,
+                                                         int B, int T, int H, int ld) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * T * H) return;
+  const int h = idx % H;
+  const int64_t row = idx / H;
+  const int b = row / T, t = row - (int64_t)b * T;
+  const bf16* po = o + row * ld + h * 64;
+  const bf16* pd = d_o + row * ld + h * 64;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const bf16x8 a = *(const bf16x8*)(po + 8 * k);
+    const bf16x8 c = *(const bf16x8*)(pd + 8 * k);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)c[e];
+  }
+  delta[((size_t)b * H + h) * T + t] = s;
+}
+
+constexpr int kTile32 = 32 * 128;   // bytes of a [32][64] bf16 tile
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+                                                            const float* __restrict__ lse, const float* __restrict__ delta,
+                                                            bf16* __restrict__ dqkv, int T, int H, int ld_qkv, int ld_o, float scale,
+                                                            float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][Q tile 4K | dO tile 4K | lse' 128 B | delta 128 B]
+  constexpr int kBuf = 2 * kTile32 + 256;
+  const int b = blockIdx.z, head = blockIdx.y, k0 = blockIdx.x * 128;
+  const int lane = lane_id(), wave = wave_id();
+  const int r31 = lane & 31, hh = lane >> 5;
+  const int inner = H * 64;
+  const bf16* qbase = qkv + (size_t)b * T * ld_qkv + head * 64;
+  const bf16* dobase = d_o + (size_t)b * T * ld_o + head * 64;
+  const float* lse_b = lse + ((size_t)b * H + head) * T;
+  const float* del_b = delta + ((size_t)b * H + head) * T;
+
+  // K, V fragments of this wave's 32 keys: B operands (col = key, k = d)
+  const int key = k0 + wave * 32 + r31;
+  const int keyc = min(key, T - 1);
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kf[ks] = *(const bf16x8*)(qbase + inner + (size_t)keyc * ld_qkv + 16 * ks + 8 * hh);
+    vf[ks] = *(const bf16x8*)(qbase + 2 * inner + (size_t)keyc * ld_qkv + 16 * ks + 8 * hh);
+  }
+
+  const float inv_scale = 1.0f / scale;
+  auto stage = [&](int buf, int qt) {
+    char* sQ = smem + buf * kBuf;
+    char* sD = sQ + kTile32;
+    float* sL = (float*)(sD + kTile32);
+    const int row = wave * 8 + (lane >> 3), slot = lane & 7;
+    const int q = min(qt * 32 + row, T - 1);
+    const int chunk = slot ^ swz_b(row);
+    glds16(qbase + (size_t)q * ld_qkv + chunk * 8, sQ + wave * 8 * 128);
+    glds16(dobase + (size_t)q * ld_o + chunk * 8, sD + wave * 8 * 128);
+    if (wave == 0) {
+      const int qq = qt * 32 + r31;
+      if (hh == 0) sL[r31] = (qq < T) ? -lse_b[qq] * inv_scale : -INFINITY;   // rows >= T: P = exp2(-inf) = 0
+      else sL[32 + r31] = (qq < T) ? del_b[qq] : 0.f;
+    }
+  };
+
+  f32x16 dkt[2], dvt[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { dkt[i] = f32x16{}; dvt[i] = f32x16{}; }
+
+  const int nqt = (T + 31) / 32;
+  const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  stage(0, 0);
+  __syncthreads();
+  for (int qt = 0; qt < nqt; ++qt) {
+    const int buf = qt & 1;
+    if (qt + 1 < nqt) stage(buf ^ 1, qt + 1);
+    const char* sQ = smem + buf * kBuf;
+    const char* sD = sQ + kTile32;
+    const float* sL = (const float*)(sD + kTile32);
+    // S'[q][key] = Q.K^T - lse/scale ;  dP[q][key] = dO.V^T
+    f32x16 s, dp;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 l4 = *(const f32x4*)(sL + 8 * g4 + 4 * hh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[4 * g4 + e] = l4[e];
+    }
+    dp = f32x16{};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int chunk = 2 * ks + hh;
+      const bf16x8 qa = *(const bf16x8*)(sQ + r31 * 128 + ((chunk ^ swz_b(r31)) << 4));
+      const bf16x8 da = *(const bf16x8*)(sD + r31 * 128 + ((chunk ^ swz_b(r31)) << 4));
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
+    }
+    // P = exp2(c * S');  dS = P * (dP - delta[q])
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 d4 = *(const f32x4*)(sL + 32 + 8 * g4 + 4 * hh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pr = __builtin_amdgcn_exp2f(s[4 * g4 + e] * scale_log2e);
+        s[4 * g4 + e] = pr;
+        dp[4 * g4 + e] = pr * (dp[4 * g4 + e] - d4[e]);
+      }
+    }
+    // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]   (k = q, accumulator row order)
+#pragma unroll
+    for (int sk = 0; sk < 2; ++sk) {
+      bf16x8 pf, dsf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { pf[j] = (bf16)s[8 * sk + j]; dsf[j] = (bf16)dp[8 * sk + j]; }
+      const int q0r = 16 * sk + 4 * (g >> 1);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
+        const int ra = q0r + tq, rb = q0r + 8 + tq;
+        const int oa = ra * 128 + ((chunk ^ swz_b(ra)) << 4) + (tp & 1) * 8;
+        const int ob = rb * 128 + ((chunk ^ swz_b(rb)) << 4) + (tp & 1) * 8;
+        const bf16x4 da0 = lds_read_tr16(sD + oa), da1 = lds_read_tr16(sD + ob);
+        const bf16x4 qa0 = lds_read_tr16(sQ + oa), qa1 = lds_read_tr16(sQ + ob);
+        const bf16x8 dof = {da0[0], da0[1], da0[2], da0[3], da1[0], da1[1], da1[2], da1[3]};
+        const bf16x8 qf = {qa0[0], qa0[1], qa0[2], qa0[3], qa1[0], qa1[1], qa1[2], qa1[3]};
+        dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dvt[db], 0, 0, 0);
+        dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, dsf, dkt[db], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (key < T) {
+    bf16* dk_row = dqkv + ((size_t)b * T + key) * ld_qkv + inner + head * 64;
+    bf16* dv_row = dk_row + inner;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d = db * 32 + 8 * g4 + 4 * hh;
+        bf16x4 ok = {(bf16)(dkt[db][4 * g4] * scale), (bf16)(dkt[db][4 * g4 + 1] * scale), (bf16)(dkt[db][4 * g4 + 2] * scale),
+                     (bf16)(dkt[db][4 * g4 + 3] * scale)};
+        bf16x4 ov = {(bf16)dvt[db][4 * g4], (bf16)dvt[db][4 * g4 + 1], (bf16)dvt[db][4 * g4 + 2], (bf16)dvt[db][4 * g4 + 3]};
+        *(bf16x4*)(dk_row + d) = ok;
+        *(bf16x4*)(dv_row + d) = ov;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+constexpr int kKB2 = 64;
+constexpr int kTile64 = 64 * 128;
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          bf16* __restrict__ dqkv, int T, int H, int ld_qkv, int ld_o, float scale,
+                                                          float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][K tile | V tile]
+  const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
+  const int lane = lane_id(), wave = wave_id();
+  const int r31 = lane & 31, hh = lane >> 5;
+  const int inner = H * 64;
+  const bf16* base = qkv + (size_t)b * T * ld_qkv + head * 64;
+  const bf16* kbase = base + inner;
+  const bf16* vbase = base + 2 * inner;
+  const int q = q0 + wave * 32 + r31;
+  const int qc = min(q, T - 1);
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    qf[ks] = *(const bf16x8*)(base + (size_t)qc * ld_qkv + 16 * ks + 8 * hh);
+    dof[ks] = *(const bf16x8*)(d_o + ((size_t)b * T + qc) * ld_o + head * 64 + 16 * ks + 8 * hh);
+  }
+  const float sinit = -lse[((size_t)b * H + head) * T + qc] / scale;
+  const float del = delta[((size_t)b * H + head) * T + qc];
+
+  auto stage = [&](int buf, int kt) {
+    char* sK = smem + buf * 2 * kTile64;
+    char* sV = sK + kTile64;
+    const int rsub = lane >> 3, slot = lane & 7;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int row = r * 32 + wave * 8 + rsub;
+      const int key = min(kt * kKB2 + row, T - 1);
+      const int chunk = slot ^ swz_b(row);
+      glds16(kbase + (size_t)key * ld_qkv + chunk * 8, sK + (r * 32 + wave * 8) * 128);
+      glds16(vbase + (size_t)key * ld_qkv + chunk * 8, sV + (r * 32 + wave * 8) * 128);
+    }
+  };
+
+  f32x16 dqt[2];
+  dqt[0] = f32x16{};
+  dqt[1] = f32x16{};
+  const int nkt = (T + kKB2 - 1) / kKB2;
+  const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
+    const char* sK = smem + buf * 2 * kTile64;
+    const char* sV = sK + kTile64;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 st, dpt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = sinit;
+      dpt = f32x16{};
+      const int row = kb * 32 + r31;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int chunk = 2 * ks + hh;
+        const int off = row * 128 + ((chunk ^ swz_b(row)) << 4);
+        const bf16x8 ka = *(const bf16x8*)(sK + off);
+        const bf16x8 va = *(const bf16x8*)(sV + off);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], st, 0, 0, 0);
+        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dpt, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * kKB2 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float pr = (key < T) ? __builtin_amdgcn_exp2f(st[r] * scale_log2e) : 0.f;
+        st[r] = pr * (dpt[r] - del);     // dS^T
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 dsf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsf[j] = (bf16)st[8 * s + j];
+        const int key0 = kb * 32 + 16 * s + 4 * (g >> 1);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
+          const int ra = key0 + tq, rb = key0 + 8 + tq;
+          const bf16x4 ka0 = lds_read_tr16(sK + ra * 128 + ((chunk ^ swz_b(ra)) << 4) + (tp & 1) * 8);
+          const bf16x4 ka1 = lds_read_tr16(sK + rb * 128 + ((chunk ^ swz_b(rb)) << 4) + (tp & 1) * 8);
+          const bf16x8 kt8 = {ka0[0], ka0[1], ka0[2], ka0[3], ka1[0], ka1[1], ka1[2], ka1[3]};
+          dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt8, dsf, dqt[db], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (q < T) {
+    bf16* dq_row = dqkv + ((size_t)b * T + q) * ld_qkv + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 o = {(bf16)(dqt[db][4 * g4] * scale), (bf16)(dqt[db][4 * g4 + 1] * scale), (bf16)(dqt[db][4 * g4 + 2] * scale),
+                    (bf16)(dqt[db][4 * g4 + 3] * scale)};
+        *(bf16x4*)(dq_row + db * 32 + 8 * g4 + 4 * hh) = o;
+      }
+  }
+}
+
+}  // namespace gvk
+
+extern "C" int gvk_attention_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
+                                      int T, int H, int ld_qkv, int ld_out, float scale, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(qkv && out && dout && lse && delta && dqkv, "gvk_attention_bwd_bf16: null pointer");
+  GVK_REQUIRE(B > 0 && T > 0 && H > 0, "gvk_attention_bwd_bf16: empty shape");
+  GVK_REQUIRE(ld_qkv >= 3 * H * 64 && ld_qkv % 8 == 0 && ld_out >= H * 64 && ld_out % 8 == 0,
+              "gvk_attention_bwd_bf16: head dim is fixed at 64; ld_qkv=%d ld_out=%d inconsistent with H=%d", ld_qkv, ld_out, H);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n = (int64_t)B * T * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)out, (const bf16*)dout, delta, B, T, H,
+                     ld_out);
+  int rc = check_launch("attention_bwd/delta");
+  if (rc) return rc;
+  const float sl2 = scale * 1.44269504088896340736f;
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((T + 127) / 128, H, B), dim3(256), 2 * (2 * kTile32 + 256), s, (const bf16*)qkv,
+                     (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H, ld_qkv, ld_out, scale, sl2);
+  rc = check_launch("attention_bwd/dkdv");
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((T + 127) / 128, H, B), dim3(256), 2 * 2 * kTile64, s, (const bf16*)qkv, (const bf16*)dout, lse,
+                     delta, (bf16*)dqkv, T, H, ld_qkv, ld_out, scale, sl2);
+  return check_launch("attention_bwd/dq");
+}

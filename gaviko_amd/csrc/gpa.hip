@@ -1,0 +1,435 @@
+// Gated prompt awakening (GPA) core for GAViKO in the L-dim latent space, fp32.
+// Replaces gaviko.py:159-185 (Awakening_Prompt.forward between proj_down and proj_up):
+//   PRE gate   imp[b][p] = sigmoid(W3 . GELU(W1 . LN(cls) + b1) + b3)                       gaviko.py:23-29,164
+//   PCF weight gw[b]     = sigmoid(wg . LN'(cls) + bg)                                       gaviko.py:51-55,167
+//   GXA / LXA  ctx = softmax(q . tok^T * L^-1/2) . tok, q = Wq . prompt + bq                 gaviko.py:84-94
+//              global tokens = rows 2P+2 .. T-1 of the global latent (the reference slices [P+1:] twice: 106-107,170)
+//              local tokens  = all N local latents                                            gaviko.py:118-119,172
+//   enh[b][p]  = (gw * ctx_g + (1 - gw) * ctx_l) * imp[b][p]                                 gaviko.py:175,178
+// and the whole backward of the above.  ~25 tiny ATen launches per layer become 2 forward / 3 backward kernels.
+// One wave per (sample, prompt) for the cross-attention (lanes over the ~1000 tokens); the token-side gradient is a
+// gather over the P prompts (no atomics).
+#include "common.hpp"
+#include "../../include/gaviko_hip.h"
+
+namespace gvk {
+
+struct GpaArgs {
+  // forward inputs
+  const float* xl; const float* ll;          // activated latents: global [B*T][L], local [B*N][L]
+  const float* ca0_g; const float* ca0_b; const float* ca1_w; const float* ca1_b; const float* ca3_w; const float* ca3_b;
+  const float* gl0_g; const float* gl0_b; const float* gl1_w; const float* gl1_b;
+  const float* wgq; const float* bgq; const float* wlq; const float* blq;
+  // forward outputs / saved
+  float* imp; float* gw;                     // [B][P], [B]
+  float* enh;                                // [B][P][L]
+  float* prm; float* qg; float* ql; float* cg; float* cl; float* lse_g; float* lse_l;   // [B][P][L] x5, [B][P] x2
+  // backward
+  const float* dcomb;                        // [B*T][L]  gradient wrt the combined latent (proj_up input)
+  const float* zx; const float* zl;          // pre-activations of proj_down (QuickGELU'), [B*T][L], [B*N][L]
+  float* dimp; float* dgw_part;              // [B][P]
+  float* dqg; float* dql; float* dcg; float* dcl; float* delta_g; float* delta_l; float* dprm;
+  float* dcls;                               // [B][L] gradient wrt the CLS latent from both gates
+  float* gate_partials;                      // [B][n_gate]
+  float* dzx; float* dzl;                    // outputs: gradient wrt proj_down pre-activations
+  int B, T, N, P;
+  float scale;
+};
+
+template <int L>
+__device__ __forceinline__ void ln_small(const float* x, const float* g, const float* b, float* out, float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int l = 0; l < L; ++l) s += x[l];
+  mean = s / L;
+  float q = 0.f;
+#pragma unroll
+  for (int l = 0; l < L; ++l) { const float d = x[l] - mean; q += d * d; }
+  rstd = rsqrtf(q / L + 1e-5f);
+#pragma unroll
+  for (int l = 0; l < L; ++l) out[l] = (x[l] - mean) * rstd * g[l] + b[l];
+}
+// dx += LN backward of (dy) given x-hat = (x-mean)*rstd
+template <int L>
+__device__ __forceinline__ void ln_small_bwd(const float* x, float mean, float rstd, const float* g, const float* dy, float* dx_acc) {
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int l = 0; l < L; ++l) { const float xh = (x[l] - mean) * rstd, dh = dy[l] * g[l]; m1 += dh; m2 += dh * xh; }
+  m1 /= L; m2 /= L;
+#pragma unroll
+  for (int l = 0; l < L; ++l) { const float xh = (x[l] - mean) * rstd; dx_acc[l] += rstd * (dy[l] * g[l] - m1 - xh * m2); }
+}
+
+// ---- gates forward: one wave per sample
+template <int L>
+__global__ __launch_bounds__(64) void gpa_gates_fwd_kernel(GpaArgs p) {
+  __shared__ float a1_s[64];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float cls[L], hn[L], gn[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) cls[l] = p.xl[((size_t)b * p.T + p.P) * L + l];
+  float mean, rstd;
+  ln_small<L>(cls, p.ca0_g, p.ca0_b, hn, mean, rstd);
+  float a = p.ca1_b[lane];
+#pragma unroll
+  for (int l = 0; l < L; ++l) a += p.ca1_w[lane * L + l] * hn[l];
+  a1_s[lane] = gelu_erf(a);
+  __syncthreads();
+  for (int q = lane; q < p.P; q += 64) {
+    float t = p.ca3_b[q];
+    for (int u = 0; u < 64; ++u) t += p.ca3_w[q * 64 + u] * a1_s[u];
+    p.imp[b * p.P + q] = sigmoidf_(t);
+  }
+  ln_small<L>(cls, p.gl0_g, p.gl0_b, gn, mean, rstd);
+  float t = p.gl1_b[0];
+#pragma unroll
+  for (int l = 0; l < L; ++l) t += p.gl1_w[l] * gn[l];
+  if (lane == 0) p.gw[b] = sigmoidf_(t);
+}
+
+// softmax(q . tok^T) . tok over n tokens (rows `tok`, stride L); lanes over tokens; returns ctx (all lanes) and lse.
+template <int L>
+__device__ __forceinline__ void cross_one(const float* q, const float* tok, int n, int lane, float* ctx, float& lse) {
+  float m = -INFINITY, s = 0.f;
+  for (int i = lane; i < n; i += 64) {
+    const float* t = tok + (size_t)i * L;
+    float d = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) d += q[l] * t[l];
+    const float mn = fmaxf(m, d);
+    s = s * __expf(m - mn) + __expf(d - mn);
+    m = mn;
+  }
+  const float mw = wave_max(m);
+  s = wave_sum(s * __expf(m - mw));
+  lse = mw + __logf(s);
+  float c[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) c[l] = 0.f;
+  for (int i = lane; i < n; i += 64) {
+    const float* t = tok + (size_t)i * L;
+    float d = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) d += q[l] * t[l];
+    const float pr = __expf(d - lse);
+#pragma unroll
+    for (int l = 0; l < L; ++l) c[l] += pr * t[l];
+  }
+#pragma unroll
+  for (int l = 0; l < L; ++l) ctx[l] = wave_sum(c[l]);
+}
+
+// ---- cross-attention forward: one wave per (sample, prompt)
+template <int L>
+__global__ __launch_bounds__(256) void gpa_cross_fwd_kernel(GpaArgs p) {
+  const int b = blockIdx.y, pi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pi >= p.P) return;
+  const int lane = lane_id();
+  const size_t o = ((size_t)b * p.P + pi) * L;
+  float pr[L], qg[L], ql[L], cg[L], cl[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) pr[l] = p.xl[((size_t)b * p.T + pi) * L + l];
+#pragma unroll
+  for (int j = 0; j < L; ++j) {
+    float a = p.bgq[j], c = p.blq[j];
+#pragma unroll
+    for (int l = 0; l < L; ++l) { a += p.wgq[j * L + l] * pr[l]; c += p.wlq[j * L + l] * pr[l]; }
+    qg[j] = a * p.scale; ql[j] = c * p.scale;       // scale folded into the query
+  }
+  float lg, lloc;
+  const int ng = p.T - (2 * p.P + 2);
+  cross_one<L>(qg, p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L, ng, lane, cg, lg);
+  cross_one<L>(ql, p.ll + (size_t)b * p.N * L, p.N, lane, cl, lloc);
+  const float gw = p.gw[b], im = p.imp[b * p.P + pi];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    if (lane == l) {
+      p.enh[o + l] = (gw * cg[l] + (1.f - gw) * cl[l]) * im;
+      p.prm[o + l] = pr[l]; p.qg[o + l] = qg[l]; p.ql[o + l] = ql[l]; p.cg[o + l] = cg[l]; p.cl[o + l] = cl[l];
+    }
+  }
+  if (lane == 0) { p.lse_g[b * p.P + pi] = lg; p.lse_l[b * p.P + pi] = lloc; }
+}
+
+// dq (already-scaled query space) of softmax cross attention: dq[l] = sum_n A_n (dA_n - delta) tok_n[l]
+template <int L>
+__device__ __forceinline__ void cross_dq(const float* q, const float* dc, const float* tok, int n, int lane, float lse, float delta, float* dq) {
+  float a[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) a[l] = 0.f;
+  for (int i = lane; i < n; i += 64) {
+    const float* t = tok + (size_t)i * L;
+    float d = 0.f, da = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) { d += q[l] * t[l]; da += dc[l] * t[l]; }
+    const float ds = __expf(d - lse) * (da - delta);
+#pragma unroll
+    for (int l = 0; l < L; ++l) a[l] += ds * t[l];
+  }
+#pragma unroll
+  for (int l = 0; l < L; ++l) dq[l] = wave_sum(a[l]);
+}
+
+// ---- backward, prompt side: one wave per (sample, prompt)
+template <int L>
+__global__ __launch_bounds__(256) void gpa_cross_bwd_p_kernel(GpaArgs p) {
+  const int b = blockIdx.y, pi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pi >= p.P) return;
+  const int lane = lane_id();
+  const size_t o = ((size_t)b * p.P + pi) * L;
+  const float gw = p.gw[b], im = p.imp[b * p.P + pi];
+  float denh[L], cg[L], cl[L], dcg[L], dcl[L], qg[L], ql[L];
+  float dimp = 0.f, dgw = 0.f, delg = 0.f, dell = 0.f;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    denh[l] = p.dcomb[((size_t)b * p.T + pi) * L + l];
+    cg[l] = p.cg[o + l]; cl[l] = p.cl[o + l]; qg[l] = p.qg[o + l]; ql[l] = p.ql[o + l];
+    const float fused = gw * cg[l] + (1.f - gw) * cl[l];
+    dimp += denh[l] * fused;
+    const float df = denh[l] * im;
+    dgw += df * (cg[l] - cl[l]);
+    dcg[l] = gw * df; dcl[l] = (1.f - gw) * df;
+    delg += dcg[l] * cg[l]; dell += dcl[l] * cl[l];
+  }
+  float dqg[L], dql[L];
+  const int ng = p.T - (2 * p.P + 2);
+  cross_dq<L>(qg, dcg, p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L, ng, lane, p.lse_g[b * p.P + pi], delg, dqg);
+  cross_dq<L>(ql, dcl, p.ll + (size_t)b * p.N * L, p.N, lane, p.lse_l[b * p.P + pi], dell, dql);
+  // unscaled-query gradients (q_scaled = scale * (W prompt + b)), and the prompt latent gradient through both query projections
+#pragma unroll
+  for (int l = 0; l < L; ++l) { dqg[l] *= p.scale; dql[l] *= p.scale; }
+  float dpr[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < L; ++j) a += p.wgq[j * L + l] * dqg[j] + p.wlq[j * L + l] * dql[j];
+    dpr[l] = a;
+  }
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    if (lane == l) {
+      p.dqg[o + l] = dqg[l]; p.dql[o + l] = dql[l]; p.dcg[o + l] = dcg[l]; p.dcl[o + l] = dcl[l]; p.dprm[o + l] = dpr[l];
+    }
+  }
+  if (lane == 0) {
+    p.dimp[b * p.P + pi] = dimp; p.dgw_part[b * p.P + pi] = dgw; p.delta_g[b * p.P + pi] = delg; p.delta_l[b * p.P + pi] = dell;
+  }
+}
+
+// ---- gates backward: one wave per sample; recomputes the tiny forward.  Per-sample parameter-gradient partials are
+// written to gate_partials[b][:] in the order [ca0_g L | ca0_b L | ca1_w 64L | ca1_b 64 | ca3_w 64P | ca3_b P | gl0_g L | gl0_b L | gl1_w L | gl1_b 1].
+template <int L>
+__global__ __launch_bounds__(64) void gpa_gates_bwd_kernel(GpaArgs p) {
+  __shared__ float a1_s[64], da1_s[64], dpre3_s[64], dhn_s[64][L + 1];
+  const int b = blockIdx.x, lane = threadIdx.x, P = p.P;
+  const int n_gate = 4 * L + 64 * L + 64 + 64 * P + P + L + 1;
+  float* out = p.gate_partials + (size_t)b * n_gate;
+  float* o_ca0g = out; float* o_ca0b = out + L; float* o_ca1w = out + 2 * L; float* o_ca1b = o_ca1w + 64 * L;
+  float* o_ca3w = o_ca1b + 64; float* o_ca3b = o_ca3w + 64 * P; float* o_gl0g = o_ca3b + P; float* o_gl0b = o_gl0g + L;
+  float* o_gl1w = o_gl0b + L; float* o_gl1b = o_gl1w + L;
+  float cls[L], hn[L], gn[L], dcls[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) { cls[l] = p.xl[((size_t)b * p.T + P) * L + l]; dcls[l] = 0.f; }
+  float mean_a, rstd_a, mean_g, rstd_g;
+  ln_small<L>(cls, p.ca0_g, p.ca0_b, hn, mean_a, rstd_a);
+  float pre1 = p.ca1_b[lane];
+#pragma unroll
+  for (int l = 0; l < L; ++l) pre1 += p.ca1_w[lane * L + l] * hn[l];
+  a1_s[lane] = gelu_erf(pre1);
+  da1_s[lane] = 0.f;
+  __syncthreads();
+  // layer 3 (P outputs): dpre3[q] = dimp * imp * (1 - imp)
+  for (int q = lane; q < 64; q += 64) {
+    float d3 = 0.f;
+    if (q < P) {
+      const float im = p.imp[b * P + q];
+      d3 = p.dimp[b * P + q] * im * (1.f - im);
+      o_ca3b[q] = d3;
+    }
+    dpre3_s[q] = d3;
+  }
+  __syncthreads();
+  // d ca3_w[q][u] = dpre3[q] * a1[u];  da1[u] = sum_q dpre3[q] * ca3_w[q][u]   (lane = u)
+  {
+    float da = 0.f;
+    for (int q = 0; q < P && q < 64; ++q) {
+      const float d3 = dpre3_s[q];
+      o_ca3w[q * 64 + lane] = d3 * a1_s[lane];
+      da += d3 * p.ca3_w[q * 64 + lane];
+    }
+    da1_s[lane] = da;
+  }
+  // layer 1 (lane = u): dpre1 = da1 * GELU'(pre1)
+  const float dpre1 = da1_s[lane] * gelu_erf_grad(pre1);
+  o_ca1b[lane] = dpre1;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    o_ca1w[lane * L + l] = dpre1 * hn[l];
+    dhn_s[lane][l] = dpre1 * p.ca1_w[lane * L + l];
+  }
+  __syncthreads();
+  float dhn[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    float a = 0.f;
+    for (int u = 0; u < 64; ++u) a += dhn_s[u][l];
+    dhn[l] = a;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int l = 0; l < L; ++l) { o_ca0g[l] = dhn[l] * (cls[l] - mean_a) * rstd_a; o_ca0b[l] = dhn[l]; }
+  }
+  ln_small_bwd<L>(cls, mean_a, rstd_a, p.ca0_g, dhn, dcls);
+  // PCF balance gate
+  ln_small<L>(cls, p.gl0_g, p.gl0_b, gn, mean_g, rstd_g);
+  float dgw = 0.f;
+  for (int q = 0; q < P; ++q) dgw += p.dgw_part[b * P + q];
+  const float gwv = p.gw[b];
+  const float dpre = dgw * gwv * (1.f - gwv);
+  float dgn[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) dgn[l] = dpre * p.gl1_w[l];
+  if (lane == 0) {
+    o_gl1b[0] = dpre;
+#pragma unroll
+    for (int l = 0; l < L; ++l) { o_gl1w[l] = dpre * gn[l]; o_gl0g[l] = dgn[l] * (cls[l] - mean_g) * rstd_g; o_gl0b[l] = dgn[l]; }
+  }
+  ln_small_bwd<L>(cls, mean_g, rstd_g, p.gl0_g, dgn, dcls);
+  if (lane == 0) {
+#pragma unroll
+    for (int l = 0; l < L; ++l) p.dcls[b * L + l] = dcls[l];
+  }
+}
+
+// ---- backward, token side: one thread per latent row (global rows first, then local rows).
+// Gathers over the P prompts (staged in LDS), adds the proj_up / gate / query-path gradients, applies QuickGELU'.
+template <int L>
+__global__ __launch_bounds__(256) void gpa_bwd_tok_kernel(GpaArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.y, P = p.P;
+  float* q_s = (float*)smem;              // [2][P][L]  scaled queries (global, local)
+  float* dc_s = q_s + 2 * P * L;          // [2][P][L]  dctx
+  float* ls_s = dc_s + 2 * P * L;         // [2][P]     lse
+  float* de_s = ls_s + 2 * P;             // [2][P]     delta
+  for (int i = threadIdx.x; i < P * L; i += 256) {
+    const size_t o = (size_t)b * P * L + i;
+    q_s[i] = p.qg[o]; q_s[P * L + i] = p.ql[o]; dc_s[i] = p.dcg[o]; dc_s[P * L + i] = p.dcl[o];
+  }
+  for (int i = threadIdx.x; i < P; i += 256) {
+    ls_s[i] = p.lse_g[b * P + i]; ls_s[P + i] = p.lse_l[b * P + i];
+    de_s[i] = p.delta_g[b * P + i]; de_s[P + i] = p.delta_l[b * P + i];
+  }
+  __syncthreads();
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= p.T + p.N) return;
+  const bool is_local = r >= p.T;
+  const int t = is_local ? r - p.T : r;
+  const size_t row = is_local ? (size_t)b * p.N + t : (size_t)b * p.T + t;
+  const float* lat = (is_local ? p.ll : p.xl) + row * L;
+  float tok[L], g[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) { tok[l] = lat[l]; g[l] = 0.f; }
+  const bool attends = is_local || t >= 2 * P + 2;
+  if (attends) {
+    const int side = is_local ? 1 : 0;
+    const float* qs = q_s + side * P * L;
+    const float* dcs = dc_s + side * P * L;
+    for (int q = 0; q < P; ++q) {
+      float d = 0.f, da = 0.f;
+#pragma unroll
+      for (int l = 0; l < L; ++l) { d += qs[q * L + l] * tok[l]; da += dcs[q * L + l] * tok[l]; }
+      const float a = __expf(d - ls_s[side * P + q]);
+      const float ds = a * (da - de_s[side * P + q]);
+#pragma unroll
+      for (int l = 0; l < L; ++l) g[l] += a * dcs[q * L + l] + ds * qs[q * L + l];
+    }
+  }
+  if (!is_local) {
+    if (t < P) {
+#pragma unroll
+      for (int l = 0; l < L; ++l) g[l] = p.dprm[((size_t)b * P + t) * L + l];     // prompt rows only feed the queries
+    } else {
+#pragma unroll
+      for (int l = 0; l < L; ++l) g[l] += p.dcomb[row * L + l];                  // cls / image rows pass through proj_up
+      if (t == P) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) g[l] += p.dcls[b * L + l];
+      }
+    }
+  }
+  const float* z = (is_local ? p.zl : p.zx) + row * L;
+  float* dz = (is_local ? p.dzl : p.dzx) + row * L;
+#pragma unroll
+  for (int l = 0; l < L; ++l) dz[l] = g[l] * quick_gelu_grad(z[l]);
+}
+
+static void fill_gpa(GpaArgs& a, const gvk_gpa_desc* d) {
+  a.xl = d->xl; a.ll = d->ll;
+  a.ca0_g = d->ca0_g; a.ca0_b = d->ca0_b; a.ca1_w = d->ca1_w; a.ca1_b = d->ca1_b; a.ca3_w = d->ca3_w; a.ca3_b = d->ca3_b;
+  a.gl0_g = d->gl0_g; a.gl0_b = d->gl0_b; a.gl1_w = d->gl1_w; a.gl1_b = d->gl1_b;
+  a.wgq = d->wgq; a.bgq = d->bgq; a.wlq = d->wlq; a.blq = d->blq;
+  a.imp = d->imp; a.gw = d->gw; a.enh = d->enh; a.prm = d->prm; a.qg = d->qg; a.ql = d->ql; a.cg = d->cg; a.cl = d->cl;
+  a.lse_g = d->lse_g; a.lse_l = d->lse_l; a.dcomb = d->dcomb; a.zx = d->zx; a.zl = d->zl; a.dimp = d->dimp; a.dgw_part = d->dgw_part;
+  a.dqg = d->dqg; a.dql = d->dql; a.dcg = d->dcg; a.dcl = d->dcl; a.delta_g = d->delta_g; a.delta_l = d->delta_l; a.dprm = d->dprm;
+  a.dcls = d->dcls; a.gate_partials = d->gate_partials; a.dzx = d->dzx; a.dzl = d->dzl;
+  a.B = d->B; a.T = d->T; a.N = d->N; a.P = d->P; a.scale = d->scale;
+}
+
+}  // namespace gvk
+
+#define GVK_GPA_LAUNCH(KERNEL, grid, block, lds)                                                        \
+  switch (d->L) {                                                                                       \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), grid, block, lds, s, a); break;                            \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), grid, block, lds, s, a); break;                            \
+    case 16: hipLaunchKernelGGL((KERNEL<16>), grid, block, lds, s, a); break;                          \
+    case 20: hipLaunchKernelGGL((KERNEL<20>), grid, block, lds, s, a); break;                          \
+    case 32: hipLaunchKernelGGL((KERNEL<32>), grid, block, lds, s, a); break;                          \
+    default: return set_error(-2, "gvk_gpa: L=%d unsupported (4, 8, 16, 20, 32)", d->L);               \
+  }
+
+static int gpa_check(const gvk_gpa_desc* d, const char* what) {
+  using namespace gvk;
+  GVK_REQUIRE(d && d->xl && d->ll, "%s: null latents", what);
+  GVK_REQUIRE(d->B > 0 && d->P > 0 && d->P <= 64 && d->N > 0, "%s: need 0 < P <= 64 (P=%d)", what, d->P);
+  GVK_REQUIRE(d->T - (2 * d->P + 2) > 0, "%s: T=%d leaves no global image tokens after the double slice (P=%d)", what, d->T, d->P);
+  return 0;
+}
+
+extern "C" int gvk_gpa_fwd(const gvk_gpa_desc* d, void* stream) {
+  using namespace gvk;
+  int rc = gpa_check(d, "gvk_gpa_fwd");
+  if (rc) return rc;
+  GVK_REQUIRE(d->imp && d->gw && d->enh && d->prm && d->qg && d->ql && d->cg && d->cl && d->lse_g && d->lse_l, "gvk_gpa_fwd: null output");
+  GpaArgs a{};
+  fill_gpa(a, d);
+  hipStream_t s = (hipStream_t)stream;
+  GVK_GPA_LAUNCH(gpa_gates_fwd_kernel, dim3(d->B), dim3(64), 0);
+  rc = check_launch("gpa_gates_fwd");
+  if (rc) return rc;
+  GVK_GPA_LAUNCH(gpa_cross_fwd_kernel, dim3((d->P + 3) / 4, d->B), dim3(256), 0);
+  return check_launch("gpa_cross_fwd");
+}
+
+extern "C" int gvk_gpa_bwd(const gvk_gpa_desc* d, void* stream) {
+  using namespace gvk;
+  int rc = gpa_check(d, "gvk_gpa_bwd");
+  if (rc) return rc;
+  GVK_REQUIRE(d->dcomb && d->zx && d->zl && d->dimp && d->dgw_part && d->dqg && d->dql && d->dcg && d->dcl && d->delta_g && d->delta_l &&
+                  d->dprm && d->dcls && d->gate_partials && d->dzx && d->dzl,
+              "gvk_gpa_bwd: null pointer");
+  GpaArgs a{};
+  fill_gpa(a, d);
+  hipStream_t s = (hipStream_t)stream;
+  GVK_GPA_LAUNCH(gpa_cross_bwd_p_kernel, dim3((d->P + 3) / 4, d->B), dim3(256), 0);
+  rc = check_launch("gpa_cross_bwd_p");
+  if (rc) return rc;
+  GVK_GPA_LAUNCH(gpa_gates_bwd_kernel, dim3(d->B), dim3(64), 0);
+  rc = check_launch("gpa_gates_bwd");
+  if (rc) return rc;
+  const int lds = (4 * d->P * d->L + 4 * d->P) * 4;
+  GVK_GPA_LAUNCH(gpa_bwd_tok_kernel, dim3((d->T + d->N + 255) / 256, d->B), dim3(256), lds);
+  return check_launch("gpa_bwd_tok");
+}
+
+extern "C" int gvk_gpa_gate_param_count(int L, int P) { return 4 * L + 64 * L + 64 + 64 * P + P + L + 1; }

@@ -1,0 +1,253 @@
+// Token assembly and the pooled classification head.
+//   rows_broadcast : G[b][row_off + r][:] = src[r][:] + add[r][:]      (cls_token + pos[0], prompts + prompt_pos;
+//                    vision_transformer.py:154-156, gaviko.py:536-543, vpt.py:127-131,147-153)
+//   rows_batch_sum : out[r][:] = sum_b dG[b][row_off + r][:]            (gradient of a batch-broadcast parameter)
+//   head_fwd       : logits = Linear(mean_r LN(G[b][r0 .. r0+R)))       (final LN restricted to the pooled rows:
+//                    gaviko.py:306,316 pools rows 0..P; vision_transformer.py:89,161 pools row 0 or all rows)
+//   head_bwd       : dWh, dbh and the gradient into the pooled rows of the final residual stream (other rows: zero)
+#include "common.hpp"
+#include "../../include/gaviko_hip.h"
+
+namespace gvk {
+
+__global__ __launch_bounds__(256) void rows_broadcast_kernel(float* __restrict__ out, const float* __restrict__ src, const float* __restrict__ add,
+                                                             int B, int T, int row_off, int R, int C) {
+  const int64_t total = (int64_t)B * R * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = i % C;
+    const int64_t t = i / C;
+    const int r = t % R, b = t / R;
+    out[((int64_t)b * T + row_off + r) * C + c] = src[(int64_t)r * C + c] + (add ? add[(int64_t)r * C + c] : 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void rows_batch_sum_kernel(const float* __restrict__ dg, float* __restrict__ out, float* __restrict__ out2,
+                                                             int B, int T, int row_off, int R, int C, int accumulate) {
+  const int64_t total = (int64_t)R * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = i % C, r = i / C;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dg[((int64_t)b * T + row_off + r) * C + c];
+    out[i] = accumulate ? out[i] + a : a;
+    if (out2) out2[i] = accumulate ? out2[i] + a : a;
+  }
+}
+
+struct HeadArgs {
+  const float* g;        // final residual stream [B*T][C]
+  const float* ln_g; const float* ln_b;
+  const float* wh; const float* bh;   // [K][C], [K]
+  float* logits;         // [B][K]
+  float* pooled;         // [B][C] (saved)
+  const float* dlogits;  // [B][K]
+  float* dg;             // [B*T][C]: rows r0..r0+R of each sample are written
+  float* dwh; float* dbh;
+  int B, T, C, K, r0, R, accumulate;
+};
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* pool_s = (float*)smem;   // [4][C] then reduced into [0][C]
+  const int b = blockIdx.x, lane = lane_id(), wave = wave_id(), C = p.C;
+  f32x4 acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = wave; r < p.R; r += 4) {
+    const float* xr = p.g + ((size_t)b * p.T + p.r0 + r) * C;
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = k * 256 + lane * 4;
+      v[k] = (c < C) ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = k * 256 + lane * 4;
+      if (c < C) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[k][e] - mean; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = k * 256 + lane * 4;
+      if (c < C) {
+        const f32x4 g = *(const f32x4*)(p.ln_g + c);
+        const f32x4 bb = *(const f32x4*)(p.ln_b + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[k][e] += (v[k][e] - mean) * rstd * g[e] + bb[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = k * 256 + lane * 4;
+    if (c < C) *(f32x4*)(pool_s + wave * C + c) = acc[k];
+  }
+  __syncthreads();
+  const float invR = 1.f / (float)p.R;
+  float tsum[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = k * 256 + threadIdx.x;
+    tsum[k] = (c < C) ? (pool_s[c] + pool_s[C + c] + pool_s[2 * C + c] + pool_s[3 * C + c]) * invR : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = k * 256 + threadIdx.x;
+    if (c < C) {
+      pool_s[c] = tsum[k];
+      if (p.pooled) p.pooled[(size_t)b * C + c] = tsum[k];
+    }
+  }
+  __syncthreads();
+  for (int k = wave; k < p.K; k += 4) {
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a += pool_s[c] * p.wh[(size_t)k * C + c];
+    a = wave_sum(a);
+    if (lane == 0) p.logits[b * p.K + k] = a + p.bh[k];
+  }
+}
+
+// grid (B): dpooled = dlogits . Wh; every pooled row gets dy = dpooled / R through the LN backward
+__global__ __launch_bounds__(256) void head_bwd_rows_kernel(HeadArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* dp_s = (float*)smem;   // [C]
+  const int b = blockIdx.x, lane = lane_id(), wave = wave_id(), C = p.C;
+  const float invR = 1.f / (float)p.R;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f;
+    for (int k = 0; k < p.K; ++k) a += p.dlogits[b * p.K + k] * p.wh[(size_t)k * C + c];
+    dp_s[c] = a * invR;
+  }
+  __syncthreads();
+  for (int r = wave; r < p.R; r += 4) {
+    const size_t off = ((size_t)b * p.T + p.r0 + r) * C;
+    f32x4 xh[4], dh[4];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = k * 256 + lane * 4;
+      xh[k] = (c < C) ? *(const f32x4*)(p.g + off + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      s += xh[k][0] + xh[k][1] + xh[k][2] + xh[k][3];
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = k * 256 + lane * 4;
+      if (c < C) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = xh[k][e] - mean; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + 1e-5f);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = k * 256 + lane * 4;
+      if (c < C) {
+        const f32x4 g = *(const f32x4*)(p.ln_g + c);
+        const f32x4 dy = *(const f32x4*)(dp_s + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[k][e] = (xh[k][e] - mean) * rstd;
+          dh[k][e] = dy[e] * g[e];
+          s1 += dh[k][e];
+          s2 += dh[k][e] * xh[k][e];
+        }
+      } else {
+        dh[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = k * 256 + lane * 4;
+      if (c < C) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd * (dh[k][e] - m1 - xh[k][e] * m2);
+        *(f32x4*)(p.dg + off + c) = o;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_w_kernel(HeadArgs p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < p.K * p.C) {
+    const int k = i / p.C, c = i - k * p.C;
+    float a = 0.f;
+    for (int b = 0; b < p.B; ++b) a += p.dlogits[b * p.K + k] * p.pooled[(size_t)b * p.C + c];
+    p.dwh[i] = p.accumulate ? p.dwh[i] + a : a;
+  }
+  if (i < p.K) {
+    float a = 0.f;
+    for (int b = 0; b < p.B; ++b) a += p.dlogits[b * p.K + i];
+    p.dbh[i] = p.accumulate ? p.dbh[i] + a : a;
+  }
+}
+
+}  // namespace gvk
+
+extern "C" int gvk_rows_broadcast(float* out, const float* src, const float* add, int B, int T, int row_off, int R, int C, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(out && src && B > 0 && R > 0 && C > 0 && row_off >= 0 && row_off + R <= T, "gvk_rows_broadcast: bad arguments");
+  int64_t blocks = ((int64_t)B * R * C + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(rows_broadcast_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, src, add, B, T, row_off, R, C);
+  return check_launch("rows_broadcast");
+}
+
+extern "C" int gvk_rows_batch_sum(const float* dg, float* out, float* out2, int B, int T, int row_off, int R, int C, int accumulate, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(dg && out && B > 0 && R > 0 && C > 0 && row_off >= 0 && row_off + R <= T, "gvk_rows_batch_sum: bad arguments");
+  int64_t blocks = ((int64_t)R * C + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(rows_batch_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dg, out, out2, B, T, row_off, R, C, accumulate);
+  return check_launch("rows_batch_sum");
+}
+
+static int head_fill(gvk::HeadArgs& a, const gvk_head_desc* d) {
+  using namespace gvk;
+  GVK_REQUIRE(d && d->g && d->ln_gamma && d->ln_beta && d->wh && d->bh, "gvk_head: null pointer");
+  GVK_REQUIRE(d->B > 0 && d->C > 0 && d->C % 4 == 0 && d->C <= 1024 && d->K > 0 && d->R > 0 && d->r0 >= 0 && d->r0 + d->R <= d->T,
+              "gvk_head: bad shape (C=%d must be a multiple of 4 and <= 1024; rows %d..%d of T=%d)", d->C, d->r0, d->r0 + d->R, d->T);
+  a.g = d->g; a.ln_g = d->ln_gamma; a.ln_b = d->ln_beta; a.wh = d->wh; a.bh = d->bh; a.logits = d->logits; a.pooled = d->pooled;
+  a.dlogits = d->dlogits; a.dg = d->dg; a.dwh = d->dwh; a.dbh = d->dbh;
+  a.B = d->B; a.T = d->T; a.C = d->C; a.K = d->K; a.r0 = d->r0; a.R = d->R; a.accumulate = d->accumulate;
+  return 0;
+}
+
+extern "C" int gvk_head_fwd(const gvk_head_desc* d, void* stream) {
+  using namespace gvk;
+  HeadArgs a{};
+  int rc = head_fill(a, d);
+  if (rc) return rc;
+  GVK_REQUIRE(d->logits, "gvk_head_fwd: logits null");
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(d->B), dim3(256), 4 * d->C * 4, (hipStream_t)stream, a);
+  return check_launch("head_fwd");
+}
+
+extern "C" int gvk_head_bwd(const gvk_head_desc* d, void* stream) {
+  using namespace gvk;
+  HeadArgs a{};
+  int rc = head_fill(a, d);
+  if (rc) return rc;
+  GVK_REQUIRE(d->dlogits && d->pooled && d->dwh && d->dbh, "gvk_head_bwd: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dg != nullptr) {
+    hipLaunchKernelGGL(head_bwd_rows_kernel, dim3(d->B), dim3(256), d->C * 4, s, a);
+    rc = check_launch("head_bwd_rows");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(head_bwd_w_kernel, dim3((d->K * d->C + 255) / 256), dim3(256), 0, s, a);
+  return check_launch("head_bwd_w");
+}

@@ -1,0 +1,408 @@
+// "Skinny" fp32 kernels for GAViKO's trainable rank-L side paths (L = latent dim, 20 by default):
+//   down   y[m][0:L]   = act( LN?(x[m][:]) . W^T + b )          (+ optional second tiny matrix: y2 = y . W2^T)
+//   up     out[m][:]   = res + drop( lat[m][0:L] . W^T + b )      (or accumulate into out)
+//   outer  dW[l][c]    = sum_m narrow[m][l] * wide'[m][c]          (weight gradients of down / up projections)
+//   small  dW[j][l]    = sum_m a[m][j] * b[m][l]                   (L x L sized weight gradients)
+//   colsum db[c]       = sum_m x[m][c]
+// All of them are HBM-bound streams over a [M][C] fp32 token matrix (C = 768/1024) with ~2*L flop per byte;
+// fp32 VALU throughout because these feed trainable parameters.  Reductions are two-stage and deterministic.
+// Replaces: gaviko.py:231 (norm + proj_down), :232 (qkv), :242 (proj_up), :155-156 (GPA proj_down + QuickGELU),
+//           :187 (GPA proj_up) and the autograd wgrad/dgrad of each.
+#include "common.hpp"
+#include "../../include/gaviko_hip.h"
+
+namespace gvk {
+
+// counter-based dropout mask: keep iff hash(seed, idx) >= p * 2^32
+__device__ __forceinline__ unsigned int hash_u32(unsigned long long seed, unsigned long long idx) {
+  unsigned long long x = idx * 0x9E3779B97F4A7C15ull + seed;
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  return (unsigned int)x;
+}
+__device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned long long idx, unsigned int thresh, float inv_keep) {
+  return (hash_u32(seed, idx) >= thresh) ? inv_keep : 0.f;
+}
+
+struct DownArgs {
+  const float* x; const float* w; const float* bias;      // x [M][C]; w [L][C] (layout 0) or [C][L] (layout 1)
+  const float* ln_g; const float* ln_b;                   // optional LayerNorm on the input row (eps 1e-5)
+  float* mean; float* rstd;                               // saved LN statistics (optional)
+  float* z; float* y;                                     // pre-activation (optional) / activated output [M][L]
+  const float* w2; float* y2; int L2;                     // optional second stage y2[m][0:L2] = y . w2^T, w2 [L2][L]
+  int M, C, act, w_layout;
+  float eps;
+  unsigned long long seed; unsigned int drop_thresh; float inv_keep;   // optional dropout mask on the INPUT (bwd of proj_drop)
+};
+
+constexpr int kDownRows = 16;
+
+template <int L>
+__global__ __launch_bounds__(256) void skinny_down_kernel(DownArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ws = (float*)smem;   // [L][C]
+  const int C = p.C;
+  for (int i = threadIdx.x; i < L * C; i += 256) {
+    const int j = i / C, c = i - j * C;
+    ws[i] = p.w_layout == 0 ? p.w[i] : p.w[(size_t)c * L + j];
+  }
+  __syncthreads();
+  const int lane = lane_id(), wave = wave_id();
+  const int r_end = min(p.M, (int)(blockIdx.x + 1) * kDownRows);
+  for (int row = blockIdx.x * kDownRows + wave; row < r_end; row += 4) {
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = k * 256 + lane * 4;
+      v[k] = (c < C) ? *(const f32x4*)(p.x + (size_t)row * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.drop_thresh != 0u && c < C) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[k][e] *= drop_scale(p.seed, (unsigned long long)row * C + c + e, p.drop_thresh, p.inv_keep);
+      }
+      s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+    }
+    if (p.ln_g != nullptr) {
+      const float mean = wave_sum(s) / (float)C;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = k * 256 + lane * 4;
+        if (c < C) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = v[k][e] - mean; q += d * d; }
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(q) / (float)C + p.eps);
+      if (lane == 0) {
+        if (p.mean) p.mean[row] = mean;
+        if (p.rstd) p.rstd[row] = rstd;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = k * 256 + lane * 4;
+        if (c < C) {
+          const f32x4 g = *(const f32x4*)(p.ln_g + c);
+          const f32x4 b = *(const f32x4*)(p.ln_b + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[k][e] = (v[k][e] - mean) * rstd * g[e] + b[e];
+        }
+      }
+    }
+    float acc[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = k * 256 + lane * 4;
+        if (c < C) {
+          const f32x4 wv = *(const f32x4*)(ws + j * C + c);
+          a += v[k][0] * wv[0] + v[k][1] * wv[1] + v[k][2] * wv[2] + v[k][3] * wv[3];
+        }
+      }
+      acc[j] = a;
+    }
+#pragma unroll
+    for (int j = 0; j < L; ++j) acc[j] = wave_sum(acc[j]);
+    // every lane now holds the L sums; finish (bias, activation) redundantly, lane j stores element j
+    float yv[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      const float zz = acc[j] + (p.bias ? p.bias[j] : 0.f);
+      yv[j] = p.act == 1 ? quick_gelu(zz) : zz;
+      if (lane == j) {
+        if (p.z) p.z[(size_t)row * L + j] = zz;
+        if (p.y) p.y[(size_t)row * L + j] = yv[j];
+      }
+    }
+    if (p.w2 != nullptr) {
+      for (int j2 = lane; j2 < p.L2; j2 += 64) {
+        float a = 0.f;
+#pragma unroll
+        for (int l = 0; l < L; ++l) a += yv[l] * p.w2[j2 * L + l];
+        p.y2[(size_t)row * p.L2 + j2] = a;
+      }
+    }
+  }
+}
+
+struct UpArgs {
+  const float* lat; const float* w; const float* bias;    // lat [M][L]; w [C][L] (layout 0) or [L][C] (layout 1)
+  const float* res; float* out;                           // out = res + (...)  (res may be NULL / alias out); accumulate: out += (...)
+  const float* lat_override; int T, P;                    // rows with (m % T) < P read lat_override[(m / T) * P + m % T][:]
+  int M, C, w_layout, accumulate;
+  unsigned long long seed; unsigned int drop_thresh; float inv_keep;   // dropout on the projected value (proj_drop)
+};
+
+constexpr int kUpRows = 16;
+
+template <int L>
+__global__ __launch_bounds__(256) void skinny_up_kernel(UpArgs p) {
+  __shared__ float lat_s[kUpRows][L];
+  const int C = p.C;
+  const int r0 = blockIdx.x * kUpRows, nr = min(kUpRows, p.M - r0);
+  for (int i = threadIdx.x; i < nr * L; i += 256) {
+    const int r = i / L, l = i - r * L, m = r0 + r;
+    const float* src = p.lat + (size_t)m * L;
+    if (p.lat_override != nullptr) {
+      const int s = m / p.T, t = m - s * p.T;
+      if (t < p.P) src = p.lat_override + ((size_t)s * p.P + t) * L;
+    }
+    lat_s[r][l] = src[l];
+  }
+  float wr[4][L];
+  float br[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = k * 256 + threadIdx.x;
+    br[k] = (c < C && p.bias) ? p.bias[c] : 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) wr[k][l] = (c < C) ? (p.w_layout == 0 ? p.w[(size_t)c * L + l] : p.w[(size_t)l * C + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int r = 0; r < nr; ++r) {
+    const int m = r0 + r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = k * 256 + threadIdx.x;
+      if (c < C) {
+        float a = br[k];
+#pragma unroll
+        for (int l = 0; l < L; ++l) a += lat_s[r][l] * wr[k][l];
+        if (p.drop_thresh != 0u) a *= drop_scale(p.seed, (unsigned long long)m * C + c, p.drop_thresh, p.inv_keep);
+        const size_t o = (size_t)m * C + c;
+        if (p.accumulate) a += p.out[o];
+        else if (p.res) a += p.res[o];
+        p.out[o] = a;
+      }
+    }
+  }
+}
+
+struct OuterArgs {
+  const float* narrow; const float* wide;                 // narrow [M][L], wide [M][C]
+  const float* lat_override; int T, P;                    // as UpArgs (narrow side)
+  const float* mean; const float* rstd; const float* ln_g; const float* ln_b;   // optional LN applied to `wide` on the fly
+  float* scratch;                                         // [64][L+1][C]
+  int M, C;
+  unsigned long long seed; unsigned int drop_thresh; float inv_keep;   // optional dropout mask on `wide`
+};
+
+constexpr int kSlabs = 64;
+constexpr int kOuterChunk = 32;
+
+template <int L>
+__global__ __launch_bounds__(256) void outer_partial_kernel(OuterArgs p) {
+  __shared__ float nar[kOuterChunk][L];
+  __shared__ float st[kOuterChunk][2];
+  const int C = p.C, c = blockIdx.x * 256 + threadIdx.x, slab = blockIdx.y;
+  const int rows_per = (p.M + kSlabs - 1) / kSlabs;
+  const int r0 = slab * rows_per, r1 = min(p.M, r0 + rows_per);
+  float acc[L + 1];
+#pragma unroll
+  for (int l = 0; l <= L; ++l) acc[l] = 0.f;
+  const float g = (p.ln_g && c < C) ? p.ln_g[c] : 1.f, bt = (p.ln_b && c < C) ? p.ln_b[c] : 0.f;
+  for (int rb = r0; rb < r1; rb += kOuterChunk) {
+    const int nr = min(kOuterChunk, r1 - rb);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nr * L; i += 256) {
+      const int r = i / L, l = i - r * L, m = rb + r;
+      const float* src = p.narrow + (size_t)m * L;
+      if (p.lat_override != nullptr) {
+        const int s = m / p.T, t = m - s * p.T;
+        if (t < p.P) src = p.lat_override + ((size_t)s * p.P + t) * L;
+      }
+      nar[r][l] = src[l];
+    }
+    if (p.mean != nullptr && threadIdx.x < nr) {
+      st[threadIdx.x][0] = p.mean[rb + threadIdx.x];
+      st[threadIdx.x][1] = p.rstd[rb + threadIdx.x];
+    }
+    __syncthreads();
+    if (c < C) {
+      for (int r = 0; r < nr; ++r) {
+        const int m = rb + r;
+        float w = p.wide[(size_t)m * C + c];
+        if (p.drop_thresh != 0u) w *= drop_scale(p.seed, (unsigned long long)m * C + c, p.drop_thresh, p.inv_keep);
+        if (p.mean != nullptr) w = (w - st[r][0]) * st[r][1] * g + bt;
+#pragma unroll
+        for (int l = 0; l < L; ++l) acc[l] += nar[r][l] * w;
+        acc[L] += w;
+      }
+    }
+  }
+  if (c < C) {
+#pragma unroll
+    for (int l = 0; l <= L; ++l) p.scratch[((size_t)slab * (L + 1) + l) * C + c] = acc[l];
+  }
+}
+
+// out[l][c] (transposed=0) or out[c][l] (transposed=1); colsum[c] optional
+__global__ __launch_bounds__(256) void outer_final_kernel(const float* __restrict__ scratch, float* __restrict__ out, float* __restrict__ colsum,
+                                                          int L, int C, int transposed, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int s = 0; s < kSlabs; ++s) a += scratch[((size_t)s * (L + 1) + l) * C + c];
+  if (l < L) {
+    if (out == nullptr) return;
+    float* o = transposed ? out + (size_t)c * L + l : out + (size_t)l * C + c;
+    *o = accumulate ? *o + a : a;
+  } else if (colsum != nullptr) {
+    colsum[c] = accumulate ? colsum[c] + a : a;
+  }
+}
+
+// dW[j][l] = sum_m a[m][j] * b[m][l], J, Lb <= 64: stage 1 per row slab, stage 2 sums slabs.
+__global__ __launch_bounds__(256) void small_wgrad_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ scratch,
+                                                                  int M, int J, int Lb) {
+  const int slab = blockIdx.x, nout = J * Lb;
+  const int rows_per = (M + kSlabs - 1) / kSlabs;
+  const int r0 = slab * rows_per, r1 = min(M, r0 + rows_per);
+  for (int o = threadIdx.x; o < nout; o += 256) {
+    const int j = o / Lb, l = o - j * Lb;
+    float acc = 0.f;
+    for (int m = r0; m < r1; ++m) acc += a[(size_t)m * J + j] * b[(size_t)m * Lb + l];
+    scratch[(size_t)slab * nout + o] = acc;
+  }
+}
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ scratch, float* __restrict__ out, int n, int nslabs, int accumulate) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= n) return;
+  float a = 0.f;
+  for (int s = 0; s < nslabs; ++s) a += scratch[(size_t)s * n + o];
+  out[o] = accumulate ? out[o] + a : a;
+}
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ scratch, int M, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x, slab = blockIdx.y;
+  if (c >= C) return;
+  const int rows_per = (M + kSlabs - 1) / kSlabs;
+  const int r0 = slab * rows_per, r1 = min(M, r0 + rows_per);
+  float a = 0.f;
+  for (int m = r0; m < r1; ++m) a += x[(size_t)m * C + c];
+  scratch[(size_t)slab * C + c] = a;
+}
+
+template <int L>
+static int launch_down(const DownArgs& a, hipStream_t s) {
+  const int lds = L * a.C * 4;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_down_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(skinny_down): %s", hipGetErrorString(e));
+    attr = true;
+  }
+  hipLaunchKernelGGL((skinny_down_kernel<L>), dim3((a.M + kDownRows - 1) / kDownRows), dim3(256), lds, s, a);
+  return check_launch("skinny_down");
+}
+template <int L>
+static int launch_up(const UpArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((skinny_up_kernel<L>), dim3((a.M + kUpRows - 1) / kUpRows), dim3(256), 0, s, a);
+  return check_launch("skinny_up");
+}
+template <int L>
+static int launch_outer(const OuterArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((outer_partial_kernel<L>), dim3((a.C + 255) / 256, kSlabs), dim3(256), 0, s, a);
+  return check_launch("outer_partial");
+}
+
+static unsigned int drop_threshold(float p) {
+  if (p <= 0.f) return 0u;
+  double t = (double)p * 4294967296.0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (unsigned int)t;
+}
+
+}  // namespace gvk
+
+extern "C" int gvk_skinny_down(const gvk_skinny_down_desc* d, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(d && d->x && d->w && (d->y || d->z || d->y2), "gvk_skinny_down: null pointer");
+  GVK_REQUIRE(d->M > 0 && d->C > 0 && d->C % 4 == 0 && d->C <= 1024, "gvk_skinny_down: C=%d must be a multiple of 4 and <= 1024", d->C);
+  GVK_REQUIRE(d->L * d->C * 4 <= 160 * 1024, "gvk_skinny_down: W does not fit the 160 KiB LDS");
+  GVK_REQUIRE((d->ln_gamma == nullptr) == (d->ln_beta == nullptr), "gvk_skinny_down: LN gamma/beta must come together");
+  GVK_REQUIRE(d->w2 == nullptr || (d->y2 != nullptr && d->L2 > 0), "gvk_skinny_down: second stage needs y2 and L2");
+  DownArgs a{};
+  a.x = d->x; a.w = d->w; a.bias = d->bias; a.ln_g = d->ln_gamma; a.ln_b = d->ln_beta; a.mean = d->mean; a.rstd = d->rstd;
+  a.z = d->z; a.y = d->y; a.w2 = d->w2; a.y2 = d->y2; a.L2 = d->L2; a.M = d->M; a.C = d->C; a.act = d->act; a.w_layout = d->w_layout;
+  a.eps = d->eps > 0.f ? d->eps : 1e-5f;
+  a.seed = d->seed; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
+  hipStream_t s = (hipStream_t)stream;
+  switch (d->L) {
+    case 4: return launch_down<4>(a, s);
+    case 8: return launch_down<8>(a, s);
+    case 16: return launch_down<16>(a, s);
+    case 20: return launch_down<20>(a, s);
+    case 32: return launch_down<32>(a, s);
+    default: return set_error(-2, "gvk_skinny_down: L=%d unsupported (4, 8, 16, 20, 32)", d->L);
+  }
+}
+
+extern "C" int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(d && d->lat && d->w && d->out, "gvk_skinny_up: null pointer");
+  GVK_REQUIRE(d->M > 0 && d->C > 0 && d->C <= 1024, "gvk_skinny_up: C=%d must be <= 1024", d->C);
+  GVK_REQUIRE(d->lat_override == nullptr || (d->T > 0 && d->P > 0 && d->P <= d->T), "gvk_skinny_up: override needs 0 < P <= T");
+  UpArgs a{};
+  a.lat = d->lat; a.w = d->w; a.bias = d->bias; a.res = d->res; a.out = d->out; a.lat_override = d->lat_override; a.T = d->T; a.P = d->P;
+  a.M = d->M; a.C = d->C; a.w_layout = d->w_layout; a.accumulate = d->accumulate;
+  a.seed = d->seed; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
+  hipStream_t s = (hipStream_t)stream;
+  switch (d->L) {
+    case 4: return launch_up<4>(a, s);
+    case 8: return launch_up<8>(a, s);
+    case 16: return launch_up<16>(a, s);
+    case 20: return launch_up<20>(a, s);
+    case 32: return launch_up<32>(a, s);
+    default: return set_error(-2, "gvk_skinny_up: L=%d unsupported (4, 8, 16, 20, 32)", d->L);
+  }
+}
+
+extern "C" int gvk_outer_reduce(const gvk_outer_desc* d, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(d && d->narrow && d->wide && d->scratch && (d->out || d->colsum), "gvk_outer_reduce: null pointer");
+  GVK_REQUIRE(d->M > 0 && d->C > 0, "gvk_outer_reduce: empty shape");
+  GVK_REQUIRE((d->mean == nullptr) == (d->rstd == nullptr), "gvk_outer_reduce: mean/rstd must come together");
+  OuterArgs a{};
+  a.narrow = d->narrow; a.wide = d->wide; a.lat_override = d->lat_override; a.T = d->T; a.P = d->P;
+  a.mean = d->mean; a.rstd = d->rstd; a.ln_g = d->ln_gamma; a.ln_b = d->ln_beta; a.scratch = d->scratch; a.M = d->M; a.C = d->C;
+  a.seed = d->seed; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  switch (d->L) {
+    case 4: rc = launch_outer<4>(a, s); break;
+    case 8: rc = launch_outer<8>(a, s); break;
+    case 16: rc = launch_outer<16>(a, s); break;
+    case 20: rc = launch_outer<20>(a, s); break;
+    case 32: rc = launch_outer<32>(a, s); break;
+    default: return set_error(-2, "gvk_outer_reduce: L=%d unsupported (4, 8, 16, 20, 32)", d->L);
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(outer_final_kernel, dim3((d->C + 255) / 256, d->L + 1), dim3(256), 0, s, d->scratch, d->out, d->colsum, d->L, d->C,
+                     d->transposed, d->accumulate);
+  return check_launch("outer_final");
+}
+
+extern "C" int gvk_small_wgrad(const float* a, const float* b, float* out, float* scratch, int M, int J, int L, int accumulate, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(a && b && out && scratch && M > 0 && J > 0 && L > 0, "gvk_small_wgrad: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(small_wgrad_partial_kernel, dim3(kSlabs), dim3(256), 0, s, a, b, scratch, M, J, L);
+  int rc = check_launch("small_wgrad_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((J * L + 255) / 256), dim3(256), 0, s, scratch, out, J * L, kSlabs, accumulate);
+  return check_launch("small_wgrad_final");
+}
+
+extern "C" int gvk_colsum(const float* x, float* out, float* scratch, int M, int C, int accumulate, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(x && out && scratch && M > 0 && C > 0, "gvk_colsum: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 255) / 256, kSlabs), dim3(256), 0, s, x, scratch, M, C);
+  int rc = check_launch("colsum_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, s, scratch, out, C, kSlabs, accumulate);
+  return check_launch("colsum_final");
+}

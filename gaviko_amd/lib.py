@@ -25,6 +25,31 @@ class GemmDesc(C.Structure):
     ]
 
 
+def _struct(name, ptrs, ints, floats=(), u64=()):
+    """C struct with the header's field order: pointers, int32s, floats, uint64s."""
+    fields = [(f, C.c_void_p) for f in ptrs] + [(f, C.c_int32) for f in ints] + [(f, C.c_float) for f in floats] + \
+             [(f, C.c_uint64) for f in u64]
+    return type(name, (C.Structure,), {"_fields_": fields})
+
+
+SkinnyDownDesc = _struct("SkinnyDownDesc",
+                         ["x", "w", "bias", "ln_gamma", "ln_beta", "mean", "rstd", "z", "y", "w2", "y2"],
+                         ["M", "C", "L", "L2", "act", "w_layout"], ["eps", "drop_p"], ["seed"])
+SkinnyUpDesc = _struct("SkinnyUpDesc", ["lat", "w", "bias", "res", "out", "lat_override"],
+                       ["M", "C", "L", "T", "P", "w_layout", "accumulate"], ["drop_p"], ["seed"])
+OuterDesc = _struct("OuterDesc", ["narrow", "wide", "lat_override", "mean", "rstd", "ln_gamma", "ln_beta", "scratch", "out", "colsum"],
+                    ["M", "C", "L", "T", "P", "transposed", "accumulate"], ["drop_p"], ["seed"])
+WindowAttnDesc = _struct("WindowAttnDesc", ["qkv", "ctx", "lse", "dctx", "delta", "dqkv"],
+                         ["B", "D", "H", "W", "kd", "kh", "kw", "L"], ["scale", "drop_p"], ["seed"])
+GpaDesc = _struct("GpaDesc",
+                  ["xl", "ll", "ca0_g", "ca0_b", "ca1_w", "ca1_b", "ca3_w", "ca3_b", "gl0_g", "gl0_b", "gl1_w", "gl1_b",
+                   "wgq", "bgq", "wlq", "blq", "imp", "gw", "enh", "prm", "qg", "ql", "cg", "cl", "lse_g", "lse_l",
+                   "dcomb", "zx", "zl", "dimp", "dgw_part", "dqg", "dql", "dcg", "dcl", "delta_g", "delta_l", "dprm",
+                   "dcls", "gate_partials", "dzx", "dzl"],
+                  ["B", "T", "N", "P", "L"], ["scale"])
+HeadDesc = _struct("HeadDesc", ["g", "ln_gamma", "ln_beta", "wh", "bh", "logits", "pooled", "dlogits", "dg", "dwh", "dbh"],
+                   ["B", "T", "C", "K", "r0", "R", "accumulate"])
+
 EPI_STORE_BF16, EPI_BIAS_RES_F32, EPI_BIAS_GELU_BF16, EPI_PATCH_F32, EPI_GELU_BWD_BF16, EPI_STORE_F32, EPI_BIAS_RES_F32_BF16 = range(7)
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
@@ -38,8 +63,25 @@ SIGNATURES = {
     "gvk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "gvk_layernorm_bwd_affine": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gvk_attention_fwd_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "gvk_attention_bwd_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "gvk_skinny_down": [C.POINTER(SkinnyDownDesc), _P],
+    "gvk_skinny_up": [C.POINTER(SkinnyUpDesc), _P],
+    "gvk_outer_reduce": [C.POINTER(OuterDesc), _P],
+    "gvk_small_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "gvk_colsum": [_P, _P, _P, _I, _I, _I, _P],
+    "gvk_window_attn_fwd": [C.POINTER(WindowAttnDesc), _P],
+    "gvk_window_attn_bwd": [C.POINTER(WindowAttnDesc), _P],
+    "gvk_gpa_fwd": [C.POINTER(GpaDesc), _P],
+    "gvk_gpa_bwd": [C.POINTER(GpaDesc), _P],
+    "gvk_rows_broadcast": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gvk_rows_batch_sum": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gvk_head_fwd": [C.POINTER(HeadDesc), _P],
+    "gvk_head_bwd": [C.POINTER(HeadDesc), _P],
 }
-NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, []), "gvk_abi_version": (C.c_int, [])}
+NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, []), "gvk_abi_version": (C.c_int, []),
+             "gvk_gpa_gate_param_count": (C.c_int, [C.c_int, C.c_int])}
+STRUCTS = {"gvk_gemm_desc": GemmDesc, "gvk_skinny_down_desc": SkinnyDownDesc, "gvk_skinny_up_desc": SkinnyUpDesc,
+           "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc}
 
 _lib = None
 

@@ -136,3 +136,115 @@ def attention_fwd(qkv, out, lse, B, T, H, scale):
     _chk(lse, torch.float32, "attn lse", B * H * T)
     L.check(L.load().gvk_attention_fwd_bf16(L.ptr(qkv), L.ptr(out), L.ptr(lse), B, T, H, 3 * inner, inner, scale, L.stream_ptr()),
             "gvk_attention_fwd_bf16")
+
+
+def _desc(cls, what, **kw):
+    """Fill a descriptor struct: tensors -> device pointers (validated fp32, contiguous, on device), None -> NULL."""
+    d = cls()
+    for name, ctype in cls._fields_:
+        v = kw.pop(name, None)
+        if ctype is C.c_void_p:
+            if v is not None:
+                _chk(v, torch.float32, f"{what}.{name}")
+            setattr(d, name, L.ptr(v))
+        elif v is not None:
+            setattr(d, name, v)
+    if kw:
+        raise TypeError(f"{what}: unknown fields {sorted(kw)}")
+    return d
+
+
+def skinny_down(**kw):
+    d = _desc(L.SkinnyDownDesc, "skinny_down", **kw)
+    L.check(L.load().gvk_skinny_down(C.byref(d), L.stream_ptr()), "gvk_skinny_down")
+
+
+def skinny_up(**kw):
+    d = _desc(L.SkinnyUpDesc, "skinny_up", **kw)
+    L.check(L.load().gvk_skinny_up(C.byref(d), L.stream_ptr()), "gvk_skinny_up")
+
+
+def outer_reduce(**kw):
+    d = _desc(L.OuterDesc, "outer_reduce", **kw)
+    L.check(L.load().gvk_outer_reduce(C.byref(d), L.stream_ptr()), "gvk_outer_reduce")
+
+
+def outer_scratch_elems(Lat, C_):
+    return 64 * (Lat + 1) * C_
+
+
+def small_wgrad(a, b, out, scratch, M, J, Lb, accumulate=False):
+    for t, n in ((a, "a"), (b, "b"), (out, "out"), (scratch, "scratch")):
+        _chk(t, torch.float32, "small_wgrad " + n)
+    if scratch.numel() < 64 * J * Lb or a.numel() < M * J or b.numel() < M * Lb or out.numel() < J * Lb:
+        raise L.GavikoHipError("small_wgrad: buffer too small")
+    L.check(L.load().gvk_small_wgrad(L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(scratch), M, J, Lb, int(accumulate), L.stream_ptr()), "gvk_small_wgrad")
+
+
+def colsum(x, out, scratch, M, C_, accumulate=False):
+    for t, n in ((x, "x"), (out, "out"), (scratch, "scratch")):
+        _chk(t, torch.float32, "colsum " + n)
+    if scratch.numel() < 64 * C_ or x.numel() < M * C_ or out.numel() < C_:
+        raise L.GavikoHipError("colsum: buffer too small")
+    L.check(L.load().gvk_colsum(L.ptr(x), L.ptr(out), L.ptr(scratch), M, C_, int(accumulate), L.stream_ptr()), "gvk_colsum")
+
+
+def window_attn_fwd(**kw):
+    d = _desc(L.WindowAttnDesc, "window_attn", **kw)
+    L.check(L.load().gvk_window_attn_fwd(C.byref(d), L.stream_ptr()), "gvk_window_attn_fwd")
+
+
+def window_attn_bwd(**kw):
+    d = _desc(L.WindowAttnDesc, "window_attn", **kw)
+    L.check(L.load().gvk_window_attn_bwd(C.byref(d), L.stream_ptr()), "gvk_window_attn_bwd")
+
+
+def gpa_fwd(**kw):
+    d = _desc(L.GpaDesc, "gpa", **kw)
+    L.check(L.load().gvk_gpa_fwd(C.byref(d), L.stream_ptr()), "gvk_gpa_fwd")
+
+
+def gpa_bwd(**kw):
+    d = _desc(L.GpaDesc, "gpa", **kw)
+    L.check(L.load().gvk_gpa_bwd(C.byref(d), L.stream_ptr()), "gvk_gpa_bwd")
+
+
+def gpa_gate_param_count(Lat, P):
+    return L.load().gvk_gpa_gate_param_count(Lat, P)
+
+
+def rows_broadcast(out, src, add, B, T, row_off, R, C_):
+    _chk(out, torch.float32, "rows_broadcast out", B * T * C_)
+    _chk(src, torch.float32, "rows_broadcast src", R * C_)
+    _chk(add, torch.float32, "rows_broadcast add", R * C_)
+    L.check(L.load().gvk_rows_broadcast(L.ptr(out), L.ptr(src), L.ptr(add), B, T, row_off, R, C_, L.stream_ptr()), "gvk_rows_broadcast")
+
+
+def rows_batch_sum(dg, out, out2, B, T, row_off, R, C_, accumulate=False):
+    _chk(dg, torch.float32, "rows_batch_sum dg", B * T * C_)
+    _chk(out, torch.float32, "rows_batch_sum out", R * C_)
+    _chk(out2, torch.float32, "rows_batch_sum out2", R * C_)
+    L.check(L.load().gvk_rows_batch_sum(L.ptr(dg), L.ptr(out), L.ptr(out2), B, T, row_off, R, C_, int(accumulate), L.stream_ptr()),
+            "gvk_rows_batch_sum")
+
+
+def head_fwd(**kw):
+    d = _desc(L.HeadDesc, "head", **kw)
+    L.check(L.load().gvk_head_fwd(C.byref(d), L.stream_ptr()), "gvk_head_fwd")
+
+
+def head_bwd(**kw):
+    d = _desc(L.HeadDesc, "head", **kw)
+    L.check(L.load().gvk_head_bwd(C.byref(d), L.stream_ptr()), "gvk_head_bwd")
+
+
+def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, scale):
+    inner = H * 64
+    _chk(qkv, torch.bfloat16, "attn_bwd qkv", pad_rows(B * T) * 3 * inner)
+    _chk(out, torch.bfloat16, "attn_bwd out", pad_rows(B * T) * inner)
+    _chk(dout, torch.bfloat16, "attn_bwd dout", pad_rows(B * T) * inner)
+    _chk(dqkv, torch.bfloat16, "attn_bwd dqkv", B * T * 3 * inner)
+    _chk(lse, torch.float32, "attn_bwd lse", B * H * T)
+    _chk(delta, torch.float32, "attn_bwd delta", B * H * T)
+    L.check(L.load().gvk_attention_bwd_bf16(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), B, T, H,
+                                            3 * inner, inner, scale, L.stream_ptr()), "gvk_attention_bwd_bf16")

@@ -84,6 +84,119 @@ int gvk_layernorm_bwd_affine(const float* dy, const float* x, const float* mean,
 int gvk_attention_fwd_bf16(const void* qkv, void* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale,
                            void* stream);
 
+/* backward: dqkv bf16 [B*T][ld_qkv] = [dq | dk | dv] in the qkv layout, from qkv, out (forward output, for
+ * delta = rowsum(dout*out)), dout and lse.  delta f32 [B][H][T] is scratch.  Deterministic (no atomics). */
+int gvk_attention_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                           int B, int T, int H, int ld_qkv, int ld_out, float scale, void* stream);
+
+/* ------------------------------------------------------------------ rank-L ("skinny") fp32 projections of the trainable
+ * side paths, L in {4, 8, 16, 20, 32}.  GAViKO: gaviko.py:231-232,242 (MWSA norm/proj_down/qkv/proj_up) and
+ * gaviko.py:155-156,187 (GPA proj_down+QuickGELU / proj_up), plus their autograd dgrad / wgrad.
+ *
+ * down:  y[m][0:L] = act( LN?(drop?(x[m][:])) . W^T + bias );  optional  y2[m][0:L2] = y . W2^T
+ *        act: 0 none, 1 QuickGELU (x*sigmoid(1.702x)); w_layout 0: W [L][C], 1: W [C][L];
+ *        ln_gamma/ln_beta non-NULL: LayerNorm(eps) of the row first (mean/rstd saved when non-NULL);
+ *        drop_p > 0: the input row is multiplied by the counter-based dropout mask(seed, m*C + c) / (1-p). */
+typedef struct gvk_skinny_down_desc {
+  const float* x; const float* w; const float* bias;
+  const float* ln_gamma; const float* ln_beta; float* mean; float* rstd;
+  float* z; float* y;               /* pre-activation / activated output [M][L], either may be NULL */
+  const float* w2; float* y2;       /* second stage, W2 [L2][L] */
+  int32_t M, C, L, L2, act, w_layout;
+  float eps, drop_p;
+  uint64_t seed;
+} gvk_skinny_down_desc;
+int gvk_skinny_down(const gvk_skinny_down_desc* d, void* stream);
+
+/* up:    v = drop?( lat[m][0:L] . W^T + bias );  out = accumulate ? out + v : (res ? res + v : v)
+ *        w_layout 0: W [C][L], 1: W [L][C].  lat_override (optional, [B][P][L]): rows with (m % T) < P take their latent
+ *        from lat_override[(m / T) * P + m % T] (GPA: prompt rows replaced by the fused context, gaviko.py:181-185). */
+typedef struct gvk_skinny_up_desc {
+  const float* lat; const float* w; const float* bias; const float* res; float* out; const float* lat_override;
+  int32_t M, C, L, T, P, w_layout, accumulate;
+  float drop_p;
+  uint64_t seed;
+} gvk_skinny_up_desc;
+int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream);
+
+/* outer: out[l][c] (transposed=0) or out[c][l] (transposed=1) (+)= sum_m narrow[m][l] * wide'[m][c];
+ *        colsum[c] (+)= sum_m wide'[m][c] (optional).  wide' = LN(wide) when mean/rstd(/gamma/beta) are given, times the
+ *        dropout mask when drop_p > 0.  scratch: f32 [64*(L+1)*C].  Deterministic (two-stage, no atomics). */
+typedef struct gvk_outer_desc {
+  const float* narrow; const float* wide; const float* lat_override;
+  const float* mean; const float* rstd; const float* ln_gamma; const float* ln_beta;
+  float* scratch; float* out; float* colsum;
+  int32_t M, C, L, T, P, transposed, accumulate;
+  float drop_p;
+  uint64_t seed;
+} gvk_outer_desc;
+int gvk_outer_reduce(const gvk_outer_desc* d, void* stream);
+/* out[j][l] (+)= sum_m a[m][j] * b[m][l]  (J, L <= 64); scratch f32 [64*J*L] */
+int gvk_small_wgrad(const float* a, const float* b, float* out, float* scratch, int M, int J, int L, int accumulate, void* stream);
+/* out[c] (+)= sum_m x[m][c]; scratch f32 [64*C] */
+int gvk_colsum(const float* x, float* out, float* scratch, int M, int C, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ GAViKO masked-window local self-attention core (fp32)
+ * qkv f32 [B*N][3L] = [q | k | v] latents; single head; scale = model_dim^-0.5 (gaviko.py:201, NOT L^-0.5).
+ * The 0/-inf [N,N] mask of gaviko.py:212-227 is index arithmetic here: query (d,h,w) attends key (d',h',w') iff
+ * d - kd/2 <= d' < d - kd/2 + kd (likewise h, w), clipped to the DxHxW patch grid.  attn_drop (gaviko.py:239) is a
+ * counter-based mask(seed, (b*N+i)*N + j) so that the backward regenerates it.
+ * fwd writes ctx [B*N][L], lse [B*N];  bwd needs those + dctx and writes dqkv [B*N][3L] (delta [B*N] is scratch). */
+typedef struct gvk_window_attn_desc {
+  const float* qkv; float* ctx; float* lse;
+  const float* dctx; float* delta; float* dqkv;
+  int32_t B, D, H, W, kd, kh, kw, L;
+  float scale, drop_p;
+  uint64_t seed;
+} gvk_window_attn_desc;
+int gvk_window_attn_fwd(const gvk_window_attn_desc* d, void* stream);
+int gvk_window_attn_bwd(const gvk_window_attn_desc* d, void* stream);
+
+/* ------------------------------------------------------------------ GAViKO gated prompt awakening core (fp32), gaviko.py:159-185
+ * Works on the activated latents xl [B*T][L] (global: rows [P prompts | cls | N image]) and ll [B*N][L] (local).
+ * fwd: gates + both cross-attentions -> enh [B][P][L] (what replaces the prompt rows before proj_up); the other
+ *      outputs are saved for the backward.  bwd: consumes dcomb [B*T][L] (= d proj_up input) and writes the gradients
+ *      wrt the proj_down pre-activations (dzx [B*T][L], dzl [B*N][L]), dqg/dql [B][P][L] (query-projection outputs;
+ *      wgrad = gvk_small_wgrad(dq, prm)), and gate_partials [B][gvk_gpa_gate_param_count(L,P)] -- per-sample gradients
+ *      of [ca0_g L | ca0_b L | ca1_w 64L | ca1_b 64 | ca3_w 64P | ca3_b P | gl0_g L | gl0_b L | gl1_w L | gl1_b 1]
+ *      (sum over B with gvk_colsum).  scale = L^-0.5 (gaviko.py:76). */
+typedef struct gvk_gpa_desc {
+  const float* xl; const float* ll;
+  const float* ca0_g; const float* ca0_b; const float* ca1_w; const float* ca1_b; const float* ca3_w; const float* ca3_b;
+  const float* gl0_g; const float* gl0_b; const float* gl1_w; const float* gl1_b;
+  const float* wgq; const float* bgq; const float* wlq; const float* blq;
+  float* imp; float* gw; float* enh;
+  float* prm; float* qg; float* ql; float* cg; float* cl; float* lse_g; float* lse_l;
+  const float* dcomb; const float* zx; const float* zl;
+  float* dimp; float* dgw_part;
+  float* dqg; float* dql; float* dcg; float* dcl; float* delta_g; float* delta_l; float* dprm;
+  float* dcls; float* gate_partials; float* dzx; float* dzl;
+  int32_t B, T, N, P, L;
+  float scale;
+} gvk_gpa_desc;
+int gvk_gpa_fwd(const gvk_gpa_desc* d, void* stream);
+int gvk_gpa_bwd(const gvk_gpa_desc* d, void* stream);
+int gvk_gpa_gate_param_count(int L, int P);
+
+/* ------------------------------------------------------------------ token assembly and the pooled head
+ * rows_broadcast: out[b][row_off + r][:] = src[r][:] + add[r][:]  (cls_token + pos[0]; prompts + prompt_pos;
+ *                 vision_transformer.py:154-156, gaviko.py:536-543, vpt.py:127-131).  out is [B*T][C].
+ * rows_batch_sum: out[r][:] (+)= sum_b dg[b][row_off + r][:]; out2 (optional) receives the same (two parameters that
+ *                 enter as a sum share a gradient: prompt_embeddings / prompt_positional_embedding). */
+int gvk_rows_broadcast(float* out, const float* src, const float* add, int B, int T, int row_off, int R, int C, void* stream);
+int gvk_rows_batch_sum(const float* dg, float* out, float* out2, int B, int T, int row_off, int R, int C, int accumulate, void* stream);
+/* head: logits[b] = Wh . mean_{r in [r0, r0+R)} LN(g[b][r]) + bh   -- the final LayerNorm is evaluated only on the rows
+ * the head consumes (gaviko.py:306,316: rows 0..P; vision_transformer.py:89,161: row 0, or all rows for pool='mean').
+ * bwd: dwh/dbh (+)= ...; dg rows r0..r0+R of every sample receive the LN backward (caller zero-fills the rest). */
+typedef struct gvk_head_desc {
+  const float* g; const float* ln_gamma; const float* ln_beta; const float* wh; const float* bh;
+  float* logits; float* pooled;
+  const float* dlogits; float* dg; float* dwh; float* dbh;
+  int32_t B, T, C, K, r0, R, accumulate;
+} gvk_head_desc;
+int gvk_head_fwd(const gvk_head_desc* d, void* stream);
+int gvk_head_bwd(const gvk_head_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,296 @@
+"""-m gpu: attention backward, the rank-L 'skinny' kernels, MWSA window attention, the GPA core and the head,
+each through the C-ABI against a float64 torch autograd computation (the oracle's functions where one exists)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
+
+
+def _bf(x):
+    return x.float().to(torch.bfloat16).double()
+
+
+def _close(got, want, rtol, name=""):
+    got = got.detach().cpu().double()
+    err = (got - want).abs().max().item()
+    ref = max(1e-6, want.abs().max().item())
+    assert err <= rtol * ref, f"{name}: max err {err:.3e} vs scale {ref:.3e} (tol {rtol})"
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 1033, 3), (1, 1001, 2), (2, 65, 1), (1, 393, 3)])
+def test_attention_bwd(dev, B, T, H):
+    from gaviko_amd import ops
+    inner = H * 64
+    qkv = _bf(_rand((B, T, 3 * inner), 61, 2.0)).requires_grad_(True)
+    dO = _bf(_rand((B, T, inner), 62, 1.0))
+    q, k, v = (t.reshape(B, T, H, 64).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=-1))
+    s = q @ k.transpose(-1, -2) * 0.125
+    o = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B, T, inner)
+    o.backward(dO)
+    Q = ops.act_zeros(B * T, 3 * inner, torch.bfloat16, dev)
+    Q[: B * T] = qkv.detach().reshape(B * T, -1).to(dev).bfloat16()
+    O = ops.act_zeros(B * T, inner, torch.bfloat16, dev)
+    lse = torch.zeros((B, H, T), device=dev)
+    ops.attention_fwd(Q, O, lse, B, T, H, 0.125)
+    DO = ops.act_zeros(B * T, inner, torch.bfloat16, dev)
+    DO[: B * T] = dO.reshape(B * T, -1).to(dev).bfloat16()
+    DQ = ops.act_zeros(B * T, 3 * inner, torch.bfloat16, dev)
+    delta = torch.zeros((B, H, T), device=dev)
+    ops.attention_bwd(Q, O, DO, lse, delta, DQ, B, T, H, 0.125)
+    torch.cuda.synchronize()
+    got = DQ[: B * T].view(B, T, 3 * inner).cpu().double()
+    want = qkv.grad
+    for name, sl in (("dq", slice(0, inner)), ("dk", slice(inner, 2 * inner)), ("dv", slice(2 * inner, 3 * inner))):
+        _close(got[..., sl], want[..., sl], 2.5e-2, name)
+
+
+@pytest.mark.parametrize("M,C_,Lat", [(1033, 768, 20), (300, 192, 20), (77, 1024, 8)])
+def test_skinny_down_up_outer(dev, M, C_, Lat):
+    from gaviko_amd import ops
+    x = _rand((M, C_), 71, 1.5) + 0.2
+    w = _rand((Lat, C_), 72, 1 / math.sqrt(C_))
+    bias = _rand((Lat,), 73, 0.1)
+    g = 1 + _rand((C_,), 74, 0.2)
+    bt = _rand((C_,), 75, 0.1)
+    w2 = _rand((3 * Lat, Lat), 76, 0.5)
+    f = lambda t: t.float().to(dev).contiguous()
+    # LN + down + second stage
+    z = torch.zeros((M, Lat), device=dev); y = torch.zeros_like(z); y2 = torch.zeros((M, 3 * Lat), device=dev)
+    mean = torch.zeros(M, device=dev); rstd = torch.zeros(M, device=dev)
+    ops.skinny_down(x=f(x), w=f(w), bias=f(bias), ln_gamma=f(g), ln_beta=f(bt), mean=mean, rstd=rstd, z=z, y=y, w2=f(w2), y2=y2,
+                    M=M, C=C_, L=Lat, L2=3 * Lat, act=0, w_layout=0, eps=1e-5)
+    n = F.layer_norm(x, (C_,), g, bt, 1e-5)
+    want = n @ w.T + bias
+    _close(y, want, 2e-5, "down")
+    _close(y2, want @ w2.T, 3e-5, "down second stage")
+    # QuickGELU + transposed weight layout, no LN
+    ops.skinny_down(x=f(x), w=f(w.T.contiguous()), bias=f(bias), z=z, y=y, M=M, C=C_, L=Lat, act=1, w_layout=1)
+    pre = x @ w.T + bias
+    _close(z, pre, 2e-5, "down z")
+    _close(y, pre * torch.sigmoid(1.702 * pre), 2e-5, "down quickgelu")
+    # up: res + lat.W^T + b, with the prompt-row override
+    wu = _rand((C_, Lat), 77, 0.3)
+    bu = _rand((C_,), 78, 0.1)
+    lat = _rand((M, Lat), 79)
+    res = _rand((M, C_), 80)
+    out = torch.zeros((M, C_), device=dev)
+    ops.skinny_up(lat=f(lat), w=f(wu), bias=f(bu), res=f(res), out=out, M=M, C=C_, L=Lat, w_layout=0)
+    _close(out, res + lat @ wu.T + bu, 2e-5, "up")
+    T, P = M // 2, 5
+    ov = _rand((2, P, Lat), 81)
+    lat2 = lat.clone()
+    for s in range(2):
+        lat2[s * T: s * T + P] = ov[s]
+    acc0 = _rand((M, C_), 82)
+    out2 = f(acc0)
+    ops.skinny_up(lat=f(lat), w=f(wu.T.contiguous()), bias=f(bu), out=out2, lat_override=f(ov), M=2 * T, C=C_, L=Lat, T=T, P=P,
+                  w_layout=1, accumulate=1)
+    _close(out2[: 2 * T], (acc0 + lat2 @ wu.T + bu)[: 2 * T], 2e-5, "up accumulate+override")
+    # outer: dW[l][c] = sum_m narrow * LN(wide); transposed + colsum
+    scratch = torch.zeros(ops.outer_scratch_elems(Lat, C_), device=dev)
+    dW = torch.zeros((Lat, C_), device=dev)
+    ops.outer_reduce(narrow=f(lat), wide=f(x), mean=mean, rstd=rstd, ln_gamma=f(g), ln_beta=f(bt), scratch=scratch, out=dW,
+                     M=M, C=C_, L=Lat, transposed=0, accumulate=0)
+    _close(dW, lat.T @ n, 5e-5, "outer LN")
+    dWt = torch.ones((C_, Lat), device=dev)
+    cs = torch.ones(C_, device=dev)
+    ops.outer_reduce(narrow=f(lat), wide=f(res), scratch=scratch, out=dWt, colsum=cs, M=M, C=C_, L=Lat, transposed=1, accumulate=1)
+    _close(dWt, 1 + res.T @ lat, 5e-5, "outer transposed accumulate")
+    _close(cs, 1 + res.sum(0), 5e-5, "outer colsum")
+    # small wgrad / colsum
+    a = _rand((M, 3 * Lat), 83); b = _rand((M, Lat), 84)
+    o = torch.zeros((3 * Lat, Lat), device=dev)
+    sc = torch.zeros(64 * 3 * Lat * Lat, device=dev)
+    ops.small_wgrad(f(a), f(b), o, sc, M, 3 * Lat, Lat)
+    _close(o, a.T @ b, 5e-5, "small_wgrad")
+    o1 = torch.zeros(Lat, device=dev)
+    ops.colsum(f(b), o1, sc, M, Lat)
+    _close(o1, b.sum(0), 5e-5, "colsum")
+
+
+def test_skinny_dropout_consistency(dev):
+    """The counter-based mask is identical in up (fwd) and down/outer (bwd): d/dlat of sum(drop(lat.W^T)*dy) matches."""
+    from gaviko_amd import ops
+    M, C_, Lat, p = 200, 192, 20, 0.2
+    f = lambda t: t.float().to(dev).contiguous()
+    lat = _rand((M, Lat), 91); wu = _rand((C_, Lat), 92, 0.3); dy = _rand((M, C_), 93)
+    out = torch.zeros((M, C_), device=dev)
+    ops.skinny_up(lat=f(lat), w=f(wu), out=out, M=M, C=C_, L=Lat, w_layout=0, drop_p=p, seed=1234)
+    raw = (lat @ wu.T)
+    mask = (out.cpu().double().abs() > 0).double() / (1 - p)
+    keep = (out.cpu().double().abs() > 0).double().mean().item()
+    assert abs(keep - (1 - p)) < 0.02
+    _close(out, raw * mask, 2e-5, "dropout fwd")
+    dlat = torch.zeros((M, Lat), device=dev)
+    ops.skinny_down(x=f(dy), w=f(wu), y=dlat, M=M, C=C_, L=Lat, act=0, w_layout=1, drop_p=p, seed=1234)
+    _close(dlat, (dy * mask) @ wu, 3e-5, "dropout bwd (down)")
+    scratch = torch.zeros(ops.outer_scratch_elems(Lat, C_), device=dev)
+    dW = torch.zeros((C_, Lat), device=dev)
+    ops.outer_reduce(narrow=f(lat), wide=f(dy), scratch=scratch, out=dW, M=M, C=C_, L=Lat, transposed=1, drop_p=p, seed=1234)
+    _close(dW, (dy * mask).T @ lat, 5e-5, "dropout bwd (outer)")
+
+
+@pytest.mark.parametrize("local_k", [(6, 6, 6), (3, 6, 6), (3, 3, 3)])
+def test_window_attention_fwd_bwd(dev, local_k):
+    from gaviko_amd import ops
+    from oracle.gaviko_ref import window_mask
+    B, Lat, C_ = 2, 20, 768
+    N = 1000
+    qkv = _rand((B, N, 3 * Lat), 101, 6.0).requires_grad_(True)
+    mask = window_mask((10, 10, 10), local_k, dtype=torch.float64)
+    q, k, v = qkv.chunk(3, -1)
+    attn = (q @ k.transpose(-2, -1) * C_ ** -0.5 + mask).softmax(-1)
+    ctx = attn @ v
+    dctx = _rand((B, N, Lat), 102)
+    ctx.backward(dctx)
+    f = lambda t: t.detach().float().to(dev).contiguous()
+    ctx_d = torch.zeros((B * N, Lat), device=dev); lse = torch.zeros(B * N, device=dev)
+    kw = dict(qkv=f(qkv.reshape(B * N, -1)), ctx=ctx_d, lse=lse, B=B, D=10, H=10, W=10, kd=local_k[0], kh=local_k[1], kw=local_k[2], L=Lat,
+              scale=C_ ** -0.5)
+    ops.window_attn_fwd(**kw)
+    _close(ctx_d.view(B, N, Lat), ctx.detach(), 3e-5, "window ctx")
+    dq = torch.zeros((B * N, 3 * Lat), device=dev); delta = torch.zeros(B * N, device=dev)
+    ops.window_attn_bwd(dctx=f(dctx.reshape(B * N, -1)), delta=delta, dqkv=dq, **kw)
+    _close(dq.view(B, N, 3 * Lat), qkv.grad, 5e-5, "window dqkv")
+
+
+def test_window_attention_matches_reference_masks():
+    """(CPU part of the contract is in test_oracle; here: the golden allow-maps have the per-row counts the kernel's
+    index arithmetic implies.)"""
+    from conftest import golden
+    for lk in ((6, 6, 6), (3, 6, 6), (3, 3, 3)):
+        gz = golden(f"mwsa_mask_{lk[0]}{lk[1]}{lk[2]}")
+        cnt = gz["count"]
+        n = 0
+        for i in range(1000):
+            d, h, w = i // 100, (i // 10) % 10, i % 10
+            c = 1
+            for q, kk in ((d, lk[0]), (h, lk[1]), (w, lk[2])):
+                lo, hi = max(0, q - kk // 2), min(10, q - kk // 2 + kk)
+                c *= hi - lo
+            n += int(c == cnt[i])
+        assert n == 1000
+
+
+def _gpa_params(Lat, P, seed):
+    names = {"ca0_g": (Lat,), "ca0_b": (Lat,), "ca1_w": (64, Lat), "ca1_b": (64,), "ca3_w": (P, 64), "ca3_b": (P,),
+             "gl0_g": (Lat,), "gl0_b": (Lat,), "gl1_w": (1, Lat), "gl1_b": (1,),
+             "wgq": (Lat, Lat), "bgq": (Lat,), "wlq": (Lat, Lat), "blq": (Lat,)}
+    out = {}
+    for i, (k, shp) in enumerate(names.items()):
+        t = _rand(shp, seed + i, 0.6)
+        if k in ("ca0_g", "gl0_g"):
+            t = 1 + 0.3 * t
+        out[k] = t.requires_grad_(True)
+    return out
+
+
+@pytest.mark.parametrize("B,P,N", [(2, 32, 1000), (3, 8, 1000)])
+def test_gpa_core_fwd_bwd(dev, B, P, N):
+    """gvk_gpa_fwd/bwd vs the oracle's awakening_prompt internals (latent space part) under float64 autograd."""
+    from gaviko_amd import ops
+    Lat = 20
+    T = P + 1 + N
+    prm = _gpa_params(Lat, P, 200)
+    zx = _rand((B, T, Lat), 111, 2.0).requires_grad_(True)
+    zl = _rand((B, N, Lat), 112, 2.0).requires_grad_(True)
+    qg_ = lambda t: t * torch.sigmoid(1.702 * t)
+    xl, ll = qg_(zx), qg_(zl)
+    prompts, cls, img = xl[:, :P], xl[:, P:P + 1], xl[:, P + 1:]
+    h = F.gelu(F.linear(F.layer_norm(cls, (Lat,), prm["ca0_g"], prm["ca0_b"]), prm["ca1_w"], prm["ca1_b"]))
+    imp = torch.sigmoid(F.linear(h, prm["ca3_w"], prm["ca3_b"]))
+    gw = torch.sigmoid(F.linear(F.layer_norm(cls, (Lat,), prm["gl0_g"], prm["gl0_b"]), prm["gl1_w"], prm["gl1_b"]))
+
+    def cross(qq, tok):
+        w = torch.einsum("bpd,bnd->bpn", qq, tok) * Lat ** -0.5
+        return torch.einsum("bpn,bnd->bpd", w.softmax(-1), tok)
+
+    cg = cross(F.linear(prompts, prm["wgq"], prm["bgq"]), img[:, P + 1:])
+    cl = cross(F.linear(prompts, prm["wlq"], prm["blq"]), ll)
+    enh = (gw * cg + (1 - gw) * cl) * imp.transpose(1, 2)
+    comb = torch.cat([enh, cls, img], 1)
+    dcomb = _rand((B, T, Lat), 113)
+    comb.backward(dcomb)
+
+    f = lambda t: t.detach().float().to(dev).contiguous()
+    z = lambda *s: torch.zeros(s, device=dev)
+    pd = {k: f(v) for k, v in prm.items()}
+    bufs = dict(imp=z(B, P), gw=z(B), enh=z(B, P, Lat), prm=z(B, P, Lat), qg=z(B, P, Lat), ql=z(B, P, Lat), cg=z(B, P, Lat), cl=z(B, P, Lat),
+                lse_g=z(B, P), lse_l=z(B, P))
+    common = dict(xl=f(xl.reshape(B * T, Lat)), ll=f(ll.reshape(B * N, Lat)), B=B, T=T, N=N, P=P, L=Lat, scale=Lat ** -0.5, **pd, **bufs)
+    ops.gpa_fwd(**common)
+    _close(bufs["imp"], imp.detach().reshape(B, P), 2e-5, "imp")
+    _close(bufs["gw"], gw.detach().reshape(B), 2e-5, "gw")
+    _close(bufs["enh"], enh.detach(), 3e-5, "enh")
+    ng = ops.gpa_gate_param_count(Lat, P)
+    bw = dict(dimp=z(B, P), dgw_part=z(B, P), dqg=z(B, P, Lat), dql=z(B, P, Lat), dcg=z(B, P, Lat), dcl=z(B, P, Lat), delta_g=z(B, P),
+              delta_l=z(B, P), dprm=z(B, P, Lat), dcls=z(B, Lat), gate_partials=z(B, ng), dzx=z(B * T, Lat), dzl=z(B * N, Lat))
+    ops.gpa_bwd(dcomb=f(dcomb.reshape(B * T, Lat)), zx=f(zx.reshape(B * T, Lat)), zl=f(zl.reshape(B * N, Lat)), **common, **bw)
+    _close(bw["dzx"].view(B, T, Lat), zx.grad, 1e-4, "dzx")
+    _close(bw["dzl"].view(B, N, Lat), zl.grad, 1e-4, "dzl")
+    gp = bw["gate_partials"].cpu().double().sum(0)
+    order = ["ca0_g", "ca0_b", "ca1_w", "ca1_b", "ca3_w", "ca3_b", "gl0_g", "gl0_b", "gl1_w", "gl1_b"]
+    off = 0
+    for k in order:
+        n = prm[k].numel()
+        _close(gp[off: off + n].view(prm[k].shape), prm[k].grad, 1e-4, "grad " + k)
+        off += n
+    assert off == ng
+    # query projections: wgrad = dq^T . prompts, bias = colsum(dq)
+    sc = z(64 * Lat * Lat)
+    for nm, dq in (("wgq", bw["dqg"]), ("wlq", bw["dql"])):
+        o = z(Lat, Lat)
+        ops.small_wgrad(dq.view(B * P, Lat), bufs["prm"].view(B * P, Lat), o, sc, B * P, Lat, Lat)
+        _close(o, prm[nm].grad, 1e-4, "grad " + nm)
+        ob = z(Lat)
+        ops.colsum(dq.view(B * P, Lat), ob, sc, B * P, Lat)
+        _close(ob, prm["b" + nm[1:]].grad, 1e-4, "grad b" + nm[1:])
+
+
+@pytest.mark.parametrize("B,T,C_,r0,R", [(2, 1033, 768, 0, 33), (3, 1001, 192, 0, 1), (2, 300, 1024, 0, 300)])
+def test_head_fwd_bwd(dev, B, T, C_, r0, R):
+    from gaviko_amd import ops
+    K = 5
+    g = (_rand((B, T, C_), 121, 3.0) + 0.5).requires_grad_(True)
+    lg = (1 + _rand((C_,), 122, 0.2)); lb = _rand((C_,), 123, 0.1)
+    wh = _rand((K, C_), 124, 0.1).requires_grad_(True); bh = _rand((K,), 125, 0.1).requires_grad_(True)
+    pooled = F.layer_norm(g, (C_,), lg, lb, 1e-5)[:, r0:r0 + R].mean(1)
+    logits = F.linear(pooled, wh, bh)
+    dl = _rand((B, K), 126)
+    logits.backward(dl)
+    f = lambda t: t.detach().float().to(dev).contiguous()
+    G = f(g.reshape(B * T, C_))
+    lo = torch.zeros((B, K), device=dev); po = torch.zeros((B, C_), device=dev)
+    kw = dict(g=G, ln_gamma=f(lg), ln_beta=f(lb), wh=f(wh), bh=f(bh), logits=lo, pooled=po, B=B, T=T, C=C_, K=K, r0=r0, R=R)
+    ops.head_fwd(**kw)
+    _close(lo, logits.detach(), 3e-5, "logits")
+    dG = torch.zeros((B * T, C_), device=dev); dwh = torch.zeros((K, C_), device=dev); dbh = torch.zeros(K, device=dev)
+    ops.head_bwd(dlogits=f(dl), dg=dG, dwh=dwh, dbh=dbh, accumulate=0, **kw)
+    _close(dG.view(B, T, C_), g.grad, 5e-5, "dG")
+    _close(dwh, wh.grad, 5e-5, "dwh")
+    _close(dbh, bh.grad, 5e-5, "dbh")
+
+
+def test_rows_broadcast_and_sum(dev):
+    from gaviko_amd import ops
+    B, T, C_, R, off = 3, 50, 192, 8, 1
+    src = _rand((R, C_), 131); add = _rand((R, C_), 132)
+    out = torch.full((B * T, C_), 9.0, device=dev)
+    f = lambda t: t.float().to(dev).contiguous()
+    ops.rows_broadcast(out, f(src), f(add), B, T, off, R, C_)
+    o = out.view(B, T, C_).cpu().double()
+    _close(o[:, off:off + R], (src + add).expand(B, R, C_), 1e-6, "rows_broadcast")
+    assert (o[:, :off] == 9).all() and (o[:, off + R:] == 9).all()
+    dg = _rand((B, T, C_), 133)
+    a = torch.zeros((R, C_), device=dev); b2 = torch.ones((R, C_), device=dev)
+    ops.rows_batch_sum(f(dg.reshape(B * T, C_)), a, None, B, T, off, R, C_)
+    _close(a, dg[:, off:off + R].sum(0), 1e-5, "rows_batch_sum")
