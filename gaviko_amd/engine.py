@@ -1,0 +1,455 @@
+"""Launch plans (forward + backward) of the 3D-ViT hot path on MI355X.
+
+One `Engine` per model instance.  It owns
+  * bf16 MFMA-operand shadows of the frozen fp32 weights, W and W^T (the dgrad of a frozen Linear is an NT GEMM against
+    the pre-transposed weight; frozen weights need no wgrad and their GEMM inputs are never saved),
+  * the per-batch-size workspace (fp32 residual streams per layer, bf16 GEMM operands, saved statistics),
+  * the ordered list of C-ABI launches that make up forward() and backward().
+Everything is enqueued on torch's current HIP stream; nothing synchronises, so a whole step can be captured in a HIP
+graph.  There is no CPU / eager fallback.
+
+Data layout in HBM (B samples, T tokens, C channels, M = B*T):
+  G[i], G1[i]   fp32 [pad128(M)][C]   global residual stream entering layer i / after its attention block
+  Lc[i]         fp32 [B*N][C]         GAViKO local stream entering layer i
+  xn / act / dpre ... bf16 [pad128(M)][*]  MFMA operands (transient, reused by every layer)
+  qkv[i], ctx[i], pre[i]  bf16        saved for the backward (flash attention recompute, GELU')
+Reference call structure mirrored here: gaviko.py:291-306 (layer loop), 531-552 (embedding + head).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import lib as L
+from . import ops
+
+N_HID_PRE = 64  # hidden width of the PRE gate MLP (gaviko.py:25)
+
+
+class Names:
+    """Maps logical backbone tensors to the state_dict names of each reference class."""
+
+    def __init__(self, kind: str):
+        self.kind = kind
+        self.root = {"vpt": "vision_transformer.", "melo": "lora_vit."}.get(kind, "")
+
+    def attn(self, i):
+        if self.kind == "gaviko":
+            return f"transformer.attns.{i}"
+        return f"{self.root}transformer.layers.{i}.0"
+
+    def mlp(self, i):
+        if self.kind == "gaviko":
+            return f"transformer.mlps.{i}"
+        return f"{self.root}transformer.layers.{i}." + ("2" if self.kind == "adaptformer" else "1")
+
+    def qkv_weight(self, i):
+        return self.attn(i) + (".to_qkv.qkv.weight" if self.kind == "melo" else ".to_qkv.weight")
+
+    def head(self):
+        return "mlp_head.head" if self.kind == "gaviko" else f"{self.root}mlp_head"
+
+
+class Engine:
+    def __init__(self, kind: str, cfg: dict, params: Dict[str, torch.nn.Parameter], depth, heads, dim, mlp_dim):
+        self.kind, self.cfg, self.p = kind, cfg, params
+        self.depth, self.heads, self.C, self.mlp = depth, heads, dim, mlp_dim
+        self.names = Names(kind)
+        fp, ip = cfg["frame_patch_size"], cfg["image_patch_size"]
+        self.patch = (fp, ip, ip)
+        self.grid = (cfg["frames"] // fp, cfg["image_size"] // ip, cfg["image_size"] // ip)
+        self.N = self.grid[0] * self.grid[1] * self.grid[2]
+        self.Kp = fp * ip * ip
+        self.K = cfg["num_classes"]
+        if cfg.get("dim_head", 64) != 64:
+            raise L.GavikoHipError("the attention kernels are built for dim_head = 64")
+        if cfg.get("channels", 1) != 1:
+            raise L.GavikoHipError("patch embedding is built for single-channel volumes (channels = 1)")
+        self.pool = cfg.get("pool", "cls")
+        if kind == "gaviko":
+            self.P = cfg["num_prompts"]
+            self.Lat = cfg.get("prompt_latent_dim", 20)
+            if cfg.get("local_dim", 20) != self.Lat:
+                raise L.GavikoHipError("local_dim and prompt_latent_dim must match (one latent width per build)")
+            self.share = cfg.get("share_factor", 1)
+            self.T = self.P + 1 + self.N
+            self.row_off = self.P + 1
+            dhw = cfg.get("DHW", (10, 10, 10))
+            if dhw is None:
+                self.win = tuple(2 * g + 1 for g in self.grid)     # no mask == a window that always covers the grid
+            else:
+                if tuple(dhw) != self.grid:
+                    raise L.GavikoHipError(f"DHW={tuple(dhw)} does not match the patch grid {self.grid}")
+                self.win = tuple(cfg.get("local_k", (3, 6, 6)))
+        else:
+            self.P, self.T, self.row_off = 0, 1 + self.N, 1
+        self._w16: Dict[str, torch.Tensor] = {}
+        self._w16_version = None
+        self._ws = None
+        self._step = 0
+        self._flat_grad = None
+        self._saved = None
+
+    # ------------------------------------------------------------------ weights
+    def _d(self, name) -> torch.Tensor:
+        return self.p[name].detach()
+
+    def _backbone_weight_names(self) -> List[str]:
+        n = [self.names.root + "conv_proj.0.weight"]
+        for i in range(self.depth):
+            n += [self.names.qkv_weight(i), self.names.attn(i) + ".to_out.0.weight", self.names.mlp(i) + ".net.1.weight",
+                  self.names.mlp(i) + ".net.4.weight"]
+        return n
+
+    def refresh_weights(self, need_dgrad: bool) -> None:
+        """(Re)build the bf16 shadows when a source weight changed (load_state_dict, .to(), optimizer step)."""
+        names = self._backbone_weight_names()
+        version = tuple(self.p[n]._version for n in names) + tuple(self.p[n].data_ptr() for n in names) + (need_dgrad,)
+        if version == self._w16_version:
+            return
+        w = self._w16
+        conv = self._d(names[0])
+        w["conv"] = ops.cast_bf16(conv.reshape(self.C, self.Kp).contiguous())
+        for i in range(self.depth):
+            for tag, nm in (("qkv", self.names.qkv_weight(i)), ("out", self.names.attn(i) + ".to_out.0.weight"),
+                            ("fc1", self.names.mlp(i) + ".net.1.weight"), ("fc2", self.names.mlp(i) + ".net.4.weight")):
+                src = self._d(nm).contiguous()
+                w[f"{tag}{i}"] = ops.cast_bf16(src)
+                if need_dgrad:
+                    w[f"{tag}{i}_t"] = ops.transpose_cast_bf16(src)
+        self._w16_version = version
+
+    # ------------------------------------------------------------------ workspace
+    def workspace(self, B: int, device, train: bool):
+        key = (B, train, str(device))
+        if self._ws is not None and self._ws["key"] == key:
+            return self._ws
+        C, T, N, M = self.C, self.T, self.N, B * self.T
+        z = lambda r, c, dt: ops.act_zeros(r, c, dt, device)
+        f32, bf16 = torch.float32, torch.bfloat16
+        nsave = self.depth if train else 1
+        ws = {"key": key, "B": B, "M": M}
+        ws["cols"] = z(B * N, self.Kp, bf16)
+        ws["G"] = [z(M, C, f32) for _ in range(self.depth + 1)] if train else [z(M, C, f32), z(M, C, f32)]
+        ws["G1"] = [z(M, C, f32) for _ in range(nsave)]
+        ws["xn"] = z(M, C, bf16)
+        ws["qkv"] = [z(M, 3 * C, bf16) for _ in range(nsave)]
+        ws["ctx"] = [z(M, C, bf16) for _ in range(nsave)]
+        ws["lse"] = [torch.zeros((B, self.heads, T), device=device) for _ in range(nsave)]
+        ws["pre"] = [z(M, self.mlp, bf16) for _ in range(nsave)] if train else [None]
+        ws["act"] = z(M, self.mlp, bf16)
+        ws["stat"] = [[torch.zeros(M, device=device) for _ in range(4)] for _ in range(nsave)]   # mean1, rstd1, mean2, rstd2
+        ws["pooled"] = torch.zeros((B, C), device=device)
+        if self.kind == "gaviko":
+            Lt, P, BN = self.Lat, self.P, B * N
+            ws["Lc"] = [torch.zeros((BN, C), device=device) for _ in range((self.depth + 1) if train else 2)]
+            mk = lambda *s: torch.zeros(s, device=device)
+            ws["mw"] = [dict(mean=mk(BN), rstd=mk(BN), lat=mk(BN, Lt), qkv=mk(BN, 3 * Lt), ctx=mk(BN, Lt), lse=mk(BN)) for _ in range(nsave)]
+            ws["gp"] = [dict(zx=mk(M, Lt), xl=mk(M, Lt), zl=mk(BN, Lt), ll=mk(BN, Lt), imp=mk(B, P), gw=mk(B), enh=mk(B, P, Lt),
+                             prm=mk(B, P, Lt), qg=mk(B, P, Lt), ql=mk(B, P, Lt), cg=mk(B, P, Lt), cl=mk(B, P, Lt), lse_g=mk(B, P),
+                             lse_l=mk(B, P)) for _ in range(nsave)]
+        if train:
+            ws["dG"] = [z(M, C, f32), z(M, C, f32)]          # ping-pong gradient of the global stream
+            ws["dG16"] = z(M, C, bf16)
+            ws["dpre"] = z(M, self.mlp, bf16)
+            ws["dx32"] = z(M, C, f32)
+            ws["dctx"] = z(M, C, bf16)
+            ws["dqkv"] = z(M, 3 * C, bf16)
+            ws["delta"] = torch.zeros((B, self.heads, T), device=device)
+            if self.kind == "gaviko":
+                Lt, P, BN = self.Lat, self.P, B * N
+                mk = lambda *s: torch.zeros(s, device=device)
+                ng = ops.gpa_gate_param_count(Lt, P)
+                ws["dL"] = [mk(BN, C), mk(BN, C)]
+                ws["bw"] = dict(dcomb=mk(M, Lt), dimp=mk(B, P), dgw_part=mk(B, P), dqg=mk(B, P, Lt), dql=mk(B, P, Lt), dcg=mk(B, P, Lt),
+                                dcl=mk(B, P, Lt), delta_g=mk(B, P), delta_l=mk(B, P), dprm=mk(B, P, Lt), dcls=mk(B, Lt),
+                                gate_partials=mk(B, ng), dzx=mk(M, Lt), dzl=mk(BN, Lt),
+                                dctx=mk(BN, Lt), dqkv=mk(BN, 3 * Lt), wdelta=mk(BN), dlat=mk(BN, Lt), dn=mk(BN, C))
+                ws["scratch"] = mk(max(ops.outer_scratch_elems(Lt, C), 128 * C, 64 * 3 * Lt * Lt, 64 * ng))
+            else:
+                ws["scratch"] = torch.zeros(128 * C, device=device)
+        self._ws = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, img: torch.Tensor, train: bool, drop: Optional[dict] = None) -> torch.Tensor:
+        L.require_device()
+        if not img.is_cuda:
+            raise L.GavikoHipError("input volume must be on the HIP device: gaviko_amd has no CPU path")
+        if img.dim() != 5 or img.shape[1] != 1 or tuple(img.shape[2:]) != tuple(g * p for g, p in zip(self.grid, self.patch)):
+            raise L.GavikoHipError(f"expected img [B,1,{self.grid[0] * self.patch[0]},{self.grid[1] * self.patch[1]},"
+                                   f"{self.grid[2] * self.patch[2]}], got {tuple(img.shape)}")
+        img = img.detach().to(torch.float32).contiguous()
+        B, C, T, N = img.shape[0], self.C, self.T, self.N
+        self.refresh_weights(need_dgrad=train)
+        ws = self.workspace(B, img.device, train)
+        M = B * T
+        nm, w, d = self.names, self._w16, self._d
+        self._step += 1
+        drop = drop or {}
+        sv = {"B": B, "train": train, "seed": 0x5EED0000 + 7919 * self._step, "attn_drop": float(drop.get("attn_drop", 0.0)),
+              "proj_drop": float(drop.get("proj_drop", 0.0))}
+        # ---- embedding: patch GEMM (+bias +pos, scattered to rows row_off..) and the broadcast rows
+        ops.patchify(img, ws["cols"], self.patch)
+        pos = d(nm.root + "pos_embedding")[0]
+        G0 = ws["G"][0]
+        ops.gemm_nt(ws["cols"], w["conv"], B * N, G0, epilogue=ops.EPI_PATCH_F32, out1=ws["Lc"][0] if self.kind == "gaviko" else None,
+                    bias=d(nm.root + "conv_proj.0.bias"), pos=pos[1:], rows_in=N, rows_out=T, row_off=self.row_off)
+        cls = d(nm.root + "cls_token")[0]
+        if self.kind == "gaviko":
+            ops.rows_broadcast(G0, d("prompt_embeddings")[0], d("prompt_positional_embedding")[0], B, T, 0, self.P, C)
+            ops.rows_broadcast(G0, cls, pos[0:1], B, T, self.P, 1, C)
+        else:
+            ops.rows_broadcast(G0, cls, pos[0:1], B, T, 0, 1, C)
+        # ---- layers
+        for i in range(self.depth):
+            si = i if train else 0
+            gi, go = (i, i + 1) if train else (i & 1, (i + 1) & 1)
+            if self.kind == "gaviko":
+                self._mwsa_fwd(ws, sv, i, si, ws["Lc"][gi], ws["Lc"][go])
+            self._attn_block_fwd(ws, i, si, ws["G"][gi], ws["G1"][si], M)
+            if self.kind == "gaviko":
+                self._gpa_fwd_latents(ws, i, si, ws["G1"][si], ws["Lc"][go], M, B)
+            self._mlp_block_fwd(ws, i, si, ws["G1"][si], ws["G"][go], M, train)
+            if self.kind == "gaviko":
+                self._gpa_fwd_up(ws, i, si, ws["G"][go], M)
+        gfin = ws["G"][self.depth] if train else ws["G"][self.depth & 1]
+        logits = torch.empty((B, self.K), dtype=torch.float32, device=img.device)
+        r0, R = self._pool_rows()
+        ops.head_fwd(g=gfin, ln_gamma=d(nm.root + "transformer.norm.weight"), ln_beta=d(nm.root + "transformer.norm.bias"),
+                     wh=d(nm.head() + ".weight"), bh=d(nm.head() + ".bias"), logits=logits, pooled=ws["pooled"],
+                     B=B, T=T, C=C, K=self.K, r0=r0, R=R)
+        self._saved = sv if train else None
+        return logits
+
+    def _pool_rows(self):
+        if self.kind == "gaviko":
+            return 0, self.P + 1                      # gaviko.py:316 prompts + CLS
+        return (0, self.T) if self.pool == "mean" else (0, 1)
+
+    def _attn_block_fwd(self, ws, i, si, gin, g1, M):
+        nm, w, d, C = self.names, self._w16, self._d, self.C
+        a = nm.attn(i)
+        st = ws["stat"][si]
+        ops.layernorm_fwd(gin, d(a + ".norm.weight"), d(a + ".norm.bias"), M, C, y16=ws["xn"], mean=st[0], rstd=st[1])
+        ops.gemm_nt(ws["xn"], w[f"qkv{i}"], M, ws["qkv"][si], epilogue=ops.EPI_STORE_BF16)
+        ops.attention_fwd(ws["qkv"][si], ws["ctx"][si], ws["lse"][si], ws["B"], self.T, self.heads, 64 ** -0.5)
+        ops.gemm_nt(ws["ctx"][si], w[f"out{i}"], M, g1, epilogue=ops.EPI_BIAS_RES_F32, bias=d(a + ".to_out.0.bias"), res=gin)
+
+    def _mlp_block_fwd(self, ws, i, si, g1, gout, M, train):
+        nm, w, d, C = self.names, self._w16, self._d, self.C
+        m = nm.mlp(i)
+        st = ws["stat"][si]
+        ops.layernorm_fwd(g1, d(m + ".net.0.weight"), d(m + ".net.0.bias"), M, C, y16=ws["xn"], mean=st[2], rstd=st[3])
+        ops.gemm_nt(ws["xn"], w[f"fc1{i}"], M, ws["pre"][si] if train else None, epilogue=ops.EPI_BIAS_GELU_BF16, out1=ws["act"],
+                    bias=d(m + ".net.1.bias"))           # inference keeps no pre-activation (out0 = NULL)
+        ops.gemm_nt(ws["act"], w[f"fc2{i}"], M, gout, epilogue=ops.EPI_BIAS_RES_F32, bias=d(m + ".net.4.bias"), res=g1)
+
+    # ---- GAViKO side paths --------------------------------------------------------------------------------------
+    def _mwsa_fwd(self, ws, sv, i, si, lin, lout):
+        s = i // self.share
+        pre = f"transformer.local_attns.{s}"
+        d, C, Lt, B = self._d, self.C, self.Lat, ws["B"]
+        BN = B * self.N
+        m = ws["mw"][si]
+        ops.skinny_down(x=lin, w=d(pre + ".proj_down.weight"), bias=d(pre + ".proj_down.bias"), ln_gamma=d(pre + ".norm.weight"),
+                        ln_beta=d(pre + ".norm.bias"), mean=m["mean"], rstd=m["rstd"], y=m["lat"], w2=d(pre + ".qkv.weight"), y2=m["qkv"],
+                        M=BN, C=C, L=Lt, L2=3 * Lt, act=0, w_layout=0, eps=1e-5)
+        ops.window_attn_fwd(qkv=m["qkv"], ctx=m["ctx"], lse=m["lse"], B=B, D=self.grid[0], H=self.grid[1], W=self.grid[2],
+                            kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt, scale=C ** -0.5, drop_p=sv["attn_drop"],
+                            seed=sv["seed"] + 2 * i)
+        ops.skinny_up(lat=m["ctx"], w=d(pre + ".proj_up.weight"), bias=d(pre + ".proj_up.bias"), res=lin, out=lout, M=BN, C=C, L=Lt,
+                      w_layout=0, drop_p=sv["proj_drop"], seed=sv["seed"] + 2 * i + 1)
+
+    def _gpa_names(self, i):
+        s = i // self.share
+        pre = f"transformer.prompt_projs.{s}"
+        ca, gl = pre + ".cls_analyzer.cls_analyzer_", pre + ".gl_balancer.gl_balancer_"
+        return pre, dict(ca0_g=ca + ".0.weight", ca0_b=ca + ".0.bias", ca1_w=ca + ".1.weight", ca1_b=ca + ".1.bias", ca3_w=ca + ".3.weight",
+                         ca3_b=ca + ".3.bias", gl0_g=gl + ".0.weight", gl0_b=gl + ".0.bias", gl1_w=gl + ".1.weight", gl1_b=gl + ".1.bias",
+                         wgq=pre + ".global_attention.query_proj.weight", bgq=pre + ".global_attention.query_proj.bias",
+                         wlq=pre + ".local_attention.query_proj.weight", blq=pre + ".local_attention.query_proj.bias")
+
+    def _gpa_fwd_latents(self, ws, i, si, g1, lnew, M, B):
+        pre, names = self._gpa_names(i)
+        d, C, Lt = self._d, self.C, self.Lat
+        g = ws["gp"][si]
+        wd, bd = d(pre + ".proj_down.0.weight"), d(pre + ".proj_down.0.bias")
+        ops.skinny_down(x=g1, w=wd, bias=bd, z=g["zx"], y=g["xl"], M=M, C=C, L=Lt, act=1, w_layout=0)
+        ops.skinny_down(x=lnew, w=wd, bias=bd, z=g["zl"], y=g["ll"], M=B * self.N, C=C, L=Lt, act=1, w_layout=0)
+        ops.gpa_fwd(xl=g["xl"], ll=g["ll"], B=B, T=self.T, N=self.N, P=self.P, L=Lt, scale=Lt ** -0.5,
+                    imp=g["imp"], gw=g["gw"], enh=g["enh"], prm=g["prm"], qg=g["qg"], ql=g["ql"], cg=g["cg"], cl=g["cl"],
+                    lse_g=g["lse_g"], lse_l=g["lse_l"], **{k: d(v) for k, v in names.items()})
+
+    def _gpa_fwd_up(self, ws, i, si, gout, M):
+        pre, _ = self._gpa_names(i)
+        d, g = self._d, ws["gp"][si]
+        ops.skinny_up(lat=g["xl"], w=d(pre + ".proj_up.weight"), bias=d(pre + ".proj_up.bias"), out=gout, lat_override=g["enh"],
+                      M=M, C=self.C, L=self.Lat, T=self.T, P=self.P, w_layout=0, accumulate=1)
+
+    # ------------------------------------------------------------------ backward
+    def trainable_names(self) -> List[str]:
+        return [k for k, p in self.p.items() if p.requires_grad]
+
+    def _grad_views(self, device) -> Dict[str, torch.Tensor]:
+        names = self.trainable_names()
+        sig = tuple((n, tuple(self.p[n].shape)) for n in names)
+        if self._flat_grad is None or self._flat_grad["sig"] != sig or self._flat_grad["buf"].device != device:
+            total = sum(self.p[n].numel() for n in names)
+            buf = torch.zeros(total, device=device)
+            views, off = {}, 0
+            for n in names:
+                k = self.p[n].numel()
+                views[n] = buf[off: off + k].view(self.p[n].shape)
+                off += k
+            self._flat_grad = {"sig": sig, "buf": buf, "views": views}
+        return self._flat_grad["views"]
+
+    @property
+    def flat_grad(self) -> Optional[torch.Tensor]:
+        return None if self._flat_grad is None else self._flat_grad["buf"]
+
+    def backward(self, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Fills and returns {param name: gradient view into the flat fp32 gradient buffer} for every trainable tensor."""
+        sv = self._saved
+        if sv is None:
+            raise L.GavikoHipError("backward() without a preceding training-mode forward()")
+        ws = self._ws
+        B, C, T, N, M = sv["B"], self.C, self.T, self.N, sv["B"] * self.T
+        nm, w, d = self.names, self._w16, self._d
+        dlogits = dlogits.detach().to(torch.float32).contiguous()
+        gv = self._grad_views(dlogits.device)
+        unsupported = [n for n in gv if not self._grad_supported(n)]
+        if unsupported:
+            raise NotImplementedError(f"gradients for backbone tensors are not built yet (frozen-backbone PEFT only): {unsupported[:3]}...")
+        self._touched = set()
+        # ---- head
+        r0, R = self._pool_rows()
+        dG = ws["dG"][0]
+        backbone_bwd = self._needs_backbone_backward()
+        if backbone_bwd:
+            dG.zero_()
+        ops.head_bwd(g=ws["G"][self.depth], ln_gamma=d(nm.root + "transformer.norm.weight"), ln_beta=d(nm.root + "transformer.norm.bias"),
+                     wh=d(nm.head() + ".weight"), bh=d(nm.head() + ".bias"), pooled=ws["pooled"], dlogits=dlogits,
+                     dg=dG if backbone_bwd else None, dwh=gv[nm.head() + ".weight"], dbh=gv[nm.head() + ".bias"],
+                     B=B, T=T, C=C, K=self.K, r0=r0, R=R, accumulate=0)
+        if not backbone_bwd:
+            return gv
+        ops.cast_bf16(dG, ws["dG16"])
+        cur = 0
+        if self.kind == "gaviko":
+            ws["dL"][0].zero_()
+        for i in reversed(range(self.depth)):
+            dGout, dGin = ws["dG"][cur], ws["dG"][cur ^ 1]
+            # ---- MLP block: dG1 = dGout + LN'(fc1^T(GELU'(pre) * fc2^T(dGout)))
+            m = nm.mlp(i)
+            st = ws["stat"][i]
+            ops.gemm_nt(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i])
+            ops.gemm_nt(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
+            gaviko = self.kind == "gaviko"
+            ops.layernorm_bwd(ws["dx32"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), M, C, dx=dGin, dres=dGout,
+                              dx16=None if gaviko else ws["dG16"])
+            if gaviko:
+                self._gpa_bwd(ws, sv, gv, i, dGout, dGin, ws["dL"][cur], M, B)       # adds into dG1 (= dGin) and dL, refreshes dG16
+            # ---- attention block: dG0 = dG1 + LN'(qkv^T(attn'(out^T(dG1))))
+            a = nm.attn(i)
+            ops.gemm_nt(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
+            ops.attention_bwd(ws["qkv"][i], ws["ctx"][i], ws["dctx"], ws["lse"][i], ws["delta"], ws["dqkv"], B, T, self.heads, 64 ** -0.5)
+            ops.gemm_nt(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
+            ops.layernorm_bwd(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGout, dres=dGin, dx16=ws["dG16"])
+            # dGout now holds dG[i] (gradient wrt the layer input); keep `cur` pointing at it
+            if gaviko:
+                self._mwsa_bwd(ws, sv, gv, i, ws["dL"][cur], ws["dL"][cur ^ 1], B)
+                ws["dL"][cur], ws["dL"][cur ^ 1] = ws["dL"][cur ^ 1], ws["dL"][cur]
+        # ---- embedding rows
+        dG0 = ws["dG"][cur]
+        if self.kind == "gaviko":
+            ops.rows_batch_sum(dG0, gv["prompt_embeddings"].view(self.P, C), gv["prompt_positional_embedding"].view(self.P, C), B, T, 0,
+                               self.P, C)
+        return gv
+
+    def _grad_supported(self, name: str) -> bool:
+        if name.startswith(self.names.head()):
+            return True
+        if self.kind == "gaviko":
+            return ("local_attns" in name or "prompt_projs" in name or name in ("prompt_embeddings", "prompt_positional_embedding"))
+        return False
+
+    def _needs_backbone_backward(self) -> bool:
+        return any(not n.startswith(self.names.head()) for n in self.trainable_names())
+
+    def _acc(self, key) -> int:
+        """0 on the first gradient contribution to `key` in this backward, 1 afterwards (shared modules, share_factor > 1)."""
+        if key in self._touched:
+            return 1
+        self._touched.add(key)
+        return 0
+
+    def _gpa_bwd(self, ws, sv, gv, i, dGout, dG1, dLnew, M, B):
+        pre, names = self._gpa_names(i)
+        d, C, Lt, P, T, N = self._d, self.C, self.Lat, self.P, self.T, self.N
+        g, bw, sc = ws["gp"][i], ws["bw"], ws["scratch"]
+        wup = d(pre + ".proj_up.weight")
+        acc = self._acc(pre)
+        # proj_up: dcomb = dGout . Wup ; dWup = dGout^T . comb ; dbup = colsum(dGout)
+        ops.skinny_down(x=dGout, w=wup, y=bw["dcomb"], M=M, C=C, L=Lt, act=0, w_layout=1)
+        ops.outer_reduce(narrow=g["xl"], wide=dGout, lat_override=g["enh"], scratch=sc, out=gv[pre + ".proj_up.weight"],
+                         colsum=gv[pre + ".proj_up.bias"], M=M, C=C, L=Lt, T=T, P=P, transposed=1, accumulate=acc)
+        ops.gpa_bwd(xl=g["xl"], ll=g["ll"], B=B, T=T, N=N, P=P, L=Lt, scale=Lt ** -0.5, imp=g["imp"], gw=g["gw"], enh=g["enh"], prm=g["prm"],
+                    qg=g["qg"], ql=g["ql"], cg=g["cg"], cl=g["cl"], lse_g=g["lse_g"], lse_l=g["lse_l"], dcomb=bw["dcomb"], zx=g["zx"], zl=g["zl"],
+                    dimp=bw["dimp"], dgw_part=bw["dgw_part"], dqg=bw["dqg"], dql=bw["dql"], dcg=bw["dcg"], dcl=bw["dcl"],
+                    delta_g=bw["delta_g"], delta_l=bw["delta_l"], dprm=bw["dprm"], dcls=bw["dcls"], gate_partials=bw["gate_partials"],
+                    dzx=bw["dzx"], dzl=bw["dzl"], **{k: d(v) for k, v in names.items()})
+        # gate parameters: one contiguous slice of the flat gradient buffer, in the kernel's order
+        ng = ops.gpa_gate_param_count(Lt, P)
+        first = gv[names["ca0_g"]]
+        gate_flat = self._flat_grad["buf"][self._offset_of(names["ca0_g"]): self._offset_of(names["ca0_g"]) + ng]
+        assert gate_flat.data_ptr() == first.data_ptr()
+        ops.colsum(bw["gate_partials"], gate_flat, sc, B, ng, accumulate=bool(acc))
+        for wn, bn, dq in (("wgq", "bgq", bw["dqg"]), ("wlq", "blq", bw["dql"])):
+            ops.small_wgrad(dq, g["prm"], gv[names[wn]], sc, B * P, Lt, Lt, accumulate=bool(acc))
+            ops.colsum(dq, gv[names[bn]], sc, B * P, Lt, accumulate=bool(acc))
+        # proj_down (shared by both streams): dWd = dzx^T.G1 + dzl^T.Lnew ; dbd ; dG1 += dzx.Wd ; dLnew += dzl.Wd
+        wd = d(pre + ".proj_down.0.weight")
+        gwd, gbd = gv[pre + ".proj_down.0.weight"], gv[pre + ".proj_down.0.bias"]
+        ops.outer_reduce(narrow=bw["dzx"], wide=ws["G1"][i], scratch=sc, out=gwd, M=M, C=C, L=Lt, transposed=0, accumulate=acc)
+        ops.outer_reduce(narrow=bw["dzl"], wide=ws["Lc"][i + 1], scratch=sc, out=gwd, M=B * N, C=C, L=Lt, transposed=0, accumulate=1)
+        ops.colsum(bw["dzx"], gbd, sc, M, Lt, accumulate=bool(acc))
+        ops.colsum(bw["dzl"], gbd, sc, B * N, Lt, accumulate=True)
+        ops.skinny_up(lat=bw["dzx"], w=wd, out=dG1, M=M, C=C, L=Lt, w_layout=1, accumulate=1)
+        ops.skinny_up(lat=bw["dzl"], w=wd, out=dLnew, M=B * N, C=C, L=Lt, w_layout=1, accumulate=1)
+        ops.cast_bf16(dG1, ws["dG16"])
+
+    def _offset_of(self, name) -> int:
+        return (self._flat_grad["views"][name].data_ptr() - self._flat_grad["buf"].data_ptr()) // 4
+
+    def _mwsa_bwd(self, ws, sv, gv, i, dLout, dLin, B):
+        s = i // self.share
+        pre = f"transformer.local_attns.{s}"
+        d, C, Lt, N = self._d, self.C, self.Lat, self.N
+        BN = B * N
+        m, bw, sc = ws["mw"][i], ws["bw"], ws["scratch"]
+        lin = ws["Lc"][i]
+        acc = self._acc(pre)
+        pd, seed_p, seed_a = sv["proj_drop"], sv["seed"] + 2 * i + 1, sv["seed"] + 2 * i
+        wup = d(pre + ".proj_up.weight")
+        ops.skinny_down(x=dLout, w=wup, y=bw["dctx"], M=BN, C=C, L=Lt, act=0, w_layout=1, drop_p=pd, seed=seed_p)
+        ops.outer_reduce(narrow=m["ctx"], wide=dLout, scratch=sc, out=gv[pre + ".proj_up.weight"], colsum=gv[pre + ".proj_up.bias"],
+                         M=BN, C=C, L=Lt, transposed=1, accumulate=acc, drop_p=pd, seed=seed_p)
+        ops.window_attn_bwd(qkv=m["qkv"], ctx=m["ctx"], lse=m["lse"], dctx=bw["dctx"], delta=bw["wdelta"], dqkv=bw["dqkv"], B=B,
+                            D=self.grid[0], H=self.grid[1], W=self.grid[2], kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt,
+                            scale=C ** -0.5, drop_p=sv["attn_drop"], seed=seed_a)
+        wqkv = d(pre + ".qkv.weight")
+        ops.small_wgrad(bw["dqkv"], m["lat"], gv[pre + ".qkv.weight"], sc, BN, 3 * Lt, Lt, accumulate=bool(acc))
+        ops.skinny_down(x=bw["dqkv"], w=wqkv, y=bw["dlat"], M=BN, C=3 * Lt, L=Lt, act=0, w_layout=1)
+        wd = d(pre + ".proj_down.weight")
+        ops.outer_reduce(narrow=bw["dlat"], wide=lin, mean=m["mean"], rstd=m["rstd"], ln_gamma=d(pre + ".norm.weight"),
+                         ln_beta=d(pre + ".norm.bias"), scratch=sc, out=gv[pre + ".proj_down.weight"], M=BN, C=C, L=Lt, transposed=0,
+                         accumulate=acc)
+        ops.colsum(bw["dlat"], gv[pre + ".proj_down.bias"], sc, BN, Lt, accumulate=bool(acc))
+        ops.skinny_up(lat=bw["dlat"], w=wd, out=bw["dn"], M=BN, C=C, L=Lt, w_layout=1)
+        ops.layernorm_bwd(bw["dn"], lin, m["mean"], m["rstd"], d(pre + ".norm.weight"), BN, C, dx=dLin, dres=dLout)
+        ops.layernorm_bwd_affine(bw["dn"], lin, m["mean"], m["rstd"], gv[pre + ".norm.weight"], gv[pre + ".norm.bias"], sc, BN, C,
+                                 accumulate=bool(acc))

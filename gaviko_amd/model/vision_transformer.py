@@ -1,0 +1,163 @@
+"""Host-side mirror of the reference's model/vision_transformer.py for the MI355X path.
+
+Same class names, constructor kwargs, parameter / state_dict names and forward signature
+(`forward(img[B,1,D,H,W]) -> logits[B,num_classes]`, vision_transformer.py:91-164), so the reference's train.py /
+eval.py loop and its trainable-only checkpoints (train.py:473-483) work unchanged.  The sub-modules below are
+*parameter containers*: the arithmetic of the whole forward/backward runs in the HIP kernels behind
+include/gaviko_hip.h (see gaviko_amd/engine.py); there is no eager or CPU implementation here.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import lib as L
+from ..engine import Engine
+from ..utils.load_pretrained import mapping_vit
+
+
+def pair(t):
+    return t if isinstance(t, tuple) else (t, t)
+
+
+class _Container(nn.Module):
+    """A module that only owns parameters; calling it is a usage error (the engine runs the math)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise L.GavikoHipError(f"{type(self).__name__} is a parameter container: call the top-level model, "
+                               "which runs the fused HIP path")
+
+
+class FeedForward(_Container):
+    """Parameters of vision_transformer.py:26-38: net = [LayerNorm, Linear, GELU, Dropout, Linear, Dropout]."""
+
+    def __init__(self, dim, hidden_dim, dropout=0.0):
+        super().__init__()
+        self.net = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                 nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
+
+
+class Attention(_Container):
+    """Parameters of vision_transformer.py:40-58: pre-norm, bias-free fused qkv, to_out = [Linear, Dropout]."""
+
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.0):
+        super().__init__()
+        inner = dim_head * heads
+        if heads == 1 and dim_head == dim:
+            raise L.GavikoHipError("the single-head identity-projection corner of the reference Attention is not built")
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.norm = nn.LayerNorm(dim)
+        self.attend = nn.Softmax(dim=-1)
+        self.dropout = nn.Dropout(dropout)
+        self.to_qkv = nn.Linear(dim, inner * 3, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(dropout))
+
+
+class Transformer(_Container):
+    """vision_transformer.py:74-89: layers[i] = [Attention, FeedForward]; final norm."""
+
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0.0):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.layers = nn.ModuleList([nn.ModuleList([Attention(dim, heads, dim_head, dropout), FeedForward(dim, mlp_dim, dropout)])
+                                     for _ in range(depth)])
+
+
+class _HotPathFn(torch.autograd.Function):
+    """Bridges torch autograd to the engine: one node for the whole model.  The engine writes parameter gradients
+    straight into views of its flat gradient buffer (what the data-parallel all-reduce sends), so the per-parameter
+    results returned to autograd are None."""
+
+    @staticmethod
+    def forward(ctx, owner, img, drop, *params):
+        ctx.owner = owner
+        ctx.nparams = len(params)
+        return owner._engine().forward(img, train=True, drop=drop)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        owner = ctx.owner
+        eng = owner._engine()
+        named = dict(owner.named_parameters())
+        had_grads = [n for n in eng.trainable_names() if named[n].grad is not None]
+        if not had_grads:
+            gv = eng.backward(dlogits)
+            for n, g in gv.items():
+                named[n].grad = g
+        else:                                   # gradient accumulation: keep what is there, add the new contribution
+            old = {n: named[n].grad.clone() for n in had_grads}
+            gv = eng.backward(dlogits)
+            for n, g in gv.items():
+                if n in old:
+                    g.add_(old[n])
+                named[n].grad = g
+        return (None, None, None) + (None,) * ctx.nparams
+
+
+class HotPathModule(nn.Module):
+    """Shared plumbing of every --method class: engine construction, the autograd bridge, loud failure off-GPU."""
+
+    _kind = "vit"
+
+    def _engine(self) -> Engine:
+        eng = self.__dict__.get("_eng")
+        if eng is None:
+            depth, heads, dim, mlp_dim = mapping_vit(self._cfg["backbone"])
+            eng = Engine(self._kind, self._cfg, dict(self.named_parameters()), depth, heads, dim, mlp_dim)
+            self.__dict__["_eng"] = eng
+        return eng
+
+    def _apply(self, fn, *a, **k):
+        # .to()/.cuda()/.float() re-create parameter storage: drop the engine (bf16 shadows, workspaces) with it
+        self.__dict__.pop("_eng", None)
+        return super()._apply(fn, *a, **k)
+
+    def _drop_config(self) -> dict:
+        return {}
+
+    def _run(self, img: torch.Tensor) -> torch.Tensor:
+        if not isinstance(img, torch.Tensor) or not img.is_cuda:
+            raise L.GavikoHipError("gaviko_amd runs on MI355X only: move the model and the input to the HIP device "
+                                   "(there is no CPU fallback)")
+        params = [p for p in self.parameters() if p.requires_grad]
+        if torch.is_grad_enabled() and params:
+            return _HotPathFn.apply(self, img, self._drop_config(), *params)
+        return self._engine().forward(img, train=False)
+
+
+class VisionTransformer(HotPathModule):
+    """vision_transformer.py:91-164.  `linear` / `bitfit` / `fft` select which parameters train (train.py:117-137)."""
+
+    _kind = "vit"
+
+    def __init__(self, *, image_size, image_patch_size, frames, frame_patch_size, num_classes, pool="cls", channels=3,
+                 dim_head=64, dropout=0.0, emb_dropout=0.0, backbone=None, **kwargs):
+        super().__init__()
+        depth, heads, dim, mlp_dim = mapping_vit(backbone)
+        ih, iw = pair(image_size)
+        ph, pw = pair(image_patch_size)
+        assert ih % ph == 0 and iw % pw == 0, "Image dimensions must be divisible by the patch size."
+        assert frames % frame_patch_size == 0, "Frames must be divisible by frame patch size"
+        assert pool in {"cls", "mean"}, "pool type must be either cls (cls token) or mean (mean pooling)"
+        self.num_patches = (ih // ph) * (iw // pw) * (frames // frame_patch_size)
+        self.image_size, self.image_patch_size = image_size, image_patch_size
+        self.frames, self.frame_patch_size, self.depth = frames, frame_patch_size, depth
+        self.conv_proj = nn.Sequential(nn.Conv3d(channels, dim, kernel_size=(frame_patch_size, image_patch_size, image_patch_size),
+                                                 stride=(frame_patch_size, image_patch_size, image_patch_size)))
+        self.pos_embedding = nn.Parameter(torch.randn(1, self.num_patches + 1, dim))
+        self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.dropout = nn.Dropout(emb_dropout)
+        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout)
+        self.pool = pool
+        self.to_latent = nn.Identity()
+        self.mlp_head = nn.Linear(dim, num_classes)
+        # (the reference fetches timm weights here, vision_transformer.py:140-145: outside the hot path, needs network)
+        self._cfg = dict(image_size=ih, image_patch_size=ph, frames=frames, frame_patch_size=frame_patch_size, num_classes=num_classes,
+                         pool=pool, channels=channels, dim_head=dim_head, backbone=backbone, dropout=dropout, emb_dropout=emb_dropout)
+
+    def forward(self, img):
+        if self.training and (self._cfg["dropout"] > 0 or self._cfg["emb_dropout"] > 0):
+            raise NotImplementedError("VisionTransformer has no train() override, so dropout/emb_dropout > 0 is live in training mode "
+                                      "(vision_transformer.py:157,68); dropout inside the fused backbone kernels is not built yet")
+        return self._run(img)

@@ -1,0 +1,96 @@
+"""CPU: host-side mirror of the reference interface -- registry, parameter schema, freeze rules, train() semantics,
+synthetic recipe determinism.  No kernels are launched."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gaviko_amd.registry import METHODS, build_model
+from gaviko_amd.utils import synth
+from gaviko_amd.utils.load_pretrained import mapping_vit
+
+BASE = dict(image_size=160, image_patch_size=16, frames=120, frame_patch_size=12, num_classes=5, channels=1, pool="cls", dim_head=64,
+            dropout=0.0, emb_dropout=0.0, backbone="vit-t16")
+GAVIKO = dict(num_prompts=32, prompt_latent_dim=20, local_dim=20, local_k=(6, 6, 6), DHW=(10, 10, 10), attn_drop=0.2, proj_drop=0.2,
+              freeze_vit=True, share_factor=1, fp16=False)
+
+
+def test_mapping_vit_table_and_errors():
+    assert mapping_vit("vit-b16") == (12, 12, 768, 3072)
+    assert mapping_vit("ViT-L16") == (24, 16, 1024, 4096)
+    with pytest.raises(ValueError):
+        mapping_vit(None)
+    with pytest.raises(ValueError):
+        mapping_vit("vit-h14")
+
+
+def test_registry_names():
+    assert set(METHODS) == {"gaviko", "linear", "fft", "bitfit", "adaptformer", "dvpt", "evp", "ssf", "melo", "deep_vpt", "shallow_vpt"}
+    assert type(build_model(dict(BASE, method="gaviko", **GAVIKO))).__name__ == "Gaviko"
+    for m in ("linear", "fft", "bitfit"):
+        assert type(build_model(dict(BASE, method=m))).__name__ == "VisionTransformer"
+    with pytest.raises(ValueError):
+        build_model(dict(BASE, method="nope"))
+
+
+@pytest.mark.parametrize("backbone,total,trainable", [("vit-t16", 6388289, 274049), ("vit-b16", 89052353, 894401)])
+def test_gaviko_schema_and_freeze_rule(backbone, total, trainable):
+    cfg = dict(BASE, method="gaviko", **GAVIKO)
+    cfg["backbone"] = backbone
+    m = build_model(cfg)
+    sd = m.state_dict()
+    want = oracle.gaviko_param_shapes(cfg, with_alias=True)
+    assert set(sd) == set(want) and all(tuple(sd[k].shape) == tuple(want[k]) for k in sd)
+    named = dict(m.named_parameters())
+    assert len(named) == 442 and sum(p.numel() for p in named.values()) == total            # SURVEY Appendix A [probe]
+    tr = [k for k, p in named.items() if p.requires_grad]
+    assert len(tr) == 304 and sum(named[k].numel() for k in tr) == trainable
+    assert all(oracle.gaviko_trainable(k) == named[k].requires_grad for k in named)
+    # aliases share storage with the canonical query projections (gaviko.py:144-145)
+    assert sd["transformer.prompt_projs.0.global_query.weight"].data_ptr() == sd["transformer.prompt_projs.0.global_attention.query_proj.weight"].data_ptr()
+
+
+def test_gaviko_train_override_semantics():
+    m = build_model(dict(BASE, method="gaviko", **GAVIKO))
+    assert m.train() is None                                   # gaviko.py:513-528 returns None
+    assert not m.transformer.training and not m.conv_proj.training and not m.dropout.training
+    assert m.transformer.local_attns.training and m.transformer.prompt_projs.training and m.mlp_head.training
+    assert m._drop_config() == {"attn_drop": 0.2, "proj_drop": 0.2}
+    assert m.eval() is None
+    assert not m.transformer.local_attns.training
+    assert m._drop_config() == {"attn_drop": 0.0, "proj_drop": 0.0}
+
+
+def test_linear_and_bitfit_freeze_rules():
+    m = build_model(dict(BASE, method="linear"))
+    tr = [k for k, p in m.named_parameters() if p.requires_grad]
+    assert tr == ["mlp_head.weight", "mlp_head.bias"]
+    m = build_model(dict(BASE, method="bitfit"))
+    named = dict(m.named_parameters())
+    assert all(p.requires_grad == (("bias" in k) or ("head" in k)) for k, p in named.items())
+    assert set(m.state_dict()) == set(oracle.vit_param_shapes(dict(BASE, method="linear")))
+
+
+def test_mwsa_mask_property_equals_oracle():
+    m = build_model(dict(BASE, method="gaviko", **GAVIKO))
+    mask = m.transformer.local_attns[0].mask
+    assert mask.shape == (1, 1000, 1000)
+    assert torch.equal(mask[0], oracle.window_mask((10, 10, 10), (6, 6, 6)))
+
+
+def test_containers_refuse_to_run_and_cpu_input_fails_loudly():
+    from gaviko_amd import lib
+    m = build_model(dict(BASE, method="gaviko", **GAVIKO))
+    with pytest.raises(lib.GavikoHipError):
+        m.transformer.attns[0](torch.zeros(1, 4, 192))
+    with pytest.raises(lib.GavikoHipError):
+        m(torch.zeros(1, 1, 120, 160, 160))
+
+
+def test_synth_recipe_is_deterministic_and_bounded():
+    a, b = synth.volume(3), synth.volume(3)
+    assert a.shape == (1, 120, 160, 160) and np.array_equal(a, b) and a.min() >= 0 and a.max() < 1
+    assert not np.array_equal(a, synth.volume(4))
+    w = synth.fill_param("transformer.attns.0.to_qkv.weight", (2304, 768))
+    assert abs(float(w.std()) * np.sqrt(768) - 1.0) < 0.02
+    assert np.array_equal(synth.labels(3, 4), np.array([3, 4, 0, 1]))

@@ -1,0 +1,136 @@
+"""-m gpu: whole-model parity of the HIP path against the golden fixtures generated from the reference, and against
+the oracle run on the same inputs.  bf16 MFMA operands / fp32 accumulate+residual: activations within 1e-2 of the
+reference (relative to the tensor's max), argmax bit-exact, gradients within a few percent (bf16 operand rounding)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+BASE = dict(image_size=160, image_patch_size=16, frames=120, frame_patch_size=12, num_classes=5, channels=1, pool="cls", dim_head=64,
+            dropout=0.0, emb_dropout=0.0)
+GAVIKO = dict(num_prompts=32, prompt_latent_dim=20, local_dim=20, local_k=(6, 6, 6), DHW=(10, 10, 10), attn_drop=0.0, proj_drop=0.0,
+              freeze_vit=True, share_factor=1, fp16=False)
+
+
+def sample_rows(T):
+    return sorted(set(r for r in (0, 1, 7, 8, 9, 31, 32, 33, 34, 66, 500, T - 1) if r < T))
+
+
+def sample_cols(C):
+    return list(range(0, C, max(1, C // 32)))[:32]
+
+
+def tap(t, B, T):
+    t = t[: B * T].view(B, T, -1)
+    return t[:, sample_rows(T)][:, :, sample_cols(t.shape[2])].float().cpu().numpy()
+
+
+def build(method, backbone, extra, dev):
+    from gaviko_amd.registry import build_model
+    from gaviko_amd.utils import synth
+    cfg = dict(BASE, backbone=backbone, method=method, **extra)
+    m = build_model(cfg)
+    sd = m.state_dict()
+    filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in sd.items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    m.to(dev)
+    m.train()
+    return m, cfg
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(1e-12, np.abs(b).max())
+
+
+GAVIKO_CASES = [("gaviko_t16_b2", "vit-t16", 2, dict(GAVIKO)),
+                ("gaviko_t16_b2_k366_p8", "vit-t16", 2, dict(GAVIKO, local_k=(3, 6, 6), num_prompts=8)),
+                ("gaviko_t16_b1_share2", "vit-t16", 1, dict(GAVIKO, share_factor=2)),
+                ("cfg2_gaviko_b16_b4", "vit-b16", 4, dict(GAVIKO)),
+                ("cfg5_gaviko_l16_b2", "vit-l16", 2, dict(GAVIKO))]
+
+
+@pytest.mark.parametrize("name,backbone,B,extra", GAVIKO_CASES)
+def test_gaviko_forward_backward_vs_golden(dev, name, backbone, B, extra):
+    from gaviko_amd.utils import synth
+    g = golden(name)
+    m, cfg = build("gaviko", backbone, extra, dev)
+    x = torch.from_numpy(synth.volumes(0, B)).to(dev)
+    y = torch.from_numpy(synth.labels(0, B)).to(dev)
+    logits = m(x)
+    loss = torch.nn.functional.cross_entropy(logits, y)
+    loss.backward()
+    torch.cuda.synchronize()
+    lg = logits.detach().cpu().numpy()
+    # ---- activations (bf16 tolerance 1e-2 relative to the tensor scale) and argmax
+    eng = m._engine()
+    ws = eng._ws
+    T, N = eng.T, eng.N
+    worst = 0.0
+    for i in range(eng.depth):
+        for key, buf, rows in ((f"tap/layer{i}.post_attn", ws["G1"][i], T), (f"tap/layer{i}.post_mlp", ws["G"][i + 1], T),
+                               (f"tap/layer{i}.local", ws["Lc"][i + 1], N)):
+            e = rel(tap(buf, B, rows), g[key])
+            worst = max(worst, e)
+            assert e < 1e-2, f"{key}: rel err {e:.3e}"
+    assert rel(lg, g["logits"]) < 1e-2, (lg, g["logits"])
+    assert (lg.argmax(-1) == g["argmax"]).all()
+    assert abs(loss.item() - float(g["loss_ce"])) < 1e-2
+    # ---- gradients
+    # bf16 operand rounding in the dgrad chain: per-tensor gradient norms agree to ~0.2 % (median); the few cancellation-prone
+    # scalar gates (gl_balancer, norms 1e-4..1e-3, 100x below the rest) wander a few percent.  Elementwise checks follow.
+    named = dict(m.named_parameters())
+    errs = []
+    for k in g.files:
+        if k.startswith("gradnorm/"):
+            n = k[len("gradnorm/"):]
+            assert named[n].grad is not None, n
+            want = float(g[k])
+            errs.append((abs(named[n].grad.norm().item() - want) / max(want, 1e-12), n))
+    e = np.array([x[0] for x in errs])
+    assert np.median(e) < 1e-2 and np.percentile(e, 90) < 3e-2 and e.max() < 0.15, sorted(errs, reverse=True)[:5]
+    for k in g.files:
+        if k.startswith("grad/"):
+            n = k[len("grad/"):]
+            e = rel(named[n].grad.cpu().numpy(), g[k])
+            # bf16 noise grows with depth (24-layer ViT-L: last-layer GXA query grad sits at 5 %, softmax' cancellation)
+            assert e < 4e-2 * eng.depth / 12, f"grad {n}: rel err {e:.3e}"
+    print(f"{name}: worst activation rel err {worst:.2e}, logits err {rel(lg, g['logits']):.2e}")
+
+
+def test_gaviko_eval_forward_matches_train_forward(dev):
+    from gaviko_amd.utils import synth
+    m, cfg = build("gaviko", "vit-t16", dict(GAVIKO), dev)
+    x = torch.from_numpy(synth.volumes(0, 2)).to(dev)
+    a = m(x).detach().clone()
+    with torch.no_grad():
+        b = m(x)
+    assert torch.equal(a, b)
+
+
+def test_linear_cfg1_vs_golden(dev):
+    from gaviko_amd.utils import synth
+    g = golden("cfg1_linear_t16_b1")
+    m, cfg = build("linear", "vit-t16", {}, dev)
+    x = torch.from_numpy(synth.volumes(0, 1)).to(dev)
+    y = torch.from_numpy(synth.labels(0, 1)).to(dev)
+    logits = m(x)
+    torch.nn.functional.cross_entropy(logits, y).backward()
+    lg = logits.detach().cpu().numpy()
+    assert rel(lg, g["logits"]) < 1e-2
+    assert (lg.argmax(-1) == g["argmax"]).all()
+    named = dict(m.named_parameters())
+    for k in g.files:
+        if k.startswith("grad/"):
+            assert rel(named[k[5:]].grad.cpu().numpy(), g[k]) < 2e-2, k
+
+
+def test_product_path_fails_loudly_on_cpu():
+    from gaviko_amd import lib
+    from gaviko_amd.registry import build_model
+    m = build_model(dict(BASE, backbone="vit-t16", method="gaviko", **GAVIKO))
+    with pytest.raises(lib.GavikoHipError):
+        m(torch.zeros(1, 1, 120, 160, 160))
