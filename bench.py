@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MRI volumes/sec (fwd+bwd), ViT-B/16 --method gaviko, synthetic 120x160x160 volumes.
+
+  python bench.py --gpus N --steps K --warmup W            (N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one batch: forward, loss seed, backward of every trainable tensor (frozen ViT,
+trainable prompts + MWSA + GPA + head), and for N>1 the mean all-reduce of the flat gradient buffer.  The optimizer step
+is outside the metric (BASELINE.json: fwd+bwd).  Inputs are resident in HBM before the timed region starts.
+Weak scaling: 4 volumes per GPU (BASELINE.json configs[1]).
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- the dominant kernel (the bf16 MFMA GEMM instantiation with the largest total time), HIP-event timed
+                  per launch on the launch stream in a second, instrumented pass of K steps
+  cpu_baseline -- the oracle (CPU restatement of the reference, fp32 torch) timed on this host's cores on one batch.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+MODEL = dict(image_size=160, image_patch_size=16, frames=120, frame_patch_size=12, num_classes=5, channels=1, pool="cls", dim_head=64,
+             dropout=0.1, emb_dropout=0.1, method="gaviko", num_prompts=32, prompt_latent_dim=20, local_dim=20, local_k=(6, 6, 6),
+             DHW=(10, 10, 10), attn_drop=0.2, proj_drop=0.2, freeze_vit=True, share_factor=1, fp16=False)   # configs/gaviko.yaml:13-39
+PEAK_BF16_TFLOPS = 2516.0      # 256 CU x 2.4 GHz x 4096 flop/clk/CU (MI355X dense bf16)
+GF_PER_VOLUME = {"vit-b16": 482.44, "vit-l16": 1590.06, "vit-t16": None}   # BASELINE.md section 2 (fwd+bwd, gaviko)
+
+
+def build(backbone, device):
+    from gaviko_amd.registry import build_model
+    from gaviko_amd.utils import synth
+    m = build_model(dict(MODEL, backbone=backbone))
+    filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    m.to(device)
+    m.train()
+    return m
+
+
+def cpu_baseline(backbone, batch):
+    """Oracle on the host cores: one fwd + CE + bwd step of the same batch (dropouts off: the oracle has none)."""
+    import oracle
+    from gaviko_amd.utils import synth
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(avail, 16)))          # the GPU box gives one GPU a 16-core host share
+    cfg = dict(MODEL, backbone=backbone)
+    sd = {k: torch.from_numpy(v).requires_grad_(oracle.gaviko_trainable(k)) for k, v in synth.fill_state_dict(oracle.gaviko_param_shapes(cfg)).items()}
+    x = torch.from_numpy(synth.volumes(0, batch))
+    y = torch.from_numpy(synth.labels(0, batch))
+    t0 = time.perf_counter()
+    loss = torch.nn.functional.cross_entropy(oracle.gaviko_forward(sd, x, cfg), y)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": batch / dt, "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 step (fwd + CE + bwd) of the same {batch}-volume batch, fp32 torch oracle, {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="volumes per GPU")
+    ap.add_argument("--backbone", default="vit-b16")
+    ap.add_argument("--loss", default="ce", choices=["ce", "focal"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gaviko_amd import engine as eng_mod
+    from gaviko_amd.utils import synth
+    model = build(args.backbone, dev)
+    if world > 1:
+        model.make_reducer()
+    B = args.batch
+    lo = rank * B                                    # shard of the global batch owned by this rank
+    x = torch.from_numpy(synth.volumes(lo, B)).to(dev)
+    y = torch.from_numpy(synth.labels(lo, B)).to(dev)
+    if args.loss == "focal":
+        def criterion(lg, t):                        # focal_loss.py:84-115 as it executes (double clamp+softmax)
+            p = torch.softmax(torch.clamp(lg, 1e-16, 1 - 1e-16), -1)
+            p = torch.softmax(torch.clamp(p, 1e-16, 1 - 1e-16), -1)
+            pt = p.gather(-1, t.view(-1, 1)).squeeze(-1)
+            return ((1 - pt) ** 1.2 * -torch.log(1e-16 + pt)).mean()
+    else:
+        criterion = torch.nn.functional.cross_entropy
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        loss = criterion(model(x), y)
+        loss.backward()
+        return loss
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    vps = world * B * args.steps / dt
+
+    out = {"metric": "MRI volumes/sec (fwd+bwd) ViT-B/16 gaviko, 120x160x160" if args.backbone == "vit-b16" else
+           f"MRI volumes/sec (fwd+bwd) {args.backbone} gaviko, 120x160x160",
+           "value": round(vps, 3), "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"{args.backbone} --method gaviko bf16 MFMA operands / fp32 accumulate, batch={B}/GPU, fwd + "
+                                  f"{'CrossEntropy' if args.loss == 'ce' else 'Focal(1.2)'} + bwd (frozen ViT; prompts+MWSA+GPA+head train), "
+                                  f"attn_drop=proj_drop=0.2 live, grads all-reduced over {world} rank(s)",
+                      "global_batch": world * B, "tokens": 1033, "parallelism": f"dp{world}"}}
+    gf = GF_PER_VOLUME.get(args.backbone)
+    if gf:
+        out["mfma_roofline_frac_whole_step"] = round(vps / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)
+
+    if rank == 0 and not args.no_roofline:
+        # second, instrumented pass: HIP events around every GEMM launch on the launch stream
+        eng_mod.GEMM_TIMING = {}
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        stats = eng_mod.collect_gemm_timing()
+        eng_mod.GEMM_TIMING = None
+        if stats:
+            name, s = max(stats.items(), key=lambda kv: kv[1]["total_ms"])
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(s["flops_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12, 2),
+                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(s["flops_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                               "traffic": None, "avg_launch_us": round(s["avg_ms"] * 1e3, 2), "launches": s["n"],
+                               "flop_per_launch": s["flops_per_launch"], "shape": s["shape"]}
+            out["gemm_classes"] = {k: {"avg_us": round(v["avg_ms"] * 1e3, 2), "n": v["n"], "tflops": round(v["flops_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12, 1)}
+                                   for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])}
+    elif world > 1 and not args.no_roofline:
+        pass
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.backbone, B)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,18 @@ import torch
 from . import lib as L
 from . import ops
 
-N_HID_PRE = 64  # hidden width of the PRE gate MLP (gaviko.py:25)
+# bench.py instrumentation: when a dict, every GEMM launch is bracketed by HIP events recorded on the launch stream
+GEMM_TIMING = None
+_EPI_NAMES = {0: "store_bf16", 1: "bias_res_f32", 2: "bias_gelu_bf16", 3: "patch_f32", 4: "gelu_bwd_bf16", 5: "store_f32", 6: "bias_res_f32_bf16"}
+
+
+def collect_gemm_timing():
+    """-> {class name: {avg_ms, total_ms, n, flops_per_launch, shape}} from the recorded event pairs (call after a sync)."""
+    out = {}
+    for key, rec in (GEMM_TIMING or {}).items():
+        ms = [a.elapsed_time(b) for a, b in rec["events"]]
+        out[key] = {"avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "n": len(ms), "flops_per_launch": rec["flops"], "shape": rec["shape"]}
+    return out
 
 
 class Names:
@@ -91,6 +102,18 @@ class Engine:
         self._step = 0
         self._flat_grad = None
         self._saved = None
+
+    def _gemm(self, a, w, M, out0, **kw):
+        if GEMM_TIMING is None:
+            return ops.gemm_nt(a, w, M, out0, **kw)
+        N, K = w.shape
+        key = f"gemm_nt_bf16[{_EPI_NAMES[kw['epilogue']]}] M={M} N={N} K={K}"
+        rec = GEMM_TIMING.setdefault(key, {"events": [], "flops": 2.0 * M * N * K, "shape": [M, N, K]})
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.gemm_nt(a, w, M, out0, **kw)
+        e1.record()
+        rec["events"].append((e0, e1))
 
     # ------------------------------------------------------------------ weights
     def _d(self, name) -> torch.Tensor:
@@ -195,7 +218,7 @@ class Engine:
         ops.patchify(img, ws["cols"], self.patch)
         pos = d(nm.root + "pos_embedding")[0]
         G0 = ws["G"][0]
-        ops.gemm_nt(ws["cols"], w["conv"], B * N, G0, epilogue=ops.EPI_PATCH_F32, out1=ws["Lc"][0] if self.kind == "gaviko" else None,
+        self._gemm(ws["cols"], w["conv"], B * N, G0, epilogue=ops.EPI_PATCH_F32, out1=ws["Lc"][0] if self.kind == "gaviko" else None,
                     bias=d(nm.root + "conv_proj.0.bias"), pos=pos[1:], rows_in=N, rows_out=T, row_off=self.row_off)
         cls = d(nm.root + "cls_token")[0]
         if self.kind == "gaviko":
@@ -234,18 +257,18 @@ class Engine:
         a = nm.attn(i)
         st = ws["stat"][si]
         ops.layernorm_fwd(gin, d(a + ".norm.weight"), d(a + ".norm.bias"), M, C, y16=ws["xn"], mean=st[0], rstd=st[1])
-        ops.gemm_nt(ws["xn"], w[f"qkv{i}"], M, ws["qkv"][si], epilogue=ops.EPI_STORE_BF16)
+        self._gemm(ws["xn"], w[f"qkv{i}"], M, ws["qkv"][si], epilogue=ops.EPI_STORE_BF16)
         ops.attention_fwd(ws["qkv"][si], ws["ctx"][si], ws["lse"][si], ws["B"], self.T, self.heads, 64 ** -0.5)
-        ops.gemm_nt(ws["ctx"][si], w[f"out{i}"], M, g1, epilogue=ops.EPI_BIAS_RES_F32, bias=d(a + ".to_out.0.bias"), res=gin)
+        self._gemm(ws["ctx"][si], w[f"out{i}"], M, g1, epilogue=ops.EPI_BIAS_RES_F32, bias=d(a + ".to_out.0.bias"), res=gin)
 
     def _mlp_block_fwd(self, ws, i, si, g1, gout, M, train):
         nm, w, d, C = self.names, self._w16, self._d, self.C
         m = nm.mlp(i)
         st = ws["stat"][si]
         ops.layernorm_fwd(g1, d(m + ".net.0.weight"), d(m + ".net.0.bias"), M, C, y16=ws["xn"], mean=st[2], rstd=st[3])
-        ops.gemm_nt(ws["xn"], w[f"fc1{i}"], M, ws["pre"][si] if train else None, epilogue=ops.EPI_BIAS_GELU_BF16, out1=ws["act"],
+        self._gemm(ws["xn"], w[f"fc1{i}"], M, ws["pre"][si] if train else None, epilogue=ops.EPI_BIAS_GELU_BF16, out1=ws["act"],
                     bias=d(m + ".net.1.bias"))           # inference keeps no pre-activation (out0 = NULL)
-        ops.gemm_nt(ws["act"], w[f"fc2{i}"], M, gout, epilogue=ops.EPI_BIAS_RES_F32, bias=d(m + ".net.4.bias"), res=g1)
+        self._gemm(ws["act"], w[f"fc2{i}"], M, gout, epilogue=ops.EPI_BIAS_RES_F32, bias=d(m + ".net.4.bias"), res=g1)
 
     # ---- GAViKO side paths --------------------------------------------------------------------------------------
     def _mwsa_fwd(self, ws, sv, i, si, lin, lout):
@@ -311,8 +334,10 @@ class Engine:
     def flat_grad(self) -> Optional[torch.Tensor]:
         return None if self._flat_grad is None else self._flat_grad["buf"]
 
-    def backward(self, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """Fills and returns {param name: gradient view into the flat fp32 gradient buffer} for every trainable tensor."""
+    def backward(self, dlogits: torch.Tensor, reducer=None) -> Dict[str, torch.Tensor]:
+        """Fills and returns {param name: gradient view into the flat fp32 gradient buffer} for every trainable tensor.
+        `reducer` (distributed.GradReducer) gets layer_done() after every layer of the sweep so that finished buckets of the
+        flat buffer are all-reduced on its side stream while the remaining layers still run."""
         sv = self._saved
         if sv is None:
             raise L.GavikoHipError("backward() without a preceding training-mode forward()")
@@ -335,7 +360,12 @@ class Engine:
                      wh=d(nm.head() + ".weight"), bh=d(nm.head() + ".bias"), pooled=ws["pooled"], dlogits=dlogits,
                      dg=dG if backbone_bwd else None, dwh=gv[nm.head() + ".weight"], dbh=gv[nm.head() + ".bias"],
                      B=B, T=T, C=C, K=self.K, r0=r0, R=R, accumulate=0)
+        flat = self._flat_grad["buf"]
+        if reducer is not None:
+            reducer.begin()
         if not backbone_bwd:
+            if reducer is not None:
+                reducer.finish(flat)
             return gv
         ops.cast_bf16(dG, ws["dG16"])
         cur = 0
@@ -346,8 +376,8 @@ class Engine:
             # ---- MLP block: dG1 = dGout + LN'(fc1^T(GELU'(pre) * fc2^T(dGout)))
             m = nm.mlp(i)
             st = ws["stat"][i]
-            ops.gemm_nt(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i])
-            ops.gemm_nt(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
+            self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i])
+            self._gemm(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
             gaviko = self.kind == "gaviko"
             ops.layernorm_bwd(ws["dx32"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), M, C, dx=dGin, dres=dGout,
                               dx16=None if gaviko else ws["dG16"])
@@ -355,19 +385,23 @@ class Engine:
                 self._gpa_bwd(ws, sv, gv, i, dGout, dGin, ws["dL"][cur], M, B)       # adds into dG1 (= dGin) and dL, refreshes dG16
             # ---- attention block: dG0 = dG1 + LN'(qkv^T(attn'(out^T(dG1))))
             a = nm.attn(i)
-            ops.gemm_nt(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
+            self._gemm(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
             ops.attention_bwd(ws["qkv"][i], ws["ctx"][i], ws["dctx"], ws["lse"][i], ws["delta"], ws["dqkv"], B, T, self.heads, 64 ** -0.5)
-            ops.gemm_nt(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
+            self._gemm(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
             ops.layernorm_bwd(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGout, dres=dGin, dx16=ws["dG16"])
             # dGout now holds dG[i] (gradient wrt the layer input); keep `cur` pointing at it
             if gaviko:
                 self._mwsa_bwd(ws, sv, gv, i, ws["dL"][cur], ws["dL"][cur ^ 1], B)
                 ws["dL"][cur], ws["dL"][cur ^ 1] = ws["dL"][cur ^ 1], ws["dL"][cur]
+            if reducer is not None:
+                reducer.layer_done(flat, i)
         # ---- embedding rows
         dG0 = ws["dG"][cur]
         if self.kind == "gaviko":
             ops.rows_batch_sum(dG0, gv["prompt_embeddings"].view(self.P, C), gv["prompt_positional_embedding"].view(self.P, C), B, T, 0,
                                self.P, C)
+        if reducer is not None:
+            reducer.finish(flat)
         return gv
 
     def _grad_supported(self, name: str) -> bool:

@@ -82,12 +82,12 @@ class _HotPathFn(torch.autograd.Function):
         named = dict(owner.named_parameters())
         had_grads = [n for n in eng.trainable_names() if named[n].grad is not None]
         if not had_grads:
-            gv = eng.backward(dlogits)
+            gv = eng.backward(dlogits, reducer=owner.__dict__.get("_reducer"))
             for n, g in gv.items():
                 named[n].grad = g
         else:                                   # gradient accumulation: keep what is there, add the new contribution
             old = {n: named[n].grad.clone() for n in had_grads}
-            gv = eng.backward(dlogits)
+            gv = eng.backward(dlogits, reducer=owner.__dict__.get("_reducer"))
             for n, g in gv.items():
                 if n in old:
                     g.add_(old[n])
@@ -115,6 +115,19 @@ class HotPathModule(nn.Module):
 
     def _drop_config(self) -> dict:
         return {}
+
+    def attach_reducer(self, reducer) -> None:
+        """Data parallelism: `reducer` (gaviko_amd.distributed.GradReducer) all-reduces the flat gradient buffer during backward."""
+        self.__dict__["_reducer"] = reducer
+
+    def make_reducer(self, layers_per_bucket: int = 4, group=None):
+        from ..distributed import GradReducer
+        named = dict(self.named_parameters())
+        names = [n for n, p in named.items() if p.requires_grad]
+        depth = mapping_vit(self._cfg["backbone"])[0]
+        r = GradReducer(names, [named[n].numel() for n in names], depth, self._cfg.get("share_factor", 1), layers_per_bucket, group)
+        self.attach_reducer(r)
+        return r
 
     def _run(self, img: torch.Tensor) -> torch.Tensor:
         if not isinstance(img, torch.Tensor) or not img.is_cuda:
