@@ -87,12 +87,36 @@ __global__ __launch_bounds__(64) void gpa_gates_fwd_kernel(GpaArgs p) {
   if (lane == 0) p.gw[b] = sigmoidf_(t);
 }
 
-// softmax(q . tok^T) . tok over n tokens (rows `tok`, stride L); lanes over tokens; returns ctx (all lanes) and lse.
+// Token latents of one sample staged in LDS as [n][L+1] (the +1 pad makes the per-lane row reads conflict-free).
 template <int L>
-__device__ __forceinline__ void cross_one(const float* q, const float* tok, int n, int lane, float* ctx, float& lse) {
+__device__ __forceinline__ void stage_tokens(float* tok_s, const float* __restrict__ src, int n) {
+  static_assert(L % 4 == 0, "latent width must be a multiple of 4");
+  const int n4 = n * L / 4, nt = blockDim.x;
+  for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * nt) {        // 4 independent 16-byte loads in flight per thread
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * nt;
+      v[u] = (i < n4) ? *(const f32x4*)(src + 4 * (size_t)i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * nt;
+      if (i < n4) {
+        const int e = 4 * i, r = e / L, l = e - r * L;
+        float* d = tok_s + r * (L + 1) + l;
+        d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
+      }
+    }
+  }
+}
+
+// softmax(q . tok^T) . tok over the n staged tokens; lanes over tokens; returns ctx (all lanes) and lse.
+template <int L>
+__device__ __forceinline__ void cross_one(const float* q, const float* tok_s, int n, int lane, float* ctx, float& lse) {
   float m = -INFINITY, s = 0.f;
   for (int i = lane; i < n; i += 64) {
-    const float* t = tok + (size_t)i * L;
+    const float* t = tok_s + i * (L + 1);
     float d = 0.f;
 #pragma unroll
     for (int l = 0; l < L; ++l) d += q[l] * t[l];
@@ -107,7 +131,7 @@ __device__ __forceinline__ void cross_one(const float* q, const float* tok, int 
 #pragma unroll
   for (int l = 0; l < L; ++l) c[l] = 0.f;
   for (int i = lane; i < n; i += 64) {
-    const float* t = tok + (size_t)i * L;
+    const float* t = tok_s + i * (L + 1);
     float d = 0.f;
 #pragma unroll
     for (int l = 0; l < L; ++l) d += q[l] * t[l];
@@ -119,33 +143,48 @@ __device__ __forceinline__ void cross_one(const float* q, const float* tok, int 
   for (int l = 0; l < L; ++l) ctx[l] = wave_sum(c[l]);
 }
 
-// ---- cross-attention forward: one wave per (sample, prompt)
+// ---- cross-attention forward: workgroup = up to 8 prompts of one sample (one wave each, 256-VGPR budget); the sample's global image
+// latents, then its local latents, are staged once in LDS and shared by the waves.
 template <int L>
-__global__ __launch_bounds__(256) void gpa_cross_fwd_kernel(GpaArgs p) {
-  const int b = blockIdx.y, pi = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pi >= p.P) return;
-  const int lane = lane_id();
-  const size_t o = ((size_t)b * p.P + pi) * L;
-  float pr[L], qg[L], ql[L], cg[L], cl[L];
+__global__ __launch_bounds__(512) void gpa_cross_fwd_kernel(GpaArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tok_s = (float*)smem;
+  const int b = blockIdx.y, wave = wave_id(), lane = lane_id();
+  const int pi = blockIdx.x * 8 + wave;
+  const bool live = pi < p.P;
+  const int pc = live ? pi : p.P - 1;
+  const size_t o = ((size_t)b * p.P + pc) * L;
+  // Per-prompt vectors are wave-uniform; they are kept in VGPRs on purpose (lane l owns element l, values are spread with
+  // lane shuffles): letting the compiler scalarise them overflows the SGPR file.
+  const int ll_ = lane < L ? lane : 0;
+  const float pr_l = p.xl[((size_t)b * p.T + pc) * L + ll_];
+  float qg_l = p.bgq[ll_], ql_l = p.blq[ll_];
 #pragma unroll
-  for (int l = 0; l < L; ++l) pr[l] = p.xl[((size_t)b * p.T + pi) * L + l];
-#pragma unroll
-  for (int j = 0; j < L; ++j) {
-    float a = p.bgq[j], c = p.blq[j];
-#pragma unroll
-    for (int l = 0; l < L; ++l) { a += p.wgq[j * L + l] * pr[l]; c += p.wlq[j * L + l] * pr[l]; }
-    qg[j] = a * p.scale; ql[j] = c * p.scale;       // scale folded into the query
+  for (int l = 0; l < L; ++l) {
+    const float pv = __shfl(pr_l, l, 64);
+    qg_l += p.wgq[ll_ * L + l] * pv;
+    ql_l += p.wlq[ll_ * L + l] * pv;
   }
+  qg_l *= p.scale; ql_l *= p.scale;                 // scale folded into the query
+  float qg[L], ql[L], cg[L], cl[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) { qg[l] = __shfl(qg_l, l, 64); ql[l] = __shfl(ql_l, l, 64); }
   float lg, lloc;
   const int ng = p.T - (2 * p.P + 2);
-  cross_one<L>(qg, p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L, ng, lane, cg, lg);
-  cross_one<L>(ql, p.ll + (size_t)b * p.N * L, p.N, lane, cl, lloc);
+  stage_tokens<L>(tok_s, p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L, ng);
+  __syncthreads();
+  cross_one<L>(qg, tok_s, ng, lane, cg, lg);
+  __syncthreads();
+  stage_tokens<L>(tok_s, p.ll + (size_t)b * p.N * L, p.N);
+  __syncthreads();
+  cross_one<L>(ql, tok_s, p.N, lane, cl, lloc);
+  if (!live) return;
   const float gw = p.gw[b], im = p.imp[b * p.P + pi];
 #pragma unroll
   for (int l = 0; l < L; ++l) {
     if (lane == l) {
       p.enh[o + l] = (gw * cg[l] + (1.f - gw) * cl[l]) * im;
-      p.prm[o + l] = pr[l]; p.qg[o + l] = qg[l]; p.ql[o + l] = ql[l]; p.cg[o + l] = cg[l]; p.cl[o + l] = cl[l];
+      p.prm[o + l] = pr_l; p.qg[o + l] = qg[l]; p.ql[o + l] = ql[l]; p.cg[o + l] = cg[l]; p.cl[o + l] = cl[l];
     }
   }
   if (lane == 0) { p.lse_g[b * p.P + pi] = lg; p.lse_l[b * p.P + pi] = lloc; }
@@ -153,12 +192,12 @@ __global__ __launch_bounds__(256) void gpa_cross_fwd_kernel(GpaArgs p) {
 
 // dq (already-scaled query space) of softmax cross attention: dq[l] = sum_n A_n (dA_n - delta) tok_n[l]
 template <int L>
-__device__ __forceinline__ void cross_dq(const float* q, const float* dc, const float* tok, int n, int lane, float lse, float delta, float* dq) {
+__device__ __forceinline__ void cross_dq(const float* q, const float* dc, const float* tok_s, int n, int lane, float lse, float delta, float* dq) {
   float a[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) a[l] = 0.f;
   for (int i = lane; i < n; i += 64) {
-    const float* t = tok + (size_t)i * L;
+    const float* t = tok_s + i * (L + 1);
     float d = 0.f, da = 0.f;
 #pragma unroll
     for (int l = 0; l < L; ++l) { d += q[l] * t[l]; da += dc[l] * t[l]; }
@@ -170,46 +209,58 @@ __device__ __forceinline__ void cross_dq(const float* q, const float* dc, const 
   for (int l = 0; l < L; ++l) dq[l] = wave_sum(a[l]);
 }
 
-// ---- backward, prompt side: one wave per (sample, prompt)
+// ---- backward, prompt side: same workgroup shape as the forward (tokens staged in LDS, one wave per prompt)
 template <int L>
-__global__ __launch_bounds__(256) void gpa_cross_bwd_p_kernel(GpaArgs p) {
-  const int b = blockIdx.y, pi = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pi >= p.P) return;
-  const int lane = lane_id();
-  const size_t o = ((size_t)b * p.P + pi) * L;
-  const float gw = p.gw[b], im = p.imp[b * p.P + pi];
-  float denh[L], cg[L], cl[L], dcg[L], dcl[L], qg[L], ql[L];
-  float dimp = 0.f, dgw = 0.f, delg = 0.f, dell = 0.f;
+__global__ __launch_bounds__(512) void gpa_cross_bwd_p_kernel(GpaArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tok_s = (float*)smem;
+  const int b = blockIdx.y, wave = wave_id(), lane = lane_id();
+  const int pi = blockIdx.x * 8 + wave;
+  const bool live = pi < p.P;
+  const int pc = live ? pi : p.P - 1;
+  const size_t o = ((size_t)b * p.P + pc) * L;
+  const float gw = p.gw[b], im = p.imp[b * p.P + pc];
+  // lane l owns element l of every per-prompt vector (see the forward kernel for why these stay out of SGPRs)
+  const int ll_ = lane < L ? lane : 0;
+  const bool in = lane < L;
+  const float denh_l = p.dcomb[((size_t)b * p.T + pc) * L + ll_];
+  const float cg_l = p.cg[o + ll_], cl_l = p.cl[o + ll_];
+  const float fused_l = gw * cg_l + (1.f - gw) * cl_l;
+  const float df_l = denh_l * im;
+  const float dcg_l = gw * df_l, dcl_l = (1.f - gw) * df_l;
+  const float dimp = wave_sum(in ? denh_l * fused_l : 0.f);
+  const float dgw = wave_sum(in ? df_l * (cg_l - cl_l) : 0.f);
+  const float delg = wave_sum(in ? dcg_l * cg_l : 0.f);
+  const float dell = wave_sum(in ? dcl_l * cl_l : 0.f);
+  const float qg_l = p.qg[o + ll_], ql_l = p.ql[o + ll_];
+  float dcg[L], dcl[L], qg[L], ql[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) {
-    denh[l] = p.dcomb[((size_t)b * p.T + pi) * L + l];
-    cg[l] = p.cg[o + l]; cl[l] = p.cl[o + l]; qg[l] = p.qg[o + l]; ql[l] = p.ql[o + l];
-    const float fused = gw * cg[l] + (1.f - gw) * cl[l];
-    dimp += denh[l] * fused;
-    const float df = denh[l] * im;
-    dgw += df * (cg[l] - cl[l]);
-    dcg[l] = gw * df; dcl[l] = (1.f - gw) * df;
-    delg += dcg[l] * cg[l]; dell += dcl[l] * cl[l];
+    dcg[l] = __shfl(dcg_l, l, 64); dcl[l] = __shfl(dcl_l, l, 64);
+    qg[l] = __shfl(qg_l, l, 64); ql[l] = __shfl(ql_l, l, 64);
   }
   float dqg[L], dql[L];
   const int ng = p.T - (2 * p.P + 2);
-  cross_dq<L>(qg, dcg, p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L, ng, lane, p.lse_g[b * p.P + pi], delg, dqg);
-  cross_dq<L>(ql, dcl, p.ll + (size_t)b * p.N * L, p.N, lane, p.lse_l[b * p.P + pi], dell, dql);
+  const float lsg = p.lse_g[b * p.P + pc], lsl = p.lse_l[b * p.P + pc];
+  stage_tokens<L>(tok_s, p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L, ng);
+  __syncthreads();
+  cross_dq<L>(qg, dcg, tok_s, ng, lane, lsg, delg, dqg);
+  __syncthreads();
+  stage_tokens<L>(tok_s, p.ll + (size_t)b * p.N * L, p.N);
+  __syncthreads();
+  cross_dq<L>(ql, dcl, tok_s, p.N, lane, lsl, dell, dql);
+  if (!live) return;
   // unscaled-query gradients (q_scaled = scale * (W prompt + b)), and the prompt latent gradient through both query projections
+  float dpr_l = 0.f;
 #pragma unroll
-  for (int l = 0; l < L; ++l) { dqg[l] *= p.scale; dql[l] *= p.scale; }
-  float dpr[L];
-#pragma unroll
-  for (int l = 0; l < L; ++l) {
-    float a = 0.f;
-#pragma unroll
-    for (int j = 0; j < L; ++j) a += p.wgq[j * L + l] * dqg[j] + p.wlq[j * L + l] * dql[j];
-    dpr[l] = a;
+  for (int j = 0; j < L; ++j) {
+    dqg[j] *= p.scale; dql[j] *= p.scale;
+    dpr_l += p.wgq[j * L + ll_] * dqg[j] + p.wlq[j * L + ll_] * dql[j];
   }
 #pragma unroll
   for (int l = 0; l < L; ++l) {
     if (lane == l) {
-      p.dqg[o + l] = dqg[l]; p.dql[o + l] = dql[l]; p.dcg[o + l] = dcg[l]; p.dcl[o + l] = dcl[l]; p.dprm[o + l] = dpr[l];
+      p.dqg[o + l] = dqg[l]; p.dql[o + l] = dql[l]; p.dcg[o + l] = dcg_l; p.dcl[o + l] = dcl_l; p.dprm[o + l] = dpr_l;
     }
   }
   if (lane == 0) {
@@ -388,6 +439,28 @@ static void fill_gpa(GpaArgs& a, const gvk_gpa_desc* d) {
     default: return set_error(-2, "gvk_gpa: L=%d unsupported (4, 8, 16, 20, 32)", d->L);               \
   }
 
+template <int L>
+static int gpa_set_attr() {
+  static bool done = false;
+  if (done) return 0;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gvk::gpa_cross_fwd_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gvk::gpa_cross_bwd_p_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return gvk::set_error(-3, "hipFuncSetAttribute(gpa_cross): %s", hipGetErrorString(e));
+  done = true;
+  return 0;
+}
+static int gpa_lds_attr(int L) {
+  switch (L) {
+    case 4: return gpa_set_attr<4>();
+    case 8: return gpa_set_attr<8>();
+    case 16: return gpa_set_attr<16>();
+    case 20: return gpa_set_attr<20>();
+    case 32: return gpa_set_attr<32>();
+    default: return gvk::set_error(-2, "gvk_gpa: L=%d unsupported (4, 8, 16, 20, 32)", L);
+  }
+}
+
 static int gpa_check(const gvk_gpa_desc* d, const char* what) {
   using namespace gvk;
   GVK_REQUIRE(d && d->xl && d->ll, "%s: null latents", what);
@@ -407,7 +480,11 @@ extern "C" int gvk_gpa_fwd(const gvk_gpa_desc* d, void* stream) {
   GVK_GPA_LAUNCH(gpa_gates_fwd_kernel, dim3(d->B), dim3(64), 0);
   rc = check_launch("gpa_gates_fwd");
   if (rc) return rc;
-  GVK_GPA_LAUNCH(gpa_cross_fwd_kernel, dim3((d->P + 3) / 4, d->B), dim3(256), 0);
+  const int tok_lds = (d->N > d->T - 2 * d->P - 2 ? d->N : d->T - 2 * d->P - 2) * (d->L + 1) * 4;
+  GVK_REQUIRE(tok_lds <= 160 * 1024, "gvk_gpa_fwd: %d token latents do not fit the 160 KiB LDS", d->N);
+  rc = gpa_lds_attr(d->L);
+  if (rc) return rc;
+  GVK_GPA_LAUNCH(gpa_cross_fwd_kernel, dim3((d->P + 7) / 8, d->B), dim3(512), tok_lds);
   return check_launch("gpa_cross_fwd");
 }
 
@@ -421,7 +498,11 @@ extern "C" int gvk_gpa_bwd(const gvk_gpa_desc* d, void* stream) {
   GpaArgs a{};
   fill_gpa(a, d);
   hipStream_t s = (hipStream_t)stream;
-  GVK_GPA_LAUNCH(gpa_cross_bwd_p_kernel, dim3((d->P + 3) / 4, d->B), dim3(256), 0);
+  const int tok_lds = (d->N > d->T - 2 * d->P - 2 ? d->N : d->T - 2 * d->P - 2) * (d->L + 1) * 4;
+  GVK_REQUIRE(tok_lds <= 160 * 1024, "gvk_gpa_bwd: %d token latents do not fit the 160 KiB LDS", d->N);
+  rc = gpa_lds_attr(d->L);
+  if (rc) return rc;
+  GVK_GPA_LAUNCH(gpa_cross_bwd_p_kernel, dim3((d->P + 7) / 8, d->B), dim3(512), tok_lds);
   rc = check_launch("gpa_cross_bwd_p");
   if (rc) return rc;
   GVK_GPA_LAUNCH(gpa_gates_bwd_kernel, dim3(d->B), dim3(64), 0);

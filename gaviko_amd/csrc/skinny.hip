@@ -33,97 +33,108 @@ struct DownArgs {
   const float* w2; float* y2; int L2;                     // optional second stage y2[m][0:L2] = y . w2^T, w2 [L2][L]
   int M, C, act, w_layout;
   float eps;
-  unsigned long long seed; unsigned int drop_thresh; float inv_keep;   // optional dropout mask on the INPUT (bwd of proj_drop)
+  unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;   // dropout mask on the INPUT (bwd of proj_drop)
 };
 
-constexpr int kDownRows = 16;
+constexpr int kDownRows = 16;      // one row per wave, 16 waves (1024 threads) per workgroup, W staged once in LDS
 
 template <int L>
-__global__ __launch_bounds__(256) void skinny_down_kernel(DownArgs p) {
+__global__ __launch_bounds__(1024) void skinny_down_kernel(DownArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
   float* ws = (float*)smem;   // [L][C]
   const int C = p.C;
-  for (int i = threadIdx.x; i < L * C; i += 256) {
-    const int j = i / C, c = i - j * C;
-    ws[i] = p.w_layout == 0 ? p.w[i] : p.w[(size_t)c * L + j];
+  const int lane = lane_id(), wave = wave_id();
+  const int row = blockIdx.x * kDownRows + wave;
+  const bool live = row < p.M;
+  // issue this wave's row loads first: their latency hides behind the weight staging
+  f32x4 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = k * 256 + lane * 4;
+    v[k] = (live && c < C) ? *(const f32x4*)(p.x + (size_t)row * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (p.w_layout == 0) {                       // W [L][C]: straight 16-byte copy
+    const int n4 = L * C / 4;
+    for (int i = threadIdx.x; i < n4; i += 1024) *(f32x4*)(ws + 4 * i) = *(const f32x4*)(p.w + 4 * i);
+  } else {                                     // W [C][L]: transpose while staging
+    for (int i = threadIdx.x; i < L * C; i += 1024) {
+      const int c = i / L, j = i - c * L;
+      ws[j * C + c] = p.w[i];
+    }
   }
   __syncthreads();
-  const int lane = lane_id(), wave = wave_id();
-  const int r_end = min(p.M, (int)(blockIdx.x + 1) * kDownRows);
-  for (int row = blockIdx.x * kDownRows + wave; row < r_end; row += 4) {
-    f32x4 v[4];
-    float s = 0.f;
+  if (!live) return;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = k * 256 + lane * 4;
+    if (p.drop_thresh != 0u && c < C) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[k][e] *= drop_scale(p.seed, (unsigned long long)row * C + c + e, p.drop_thresh, p.inv_keep);
+    }
+    s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+  }
+  if (p.ln_g != nullptr) {
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = k * 256 + lane * 4;
-      v[k] = (c < C) ? *(const f32x4*)(p.x + (size_t)row * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.drop_thresh != 0u && c < C) {
+      if (c < C) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[k][e] *= drop_scale(p.seed, (unsigned long long)row * C + c + e, p.drop_thresh, p.inv_keep);
-      }
-      s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
-    }
-    if (p.ln_g != nullptr) {
-      const float mean = wave_sum(s) / (float)C;
-      float q = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int c = k * 256 + lane * 4;
-        if (c < C) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { const float d = v[k][e] - mean; q += d * d; }
-        }
-      }
-      const float rstd = rsqrtf(wave_sum(q) / (float)C + p.eps);
-      if (lane == 0) {
-        if (p.mean) p.mean[row] = mean;
-        if (p.rstd) p.rstd[row] = rstd;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int c = k * 256 + lane * 4;
-        if (c < C) {
-          const f32x4 g = *(const f32x4*)(p.ln_g + c);
-          const f32x4 b = *(const f32x4*)(p.ln_b + c);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[k][e] = (v[k][e] - mean) * rstd * g[e] + b[e];
-        }
+        for (int e = 0; e < 4; ++e) { const float d = v[k][e] - mean; q += d * d; }
       }
     }
-    float acc[L];
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + p.eps);
+    if (lane == 0) {
+      if (p.mean) p.mean[row] = mean;
+      if (p.rstd) p.rstd[row] = rstd;
+    }
 #pragma unroll
-    for (int j = 0; j < L; ++j) {
+    for (int k = 0; k < 4; ++k) {
+      const int c = k * 256 + lane * 4;
+      if (c < C) {
+        const f32x4 g = *(const f32x4*)(p.ln_g + c);
+        const f32x4 b = *(const f32x4*)(p.ln_b + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[k][e] = (v[k][e] - mean) * rstd * g[e] + b[e];
+      }
+    }
+  }
+  float acc[L];
+#pragma unroll
+  for (int j = 0; j < L; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = k * 256 + lane * 4;
+      if (c < C) {
+        const f32x4 wv = *(const f32x4*)(ws + j * C + c);
+        a += v[k][0] * wv[0] + v[k][1] * wv[1] + v[k][2] * wv[2] + v[k][3] * wv[3];
+      }
+    }
+    acc[j] = a;
+  }
+#pragma unroll
+  for (int j = 0; j < L; ++j) acc[j] = wave_sum(acc[j]);
+  // every lane now holds the L sums; finish (bias, activation) redundantly, lane j stores element j
+  float yv[L];
+#pragma unroll
+  for (int j = 0; j < L; ++j) {
+    const float zz = acc[j] + (p.bias ? p.bias[j] : 0.f);
+    yv[j] = p.act == 1 ? quick_gelu(zz) : zz;
+    if (lane == j) {
+      if (p.z) p.z[(size_t)row * L + j] = zz;
+      if (p.y) p.y[(size_t)row * L + j] = yv[j];
+    }
+  }
+  if (p.w2 != nullptr) {
+    for (int j2 = lane; j2 < p.L2; j2 += 64) {
       float a = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int c = k * 256 + lane * 4;
-        if (c < C) {
-          const f32x4 wv = *(const f32x4*)(ws + j * C + c);
-          a += v[k][0] * wv[0] + v[k][1] * wv[1] + v[k][2] * wv[2] + v[k][3] * wv[3];
-        }
-      }
-      acc[j] = a;
-    }
-#pragma unroll
-    for (int j = 0; j < L; ++j) acc[j] = wave_sum(acc[j]);
-    // every lane now holds the L sums; finish (bias, activation) redundantly, lane j stores element j
-    float yv[L];
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-      const float zz = acc[j] + (p.bias ? p.bias[j] : 0.f);
-      yv[j] = p.act == 1 ? quick_gelu(zz) : zz;
-      if (lane == j) {
-        if (p.z) p.z[(size_t)row * L + j] = zz;
-        if (p.y) p.y[(size_t)row * L + j] = yv[j];
-      }
-    }
-    if (p.w2 != nullptr) {
-      for (int j2 = lane; j2 < p.L2; j2 += 64) {
-        float a = 0.f;
-#pragma unroll
-        for (int l = 0; l < L; ++l) a += yv[l] * p.w2[j2 * L + l];
-        p.y2[(size_t)row * p.L2 + j2] = a;
-      }
+      for (int l = 0; l < L; ++l) a += yv[l] * p.w2[j2 * L + l];
+      p.y2[(size_t)row * p.L2 + j2] = a;
     }
   }
 }
@@ -133,16 +144,27 @@ struct UpArgs {
   const float* res; float* out;                           // out = res + (...)  (res may be NULL / alias out); accumulate: out += (...)
   const float* lat_override; int T, P;                    // rows with (m % T) < P read lat_override[(m / T) * P + m % T][:]
   int M, C, w_layout, accumulate;
-  unsigned long long seed; unsigned int drop_thresh; float inv_keep;   // dropout on the projected value (proj_drop)
+  unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;   // dropout on the projected value (proj_drop)
 };
 
-constexpr int kUpRows = 16;
+constexpr int kUpRows = 8;      // rows per workgroup; every row's read-modify-write operand is prefetched up front
 
 template <int L>
 __global__ __launch_bounds__(256) void skinny_up_kernel(UpArgs p) {
   __shared__ float lat_s[kUpRows][L];
+  if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
   const int C = p.C;
   const int r0 = blockIdx.x * kUpRows, nr = min(kUpRows, p.M - r0);
+  // prefetch the residual / accumulation operand of all rows (independent loads in flight together)
+  float base[kUpRows][4];
+  const float* src_add = p.accumulate ? p.out : p.res;
+#pragma unroll
+  for (int r = 0; r < kUpRows; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = k * 256 + threadIdx.x;
+      base[r][k] = (src_add != nullptr && r < nr && c < C) ? src_add[(size_t)(r0 + r) * C + c] : 0.f;
+    }
   for (int i = threadIdx.x; i < nr * L; i += 256) {
     const int r = i / L, l = i - r * L, m = r0 + r;
     const float* src = p.lat + (size_t)m * L;
@@ -158,11 +180,21 @@ __global__ __launch_bounds__(256) void skinny_up_kernel(UpArgs p) {
   for (int k = 0; k < 4; ++k) {
     const int c = k * 256 + threadIdx.x;
     br[k] = (c < C && p.bias) ? p.bias[c] : 0.f;
+    if (p.w_layout == 0 && (L % 4) == 0) {
 #pragma unroll
-    for (int l = 0; l < L; ++l) wr[k][l] = (c < C) ? (p.w_layout == 0 ? p.w[(size_t)c * L + l] : p.w[(size_t)l * C + c]) : 0.f;
+      for (int l4 = 0; l4 < L / 4; ++l4) {
+        const f32x4 t = (c < C) ? *(const f32x4*)(p.w + (size_t)c * L + 4 * l4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        wr[k][4 * l4] = t[0]; wr[k][4 * l4 + 1] = t[1]; wr[k][4 * l4 + 2] = t[2]; wr[k][4 * l4 + 3] = t[3];
+      }
+    } else {
+#pragma unroll
+      for (int l = 0; l < L; ++l) wr[k][l] = (c < C) ? (p.w_layout == 0 ? p.w[(size_t)c * L + l] : p.w[(size_t)l * C + c]) : 0.f;
+    }
   }
   __syncthreads();
-  for (int r = 0; r < nr; ++r) {
+#pragma unroll
+  for (int r = 0; r < kUpRows; ++r) {
+    if (r >= nr) break;
     const int m = r0 + r;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -172,10 +204,7 @@ __global__ __launch_bounds__(256) void skinny_up_kernel(UpArgs p) {
 #pragma unroll
         for (int l = 0; l < L; ++l) a += lat_s[r][l] * wr[k][l];
         if (p.drop_thresh != 0u) a *= drop_scale(p.seed, (unsigned long long)m * C + c, p.drop_thresh, p.inv_keep);
-        const size_t o = (size_t)m * C + c;
-        if (p.accumulate) a += p.out[o];
-        else if (p.res) a += p.res[o];
-        p.out[o] = a;
+        p.out[(size_t)m * C + c] = a + base[r][k];
       }
     }
   }
@@ -187,53 +216,58 @@ struct OuterArgs {
   const float* mean; const float* rstd; const float* ln_g; const float* ln_b;   // optional LN applied to `wide` on the fly
   float* scratch;                                         // [64][L+1][C]
   int M, C;
-  unsigned long long seed; unsigned int drop_thresh; float inv_keep;   // optional dropout mask on `wide`
+  unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;   // optional dropout mask on `wide`
 };
 
-constexpr int kSlabs = 64;
-constexpr int kOuterChunk = 32;
+constexpr int kSlabs = 64;          // row slabs of the small two-stage reductions (colsum, small_wgrad)
+constexpr int kOuterSlabs = 128;    // row slabs of the outer-product reduction
+constexpr int kOuterMaxRows = 80;   // rows of one slab staged in LDS (M <= kOuterSlabs * kOuterMaxRows)
 
 template <int L>
 __global__ __launch_bounds__(256) void outer_partial_kernel(OuterArgs p) {
-  __shared__ float nar[kOuterChunk][L];
-  __shared__ float st[kOuterChunk][2];
+  if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
+  __shared__ float nar[kOuterMaxRows][L];
+  __shared__ float st[kOuterMaxRows][2];
   const int C = p.C, c = blockIdx.x * 256 + threadIdx.x, slab = blockIdx.y;
-  const int rows_per = (p.M + kSlabs - 1) / kSlabs;
+  const int rows_per = (p.M + kOuterSlabs - 1) / kOuterSlabs;
   const int r0 = slab * rows_per, r1 = min(p.M, r0 + rows_per);
+  const int nr = max(0, r1 - r0);
+  for (int i = threadIdx.x; i < nr * L; i += 256) {
+    const int r = i / L, l = i - r * L, m = r0 + r;
+    const float* src = p.narrow + (size_t)m * L;
+    if (p.lat_override != nullptr) {
+      const int s = m / p.T, t = m - s * p.T;
+      if (t < p.P) src = p.lat_override + ((size_t)s * p.P + t) * L;
+    }
+    nar[r][l] = src[l];
+  }
+  if (p.mean != nullptr && (int)threadIdx.x < nr) {
+    st[threadIdx.x][0] = p.mean[r0 + threadIdx.x];
+    st[threadIdx.x][1] = p.rstd[r0 + threadIdx.x];
+  }
+  __syncthreads();
   float acc[L + 1];
 #pragma unroll
   for (int l = 0; l <= L; ++l) acc[l] = 0.f;
-  const float g = (p.ln_g && c < C) ? p.ln_g[c] : 1.f, bt = (p.ln_b && c < C) ? p.ln_b[c] : 0.f;
-  for (int rb = r0; rb < r1; rb += kOuterChunk) {
-    const int nr = min(kOuterChunk, r1 - rb);
-    __syncthreads();
-    for (int i = threadIdx.x; i < nr * L; i += 256) {
-      const int r = i / L, l = i - r * L, m = rb + r;
-      const float* src = p.narrow + (size_t)m * L;
-      if (p.lat_override != nullptr) {
-        const int s = m / p.T, t = m - s * p.T;
-        if (t < p.P) src = p.lat_override + ((size_t)s * p.P + t) * L;
-      }
-      nar[r][l] = src[l];
-    }
-    if (p.mean != nullptr && threadIdx.x < nr) {
-      st[threadIdx.x][0] = p.mean[rb + threadIdx.x];
-      st[threadIdx.x][1] = p.rstd[rb + threadIdx.x];
-    }
-    __syncthreads();
-    if (c < C) {
-      for (int r = 0; r < nr; ++r) {
-        const int m = rb + r;
-        float w = p.wide[(size_t)m * C + c];
-        if (p.drop_thresh != 0u) w *= drop_scale(p.seed, (unsigned long long)m * C + c, p.drop_thresh, p.inv_keep);
-        if (p.mean != nullptr) w = (w - st[r][0]) * st[r][1] * g + bt;
-#pragma unroll
-        for (int l = 0; l < L; ++l) acc[l] += nar[r][l] * w;
-        acc[L] += w;
-      }
-    }
-  }
   if (c < C) {
+    const float g = p.ln_g ? p.ln_g[c] : 1.f, bt = p.ln_b ? p.ln_b[c] : 0.f;
+    for (int rb = 0; rb < nr; rb += 8) {
+      float w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = (rb + u < nr) ? p.wide[(size_t)(r0 + rb + u) * C + c] : 0.f;   // 8 loads in flight
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (rb + u < nr) {
+          const int r = rb + u, m = r0 + r;
+          float x = w[u];
+          if (p.drop_thresh != 0u) x *= drop_scale(p.seed, (unsigned long long)m * C + c, p.drop_thresh, p.inv_keep);
+          if (p.mean != nullptr) x = (x - st[r][0]) * st[r][1] * g + bt;
+#pragma unroll
+          for (int l = 0; l < L; ++l) acc[l] += nar[r][l] * x;
+          acc[L] += x;
+        }
+      }
+    }
 #pragma unroll
     for (int l = 0; l <= L; ++l) p.scratch[((size_t)slab * (L + 1) + l) * C + c] = acc[l];
   }
@@ -244,8 +278,13 @@ __global__ __launch_bounds__(256) void outer_final_kernel(const float* __restric
                                                           int L, int C, int transposed, int accumulate) {
   const int c = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
   if (c >= C) return;
-  float a = 0.f;
-  for (int s = 0; s < kSlabs; ++s) a += scratch[((size_t)s * (L + 1) + l) * C + c];
+  float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int s = 0; s < kOuterSlabs; s += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a4[u] += scratch[((size_t)(s + u) * (L + 1) + l) * C + c];
+  }
+  const float a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   if (l < L) {
     if (out == nullptr) return;
     float* o = transposed ? out + (size_t)c * L + l : out + (size_t)l * C + c;
@@ -264,15 +303,29 @@ __global__ __launch_bounds__(256) void small_wgrad_partial_kernel(const float* _
   for (int o = threadIdx.x; o < nout; o += 256) {
     const int j = o / Lb, l = o - j * Lb;
     float acc = 0.f;
-    for (int m = r0; m < r1; ++m) acc += a[(size_t)m * J + j] * b[(size_t)m * Lb + l];
+    for (int m = r0; m < r1; m += 8) {
+      float av[8], bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool ok = m + u < r1;
+        av[u] = ok ? a[(size_t)(m + u) * J + j] : 0.f;
+        bv[u] = ok ? b[(size_t)(m + u) * Lb + l] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += av[u] * bv[u];
+    }
     scratch[(size_t)slab * nout + o] = acc;
   }
 }
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ scratch, float* __restrict__ out, int n, int nslabs, int accumulate) {
   const int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= n) return;
-  float a = 0.f;
-  for (int s = 0; s < nslabs; ++s) a += scratch[(size_t)s * n + o];
+  float a4[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nslabs; s += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a4[u] += (s + u < nslabs) ? scratch[(size_t)(s + u) * n + o] : 0.f;
+  }
+  const float a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   out[o] = accumulate ? out[o] + a : a;
 }
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ scratch, int M, int C) {
@@ -281,7 +334,13 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   const int rows_per = (M + kSlabs - 1) / kSlabs;
   const int r0 = slab * rows_per, r1 = min(M, r0 + rows_per);
   float a = 0.f;
-  for (int m = r0; m < r1; ++m) a += x[(size_t)m * C + c];
+  for (int m = r0; m < r1; m += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (m + u < r1) ? x[(size_t)(m + u) * C + c] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += v[u];
+  }
   scratch[(size_t)slab * C + c] = a;
 }
 
@@ -294,7 +353,7 @@ static int launch_down(const DownArgs& a, hipStream_t s) {
     if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(skinny_down): %s", hipGetErrorString(e));
     attr = true;
   }
-  hipLaunchKernelGGL((skinny_down_kernel<L>), dim3((a.M + kDownRows - 1) / kDownRows), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((skinny_down_kernel<L>), dim3((a.M + kDownRows - 1) / kDownRows), dim3(1024), lds, s, a);
   return check_launch("skinny_down");
 }
 template <int L>
@@ -304,7 +363,7 @@ static int launch_up(const UpArgs& a, hipStream_t s) {
 }
 template <int L>
 static int launch_outer(const OuterArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL((outer_partial_kernel<L>), dim3((a.C + 255) / 256, kSlabs), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((outer_partial_kernel<L>), dim3((a.C + 255) / 256, kOuterSlabs), dim3(256), 0, s, a);
   return check_launch("outer_partial");
 }
 
@@ -328,7 +387,7 @@ extern "C" int gvk_skinny_down(const gvk_skinny_down_desc* d, void* stream) {
   a.x = d->x; a.w = d->w; a.bias = d->bias; a.ln_g = d->ln_gamma; a.ln_b = d->ln_beta; a.mean = d->mean; a.rstd = d->rstd;
   a.z = d->z; a.y = d->y; a.w2 = d->w2; a.y2 = d->y2; a.L2 = d->L2; a.M = d->M; a.C = d->C; a.act = d->act; a.w_layout = d->w_layout;
   a.eps = d->eps > 0.f ? d->eps : 1e-5f;
-  a.seed = d->seed; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
+  a.seed = d->seed; a.seed_ptr = (const unsigned long long*)d->seed_ptr; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
   hipStream_t s = (hipStream_t)stream;
   switch (d->L) {
     case 4: return launch_down<4>(a, s);
@@ -348,7 +407,7 @@ extern "C" int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream) {
   UpArgs a{};
   a.lat = d->lat; a.w = d->w; a.bias = d->bias; a.res = d->res; a.out = d->out; a.lat_override = d->lat_override; a.T = d->T; a.P = d->P;
   a.M = d->M; a.C = d->C; a.w_layout = d->w_layout; a.accumulate = d->accumulate;
-  a.seed = d->seed; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
+  a.seed = d->seed; a.seed_ptr = (const unsigned long long*)d->seed_ptr; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
   hipStream_t s = (hipStream_t)stream;
   switch (d->L) {
     case 4: return launch_up<4>(a, s);
@@ -364,11 +423,12 @@ extern "C" int gvk_outer_reduce(const gvk_outer_desc* d, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(d && d->narrow && d->wide && d->scratch && (d->out || d->colsum), "gvk_outer_reduce: null pointer");
   GVK_REQUIRE(d->M > 0 && d->C > 0, "gvk_outer_reduce: empty shape");
+  GVK_REQUIRE(d->M <= kOuterSlabs * kOuterMaxRows, "gvk_outer_reduce: M=%d exceeds %d rows", d->M, kOuterSlabs * kOuterMaxRows);
   GVK_REQUIRE((d->mean == nullptr) == (d->rstd == nullptr), "gvk_outer_reduce: mean/rstd must come together");
   OuterArgs a{};
   a.narrow = d->narrow; a.wide = d->wide; a.lat_override = d->lat_override; a.T = d->T; a.P = d->P;
   a.mean = d->mean; a.rstd = d->rstd; a.ln_g = d->ln_gamma; a.ln_b = d->ln_beta; a.scratch = d->scratch; a.M = d->M; a.C = d->C;
-  a.seed = d->seed; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
+  a.seed = d->seed; a.seed_ptr = (const unsigned long long*)d->seed_ptr; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
   hipStream_t s = (hipStream_t)stream;
   int rc;
   switch (d->L) {

@@ -28,7 +28,7 @@ struct WinArgs {
   float* dqkv;        // bwd out [B*N][3L]
   int B, D, H, W, kd, kh, kw;
   float scale;
-  unsigned long long seed; unsigned int drop_thresh; float inv_keep;
+  unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;
 };
 
 struct Win {   // forward window of a query / reverse window of a key, per axis [lo, lo+n)
@@ -51,6 +51,7 @@ __device__ __forceinline__ void axis_rev(int key, int k, int n, int& lo, int& cn
 
 template <int L>
 __global__ __launch_bounds__(256) void win_fwd_kernel(WinArgs p) {
+  if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
   const int N = p.D * p.H * p.W;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.B * N) return;
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(256) void win_fwd_kernel(WinArgs p) {
 // query side: delta_i = dctx_i . ctx_i ; dq_i = scale * sum_j ds_ij k_j
 template <int L>
 __global__ __launch_bounds__(256) void win_bwd_q_kernel(WinArgs p) {
+  if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
   const int N = p.D * p.H * p.W;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.B * N) return;
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(256) void win_bwd_q_kernel(WinArgs p) {
 // key side over the reverse window: dk_j = scale * sum_i ds_ij q_i ; dv_j = sum_i p~_ij dctx_i
 template <int L>
 __global__ __launch_bounds__(256) void win_bwd_kv_kernel(WinArgs p) {
+  if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
   const int N = p.D * p.H * p.W;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.B * N) return;
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(256) void win_bwd_kv_kernel(WinArgs p) {
 static int fill(WinArgs& a, const gvk_window_attn_desc* d) {
   a.qkv = d->qkv; a.ctx = d->ctx; a.lse = d->lse; a.dctx = d->dctx; a.delta = d->delta; a.dqkv = d->dqkv;
   a.B = d->B; a.D = d->D; a.H = d->H; a.W = d->W; a.kd = d->kd; a.kh = d->kh; a.kw = d->kw; a.scale = d->scale;
-  a.seed = d->seed;
+  a.seed = d->seed; a.seed_ptr = (const unsigned long long*)d->seed_ptr;
   a.drop_thresh = 0u; a.inv_keep = 1.f;
   if (d->drop_p > 0.f) {
     double t = (double)d->drop_p * 4294967296.0;

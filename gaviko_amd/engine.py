@@ -25,6 +25,11 @@ import torch
 from . import lib as L
 from . import ops
 
+import os
+
+USE_GRAPHS = os.environ.get("GAVIKO_HIP_GRAPHS", "1") != "0"   # capture forward / backward into HIP graphs after warm-up
+GRAPH_WARMUP = 2
+
 # bench.py instrumentation: when a dict, every GEMM launch is bracketed by HIP events recorded on the launch stream
 GEMM_TIMING = None
 _EPI_NAMES = {0: "store_bf16", 1: "bias_res_f32", 2: "bias_gelu_bf16", 3: "patch_f32", 4: "gelu_bwd_bf16", 5: "store_f32", 6: "bias_res_f32_bf16"}
@@ -98,6 +103,10 @@ class Engine:
             self.P, self.T, self.row_off = 0, 1 + self.N, 1
         self._w16: Dict[str, torch.Tensor] = {}
         self._w16_version = None
+        self._have_dgrad = False
+        self._graphs = {}
+        self._calls = {}
+        self._wss = {}
         self._ws = None
         self._step = 0
         self._flat_grad = None
@@ -127,33 +136,43 @@ class Engine:
         return n
 
     def refresh_weights(self, need_dgrad: bool) -> None:
-        """(Re)build the bf16 shadows when a source weight changed (load_state_dict, .to(), optimizer step)."""
+        """(Re)build the bf16 shadows when a source weight changed (load_state_dict, optimizer step on an unfrozen tensor).
+        Shadows are rewritten IN PLACE so that captured HIP graphs keep pointing at valid operands."""
         names = self._backbone_weight_names()
-        version = tuple(self.p[n]._version for n in names) + tuple(self.p[n].data_ptr() for n in names) + (need_dgrad,)
-        if version == self._w16_version:
-            return
+        version = tuple(self.p[n]._version for n in names) + tuple(self.p[n].data_ptr() for n in names)
+        stale = version != self._w16_version
         w = self._w16
-        conv = self._d(names[0])
-        w["conv"] = ops.cast_bf16(conv.reshape(self.C, self.Kp).contiguous())
+        if stale:
+            conv = self._d(names[0]).reshape(self.C, self.Kp).contiguous()
+            w["conv"] = ops.cast_bf16(conv, w.get("conv"))
+        if not stale and (not need_dgrad or self._have_dgrad):
+            return
         for i in range(self.depth):
             for tag, nm in (("qkv", self.names.qkv_weight(i)), ("out", self.names.attn(i) + ".to_out.0.weight"),
                             ("fc1", self.names.mlp(i) + ".net.1.weight"), ("fc2", self.names.mlp(i) + ".net.4.weight")):
                 src = self._d(nm).contiguous()
-                w[f"{tag}{i}"] = ops.cast_bf16(src)
-                if need_dgrad:
-                    w[f"{tag}{i}_t"] = ops.transpose_cast_bf16(src)
+                if stale:
+                    w[f"{tag}{i}"] = ops.cast_bf16(src, w.get(f"{tag}{i}"))
+                if need_dgrad and (stale or not self._have_dgrad):
+                    w[f"{tag}{i}_t"] = ops.transpose_cast_bf16(src, w.get(f"{tag}{i}_t"))
+        self._have_dgrad = self._have_dgrad and not stale or need_dgrad
         self._w16_version = version
 
     # ------------------------------------------------------------------ workspace
     def workspace(self, B: int, device, train: bool):
         key = (B, train, str(device))
-        if self._ws is not None and self._ws["key"] == key:
+        if key in self._wss:
+            self._ws = self._wss[key]
             return self._ws
         C, T, N, M = self.C, self.T, self.N, B * self.T
         z = lambda r, c, dt: ops.act_zeros(r, c, dt, device)
         f32, bf16 = torch.float32, torch.bfloat16
         nsave = self.depth if train else 1
         ws = {"key": key, "B": B, "M": M}
+        ws["img"] = torch.zeros((B, 1) + tuple(g * p for g, p in zip(self.grid, self.patch)), device=device)
+        ws["logits"] = torch.zeros((B, self.K), device=device)
+        ws["dlogits"] = torch.zeros((B, self.K), device=device)
+        ws["seed"] = torch.full((1,), 0x5EED0000, dtype=torch.int64, device=device)
         ws["cols"] = z(B * N, self.Kp, bf16)
         ws["G"] = [z(M, C, f32) for _ in range(self.depth + 1)] if train else [z(M, C, f32), z(M, C, f32)]
         ws["G1"] = [z(M, C, f32) for _ in range(nsave)]
@@ -193,8 +212,32 @@ class Engine:
                 ws["scratch"] = mk(max(ops.outer_scratch_elems(Lt, C), 128 * C, 64 * 3 * Lt * Lt, 64 * ng))
             else:
                 ws["scratch"] = torch.zeros(128 * C, device=device)
-        self._ws = ws
+        self._ws = self._wss[key] = ws       # one workspace (and one set of captured graphs) per (batch, mode)
         return ws
+
+    # ------------------------------------------------------------------ graphs
+    def _run(self, tag, key, fn):
+        """Run `fn` eagerly the first GRAPH_WARMUP times, then capture it into a HIP graph and replay that.
+        Everything `fn` launches reads/writes workspace buffers only, so a replay is exactly one more step."""
+        if GEMM_TIMING is not None:                         # instrumented (event-per-launch) pass: always eager
+            fn()
+            return
+        k = (tag,) + key
+        g = self._graphs.get(k)
+        if g is not None:
+            g.replay()
+            return
+        n = self._calls.get(k, 0)
+        self._calls[k] = n + 1
+        if not USE_GRAPHS or n < GRAPH_WARMUP:
+            fn()
+            return
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        self._graphs[k] = g
+        g.replay()
 
     # ------------------------------------------------------------------ forward
     def forward(self, img: torch.Tensor, train: bool, drop: Optional[dict] = None) -> torch.Tensor:
@@ -204,22 +247,29 @@ class Engine:
         if img.dim() != 5 or img.shape[1] != 1 or tuple(img.shape[2:]) != tuple(g * p for g, p in zip(self.grid, self.patch)):
             raise L.GavikoHipError(f"expected img [B,1,{self.grid[0] * self.patch[0]},{self.grid[1] * self.patch[1]},"
                                    f"{self.grid[2] * self.patch[2]}], got {tuple(img.shape)}")
-        img = img.detach().to(torch.float32).contiguous()
-        B, C, T, N = img.shape[0], self.C, self.T, self.N
+        B = img.shape[0]
+        drop = drop or {}
+        sv = {"B": B, "train": train, "attn_drop": float(drop.get("attn_drop", 0.0)), "proj_drop": float(drop.get("proj_drop", 0.0))}
         self.refresh_weights(need_dgrad=train)
         ws = self.workspace(B, img.device, train)
+        ws["img"].copy_(img.detach())                       # static input buffer (the only per-step host-visible copy-in)
+        key = (B, train, sv["attn_drop"], sv["proj_drop"])
+        self._run("fwd", key, lambda: self._forward_impl(ws, sv))
+        self._saved = sv if train else None
+        self._saved_key = key
+        return ws["logits"].clone()
+
+    def _forward_impl(self, ws, sv):
+        B, C, T, N, train = sv["B"], self.C, self.T, self.N, sv["train"]
         M = B * T
         nm, w, d = self.names, self._w16, self._d
-        self._step += 1
-        drop = drop or {}
-        sv = {"B": B, "train": train, "seed": 0x5EED0000 + 7919 * self._step, "attn_drop": float(drop.get("attn_drop", 0.0)),
-              "proj_drop": float(drop.get("proj_drop", 0.0))}
+        ws["seed"].add_(7919)                               # device-side dropout epoch (HIP-graph safe)
         # ---- embedding: patch GEMM (+bias +pos, scattered to rows row_off..) and the broadcast rows
-        ops.patchify(img, ws["cols"], self.patch)
+        ops.patchify(ws["img"], ws["cols"], self.patch)
         pos = d(nm.root + "pos_embedding")[0]
         G0 = ws["G"][0]
         self._gemm(ws["cols"], w["conv"], B * N, G0, epilogue=ops.EPI_PATCH_F32, out1=ws["Lc"][0] if self.kind == "gaviko" else None,
-                    bias=d(nm.root + "conv_proj.0.bias"), pos=pos[1:], rows_in=N, rows_out=T, row_off=self.row_off)
+                   bias=d(nm.root + "conv_proj.0.bias"), pos=pos[1:], rows_in=N, rows_out=T, row_off=self.row_off)
         cls = d(nm.root + "cls_token")[0]
         if self.kind == "gaviko":
             ops.rows_broadcast(G0, d("prompt_embeddings")[0], d("prompt_positional_embedding")[0], B, T, 0, self.P, C)
@@ -239,13 +289,10 @@ class Engine:
             if self.kind == "gaviko":
                 self._gpa_fwd_up(ws, i, si, ws["G"][go], M)
         gfin = ws["G"][self.depth] if train else ws["G"][self.depth & 1]
-        logits = torch.empty((B, self.K), dtype=torch.float32, device=img.device)
         r0, R = self._pool_rows()
         ops.head_fwd(g=gfin, ln_gamma=d(nm.root + "transformer.norm.weight"), ln_beta=d(nm.root + "transformer.norm.bias"),
-                     wh=d(nm.head() + ".weight"), bh=d(nm.head() + ".bias"), logits=logits, pooled=ws["pooled"],
+                     wh=d(nm.head() + ".weight"), bh=d(nm.head() + ".bias"), logits=ws["logits"], pooled=ws["pooled"],
                      B=B, T=T, C=C, K=self.K, r0=r0, R=R)
-        self._saved = sv if train else None
-        return logits
 
     def _pool_rows(self):
         if self.kind == "gaviko":
@@ -282,9 +329,9 @@ class Engine:
                         M=BN, C=C, L=Lt, L2=3 * Lt, act=0, w_layout=0, eps=1e-5)
         ops.window_attn_fwd(qkv=m["qkv"], ctx=m["ctx"], lse=m["lse"], B=B, D=self.grid[0], H=self.grid[1], W=self.grid[2],
                             kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt, scale=C ** -0.5, drop_p=sv["attn_drop"],
-                            seed=sv["seed"] + 2 * i)
+                            seed=2 * i, seed_ptr=ws["seed"])
         ops.skinny_up(lat=m["ctx"], w=d(pre + ".proj_up.weight"), bias=d(pre + ".proj_up.bias"), res=lin, out=lout, M=BN, C=C, L=Lt,
-                      w_layout=0, drop_p=sv["proj_drop"], seed=sv["seed"] + 2 * i + 1)
+                      w_layout=0, drop_p=sv["proj_drop"], seed=2 * i + 1, seed_ptr=ws["seed"])
 
     def _gpa_names(self, i):
         s = i // self.share
@@ -336,73 +383,87 @@ class Engine:
 
     def backward(self, dlogits: torch.Tensor, reducer=None) -> Dict[str, torch.Tensor]:
         """Fills and returns {param name: gradient view into the flat fp32 gradient buffer} for every trainable tensor.
-        `reducer` (distributed.GradReducer) gets layer_done() after every layer of the sweep so that finished buckets of the
-        flat buffer are all-reduced on its side stream while the remaining layers still run."""
+        The sweep is cut into segments at the reducer's bucket boundaries (one segment without a reducer); each segment is a
+        HIP graph after warm-up.  `reducer` (distributed.GradReducer) is told after every segment which layers are done, so
+        finished buckets of the flat buffer are all-reduced on its side stream while the next segment runs."""
         sv = self._saved
         if sv is None:
             raise L.GavikoHipError("backward() without a preceding training-mode forward()")
         ws = self._ws
-        B, C, T, N, M = sv["B"], self.C, self.T, self.N, sv["B"] * self.T
-        nm, w, d = self.names, self._w16, self._d
-        dlogits = dlogits.detach().to(torch.float32).contiguous()
         gv = self._grad_views(dlogits.device)
         unsupported = [n for n in gv if not self._grad_supported(n)]
         if unsupported:
             raise NotImplementedError(f"gradients for backbone tensors are not built yet (frozen-backbone PEFT only): {unsupported[:3]}...")
-        self._touched = set()
-        # ---- head
-        r0, R = self._pool_rows()
-        dG = ws["dG"][0]
-        backbone_bwd = self._needs_backbone_backward()
-        if backbone_bwd:
-            dG.zero_()
-        ops.head_bwd(g=ws["G"][self.depth], ln_gamma=d(nm.root + "transformer.norm.weight"), ln_beta=d(nm.root + "transformer.norm.bias"),
-                     wh=d(nm.head() + ".weight"), bh=d(nm.head() + ".bias"), pooled=ws["pooled"], dlogits=dlogits,
-                     dg=dG if backbone_bwd else None, dwh=gv[nm.head() + ".weight"], dbh=gv[nm.head() + ".bias"],
-                     B=B, T=T, C=C, K=self.K, r0=r0, R=R, accumulate=0)
+        ws["dlogits"].copy_(dlogits.detach())
         flat = self._flat_grad["buf"]
         if reducer is not None:
             reducer.begin()
-        if not backbone_bwd:
+        if not self._needs_backbone_backward():
+            self._run("bwd_head", self._saved_key, lambda: self._backward_head(ws, sv, gv, False))
             if reducer is not None:
                 reducer.finish(flat)
             return gv
-        ops.cast_bf16(dG, ws["dG16"])
-        cur = 0
-        if self.kind == "gaviko":
-            ws["dL"][0].zero_()
-        for i in reversed(range(self.depth)):
-            dGout, dGin = ws["dG"][cur], ws["dG"][cur ^ 1]
+        cuts = sorted({r for r, _, _ in reducer.ranges if r >= 0}, reverse=True) if reducer is not None else []
+        cuts = [c for c in cuts if 0 < c < self.depth]          # segment k ends (inclusive) at layer cuts[k]
+        hi = self.depth - 1
+        for seg, lo in enumerate(cuts + [0]):
+            first, last = seg == 0, lo == 0
+            self._run(f"bwd{seg}", self._saved_key + (tuple(cuts),),
+                      lambda hi=hi, lo=lo, first=first, last=last: self._backward_segment(ws, sv, gv, hi, lo, first, last))
+            if reducer is not None:
+                reducer.layer_done(flat, lo)
+            hi = lo - 1
+        if reducer is not None:
+            reducer.finish(flat)
+        return gv
+
+    def _backward_head(self, ws, sv, gv, backbone_bwd):
+        nm, d = self.names, self._d
+        B, C, T = sv["B"], self.C, self.T
+        r0, R = self._pool_rows()
+        dG = ws["dG"][0] if backbone_bwd else None
+        if backbone_bwd:
+            dG.zero_()
+        ops.head_bwd(g=ws["G"][self.depth], ln_gamma=d(nm.root + "transformer.norm.weight"), ln_beta=d(nm.root + "transformer.norm.bias"),
+                     wh=d(nm.head() + ".weight"), bh=d(nm.head() + ".bias"), pooled=ws["pooled"], dlogits=ws["dlogits"],
+                     dg=dG, dwh=gv[nm.head() + ".weight"], dbh=gv[nm.head() + ".bias"], B=B, T=T, C=C, K=self.K, r0=r0, R=R, accumulate=0)
+        if backbone_bwd:
+            ops.cast_bf16(dG, ws["dG16"])
+            if self.kind == "gaviko":
+                ws["dL"][0].zero_()
+
+    def _backward_segment(self, ws, sv, gv, hi, lo, first, last):
+        """Layers hi, hi-1, ..., lo of the backward sweep (+ the head when `first`, + the embedding rows when `last`).
+        ws['dG'][0] always holds the gradient of the global stream at a layer boundary, ws['dG'][1] the mid-layer one;
+        the local-stream gradient ping-pongs with the layer parity."""
+        nm, w, d = self.names, self._w16, self._d
+        B, C, T, M = sv["B"], self.C, self.T, sv["B"] * self.T
+        gaviko = self.kind == "gaviko"
+        if first:
+            self._backward_head(ws, sv, gv, True)
+        dGout, dGin = ws["dG"][0], ws["dG"][1]
+        for i in range(hi, lo - 1, -1):
+            par = (self.depth - 1 - i) & 1
             # ---- MLP block: dG1 = dGout + LN'(fc1^T(GELU'(pre) * fc2^T(dGout)))
             m = nm.mlp(i)
             st = ws["stat"][i]
             self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i])
             self._gemm(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
-            gaviko = self.kind == "gaviko"
             ops.layernorm_bwd(ws["dx32"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), M, C, dx=dGin, dres=dGout,
                               dx16=None if gaviko else ws["dG16"])
             if gaviko:
-                self._gpa_bwd(ws, sv, gv, i, dGout, dGin, ws["dL"][cur], M, B)       # adds into dG1 (= dGin) and dL, refreshes dG16
+                self._gpa_bwd(ws, sv, gv, i, dGout, dGin, ws["dL"][par], M, B)      # adds into dG1 (= dGin) and dL, refreshes dG16
             # ---- attention block: dG0 = dG1 + LN'(qkv^T(attn'(out^T(dG1))))
             a = nm.attn(i)
             self._gemm(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
             ops.attention_bwd(ws["qkv"][i], ws["ctx"][i], ws["dctx"], ws["lse"][i], ws["delta"], ws["dqkv"], B, T, self.heads, 64 ** -0.5)
             self._gemm(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
             ops.layernorm_bwd(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGout, dres=dGin, dx16=ws["dG16"])
-            # dGout now holds dG[i] (gradient wrt the layer input); keep `cur` pointing at it
             if gaviko:
-                self._mwsa_bwd(ws, sv, gv, i, ws["dL"][cur], ws["dL"][cur ^ 1], B)
-                ws["dL"][cur], ws["dL"][cur ^ 1] = ws["dL"][cur ^ 1], ws["dL"][cur]
-            if reducer is not None:
-                reducer.layer_done(flat, i)
-        # ---- embedding rows
-        dG0 = ws["dG"][cur]
-        if self.kind == "gaviko":
-            ops.rows_batch_sum(dG0, gv["prompt_embeddings"].view(self.P, C), gv["prompt_positional_embedding"].view(self.P, C), B, T, 0,
+                self._mwsa_bwd(ws, sv, gv, i, ws["dL"][par], ws["dL"][par ^ 1], B)
+        if last and gaviko:
+            ops.rows_batch_sum(dGout, gv["prompt_embeddings"].view(self.P, C), gv["prompt_positional_embedding"].view(self.P, C), B, T, 0,
                                self.P, C)
-        if reducer is not None:
-            reducer.finish(flat)
-        return gv
 
     def _grad_supported(self, name: str) -> bool:
         if name.startswith(self.names.head()):
@@ -414,19 +475,18 @@ class Engine:
     def _needs_backbone_backward(self) -> bool:
         return any(not n.startswith(self.names.head()) for n in self.trainable_names())
 
-    def _acc(self, key) -> int:
-        """0 on the first gradient contribution to `key` in this backward, 1 afterwards (shared modules, share_factor > 1)."""
-        if key in self._touched:
-            return 1
-        self._touched.add(key)
-        return 0
+    def _acc(self, i) -> int:
+        """0 when layer i is the first (highest) layer of the sweep that touches its shared side-path module, else 1."""
+        s = i // self.share
+        top = min(self.depth - 1, s * self.share + self.share - 1)
+        return 0 if i == top else 1
 
     def _gpa_bwd(self, ws, sv, gv, i, dGout, dG1, dLnew, M, B):
         pre, names = self._gpa_names(i)
         d, C, Lt, P, T, N = self._d, self.C, self.Lat, self.P, self.T, self.N
         g, bw, sc = ws["gp"][i], ws["bw"], ws["scratch"]
         wup = d(pre + ".proj_up.weight")
-        acc = self._acc(pre)
+        acc = self._acc(i)
         # proj_up: dcomb = dGout . Wup ; dWup = dGout^T . comb ; dbup = colsum(dGout)
         ops.skinny_down(x=dGout, w=wup, y=bw["dcomb"], M=M, C=C, L=Lt, act=0, w_layout=1)
         ops.outer_reduce(narrow=g["xl"], wide=dGout, lat_override=g["enh"], scratch=sc, out=gv[pre + ".proj_up.weight"],
@@ -466,15 +526,15 @@ class Engine:
         BN = B * N
         m, bw, sc = ws["mw"][i], ws["bw"], ws["scratch"]
         lin = ws["Lc"][i]
-        acc = self._acc(pre)
-        pd, seed_p, seed_a = sv["proj_drop"], sv["seed"] + 2 * i + 1, sv["seed"] + 2 * i
+        acc = self._acc(i)
+        pd, seed_p, seed_a, sp = sv["proj_drop"], 2 * i + 1, 2 * i, ws["seed"]
         wup = d(pre + ".proj_up.weight")
-        ops.skinny_down(x=dLout, w=wup, y=bw["dctx"], M=BN, C=C, L=Lt, act=0, w_layout=1, drop_p=pd, seed=seed_p)
+        ops.skinny_down(x=dLout, w=wup, y=bw["dctx"], M=BN, C=C, L=Lt, act=0, w_layout=1, drop_p=pd, seed=seed_p, seed_ptr=sp)
         ops.outer_reduce(narrow=m["ctx"], wide=dLout, scratch=sc, out=gv[pre + ".proj_up.weight"], colsum=gv[pre + ".proj_up.bias"],
-                         M=BN, C=C, L=Lt, transposed=1, accumulate=acc, drop_p=pd, seed=seed_p)
+                         M=BN, C=C, L=Lt, transposed=1, accumulate=acc, drop_p=pd, seed=seed_p, seed_ptr=sp)
         ops.window_attn_bwd(qkv=m["qkv"], ctx=m["ctx"], lse=m["lse"], dctx=bw["dctx"], delta=bw["wdelta"], dqkv=bw["dqkv"], B=B,
                             D=self.grid[0], H=self.grid[1], W=self.grid[2], kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt,
-                            scale=C ** -0.5, drop_p=sv["attn_drop"], seed=seed_a)
+                            scale=C ** -0.5, drop_p=sv["attn_drop"], seed=seed_a, seed_ptr=sp)
         wqkv = d(pre + ".qkv.weight")
         ops.small_wgrad(bw["dqkv"], m["lat"], gv[pre + ".qkv.weight"], sc, BN, 3 * Lt, Lt, accumulate=bool(acc))
         ops.skinny_down(x=bw["dqkv"], w=wqkv, y=bw["dlat"], M=BN, C=3 * Lt, L=Lt, act=0, w_layout=1)

@@ -33,13 +33,13 @@ def _struct(name, ptrs, ints, floats=(), u64=()):
 
 
 SkinnyDownDesc = _struct("SkinnyDownDesc",
-                         ["x", "w", "bias", "ln_gamma", "ln_beta", "mean", "rstd", "z", "y", "w2", "y2"],
+                         ["x", "w", "bias", "ln_gamma", "ln_beta", "mean", "rstd", "z", "y", "w2", "y2", "seed_ptr"],
                          ["M", "C", "L", "L2", "act", "w_layout"], ["eps", "drop_p"], ["seed"])
-SkinnyUpDesc = _struct("SkinnyUpDesc", ["lat", "w", "bias", "res", "out", "lat_override"],
+SkinnyUpDesc = _struct("SkinnyUpDesc", ["lat", "w", "bias", "res", "out", "lat_override", "seed_ptr"],
                        ["M", "C", "L", "T", "P", "w_layout", "accumulate"], ["drop_p"], ["seed"])
-OuterDesc = _struct("OuterDesc", ["narrow", "wide", "lat_override", "mean", "rstd", "ln_gamma", "ln_beta", "scratch", "out", "colsum"],
+OuterDesc = _struct("OuterDesc", ["narrow", "wide", "lat_override", "mean", "rstd", "ln_gamma", "ln_beta", "scratch", "out", "colsum", "seed_ptr"],
                     ["M", "C", "L", "T", "P", "transposed", "accumulate"], ["drop_p"], ["seed"])
-WindowAttnDesc = _struct("WindowAttnDesc", ["qkv", "ctx", "lse", "dctx", "delta", "dqkv"],
+WindowAttnDesc = _struct("WindowAttnDesc", ["qkv", "ctx", "lse", "dctx", "delta", "dqkv", "seed_ptr"],
                          ["B", "D", "H", "W", "kd", "kh", "kw", "L"], ["scale", "drop_p"], ["seed"])
 GpaDesc = _struct("GpaDesc",
                   ["xl", "ll", "ca0_g", "ca0_b", "ca1_w", "ca1_b", "ca3_w", "ca3_b", "gl0_g", "gl0_b", "gl1_w", "gl1_b",

@@ -145,7 +145,7 @@ def _desc(cls, what, **kw):
         v = kw.pop(name, None)
         if ctype is C.c_void_p:
             if v is not None:
-                _chk(v, torch.float32, f"{what}.{name}")
+                _chk(v, torch.int64 if name == "seed_ptr" else torch.float32, f"{what}.{name}")
             setattr(d, name, L.ptr(v))
         elif v is not None:
             setattr(d, name, v)
@@ -170,7 +170,7 @@ def outer_reduce(**kw):
 
 
 def outer_scratch_elems(Lat, C_):
-    return 64 * (Lat + 1) * C_
+    return 128 * (Lat + 1) * C_
 
 
 def small_wgrad(a, b, out, scratch, M, J, Lb, accumulate=False):

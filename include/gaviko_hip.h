@@ -102,6 +102,7 @@ typedef struct gvk_skinny_down_desc {
   const float* ln_gamma; const float* ln_beta; float* mean; float* rstd;
   float* z; float* y;               /* pre-activation / activated output [M][L], either may be NULL */
   const float* w2; float* y2;       /* second stage, W2 [L2][L] */
+  const uint64_t* seed_ptr;          /* optional device word added to `seed` at run time (HIP-graph-safe dropout) */
   int32_t M, C, L, L2, act, w_layout;
   float eps, drop_p;
   uint64_t seed;
@@ -113,6 +114,7 @@ int gvk_skinny_down(const gvk_skinny_down_desc* d, void* stream);
  *        from lat_override[(m / T) * P + m % T] (GPA: prompt rows replaced by the fused context, gaviko.py:181-185). */
 typedef struct gvk_skinny_up_desc {
   const float* lat; const float* w; const float* bias; const float* res; float* out; const float* lat_override;
+  const uint64_t* seed_ptr;
   int32_t M, C, L, T, P, w_layout, accumulate;
   float drop_p;
   uint64_t seed;
@@ -121,11 +123,12 @@ int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream);
 
 /* outer: out[l][c] (transposed=0) or out[c][l] (transposed=1) (+)= sum_m narrow[m][l] * wide'[m][c];
  *        colsum[c] (+)= sum_m wide'[m][c] (optional).  wide' = LN(wide) when mean/rstd(/gamma/beta) are given, times the
- *        dropout mask when drop_p > 0.  scratch: f32 [64*(L+1)*C].  Deterministic (two-stage, no atomics). */
+ *        dropout mask when drop_p > 0.  scratch: f32 [128*(L+1)*C]; M <= 10240.  Deterministic (two-stage, no atomics). */
 typedef struct gvk_outer_desc {
   const float* narrow; const float* wide; const float* lat_override;
   const float* mean; const float* rstd; const float* ln_gamma; const float* ln_beta;
   float* scratch; float* out; float* colsum;
+  const uint64_t* seed_ptr;
   int32_t M, C, L, T, P, transposed, accumulate;
   float drop_p;
   uint64_t seed;
@@ -145,6 +148,7 @@ int gvk_colsum(const float* x, float* out, float* scratch, int M, int C, int acc
 typedef struct gvk_window_attn_desc {
   const float* qkv; float* ctx; float* lse;
   const float* dctx; float* delta; float* dqkv;
+  const uint64_t* seed_ptr;
   int32_t B, D, H, W, kd, kh, kw, L;
   float scale, drop_p;
   uint64_t seed;
