@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
           bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
           *(bf16x4*)((bf16*)p.out0 + (size_t)m * p.ldo + n) = o;
         }
-        bf16x4 g = {(bf16)gelu_erf(v[0]), (bf16)gelu_erf(v[1]), (bf16)gelu_erf(v[2]), (bf16)gelu_erf(v[3])};
+        bf16x4 g = {(bf16)gelu_fast(v[0]), (bf16)gelu_fast(v[1]), (bf16)gelu_fast(v[2]), (bf16)gelu_fast(v[3])};
         *(bf16x4*)((bf16*)p.out1 + (size_t)m * p.ldo + n) = g;
       } else if constexpr (EPI == GVK_EPI_PATCH_F32) {
         const f32x4 pe = *(const f32x4*)(p.pos + (size_t)prow * p.N + n);
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
         if (p.out1 != nullptr) *(f32x4*)((float*)p.out1 + (size_t)m * p.ldo + n) = v;
       } else if constexpr (EPI == GVK_EPI_GELU_BWD_BF16) {
         const bf16x4 a = *(const bf16x4*)(p.aux + (size_t)m * p.ldaux + n);
-        bf16x4 o = {(bf16)(v[0] * gelu_erf_grad((float)a[0])), (bf16)(v[1] * gelu_erf_grad((float)a[1])),
-                    (bf16)(v[2] * gelu_erf_grad((float)a[2])), (bf16)(v[3] * gelu_erf_grad((float)a[3]))};
+        bf16x4 o = {(bf16)(v[0] * gelu_fast_grad((float)a[0])), (bf16)(v[1] * gelu_fast_grad((float)a[1])),
+                    (bf16)(v[2] * gelu_fast_grad((float)a[2])), (bf16)(v[3] * gelu_fast_grad((float)a[3]))};
         *(bf16x4*)((bf16*)p.out0 + (size_t)m * p.ldo + n) = o;
       } else if constexpr (EPI == GVK_EPI_STORE_F32) {
         *(f32x4*)((float*)p.out0 + (size_t)m * p.ldo + n) = v;

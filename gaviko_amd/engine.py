@@ -107,6 +107,7 @@ class Engine:
         self._graphs = {}
         self._calls = {}
         self._wss = {}
+        self._s2 = None
         self._ws = None
         self._step = 0
         self._flat_grad = None
@@ -215,6 +216,27 @@ class Engine:
         self._ws = self._wss[key] = ws       # one workspace (and one set of captured graphs) per (batch, mode)
         return ws
 
+    # ------------------------------------------------------------------ two-stream fork / join
+    # GAViKO's local branch (MWSA) and the latent-space GPA core are independent of the backbone's attention / MLP GEMMs within
+    # a layer; they run on a side stream and meet the main stream only where the dataflow does (gaviko.py:301-304).  Inside
+    # a HIP-graph capture these waits become graph edges, so the replayed graph has two parallel branches.
+    def _side(self):
+        if self._s2 is None:
+            self._s2 = torch.cuda.Stream()
+        return self._s2
+
+    def _after_main(self):
+        """side stream waits for everything enqueued on the main stream so far"""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._side().wait_event(ev)
+
+    def _after_side(self):
+        """main stream waits for everything enqueued on the side stream so far"""
+        ev = torch.cuda.Event()
+        ev.record(self._side())
+        torch.cuda.current_stream().wait_event(ev)
+
     # ------------------------------------------------------------------ graphs
     def _run(self, tag, key, fn):
         """Run `fn` eagerly the first GRAPH_WARMUP times, then capture it into a HIP graph and replay that.
@@ -276,17 +298,25 @@ class Engine:
             ops.rows_broadcast(G0, cls, pos[0:1], B, T, self.P, 1, C)
         else:
             ops.rows_broadcast(G0, cls, pos[0:1], B, T, 0, 1, C)
-        # ---- layers
+        # ---- layers.  main stream: attention block -> MLP block;  side stream: MWSA -> GPA latents / gates / cross-attention
+        gaviko = self.kind == "gaviko"
+        side = self._side() if gaviko else None
+        if gaviko:
+            self._after_main()
         for i in range(self.depth):
             si = i if train else 0
             gi, go = (i, i + 1) if train else (i & 1, (i + 1) & 1)
-            if self.kind == "gaviko":
-                self._mwsa_fwd(ws, sv, i, si, ws["Lc"][gi], ws["Lc"][go])
+            if gaviko:
+                with torch.cuda.stream(side):
+                    self._mwsa_fwd(ws, sv, i, si, ws["Lc"][gi], ws["Lc"][go])
             self._attn_block_fwd(ws, i, si, ws["G"][gi], ws["G1"][si], M)
-            if self.kind == "gaviko":
-                self._gpa_fwd_latents(ws, i, si, ws["G1"][si], ws["Lc"][go], M, B)
+            if gaviko:
+                self._after_main()                                   # G1 ready
+                with torch.cuda.stream(side):
+                    self._gpa_fwd_latents(ws, i, si, ws["G1"][si], ws["Lc"][go], M, B)
             self._mlp_block_fwd(ws, i, si, ws["G1"][si], ws["G"][go], M, train)
-            if self.kind == "gaviko":
+            if gaviko:
+                self._after_side()                                   # enh ready
                 self._gpa_fwd_up(ws, i, si, ws["G"][go], M)
         gfin = ws["G"][self.depth] if train else ws["G"][self.depth & 1]
         r0, R = self._pool_rows()
@@ -442,25 +472,37 @@ class Engine:
         if first:
             self._backward_head(ws, sv, gv, True)
         dGout, dGin = ws["dG"][0], ws["dG"][1]
+        side = self._side() if gaviko else None
+        if gaviko:
+            self._after_main()
         for i in range(hi, lo - 1, -1):
             par = (self.depth - 1 - i) & 1
-            # ---- MLP block: dG1 = dGout + LN'(fc1^T(GELU'(pre) * fc2^T(dGout)))
-            m = nm.mlp(i)
+            m, a = nm.mlp(i), nm.attn(i)
             st = ws["stat"][i]
+            # side stream: GPA backward up to (not including) its writes into dG1 / dL
+            if gaviko:
+                with torch.cuda.stream(side):
+                    self._gpa_bwd_core(ws, sv, gv, i, dGout, M, B)
+            # main stream, MLP block: dG1 = dGout + LN'(fc1^T(GELU'(pre) * fc2^T(dGout)))
             self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i])
             self._gemm(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
             ops.layernorm_bwd(ws["dx32"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), M, C, dx=dGin, dres=dGout,
                               dx16=None if gaviko else ws["dG16"])
             if gaviko:
-                self._gpa_bwd(ws, sv, gv, i, dGout, dGin, ws["dL"][par], M, B)      # adds into dG1 (= dGin) and dL, refreshes dG16
-            # ---- attention block: dG0 = dG1 + LN'(qkv^T(attn'(out^T(dG1))))
-            a = nm.attn(i)
+                self._after_side()
+                self._gpa_bwd_scatter(ws, i, dGin, ws["dL"][par], M, B)      # dG1 += dzx.Wd (refreshes dG16), dL += dzl.Wd
+                self._after_main()
+                with torch.cuda.stream(side):
+                    self._mwsa_bwd(ws, sv, gv, i, ws["dL"][par], ws["dL"][par ^ 1], B)
+            # main stream, attention block: dG0 = dG1 + LN'(qkv^T(attn'(out^T(dG1))))
             self._gemm(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
             ops.attention_bwd(ws["qkv"][i], ws["ctx"][i], ws["dctx"], ws["lse"][i], ws["delta"], ws["dqkv"], B, T, self.heads, 64 ** -0.5)
             self._gemm(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
             ops.layernorm_bwd(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGout, dres=dGin, dx16=ws["dG16"])
             if gaviko:
-                self._mwsa_bwd(ws, sv, gv, i, ws["dL"][par], ws["dL"][par ^ 1], B)
+                self._after_main()                                           # next layer's GPA needs this dG[i]
+        if gaviko:
+            self._after_side()
         if last and gaviko:
             ops.rows_batch_sum(dGout, gv["prompt_embeddings"].view(self.P, C), gv["prompt_positional_embedding"].view(self.P, C), B, T, 0,
                                self.P, C)
@@ -481,7 +523,8 @@ class Engine:
         top = min(self.depth - 1, s * self.share + self.share - 1)
         return 0 if i == top else 1
 
-    def _gpa_bwd(self, ws, sv, gv, i, dGout, dG1, dLnew, M, B):
+    def _gpa_bwd_core(self, ws, sv, gv, i, dGout, M, B):
+        """Everything of the GPA backward that only READS dGout / saved activations: parameter gradients and dzx / dzl."""
         pre, names = self._gpa_names(i)
         d, C, Lt, P, T, N = self._d, self.C, self.Lat, self.P, self.T, self.N
         g, bw, sc = ws["gp"][i], ws["bw"], ws["scratch"]
@@ -505,15 +548,19 @@ class Engine:
         for wn, bn, dq in (("wgq", "bgq", bw["dqg"]), ("wlq", "blq", bw["dql"])):
             ops.small_wgrad(dq, g["prm"], gv[names[wn]], sc, B * P, Lt, Lt, accumulate=bool(acc))
             ops.colsum(dq, gv[names[bn]], sc, B * P, Lt, accumulate=bool(acc))
-        # proj_down (shared by both streams): dWd = dzx^T.G1 + dzl^T.Lnew ; dbd ; dG1 += dzx.Wd ; dLnew += dzl.Wd
-        wd = d(pre + ".proj_down.0.weight")
+        # proj_down (shared by both streams): dWd = dzx^T.G1 + dzl^T.Lnew ; dbd
         gwd, gbd = gv[pre + ".proj_down.0.weight"], gv[pre + ".proj_down.0.bias"]
         ops.outer_reduce(narrow=bw["dzx"], wide=ws["G1"][i], scratch=sc, out=gwd, M=M, C=C, L=Lt, transposed=0, accumulate=acc)
         ops.outer_reduce(narrow=bw["dzl"], wide=ws["Lc"][i + 1], scratch=sc, out=gwd, M=B * N, C=C, L=Lt, transposed=0, accumulate=1)
         ops.colsum(bw["dzx"], gbd, sc, M, Lt, accumulate=bool(acc))
         ops.colsum(bw["dzl"], gbd, sc, B * N, Lt, accumulate=True)
-        ops.skinny_up(lat=bw["dzx"], w=wd, out=dG1, M=M, C=C, L=Lt, w_layout=1, accumulate=1)
-        ops.skinny_up(lat=bw["dzl"], w=wd, out=dLnew, M=B * N, C=C, L=Lt, w_layout=1, accumulate=1)
+
+    def _gpa_bwd_scatter(self, ws, i, dG1, dLnew, M, B):
+        """dG1 += dzx . Wd ; dLnew += dzl . Wd ; bf16 copy of dG1 for the out-proj dgrad."""
+        pre, _ = self._gpa_names(i)
+        wd, bw = self._d(pre + ".proj_down.0.weight"), ws["bw"]
+        ops.skinny_up(lat=bw["dzx"], w=wd, out=dG1, M=M, C=self.C, L=self.Lat, w_layout=1, accumulate=1)
+        ops.skinny_up(lat=bw["dzl"], w=wd, out=dLnew, M=B * self.N, C=self.C, L=self.Lat, w_layout=1, accumulate=1)
         ops.cast_bf16(dG1, ws["dG16"])
 
     def _offset_of(self, name) -> int:

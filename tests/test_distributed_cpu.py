@@ -1,0 +1,85 @@
+"""CPU: the N>1 path -- bucket planner and bucketed mean all-reduce -- with world_size 2 on the gloo backend."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from gaviko_amd.distributed import GradReducer, plan_buckets, shard_range
+
+CFG = dict(image_size=160, image_patch_size=16, frames=120, frame_patch_size=12, num_classes=5, channels=1, backbone="vit-t16",
+           num_prompts=32, prompt_latent_dim=20, local_dim=20, local_k=(6, 6, 6), DHW=(10, 10, 10), share_factor=1)
+
+
+def _trainable(cfg):
+    shapes = oracle.gaviko_param_shapes(cfg)
+    names = [k for k in shapes if oracle.gaviko_trainable(k)]
+    return names, [int(np.prod(shapes[k])) for k in names]
+
+
+def test_plan_buckets_covers_buffer_once_and_orders_by_readiness():
+    names, numels = _trainable(CFG)
+    ranges = plan_buckets(names, numels, depth=12, share_factor=1, layers_per_bucket=4)
+    total = sum(numels)
+    cover = np.zeros(total, np.int32)
+    for _, s, e in ranges:
+        cover[s:e] += 1
+    assert (cover == 1).all()
+    ready = [r for r, _, _ in ranges]
+    idx = [r for r in ready if r >= 0]
+    assert idx == sorted(idx, reverse=True) and ready[-1] == -1 and set(idx) == {0, 4, 8}
+    # a module shared by layers 2s, 2s+1 (share_factor 2) is final only after layer 2s
+    cfg2 = dict(CFG, share_factor=2)
+    n2, k2 = _trainable(cfg2)
+    r2 = plan_buckets(n2, k2, depth=12, share_factor=2, layers_per_bucket=4)
+    off = dict(zip(n2, np.cumsum([0] + k2[:-1])))
+    o = off["transformer.local_attns.5.norm.weight"]          # used by layers 10, 11 -> ready at layer 10 -> bucket 8
+    assert [r for r, s, e in r2 if s <= o < e] == [8]
+
+
+def test_shard_range():
+    assert [shard_range(32, r, 8) for r in (0, 7)] == [(0, 4), (28, 32)]
+    with pytest.raises(ValueError):
+        shard_range(30, 0, 8)
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    names, numels = _trainable(CFG)
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(sum(numels), generator=g)
+    mine = flat.clone()
+    red = GradReducer(names, numels, depth=12, share_factor=1, layers_per_bucket=4)
+    red.begin()
+    done = []
+    for layer in range(11, -1, -1):                 # the backward sweep
+        before = red._next
+        red.layer_done(flat, layer)
+        done.append((layer, red._next - before))
+    red.finish(flat)
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    want = sum(gathered) / world
+    ok = torch.allclose(flat, want, atol=1e-6)
+    fired = {l: n for l, n in done if n}
+    if rank == 0:
+        ret["ok"], ret["fired"] = bool(ok), fired
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_mean_allreduce_world2_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["ok"]
+    assert set(ret["fired"]) == {8, 4, 0}          # buckets go out at their lowest layer, the rest at finish()
