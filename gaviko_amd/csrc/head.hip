@@ -251,3 +251,138 @@ extern "C" int gvk_head_bwd(const gvk_head_desc* d, void* stream) {
   hipLaunchKernelGGL(head_bwd_w_kernel, dim3((d->K * d->C + 255) / 256), dim3(256), 0, s, a);
   return check_launch("head_bwd_w");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// VPT (model/vpt.py): prompt projection Linear(prompt_dim, C) on a handful of rows, and the per-layer token re-pack of
+// deep VPT.  vpt.py:147-153 rebuilds the sequence before every deep layer as [cls | P new prompts | x[:, 1+skip:]] with
+// skip = deep_prompt_embeddings[i].shape[1] = prompt_dim (NOT num_prompts -- reference quirk 16), so T shrinks by skip - P.
+namespace gvk {
+
+__global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                               float* __restrict__ out, int R, int K, int C) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= R * C) return;
+  const int r = idx / C, c = idx - r * C;
+  float a = b ? b[c] : 0.f;
+  for (int k = 0; k < K; ++k) a += x[r * K + k] * w[(size_t)c * K + k];
+  out[idx] = a;
+}
+// dw[c][k] (+)= sum_r dout[r][c] x[r][k];  db[c] (+)= sum_r dout[r][c];  dx[r][k] = sum_c dout[r][c] w[c][k]
+__global__ __launch_bounds__(256) void small_linear_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dout, float* __restrict__ dw,
+                                                                 float* __restrict__ db, int R, int K, int C, int accumulate) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < C * K) {
+    const int c = idx / K, k = idx - c * K;
+    float a = 0.f;
+    for (int r = 0; r < R; ++r) a += dout[(size_t)r * C + c] * x[r * K + k];
+    dw[idx] = accumulate ? dw[idx] + a : a;
+  }
+  if (idx < C && db != nullptr) {
+    float a = 0.f;
+    for (int r = 0; r < R; ++r) a += dout[(size_t)r * C + idx];
+    db[idx] = accumulate ? db[idx] + a : a;
+  }
+}
+__global__ __launch_bounds__(64) void small_linear_bwd_x_kernel(const float* __restrict__ w, const float* __restrict__ dout, float* __restrict__ dx,
+                                                                int R, int K, int C, int accumulate) {
+  const int r = blockIdx.x / K, k = blockIdx.x - r * K;       // one wave per dx element
+  float a = 0.f;
+  for (int c = threadIdx.x; c < C; c += 64) a += dout[(size_t)r * C + c] * w[(size_t)c * K + k];
+  a = wave_sum(a);
+  if (threadIdx.x == 0) dx[blockIdx.x] = accumulate ? dx[blockIdx.x] + a : a;
+}
+
+// out[b][0] = in[b][0]; out[b][1+p] = prompt[p]; out[b][1+P+j] = in[b][1+skip+j]
+__global__ __launch_bounds__(256) void vpt_repack_fwd_kernel(const float* __restrict__ in, const float* __restrict__ prompt, float* __restrict__ out,
+                                                             int B, int Tin, int Tout, int P, int skip, int C) {
+  const int c4 = C / 4;
+  const int64_t total = (int64_t)B * Tout * c4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (i % c4) * 4;
+    const int64_t t_ = i / c4;
+    const int t = t_ % Tout, b = t_ / Tout;
+    f32x4 v;
+    if (t == 0) v = *(const f32x4*)(in + ((int64_t)b * Tin) * C + c);
+    else if (t <= P) v = *(const f32x4*)(prompt + (int64_t)(t - 1) * C + c);
+    else v = *(const f32x4*)(in + ((int64_t)b * Tin + (t - P + skip)) * C + c);
+    *(f32x4*)(out + ((int64_t)b * Tout + t) * C + c) = v;
+  }
+}
+// din[b][0] = dout[b][0]; din[b][1..skip] = 0; din[b][1+skip+j] = dout[b][1+P+j]
+__global__ __launch_bounds__(256) void vpt_repack_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, int B, int Tin, int Tout, int P,
+                                                             int skip, int C) {
+  const int c4 = C / 4;
+  const int64_t total = (int64_t)B * Tin * c4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (i % c4) * 4;
+    const int64_t t_ = i / c4;
+    const int t = t_ % Tin, b = t_ / Tin;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t == 0) v = *(const f32x4*)(dout + ((int64_t)b * Tout) * C + c);
+    else if (t > skip) v = *(const f32x4*)(dout + ((int64_t)b * Tout + (t - skip + P)) * C + c);
+    *(f32x4*)(din + ((int64_t)b * Tin + t) * C + c) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_f32_strided_kernel(const bf16* __restrict__ in, float* __restrict__ out, int M, int C, int ld_in) {
+  const int c4 = C / 4;
+  const int64_t total = (int64_t)M * c4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (i % c4) * 4;
+    const int64_t m = i / c4;
+    const bf16x4 v = *(const bf16x4*)(in + m * ld_in + c);
+    *(f32x4*)(out + m * C + c) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  }
+}
+
+}  // namespace gvk
+
+extern "C" int gvk_small_linear_fwd(const float* x, const float* w, const float* b, float* out, int R, int K, int C, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(x && w && out && R > 0 && K > 0 && C > 0, "gvk_small_linear_fwd: bad arguments");
+  hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((R * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, w, b, out, R, K, C);
+  return check_launch("small_linear_fwd");
+}
+extern "C" int gvk_small_linear_bwd(const float* x, const float* w, const float* dout, float* dw, float* db, float* dx, int R, int K, int C,
+                                    int accumulate, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(x && w && dout && R > 0 && K > 0 && C > 0, "gvk_small_linear_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (dw != nullptr) {
+    const int n = C * K > C ? C * K : C;
+    hipLaunchKernelGGL(small_linear_bwd_w_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, dout, dw, db, R, K, C, accumulate);
+    int rc = check_launch("small_linear_bwd_w");
+    if (rc) return rc;
+  }
+  if (dx != nullptr) {
+    hipLaunchKernelGGL(small_linear_bwd_x_kernel, dim3(R * K), dim3(64), 0, s, w, dout, dx, R, K, C, accumulate);
+    return check_launch("small_linear_bwd_x");
+  }
+  return 0;
+}
+extern "C" int gvk_vpt_repack_fwd(const float* in, const float* prompt, float* out, int B, int Tin, int Tout, int P, int skip, int C, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(in && prompt && out && B > 0 && C % 4 == 0, "gvk_vpt_repack_fwd: bad arguments");
+  GVK_REQUIRE(Tout == Tin - skip + P && Tout > 1 + P && skip >= 0, "gvk_vpt_repack_fwd: Tout=%d must equal Tin-skip+P (%d-%d+%d)", Tout, Tin, skip, P);
+  int64_t blocks = ((int64_t)B * Tout * (C / 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(vpt_repack_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, prompt, out, B, Tin, Tout, P, skip, C);
+  return check_launch("vpt_repack_fwd");
+}
+extern "C" int gvk_vpt_repack_bwd(const float* dout, float* din, int B, int Tin, int Tout, int P, int skip, int C, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(dout && din && B > 0 && C % 4 == 0, "gvk_vpt_repack_bwd: bad arguments");
+  GVK_REQUIRE(Tout == Tin - skip + P && skip >= 0, "gvk_vpt_repack_bwd: Tout=%d must equal Tin-skip+P", Tout);
+  int64_t blocks = ((int64_t)B * Tin * (C / 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(vpt_repack_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, din, B, Tin, Tout, P, skip, C);
+  return check_launch("vpt_repack_bwd");
+}
+extern "C" int gvk_cast_bf16_f32_strided(const void* in, float* out, int M, int C, int ld_in, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(in && out && M > 0 && C > 0 && C % 4 == 0 && ld_in % 4 == 0 && ld_in >= C, "gvk_cast_bf16_f32_strided: bad arguments");
+  int64_t blocks = ((int64_t)M * (C / 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cast_bf16_f32_strided_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, out, M, C, ld_in);
+  return check_launch("cast_bf16_f32_strided");
+}

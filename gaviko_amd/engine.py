@@ -99,8 +99,21 @@ class Engine:
                 if tuple(dhw) != self.grid:
                     raise L.GavikoHipError(f"DHW={tuple(dhw)} does not match the patch grid {self.grid}")
                 self.win = tuple(cfg.get("local_k", (3, 6, 6)))
+        elif kind == "vpt":
+            self.P = cfg.get("num_prompts", 8)
+            self.pd = cfg.get("prompt_dim", 64)
+            self.deep = bool(cfg.get("deep_prompt", True))
+            self.T, self.row_off = 1 + self.P + self.N, 1 + self.P
         else:
             self.P, self.T, self.row_off = 0, 1 + self.N, 1
+        # tokens entering layer i.  Deep VPT rebuilds the sequence before every layer > 0 as [cls | P prompts | x[:, 1+prompt_dim:]]
+        # (vpt.py:147-153: the slice uses deep_prompt_embeddings[i].shape[1] == prompt_dim), so it shrinks by prompt_dim - P per layer.
+        self.Ts = [self.T] * depth
+        if kind == "vpt" and self.deep:
+            for i in range(1, depth):
+                self.Ts[i] = self.Ts[i - 1] - self.pd + self.P
+            if self.Ts[-1] <= 1 + self.pd:
+                raise L.GavikoHipError("deep VPT: the shrinking sequence runs out of tokens for this depth / prompt_dim")
         self._w16: Dict[str, torch.Tensor] = {}
         self._w16_version = None
         self._have_dgrad = False
@@ -193,6 +206,13 @@ class Engine:
             ws["gp"] = [dict(zx=mk(M, Lt), xl=mk(M, Lt), zl=mk(BN, Lt), ll=mk(BN, Lt), imp=mk(B, P), gw=mk(B), enh=mk(B, P, Lt),
                              prm=mk(B, P, Lt), qg=mk(B, P, Lt), ql=mk(B, P, Lt), cg=mk(B, P, Lt), cl=mk(B, P, Lt), lse_g=mk(B, P),
                              lse_l=mk(B, P)) for _ in range(nsave)]
+        if self.kind == "vpt":
+            R = (self.depth if self.deep else 1) * self.P
+            ws["vproj"] = torch.zeros((R, C), device=device)
+            ws["Go"] = z(M, C, f32)                          # layer output before the deep-VPT re-pack
+            if train:
+                ws["dvproj"] = torch.zeros((R, C), device=device)
+                ws["dGv"] = z(M, C, f32)
         if train:
             ws["dG"] = [z(M, C, f32), z(M, C, f32)]          # ping-pong gradient of the global stream
             ws["dG16"] = z(M, C, bf16)
@@ -298,6 +318,10 @@ class Engine:
             ops.rows_broadcast(G0, cls, pos[0:1], B, T, self.P, 1, C)
         else:
             ops.rows_broadcast(G0, cls, pos[0:1], B, T, 0, 1, C)
+        if self.kind == "vpt":                                # prompt_proj on every layer's prompts at once (vpt.py:56,127-153)
+            emb = d("deep_prompt_embeddings" if self.deep else "prompt_embeddings").reshape(-1, self.pd)
+            ops.small_linear_fwd(emb, d("prompt_proj.weight"), d("prompt_proj.bias"), ws["vproj"], emb.shape[0], self.pd, C)
+            ops.rows_broadcast(G0, ws["vproj"][: self.P], None, B, T, 1, self.P, C)
         # ---- layers.  main stream: attention block -> MLP block;  side stream: MWSA -> GPA latents / gates / cross-attention
         gaviko = self.kind == "gaviko"
         side = self._side() if gaviko else None
@@ -309,25 +333,36 @@ class Engine:
             if gaviko:
                 with torch.cuda.stream(side):
                     self._mwsa_fwd(ws, sv, i, si, ws["Lc"][gi], ws["Lc"][go])
-            self._attn_block_fwd(ws, i, si, ws["G"][gi], ws["G1"][si], M)
+            Mi = B * self.Ts[i]
+            repack = self.kind == "vpt" and self.deep
+            gout = ws["Go"] if repack else ws["G"][go]
+            self._attn_block_fwd(ws, i, si, ws["G"][gi], ws["G1"][si], Mi)
             if gaviko:
                 self._after_main()                                   # G1 ready
                 with torch.cuda.stream(side):
                     self._gpa_fwd_latents(ws, i, si, ws["G1"][si], ws["Lc"][go], M, B)
-            self._mlp_block_fwd(ws, i, si, ws["G1"][si], ws["G"][go], M, train)
+            self._mlp_block_fwd(ws, i, si, ws["G1"][si], gout, Mi, train)
             if gaviko:
                 self._after_side()                                   # enh ready
                 self._gpa_fwd_up(ws, i, si, ws["G"][go], M)
-        gfin = ws["G"][self.depth] if train else ws["G"][self.depth & 1]
+            if repack and i + 1 < self.depth:
+                ops.vpt_repack_fwd(gout, ws["vproj"][(i + 1) * self.P: (i + 2) * self.P], ws["G"][go], B, self.Ts[i], self.Ts[i + 1],
+                                   self.P, self.pd, C)
+        gfin = self._final_stream(ws, train)
         r0, R = self._pool_rows()
         ops.head_fwd(g=gfin, ln_gamma=d(nm.root + "transformer.norm.weight"), ln_beta=d(nm.root + "transformer.norm.bias"),
                      wh=d(nm.head() + ".weight"), bh=d(nm.head() + ".bias"), logits=ws["logits"], pooled=ws["pooled"],
-                     B=B, T=T, C=C, K=self.K, r0=r0, R=R)
+                     B=B, T=self.Ts[-1], C=C, K=self.K, r0=r0, R=R)
+
+    def _final_stream(self, ws, train):
+        if self.kind == "vpt" and self.deep:
+            return ws["Go"]
+        return ws["G"][self.depth] if train else ws["G"][self.depth & 1]
 
     def _pool_rows(self):
         if self.kind == "gaviko":
             return 0, self.P + 1                      # gaviko.py:316 prompts + CLS
-        return (0, self.T) if self.pool == "mean" else (0, 1)
+        return (0, self.Ts[-1]) if self.pool == "mean" else (0, 1)
 
     def _attn_block_fwd(self, ws, i, si, gin, g1, M):
         nm, w, d, C = self.names, self._w16, self._d, self.C
@@ -335,7 +370,7 @@ class Engine:
         st = ws["stat"][si]
         ops.layernorm_fwd(gin, d(a + ".norm.weight"), d(a + ".norm.bias"), M, C, y16=ws["xn"], mean=st[0], rstd=st[1])
         self._gemm(ws["xn"], w[f"qkv{i}"], M, ws["qkv"][si], epilogue=ops.EPI_STORE_BF16)
-        ops.attention_fwd(ws["qkv"][si], ws["ctx"][si], ws["lse"][si], ws["B"], self.T, self.heads, 64 ** -0.5)
+        ops.attention_fwd(ws["qkv"][si], ws["ctx"][si], ws["lse"][si], ws["B"], self.Ts[i], self.heads, 64 ** -0.5)
         self._gemm(ws["ctx"][si], w[f"out{i}"], M, g1, epilogue=ops.EPI_BIAS_RES_F32, bias=d(a + ".to_out.0.bias"), res=gin)
 
     def _mlp_block_fwd(self, ws, i, si, g1, gout, M, train):
@@ -454,9 +489,10 @@ class Engine:
         dG = ws["dG"][0] if backbone_bwd else None
         if backbone_bwd:
             dG.zero_()
-        ops.head_bwd(g=ws["G"][self.depth], ln_gamma=d(nm.root + "transformer.norm.weight"), ln_beta=d(nm.root + "transformer.norm.bias"),
-                     wh=d(nm.head() + ".weight"), bh=d(nm.head() + ".bias"), pooled=ws["pooled"], dlogits=ws["dlogits"],
-                     dg=dG, dwh=gv[nm.head() + ".weight"], dbh=gv[nm.head() + ".bias"], B=B, T=T, C=C, K=self.K, r0=r0, R=R, accumulate=0)
+        ops.head_bwd(g=self._final_stream(ws, True), ln_gamma=d(nm.root + "transformer.norm.weight"),
+                     ln_beta=d(nm.root + "transformer.norm.bias"), wh=d(nm.head() + ".weight"), bh=d(nm.head() + ".bias"), pooled=ws["pooled"],
+                     dlogits=ws["dlogits"], dg=dG, dwh=gv[nm.head() + ".weight"], dbh=gv[nm.head() + ".bias"], B=B, T=self.Ts[-1], C=C,
+                     K=self.K, r0=r0, R=R, accumulate=0)
         if backbone_bwd:
             ops.cast_bf16(dG, ws["dG16"])
             if self.kind == "gaviko":
@@ -472,10 +508,15 @@ class Engine:
         if first:
             self._backward_head(ws, sv, gv, True)
         dGout, dGin = ws["dG"][0], ws["dG"][1]
+        vpt_deep = self.kind == "vpt" and self.deep
+        if vpt_deep and ((self.depth - 1 - hi) & 1):           # the un-repack alternates two buffers with the layer parity
+            dGout = ws["dGv"]
         side = self._side() if gaviko else None
         if gaviko:
             self._after_main()
         for i in range(hi, lo - 1, -1):
+            M = B * self.Ts[i]
+            T = self.Ts[i]
             par = (self.depth - 1 - i) & 1
             m, a = nm.mlp(i), nm.attn(i)
             st = ws["stat"][i]
@@ -501,8 +542,21 @@ class Engine:
             ops.layernorm_bwd(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGout, dres=dGin, dx16=ws["dG16"])
             if gaviko:
                 self._after_main()                                           # next layer's GPA needs this dG[i]
+            if self.kind == "vpt" and (i == 0 or self.deep):
+                # prompt rows 1..P of this layer's input are this layer's projected prompts (vpt.py:127-131,147-153)
+                ops.rows_batch_sum(dGout, ws["dvproj"][i * self.P: (i + 1) * self.P], None, B, T, 1, self.P, C)
+            if vpt_deep and i > 0:
+                other = ws["dGv"] if dGout is ws["dG"][0] else ws["dG"][0]
+                ops.vpt_repack_bwd(dGout, other, B, self.Ts[i - 1], T, self.P, self.pd, C)
+                dGout = other
+                ops.cast_bf16(dGout, ws["dG16"])
         if gaviko:
             self._after_side()
+        if last and self.kind == "vpt":
+            emb_name = "deep_prompt_embeddings" if self.deep else "prompt_embeddings"
+            emb = d(emb_name).reshape(-1, self.pd)
+            ops.small_linear_bwd(emb, d("prompt_proj.weight"), ws["dvproj"], gv["prompt_proj.weight"], gv["prompt_proj.bias"],
+                                 gv[emb_name].view(-1, self.pd), emb.shape[0], self.pd, C)
         if last and gaviko:
             ops.rows_batch_sum(dGout, gv["prompt_embeddings"].view(self.P, C), gv["prompt_positional_embedding"].view(self.P, C), B, T, 0,
                                self.P, C)
@@ -512,6 +566,8 @@ class Engine:
             return True
         if self.kind == "gaviko":
             return ("local_attns" in name or "prompt_projs" in name or name in ("prompt_embeddings", "prompt_positional_embedding"))
+        if self.kind == "vpt":
+            return name in ("prompt_proj.weight", "prompt_proj.bias", "deep_prompt_embeddings", "prompt_embeddings")
         return False
 
     def _needs_backbone_backward(self) -> bool:

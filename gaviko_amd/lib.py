@@ -75,6 +75,11 @@ SIGNATURES = {
     "gvk_gpa_bwd": [C.POINTER(GpaDesc), _P],
     "gvk_rows_broadcast": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gvk_rows_batch_sum": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gvk_small_linear_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "gvk_small_linear_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "gvk_vpt_repack_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gvk_vpt_repack_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gvk_cast_bf16_f32_strided": [_P, _P, _I, _I, _I, _P],
     "gvk_head_fwd": [C.POINTER(HeadDesc), _P],
     "gvk_head_bwd": [C.POINTER(HeadDesc), _P],
 }

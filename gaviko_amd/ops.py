@@ -248,3 +248,38 @@ def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, scale):
     _chk(delta, torch.float32, "attn_bwd delta", B * H * T)
     L.check(L.load().gvk_attention_bwd_bf16(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), B, T, H,
                                             3 * inner, inner, scale, L.stream_ptr()), "gvk_attention_bwd_bf16")
+
+
+def small_linear_fwd(x, w, b, out, R, K, C_):
+    for t, n in ((x, "x"), (w, "w"), (b, "b"), (out, "out")):
+        _chk(t, torch.float32, "small_linear " + n)
+    if x.numel() < R * K or w.numel() < C_ * K or out.numel() < R * C_:
+        raise L.GavikoHipError("small_linear_fwd: buffer too small")
+    L.check(L.load().gvk_small_linear_fwd(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(out), R, K, C_, L.stream_ptr()), "gvk_small_linear_fwd")
+
+
+def small_linear_bwd(x, w, dout, dw, db, dx, R, K, C_, accumulate=False):
+    for t, n in ((x, "x"), (w, "w"), (dout, "dout"), (dw, "dw"), (db, "db"), (dx, "dx")):
+        _chk(t, torch.float32, "small_linear_bwd " + n)
+    L.check(L.load().gvk_small_linear_bwd(L.ptr(x), L.ptr(w), L.ptr(dout), L.ptr(dw), L.ptr(db), L.ptr(dx), R, K, C_, int(accumulate),
+                                          L.stream_ptr()), "gvk_small_linear_bwd")
+
+
+def vpt_repack_fwd(inp, prompt, out, B, Tin, Tout, P, skip, C_):
+    _chk(inp, torch.float32, "vpt_repack in", B * Tin * C_)
+    _chk(prompt, torch.float32, "vpt_repack prompt", P * C_)
+    _chk(out, torch.float32, "vpt_repack out", B * Tout * C_)
+    L.check(L.load().gvk_vpt_repack_fwd(L.ptr(inp), L.ptr(prompt), L.ptr(out), B, Tin, Tout, P, skip, C_, L.stream_ptr()), "gvk_vpt_repack_fwd")
+
+
+def vpt_repack_bwd(dout, din, B, Tin, Tout, P, skip, C_):
+    _chk(dout, torch.float32, "vpt_repack_bwd dout", B * Tout * C_)
+    _chk(din, torch.float32, "vpt_repack_bwd din", B * Tin * C_)
+    L.check(L.load().gvk_vpt_repack_bwd(L.ptr(dout), L.ptr(din), B, Tin, Tout, P, skip, C_, L.stream_ptr()), "gvk_vpt_repack_bwd")
+
+
+def cast_bf16_f32_strided(inp, out, M, C_, ld_in, col0=0):
+    """f32 out[M][C] = bf16 inp[M][ld_in] columns col0 .. col0+C."""
+    _chk(inp, torch.bfloat16, "cast_bf16_f32 in", M * ld_in)
+    _chk(out, torch.float32, "cast_bf16_f32 out", M * C_)
+    L.check(L.load().gvk_cast_bf16_f32_strided(inp.data_ptr() + 2 * col0, L.ptr(out), M, C_, ld_in, L.stream_ptr()), "gvk_cast_bf16_f32_strided")

@@ -201,6 +201,20 @@ typedef struct gvk_head_desc {
 int gvk_head_fwd(const gvk_head_desc* d, void* stream);
 int gvk_head_bwd(const gvk_head_desc* d, void* stream);
 
+/* ------------------------------------------------------------------ VPT (model/vpt.py)
+ * small_linear: out[r][:] = W . x[r] + b for a handful of rows (prompt_proj = Linear(prompt_dim, C), vpt.py:56,127-131);
+ *   bwd: dw[c][k] (+)= sum_r dout[r][c] x[r][k], db (+)= colsum(dout), dx[r][k] (+)= sum_c dout[r][c] w[c][k] (any output may be NULL).
+ * vpt_repack: the per-layer sequence rebuild of deep VPT (vpt.py:147-153): out = [in[:,0] | prompt (P rows) | in[:, 1+skip:]],
+ *   Tout = Tin - skip + P, skip = prompt_dim for layers > 0 (reference quirk: drops the old prompts AND skip-P patch tokens);
+ *   bwd scatters dout back (rows 1..skip of din are zero).  Prompt-row gradients: gvk_rows_batch_sum. */
+int gvk_small_linear_fwd(const float* x, const float* w, const float* b, float* out, int R, int K, int C, void* stream);
+int gvk_small_linear_bwd(const float* x, const float* w, const float* dout, float* dw, float* db, float* dx, int R, int K, int C,
+                         int accumulate, void* stream);
+int gvk_vpt_repack_fwd(const float* in, const float* prompt, float* out, int B, int Tin, int Tout, int P, int skip, int C, void* stream);
+int gvk_vpt_repack_bwd(const float* dout, float* din, int B, int Tin, int Tout, int P, int skip, int C, void* stream);
+/* bf16 [M][ld_in] column block -> dense f32 [M][C] (gradient blocks handed to the fp32 rank-r kernels) */
+int gvk_cast_bf16_f32_strided(const void* in, float* out, int M, int C, int ld_in, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
