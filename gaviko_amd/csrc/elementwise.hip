@@ -55,7 +55,34 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
   }
 }
 
+// out[n][k] = w[n][k] + s * sum_j B[n'][j] A[j][k] on the q rows (n < C) and the v rows (n >= 2C)
+__global__ __launch_bounds__(256) void lora_merge_kernel(const float* __restrict__ w, const float* __restrict__ a_q, const float* __restrict__ b_q,
+                                                         const float* __restrict__ a_v, const float* __restrict__ b_v, float* __restrict__ out,
+                                                         int C, int r, float s) {
+  const int64_t total = (int64_t)3 * C * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = i / C, k = i - (int64_t)n * C;
+    float v = w[i];
+    if (n < C || n >= 2 * C) {
+      const float* A = n < C ? a_q : a_v;
+      const float* Bm = n < C ? b_q + (size_t)n * r : b_v + (size_t)(n - 2 * C) * r;
+      float d = 0.f;
+      for (int j = 0; j < r; ++j) d += Bm[j] * A[(size_t)j * C + k];
+      v += s * d;
+    }
+    out[i] = v;
+  }
+}
+
 }  // namespace gvk
+
+extern "C" int gvk_lora_merge_f32(const float* w, const float* a_q, const float* b_q, const float* a_v, const float* b_v, float* out, int C, int r,
+                                  float s, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(w && a_q && b_q && a_v && b_v && out && C > 0 && r > 0, "gvk_lora_merge_f32: bad arguments");
+  hipLaunchKernelGGL(lora_merge_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, w, a_q, b_q, a_v, b_v, out, C, r, s);
+  return check_launch("lora_merge_f32");
+}
 
 extern "C" int gvk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream) {
   using namespace gvk;

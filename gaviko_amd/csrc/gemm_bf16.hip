@@ -159,6 +159,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
         *(bf16x4*)((bf16*)p.out0 + (size_t)m * p.ldo + n) = o;
       } else if constexpr (EPI == GVK_EPI_STORE_F32) {
         *(f32x4*)((float*)p.out0 + (size_t)m * p.ldo + n) = v;
+      } else if constexpr (EPI == GVK_EPI_BIAS_RELU_BF16) {
+        bf16x4 o = {(bf16)fmaxf(v[0], 0.f), (bf16)fmaxf(v[1], 0.f), (bf16)fmaxf(v[2], 0.f), (bf16)fmaxf(v[3], 0.f)};
+        *(bf16x4*)((bf16*)p.out0 + (size_t)m * p.ldo + n) = o;
+      } else if constexpr (EPI == GVK_EPI_RELU_BWD_BF16) {
+        const bf16x4 a = *(const bf16x4*)(p.aux + (size_t)m * p.ldaux + n);
+        bf16x4 o = {(bf16)((float)a[0] > 0.f ? v[0] : 0.f), (bf16)((float)a[1] > 0.f ? v[1] : 0.f), (bf16)((float)a[2] > 0.f ? v[2] : 0.f),
+                    (bf16)((float)a[3] > 0.f ? v[3] : 0.f)};
+        *(bf16x4*)((bf16*)p.out0 + (size_t)m * p.ldo + n) = o;
       }
     }
   }
@@ -243,6 +251,12 @@ extern "C" int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream) {
     case GVK_EPI_STORE_F32:
       GVK_REQUIRE(d->out0, "gemm STORE_F32: out0 null");
       return dispatch_tile<GVK_EPI_STORE_F32>(a, d->tile, s);
+    case GVK_EPI_BIAS_RELU_BF16:
+      GVK_REQUIRE(d->out0, "gemm BIAS_RELU_BF16: out0 null");
+      return dispatch_tile<GVK_EPI_BIAS_RELU_BF16>(a, d->tile, s);
+    case GVK_EPI_RELU_BWD_BF16:
+      GVK_REQUIRE(d->out0 && d->aux && d->ldaux >= d->N && d->ldaux % 4 == 0, "gemm RELU_BWD_BF16: out0/aux");
+      return dispatch_tile<GVK_EPI_RELU_BWD_BF16>(a, d->tile, s);
     default:
       return set_error(-2, "gvk_gemm_nt_bf16: unknown epilogue %d", d->epilogue);
   }

@@ -437,7 +437,8 @@ extern "C" int gvk_outer_reduce(const gvk_outer_desc* d, void* stream) {
     case 16: rc = launch_outer<16>(a, s); break;
     case 20: rc = launch_outer<20>(a, s); break;
     case 32: rc = launch_outer<32>(a, s); break;
-    default: return set_error(-2, "gvk_outer_reduce: L=%d unsupported (4, 8, 16, 20, 32)", d->L);
+    case 64: rc = launch_outer<64>(a, s); break;
+    default: return set_error(-2, "gvk_outer_reduce: L=%d unsupported (4, 8, 16, 20, 32, 64)", d->L);
   }
   if (rc) return rc;
   hipLaunchKernelGGL(outer_final_kernel, dim3((d->C + 255) / 256, d->L + 1), dim3(256), 0, s, d->scratch, d->out, d->colsum, d->L, d->C,

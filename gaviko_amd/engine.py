@@ -106,6 +106,10 @@ class Engine:
             self.T, self.row_off = 1 + self.P + self.N, 1 + self.P
         else:
             self.P, self.T, self.row_off = 0, 1 + self.N, 1
+        if kind == "melo":
+            self.r, self.lora_s = int(cfg["r"]), int(cfg["alpha"]) // int(cfg["r"])      # integer alpha // r (melo.py:45-46)
+        if kind == "adaptformer":
+            self.adim = 64                                                                # Adapter(down_dim=64), adaptformer.py:25
         # tokens entering layer i.  Deep VPT rebuilds the sequence before every layer > 0 as [cls | P prompts | x[:, 1+prompt_dim:]]
         # (vpt.py:147-153: the slice uses deep_prompt_embeddings[i].shape[1] == prompt_dim), so it shrinks by prompt_dim - P per layer.
         self.Ts = [self.T] * depth
@@ -206,6 +210,20 @@ class Engine:
             ws["gp"] = [dict(zx=mk(M, Lt), xl=mk(M, Lt), zl=mk(BN, Lt), ll=mk(BN, Lt), imp=mk(B, P), gw=mk(B), enh=mk(B, P, Lt),
                              prm=mk(B, P, Lt), qg=mk(B, P, Lt), ql=mk(B, P, Lt), cg=mk(B, P, Lt), cl=mk(B, P, Lt), lse_g=mk(B, P),
                              lse_l=mk(B, P)) for _ in range(nsave)]
+        if self.kind == "adaptformer":
+            ws["xa"] = z(M, C, bf16)
+            ws["ad"] = [dict(mean=torch.zeros(M, device=device), rstd=torch.zeros(M, device=device), h16=z(M, self.adim, bf16))
+                        for _ in range(nsave)]
+            if train:
+                ws["dh16"] = z(M, self.adim, bf16)
+                ws["h32"] = torch.zeros((M, self.adim), device=device)
+                ws["dh32"] = torch.zeros((M, self.adim), device=device)
+        if self.kind == "melo":
+            ws["merge32"] = torch.zeros((3 * C, C), device=device)
+            if train:
+                mk = lambda *s_: torch.zeros(s_, device=device)
+                ws["dq32"], ws["dv32"] = mk(M, C), mk(M, C)
+                ws["lu"] = dict(uq=mk(M, self.r), uv=mk(M, self.r), duq=mk(M, self.r), duv=mk(M, self.r))
         if self.kind == "vpt":
             R = (self.depth if self.deep else 1) * self.P
             ws["vproj"] = torch.zeros((R, C), device=device)
@@ -232,7 +250,8 @@ class Engine:
                                 dctx=mk(BN, Lt), dqkv=mk(BN, 3 * Lt), wdelta=mk(BN), dlat=mk(BN, Lt), dn=mk(BN, C))
                 ws["scratch"] = mk(max(ops.outer_scratch_elems(Lt, C), 128 * C, 64 * 3 * Lt * Lt, 64 * ng))
             else:
-                ws["scratch"] = torch.zeros(128 * C, device=device)
+                lat = {"adaptformer": 64, "melo": getattr(self, "r", 4)}.get(self.kind, 1)
+                ws["scratch"] = torch.zeros(max(128 * C, ops.outer_scratch_elems(lat, C)), device=device)
         self._ws = self._wss[key] = ws       # one workspace (and one set of captured graphs) per (batch, mode)
         return ws
 
@@ -322,6 +341,10 @@ class Engine:
             emb = d("deep_prompt_embeddings" if self.deep else "prompt_embeddings").reshape(-1, self.pd)
             ops.small_linear_fwd(emb, d("prompt_proj.weight"), d("prompt_proj.bias"), ws["vproj"], emb.shape[0], self.pd, C)
             ops.rows_broadcast(G0, ws["vproj"][: self.P], None, B, T, 1, self.P, C)
+        if self.kind == "melo":
+            self._melo_merge(ws, train)
+        if self.kind == "adaptformer":
+            self._adapter_shadows(train)
         # ---- layers.  main stream: attention block -> MLP block;  side stream: MWSA -> GPA latents / gates / cross-attention
         gaviko = self.kind == "gaviko"
         side = self._side() if gaviko else None
@@ -341,7 +364,11 @@ class Engine:
                 self._after_main()                                   # G1 ready
                 with torch.cuda.stream(side):
                     self._gpa_fwd_latents(ws, i, si, ws["G1"][si], ws["Lc"][go], M, B)
+            if self.kind == "adaptformer":
+                self._adapter_fwd_down(ws, i, si, ws["G1"][si], Mi)
             self._mlp_block_fwd(ws, i, si, ws["G1"][si], gout, Mi, train)
+            if self.kind == "adaptformer":
+                self._adapter_fwd_up(ws, i, si, gout, Mi)
             if gaviko:
                 self._after_side()                                   # enh ready
                 self._gpa_fwd_up(ws, i, si, ws["G"][go], M)
@@ -527,8 +554,11 @@ class Engine:
             # main stream, MLP block: dG1 = dGout + LN'(fc1^T(GELU'(pre) * fc2^T(dGout)))
             self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i])
             self._gemm(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
+            adapter = self.kind == "adaptformer"
             ops.layernorm_bwd(ws["dx32"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), M, C, dx=dGin, dres=dGout,
-                              dx16=None if gaviko else ws["dG16"])
+                              dx16=None if (gaviko or adapter) else ws["dG16"])
+            if adapter:
+                self._adapter_bwd(ws, gv, i, dGout, dGin, M)                 # adds LN_a'(...) into dG1 and refreshes dG16
             if gaviko:
                 self._after_side()
                 self._gpa_bwd_scatter(ws, i, dGin, ws["dL"][par], M, B)      # dG1 += dzx.Wd (refreshes dG16), dL += dzl.Wd
@@ -538,6 +568,8 @@ class Engine:
             # main stream, attention block: dG0 = dG1 + LN'(qkv^T(attn'(out^T(dG1))))
             self._gemm(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
             ops.attention_bwd(ws["qkv"][i], ws["ctx"][i], ws["dctx"], ws["lse"][i], ws["delta"], ws["dqkv"], B, T, self.heads, 64 ** -0.5)
+            if self.kind == "melo":
+                self._melo_bwd(ws, gv, i, M)
             self._gemm(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
             ops.layernorm_bwd(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGout, dres=dGin, dx16=ws["dG16"])
             if gaviko:
@@ -568,6 +600,10 @@ class Engine:
             return ("local_attns" in name or "prompt_projs" in name or name in ("prompt_embeddings", "prompt_positional_embedding"))
         if self.kind == "vpt":
             return name in ("prompt_proj.weight", "prompt_proj.bias", "deep_prompt_embeddings", "prompt_embeddings")
+        if self.kind == "adaptformer":
+            return "adapter" in name
+        if self.kind == "melo":
+            return ".linear_a_" in name or ".linear_b_" in name
         return False
 
     def _needs_backbone_backward(self) -> bool:
@@ -618,6 +654,87 @@ class Engine:
         ops.skinny_up(lat=bw["dzx"], w=wd, out=dG1, M=M, C=self.C, L=self.Lat, w_layout=1, accumulate=1)
         ops.skinny_up(lat=bw["dzl"], w=wd, out=dLnew, M=B * self.N, C=self.C, L=self.Lat, w_layout=1, accumulate=1)
         ops.cast_bf16(dG1, ws["dG16"])
+
+    # ---- AdaptFormer (adaptformer.py:58-78, 93-97): r = up(ReLU(down(LN_a(x)))), x_out = ff(x) + x + r -----------------------
+    def _adapter_prefix(self, i):
+        return f"transformer.layers.{i}.1"
+
+    def _adapter_shadows(self, train):
+        """bf16 MFMA operands of the TRAINABLE adapter weights, refreshed in place every step (inside the captured graph)."""
+        w = self._w16
+        for i in range(self.depth):
+            p = self._adapter_prefix(i)
+            wd, wu = self._d(p + ".down_adapter_proj.weight"), self._d(p + ".up_adapter_proj.weight")
+            w[f"ad_d{i}"] = ops.cast_bf16(wd, w.get(f"ad_d{i}"))
+            w[f"ad_u{i}"] = ops.cast_bf16(wu, w.get(f"ad_u{i}"))
+            if train:
+                w[f"ad_dT{i}"] = ops.transpose_cast_bf16(wd, w.get(f"ad_dT{i}"))
+                w[f"ad_uT{i}"] = ops.transpose_cast_bf16(wu, w.get(f"ad_uT{i}"))
+
+    def _adapter_fwd_down(self, ws, i, si, g1, M):
+        p, d, ad = self._adapter_prefix(i), self._d, ws["ad"][si]
+        ops.layernorm_fwd(g1, d(p + ".adapter_layer_norm_before.weight"), d(p + ".adapter_layer_norm_before.bias"), M, self.C, y16=ws["xa"],
+                          mean=ad["mean"], rstd=ad["rstd"])
+        self._gemm(ws["xa"], self._w16[f"ad_d{i}"], M, ad["h16"], epilogue=ops.EPI_BIAS_RELU_BF16, bias=d(p + ".down_adapter_proj.bias"))
+
+    def _adapter_fwd_up(self, ws, i, si, gout, M):
+        p = self._adapter_prefix(i)
+        self._gemm(ws["ad"][si]["h16"], self._w16[f"ad_u{i}"], M, gout, epilogue=ops.EPI_BIAS_RES_F32, bias=self._d(p + ".up_adapter_proj.bias"),
+                   res=gout)
+
+    def _adapter_bwd(self, ws, gv, i, dGout, dG1, M):
+        p, d, C, A = self._adapter_prefix(i), self._d, self.C, self.adim
+        ad, w, sc = ws["ad"][i], self._w16, ws["scratch"]
+        g, b = d(p + ".adapter_layer_norm_before.weight"), d(p + ".adapter_layer_norm_before.bias")
+        # up-projection: dh = (dGout . Wu) * [h > 0]; dWu = dGout^T . h; dbu = colsum(dGout)
+        self._gemm(ws["dG16"], w[f"ad_uT{i}"], M, ws["dh16"], epilogue=ops.EPI_RELU_BWD_BF16, aux=ad["h16"])
+        ops.cast_bf16_f32_strided(ad["h16"], ws["h32"], M, A, A)
+        ops.cast_bf16_f32_strided(ws["dh16"], ws["dh32"], M, A, A)
+        ops.outer_reduce(narrow=ws["h32"], wide=dGout, scratch=sc, out=gv[p + ".up_adapter_proj.weight"], colsum=gv[p + ".up_adapter_proj.bias"],
+                         M=M, C=C, L=A, transposed=1, accumulate=0)
+        # down-projection: dxa = dh . Wd; dWd = dh^T . LN_a(G1); dbd = colsum(dh)
+        self._gemm(ws["dh16"], w[f"ad_dT{i}"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
+        ops.outer_reduce(narrow=ws["dh32"], wide=ws["G1"][i], mean=ad["mean"], rstd=ad["rstd"], ln_gamma=g, ln_beta=b, scratch=sc,
+                         out=gv[p + ".down_adapter_proj.weight"], M=M, C=C, L=A, transposed=0, accumulate=0)
+        ops.colsum(ws["dh32"], gv[p + ".down_adapter_proj.bias"], sc, M, A)
+        # trainable LayerNorm in front of the adapter: input gradient accumulates into dG1, affine gradients
+        ops.layernorm_bwd(ws["dx32"], ws["G1"][i], ad["mean"], ad["rstd"], g, M, C, dx=dG1, dres=dG1, dx16=ws["dG16"])
+        ops.layernorm_bwd_affine(ws["dx32"], ws["G1"][i], ad["mean"], ad["rstd"], gv[p + ".adapter_layer_norm_before.weight"],
+                                 gv[p + ".adapter_layer_norm_before.bias"], sc, M, C)
+
+    # ---- MeLO / LoRA (melo.py:41-47): qkv = W x + s B_q A_q x (q columns) + s B_v A_v x (v columns) -------------------------
+    def _lora_names(self, i):
+        q = self.names.attn(i) + ".to_qkv"
+        return q + ".linear_a_q.weight", q + ".linear_b_q.weight", q + ".linear_a_v.weight", q + ".linear_b_v.weight"
+
+    def _melo_merge(self, ws, train):
+        """Fold the rank-r update into the bf16 QKV operand (and its transpose) every step: the forward is then the plain GEMM."""
+        w, C = self._w16, self.C
+        for i in range(self.depth):
+            aq, bq, av, bv = (self._d(n) for n in self._lora_names(i))
+            ops.lora_merge(self._d(self.names.qkv_weight(i)), aq, bq, av, bv, ws["merge32"], C, self.r, self.lora_s)
+            w[f"qkv{i}"] = ops.cast_bf16(ws["merge32"], w.get(f"qkv{i}"))
+            if train:
+                w[f"qkv{i}_t"] = ops.transpose_cast_bf16(ws["merge32"], w.get(f"qkv{i}_t"))
+
+    def _melo_bwd(self, ws, gv, i, M):
+        """dB = s dq^T u, dA = s (dq B)^T LN(x), u = LN(x) A^T -- all rank-r fp32 kernels over the bf16 dq / dv blocks."""
+        C, r, d, sc = self.C, self.r, self._d, ws["scratch"]
+        na_q, nb_q, na_v, nb_v = self._lora_names(i)
+        a = self.names.attn(i)
+        g1, b1, st, x = d(a + ".norm.weight"), d(a + ".norm.bias"), ws["stat"][i], ws["G"][i]
+        lu = ws["lu"]
+        ops.cast_bf16_f32_strided(ws["dqkv"], ws["dq32"], M, C, 3 * C, col0=0)
+        ops.cast_bf16_f32_strided(ws["dqkv"], ws["dv32"], M, C, 3 * C, col0=2 * C)
+        for na, nb, dblk, u, du in ((na_q, nb_q, ws["dq32"], lu["uq"], lu["duq"]), (na_v, nb_v, ws["dv32"], lu["uv"], lu["duv"])):
+            ops.skinny_down(x=x, w=d(na), ln_gamma=g1, ln_beta=b1, y=u, M=M, C=C, L=r, act=0, w_layout=0, eps=1e-5)
+            ops.outer_reduce(narrow=u, wide=dblk, scratch=sc, out=gv[nb], M=M, C=C, L=r, transposed=1, accumulate=0)
+            ops.skinny_down(x=dblk, w=d(nb), y=du, M=M, C=C, L=r, act=0, w_layout=1)
+            ops.outer_reduce(narrow=du, wide=x, mean=st[0], rstd=st[1], ln_gamma=g1, ln_beta=b1, scratch=sc, out=gv[na], M=M, C=C, L=r,
+                             transposed=0, accumulate=0)
+            if self.lora_s != 1:
+                gv[na].mul_(float(self.lora_s))
+                gv[nb].mul_(float(self.lora_s))
 
     def _offset_of(self, name) -> int:
         return (self._flat_grad["views"][name].data_ptr() - self._flat_grad["buf"].data_ptr()) // 4

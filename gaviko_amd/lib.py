@@ -50,7 +50,8 @@ GpaDesc = _struct("GpaDesc",
 HeadDesc = _struct("HeadDesc", ["g", "ln_gamma", "ln_beta", "wh", "bh", "logits", "pooled", "dlogits", "dg", "dwh", "dbh"],
                    ["B", "T", "C", "K", "r0", "R", "accumulate"])
 
-EPI_STORE_BF16, EPI_BIAS_RES_F32, EPI_BIAS_GELU_BF16, EPI_PATCH_F32, EPI_GELU_BWD_BF16, EPI_STORE_F32, EPI_BIAS_RES_F32_BF16 = range(7)
+(EPI_STORE_BF16, EPI_BIAS_RES_F32, EPI_BIAS_GELU_BF16, EPI_PATCH_F32, EPI_GELU_BWD_BF16, EPI_STORE_F32, EPI_BIAS_RES_F32_BF16,
+ EPI_BIAS_RELU_BF16, EPI_RELU_BWD_BF16) = range(9)
 
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 # name -> argtypes (every function returns int and takes the stream last)
@@ -80,6 +81,7 @@ SIGNATURES = {
     "gvk_vpt_repack_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gvk_vpt_repack_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gvk_cast_bf16_f32_strided": [_P, _P, _I, _I, _I, _P],
+    "gvk_lora_merge_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "gvk_head_fwd": [C.POINTER(HeadDesc), _P],
     "gvk_head_bwd": [C.POINTER(HeadDesc), _P],
 }

@@ -11,8 +11,8 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import (EPI_BIAS_GELU_BF16, EPI_BIAS_RES_F32, EPI_BIAS_RES_F32_BF16, EPI_GELU_BWD_BF16, EPI_PATCH_F32,  # noqa: F401
-                  EPI_STORE_BF16, EPI_STORE_F32)
+from .lib import (EPI_BIAS_GELU_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_RES_F32, EPI_BIAS_RES_F32_BF16, EPI_GELU_BWD_BF16,  # noqa: F401
+                  EPI_PATCH_F32, EPI_RELU_BWD_BF16, EPI_STORE_BF16, EPI_STORE_F32)
 
 ROW_PAD = 128
 
@@ -283,3 +283,12 @@ def cast_bf16_f32_strided(inp, out, M, C_, ld_in, col0=0):
     _chk(inp, torch.bfloat16, "cast_bf16_f32 in", M * ld_in)
     _chk(out, torch.float32, "cast_bf16_f32 out", M * C_)
     L.check(L.load().gvk_cast_bf16_f32_strided(inp.data_ptr() + 2 * col0, L.ptr(out), M, C_, ld_in, L.stream_ptr()), "gvk_cast_bf16_f32_strided")
+
+
+def lora_merge(w, a_q, b_q, a_v, b_v, out, C_, r, s):
+    for t, n in ((w, "w"), (a_q, "a_q"), (b_q, "b_q"), (a_v, "a_v"), (b_v, "b_v"), (out, "out")):
+        _chk(t, torch.float32, "lora_merge " + n)
+    if w.numel() != 3 * C_ * C_ or out.numel() < 3 * C_ * C_ or a_q.numel() != r * C_ or b_q.numel() != C_ * r:
+        raise L.GavikoHipError("lora_merge: shape mismatch")
+    L.check(L.load().gvk_lora_merge_f32(L.ptr(w), L.ptr(a_q), L.ptr(b_q), L.ptr(a_v), L.ptr(b_v), L.ptr(out), C_, r, float(s), L.stream_ptr()),
+            "gvk_lora_merge_f32")

@@ -36,7 +36,9 @@ enum gvk_epilogue {
                                  out1 f32 [m][n] (may be NULL) = same value (GAViKO local stream)                 */
   GVK_EPI_GELU_BWD_BF16 = 4,  /* out0 bf16 = acc * GELU'(aux bf16 [m][n])   (fc2 dgrad fused with GELU backward)   */
   GVK_EPI_STORE_F32 = 5,      /* out0 f32  = acc (+bias)                                                          */
-  GVK_EPI_BIAS_RES_F32_BF16 = 6 /* as 1, and out1 bf16 [M][ldo] = same value rounded                              */
+  GVK_EPI_BIAS_RES_F32_BF16 = 6, /* as 1, and out1 bf16 [M][ldo] = same value rounded                             */
+  GVK_EPI_BIAS_RELU_BF16 = 7, /* out0 bf16 = max(acc + bias, 0)          (AdaptFormer down-projection, adaptformer.py:63-64)   */
+  GVK_EPI_RELU_BWD_BF16 = 8   /* out0 bf16 = acc * (aux bf16 [m][n] > 0) (dgrad through that ReLU)                              */
 };
 
 typedef struct gvk_gemm_desc {
@@ -212,6 +214,10 @@ int gvk_small_linear_bwd(const float* x, const float* w, const float* dout, floa
                          int accumulate, void* stream);
 int gvk_vpt_repack_fwd(const float* in, const float* prompt, float* out, int B, int Tin, int Tout, int P, int skip, int C, void* stream);
 int gvk_vpt_repack_bwd(const float* dout, float* din, int B, int Tin, int Tout, int P, int skip, int C, void* stream);
+/* LoRA merge (model/melo.py:41-47): out f32 [3C][C] = W + s * [B_q.A_q ; 0 ; B_v.A_v], s = alpha // r, A [r][C], B [C][r].
+ * The merged matrix is then cast to the bf16 GEMM operand (and its transpose for the dgrad) like any other weight. */
+int gvk_lora_merge_f32(const float* w, const float* a_q, const float* b_q, const float* a_v, const float* b_v, float* out, int C, int r,
+                       float s, void* stream);
 /* bf16 [M][ld_in] column block -> dense f32 [M][C] (gradient blocks handed to the fp32 rank-r kernels) */
 int gvk_cast_bf16_f32_strided(const void* in, float* out, int M, int C, int ld_in, void* stream);
 

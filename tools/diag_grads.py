@@ -3,16 +3,17 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
-from test_model_gpu import build, GAVIKO_CASES, rel
+from test_model_gpu import build, GAVIKO_CASES, PEFT_CASES, rel
 from conftest import golden
 from gaviko_amd.utils import synth
 
 name = sys.argv[1] if len(sys.argv) > 1 else "gaviko_t16_b2"
-case = [c for c in GAVIKO_CASES if c[0] == name][0]
+cases = {c[0]: ("gaviko", c[1], c[2], c[3]) for c in GAVIKO_CASES}
+cases.update({c[0]: (c[1], c[2], c[3], c[4]) for c in PEFT_CASES})
+method, backbone, B, extra = cases[name]
 dev = torch.device("cuda:0")
 g = golden(name)
-m, cfg = build("gaviko", case[1], case[3], dev)
-B = case[2]
+m, cfg = build(method, backbone, extra, dev)
 x = torch.from_numpy(synth.volumes(0, B)).to(dev); y = torch.from_numpy(synth.labels(0, B)).to(dev)
 logits = m(x); torch.nn.functional.cross_entropy(logits, y).backward(); torch.cuda.synchronize()
 named = dict(m.named_parameters())
