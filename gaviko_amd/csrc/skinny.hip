@@ -36,105 +36,136 @@ struct DownArgs {
   unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;   // dropout mask on the INPUT (bwd of proj_drop)
 };
 
-constexpr int kDownRows = 16;      // one row per wave, 16 waves (1024 threads) per workgroup, W staged once in LDS
+constexpr int kDownRows = 16;      // one 16-row MFMA tile per workgroup; the 16 waves split the C (reduction) dimension
 
+// y[16 rows][L] = X[16][C] . W^T on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products and accumulation).
+// Wave w owns the 16-column "super-steps" s = w, w+16, ... of the reduction: a lane (r = lane&15, kq = lane>>4) loads
+// x[row0+r][16s + 4kq .. +3] as one float4 and uses element e as the A operand of MFMA e (k = kq), against
+// W[j = lane&15][16s + 4kq + e] read as one float4 from the LDS copy of W.  Partial 16x32 tiles of the 16 waves are summed
+// through LDS.  A fused LayerNorm is applied algebraically: y = rstd * (x.(g*W) - mean * sum(g*W)) + (beta.W + bias).
 template <int L>
 __global__ __launch_bounds__(1024) void skinny_down_kernel(DownArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = (L + 15) / 16;            // 16-column output tiles
   if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
-  float* ws = (float*)smem;   // [L][C]
-  const int C = p.C;
+  const int C = p.C, Cp = C + 4;               // padded LDS row (keeps the b128 operand reads nearly conflict-free)
+  float* cst = (float*)smem;                   // [2][32]  s1_j = sum_c g_c W_jc, s2_j = sum_c b_c W_jc + bias_j
+  float* stat = cst + 64;                      // [16 waves][16 rows][2] partial sum / sum of squares
+  float* ws = stat + 16 * 16 * 2;              // [L][Cp]  (gamma-folded when LN is fused); reused for the partial tiles
   const int lane = lane_id(), wave = wave_id();
-  const int row = blockIdx.x * kDownRows + wave;
+  const int r = lane & 15, kq = lane >> 4;
+  const int row0 = blockIdx.x * kDownRows, row = row0 + r;
   const bool live = row < p.M;
-  // issue this wave's row loads first: their latency hides behind the weight staging
-  f32x4 v[4];
+  const bool ln = p.ln_g != nullptr;
+  const int nsteps = (C + 15) / 16;
+
+  // ---- issue this wave's x loads first (latency hides behind the weight staging)
+  constexpr int kMaxSteps = 4;                 // C <= 1024 -> at most 4 super-steps per wave
+  f32x4 xv[kMaxSteps];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = k * 256 + lane * 4;
-    v[k] = (live && c < C) ? *(const f32x4*)(p.x + (size_t)row * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < kMaxSteps; ++u) {
+    const int c = 16 * (wave + 16 * u) + 4 * kq;
+    xv[u] = (live && c < C) ? *(const f32x4*)(p.x + (size_t)row * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  if (p.w_layout == 0) {                       // W [L][C]: straight 16-byte copy
-    const int n4 = L * C / 4;
-    for (int i = threadIdx.x; i < n4; i += 1024) *(f32x4*)(ws + 4 * i) = *(const f32x4*)(p.w + 4 * i);
-  } else {                                     // W [C][L]: transpose while staging
-    for (int i = threadIdx.x; i < L * C; i += 1024) {
-      const int c = i / L, j = i - c * L;
-      ws[j * C + c] = p.w[i];
-    }
+  // ---- stage W (optionally gamma-folded) into LDS
+  for (int i = threadIdx.x; i < L * C; i += 1024) {
+    int j, c;
+    float v;
+    if (p.w_layout == 0) { j = i / C; c = i - j * C; v = p.w[i]; }
+    else { c = i / L; j = i - c * L; v = p.w[i]; }
+    if (ln) v *= p.ln_g[c];
+    ws[j * Cp + c] = v;
   }
+  if (threadIdx.x < 64) cst[threadIdx.x] = 0.f;
   __syncthreads();
-  if (!live) return;
-  float s = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = k * 256 + lane * 4;
-    if (p.drop_thresh != 0u && c < C) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[k][e] *= drop_scale(p.seed, (unsigned long long)row * C + c + e, p.drop_thresh, p.inv_keep);
+  // per-output constants (one wave per j): s1_j over the folded LDS copy, s2_j = beta.W_j + bias_j
+  for (int j = wave; j < L; j += 16) {
+    float a1 = 0.f, a2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      a1 += ws[j * Cp + c];
+      if (ln) a2 += p.ln_b[c] * (p.w_layout == 0 ? p.w[(size_t)j * C + c] : p.w[(size_t)c * L + j]);
     }
-    s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+    a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if (lane == 0) { cst[j] = a1; cst[32 + j] = a2 + (p.bias ? p.bias[j] : 0.f); }
   }
-  if (p.ln_g != nullptr) {
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
+  // ---- MFMA over this wave's super-steps, plus the row statistics of its column slice
+  f32x4 acc[NT];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = k * 256 + lane * 4;
-      if (c < C) {
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = v[k][e] - mean; q += d * d; }
+  for (int u = 0; u < kMaxSteps; ++u) {
+    const int st = wave + 16 * u;
+    if (st < nsteps) {
+      const int c = 16 * st + 4 * kq;
+      f32x4 x4 = xv[u];
+      if (p.drop_thresh != 0u && live && c < C) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x4[e] *= drop_scale(p.seed, (unsigned long long)row * C + c + e, p.drop_thresh, p.inv_keep);
       }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + p.eps);
-    if (lane == 0) {
-      if (p.mean) p.mean[row] = mean;
-      if (p.rstd) p.rstd[row] = rstd;
-    }
+      s1 += x4[0] + x4[1] + x4[2] + x4[3];
+      s2 += x4[0] * x4[0] + x4[1] * x4[1] + x4[2] * x4[2] + x4[3] * x4[3];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = k * 256 + lane * 4;
-      if (c < C) {
-        const f32x4 g = *(const f32x4*)(p.ln_g + c);
-        const f32x4 b = *(const f32x4*)(p.ln_b + c);
+      for (int t = 0; t < NT; ++t) {
+        const int j = min(t * 16 + r, L - 1);                       // columns >= L re-read row L-1; their results are discarded
+        const f32x4 w4 = (c < C) ? *(const f32x4*)(ws + j * Cp + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[k][e] = (v[k][e] - mean) * rstd * g[e] + b[e];
+        for (int e = 0; e < 4; ++e) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(x4[e], w4[e], acc[t], 0, 0, 0);
       }
     }
   }
-  float acc[L];
-#pragma unroll
-  for (int j = 0; j < L; ++j) {
-    float a = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = k * 256 + lane * 4;
-      if (c < C) {
-        const f32x4 wv = *(const f32x4*)(ws + j * C + c);
-        a += v[k][0] * wv[0] + v[k][1] * wv[1] + v[k][2] * wv[2] + v[k][3] * wv[3];
-      }
-    }
-    acc[j] = a;
+  if (ln) {
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+    if (kq == 0) { stat[(wave * 16 + r) * 2] = s1; stat[(wave * 16 + r) * 2 + 1] = s2; }
   }
+  __syncthreads();                              // all waves are done reading ws: reuse it for the partial tiles
+  float* part = ws;                             // [16 waves][16 rows][32]
 #pragma unroll
-  for (int j = 0; j < L; ++j) acc[j] = wave_sum(acc[j]);
-  // every lane now holds the L sums; finish (bias, activation) redundantly, lane j stores element j
-  float yv[L];
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-  for (int j = 0; j < L; ++j) {
-    const float zz = acc[j] + (p.bias ? p.bias[j] : 0.f);
-    yv[j] = p.act == 1 ? quick_gelu(zz) : zz;
-    if (lane == j) {
-      if (p.z) p.z[(size_t)row * L + j] = zz;
-      if (p.y) p.y[(size_t)row * L + j] = yv[j];
+    for (int e = 0; e < 4; ++e) part[(wave * 16 + (4 * kq + e)) * 32 + t * 16 + r] = acc[t][e];   // D: row = 4*(lane>>4)+e, col = lane&15
+  __syncthreads();
+  float* yrow = part + 16 * 16 * 32;            // [16][32] finished activations (for the second stage)
+  if (threadIdx.x < 16 * 32) {
+    const int i = threadIdx.x >> 5, j = threadIdx.x & 31;
+    float dot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) dot += part[(w * 16 + i) * 32 + j];
+    float yv = 0.f;
+    if (j < L && row0 + i < p.M) {
+      float zz;
+      if (ln) {
+        float a = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { a += stat[(w * 16 + i) * 2]; q += stat[(w * 16 + i) * 2 + 1]; }
+        const float mean = a / (float)C;
+        const float var = fmaxf(q / (float)C - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + p.eps);
+        if (j == 0) {
+          if (p.mean) p.mean[row0 + i] = mean;
+          if (p.rstd) p.rstd[row0 + i] = rstd;
+        }
+        zz = rstd * (dot - mean * cst[j]) + cst[32 + j];
+      } else {
+        zz = dot + cst[32 + j];
+      }
+      yv = p.act == 1 ? quick_gelu(zz) : zz;
+      if (p.z) p.z[(size_t)(row0 + i) * L + j] = zz;
+      if (p.y) p.y[(size_t)(row0 + i) * L + j] = yv;
     }
+    yrow[i * 32 + j] = yv;
   }
   if (p.w2 != nullptr) {
-    for (int j2 = lane; j2 < p.L2; j2 += 64) {
-      float a = 0.f;
+    __syncthreads();
+    for (int o = threadIdx.x; o < 16 * p.L2; o += 1024) {
+      const int i = o / p.L2, j2 = o - i * p.L2;
+      if (row0 + i < p.M) {
+        float a = 0.f;
 #pragma unroll
-      for (int l = 0; l < L; ++l) a += yv[l] * p.w2[j2 * L + l];
-      p.y2[(size_t)row * p.L2 + j2] = a;
+        for (int l = 0; l < L; ++l) a += yrow[i * 32 + l] * p.w2[j2 * L + l];
+        p.y2[(size_t)(row0 + i) * p.L2 + j2] = a;
+      }
     }
   }
 }
@@ -344,9 +375,67 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   scratch[(size_t)slab * C + c] = a;
 }
 
+// ---- batched small reductions: several independent column sums / (J x L) weight-gradient products in ONE launch.
+// Single stage and deterministic: a workgroup owns up to 64 outputs of one job, its 1024 threads are (output, row slice)
+// pairs, slices are combined through LDS in a fixed order.
+constexpr int kMaxJobs = 8;
+struct ReduceJob { const float* a; const float* b; float* out; int M, J, L, accumulate, wg0, nwg; };
+struct ReduceBatch { ReduceJob job[kMaxJobs]; int njobs; };
+
+__global__ __launch_bounds__(1024) void reduce_batch_kernel(ReduceBatch bt) {
+  __shared__ float red[1024];
+  int ji = 0;
+#pragma unroll
+  for (int k = 1; k < kMaxJobs; ++k)
+    if (k < bt.njobs && (int)blockIdx.x >= bt.job[k].wg0) ji = k;
+  const ReduceJob jb = bt.job[ji];
+  const int nout = jb.b ? jb.J * jb.L : jb.J;
+  const int o0 = ((int)blockIdx.x - jb.wg0) * 64;
+  const int no = min(64, nout - o0);                 // outputs of this workgroup
+  const int nslice = 1024 / 64;                      // 16 row slices per output
+  const int oi = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (oi < no) {
+    const int o = o0 + oi;
+    if (jb.b != nullptr) {
+      const int j = o / jb.L, l = o - j * jb.L;
+      for (int m = sl; m < jb.M; m += 4 * nslice) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int mm = m + u * nslice;
+          av[u] = mm < jb.M ? jb.a[(size_t)mm * jb.J + j] : 0.f;
+          bv[u] = mm < jb.M ? jb.b[(size_t)mm * jb.L + l] : 0.f;
+        }
+        acc += (av[0] * bv[0] + av[1] * bv[1]) + (av[2] * bv[2] + av[3] * bv[3]);
+      }
+    } else {
+      for (int m = sl; m < jb.M; m += 4 * nslice) {
+        float av[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int mm = m + u * nslice;
+          av[u] = mm < jb.M ? jb.a[(size_t)mm * jb.J + o] : 0.f;
+        }
+        acc += (av[0] + av[1]) + (av[2] + av[3]);
+      }
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (sl == 0 && oi < no) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < nslice; ++k) t += red[k * 64 + oi];
+    float* dst = jb.out + o0 + oi;
+    *dst = jb.accumulate ? *dst + t : t;
+  }
+}
+
 template <int L>
 static int launch_down(const DownArgs& a, hipStream_t s) {
-  const int lds = L * a.C * 4;
+  const int lds_w = L * (a.C + 4), lds_p = 16 * 16 * 32 + 16 * 32;      // floats: staged W  vs  partial tiles + finished rows
+  const int lds = ((64 + 16 * 16 * 2) + (lds_w > lds_p ? lds_w : lds_p)) * 4;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_down_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -380,7 +469,7 @@ extern "C" int gvk_skinny_down(const gvk_skinny_down_desc* d, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(d && d->x && d->w && (d->y || d->z || d->y2), "gvk_skinny_down: null pointer");
   GVK_REQUIRE(d->M > 0 && d->C > 0 && d->C % 4 == 0 && d->C <= 1024, "gvk_skinny_down: C=%d must be a multiple of 4 and <= 1024", d->C);
-  GVK_REQUIRE(d->L * d->C * 4 <= 160 * 1024, "gvk_skinny_down: W does not fit the 160 KiB LDS");
+  GVK_REQUIRE((d->L * (d->C + 4) + 576) * 4 <= 160 * 1024, "gvk_skinny_down: W does not fit the 160 KiB LDS");
   GVK_REQUIRE((d->ln_gamma == nullptr) == (d->ln_beta == nullptr), "gvk_skinny_down: LN gamma/beta must come together");
   GVK_REQUIRE(d->w2 == nullptr || (d->y2 != nullptr && d->L2 > 0), "gvk_skinny_down: second stage needs y2 and L2");
   DownArgs a{};
@@ -466,4 +555,21 @@ extern "C" int gvk_colsum(const float* x, float* out, float* scratch, int M, int
   if (rc) return rc;
   hipLaunchKernelGGL(slab_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, s, scratch, out, C, kSlabs, accumulate);
   return check_launch("colsum_final");
+}
+
+extern "C" int gvk_reduce_batch(const gvk_reduce_job* jobs, int njobs, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(jobs && njobs > 0 && njobs <= kMaxJobs, "gvk_reduce_batch: 1..%d jobs per launch", kMaxJobs);
+  ReduceBatch bt{};
+  bt.njobs = njobs;
+  int wg = 0;
+  for (int k = 0; k < njobs; ++k) {
+    const gvk_reduce_job& j = jobs[k];
+    GVK_REQUIRE(j.a && j.out && j.M > 0 && j.J > 0 && (j.b == nullptr || j.L > 0), "gvk_reduce_batch: job %d malformed", k);
+    const int nout = j.b ? j.J * j.L : j.J;
+    bt.job[k] = ReduceJob{j.a, j.b, j.out, j.M, j.J, j.L, j.accumulate, wg, (nout + 63) / 64};
+    wg += (nout + 63) / 64;
+  }
+  hipLaunchKernelGGL(reduce_batch_kernel, dim3(wg), dim3(1024), 0, (hipStream_t)stream, bt);
+  return check_launch("reduce_batch");
 }

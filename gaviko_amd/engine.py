@@ -636,16 +636,17 @@ class Engine:
         first = gv[names["ca0_g"]]
         gate_flat = self._flat_grad["buf"][self._offset_of(names["ca0_g"]): self._offset_of(names["ca0_g"]) + ng]
         assert gate_flat.data_ptr() == first.data_ptr()
-        ops.colsum(bw["gate_partials"], gate_flat, sc, B, ng, accumulate=bool(acc))
-        for wn, bn, dq in (("wgq", "bgq", bw["dqg"]), ("wlq", "blq", bw["dql"])):
-            ops.small_wgrad(dq, g["prm"], gv[names[wn]], sc, B * P, Lt, Lt, accumulate=bool(acc))
-            ops.colsum(dq, gv[names[bn]], sc, B * P, Lt, accumulate=bool(acc))
-        # proj_down (shared by both streams): dWd = dzx^T.G1 + dzl^T.Lnew ; dbd
         gwd, gbd = gv[pre + ".proj_down.0.weight"], gv[pre + ".proj_down.0.bias"]
+        BP = B * P
+        dqg, dql, prm = bw["dqg"].view(BP, Lt), bw["dql"].view(BP, Lt), g["prm"].view(BP, Lt)
+        ops.reduce_batch([(bw["gate_partials"], None, gate_flat, acc),
+                          (dqg, prm, gv[names["wgq"]], acc), (dqg, None, gv[names["bgq"]], acc),
+                          (dql, prm, gv[names["wlq"]], acc), (dql, None, gv[names["blq"]], acc),
+                          (bw["dzx"], None, gbd, acc)])
+        ops.reduce_batch([(bw["dzl"], None, gbd, 1)])
+        # proj_down (shared by both streams): dWd = dzx^T.G1 + dzl^T.Lnew ; dbd
         ops.outer_reduce(narrow=bw["dzx"], wide=ws["G1"][i], scratch=sc, out=gwd, M=M, C=C, L=Lt, transposed=0, accumulate=acc)
         ops.outer_reduce(narrow=bw["dzl"], wide=ws["Lc"][i + 1], scratch=sc, out=gwd, M=B * N, C=C, L=Lt, transposed=0, accumulate=1)
-        ops.colsum(bw["dzx"], gbd, sc, M, Lt, accumulate=bool(acc))
-        ops.colsum(bw["dzl"], gbd, sc, B * N, Lt, accumulate=True)
 
     def _gpa_bwd_scatter(self, ws, i, dG1, dLnew, M, B):
         """dG1 += dzx . Wd ; dLnew += dzl . Wd ; bf16 copy of dG1 for the out-proj dgrad."""
@@ -756,13 +757,13 @@ class Engine:
                             D=self.grid[0], H=self.grid[1], W=self.grid[2], kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt,
                             scale=C ** -0.5, drop_p=sv["attn_drop"], seed=seed_a, seed_ptr=sp)
         wqkv = d(pre + ".qkv.weight")
-        ops.small_wgrad(bw["dqkv"], m["lat"], gv[pre + ".qkv.weight"], sc, BN, 3 * Lt, Lt, accumulate=bool(acc))
+        ops.reduce_batch([(bw["dqkv"], m["lat"], gv[pre + ".qkv.weight"], acc)])
         ops.skinny_down(x=bw["dqkv"], w=wqkv, y=bw["dlat"], M=BN, C=3 * Lt, L=Lt, act=0, w_layout=1)
         wd = d(pre + ".proj_down.weight")
         ops.outer_reduce(narrow=bw["dlat"], wide=lin, mean=m["mean"], rstd=m["rstd"], ln_gamma=d(pre + ".norm.weight"),
                          ln_beta=d(pre + ".norm.bias"), scratch=sc, out=gv[pre + ".proj_down.weight"], M=BN, C=C, L=Lt, transposed=0,
                          accumulate=acc)
-        ops.colsum(bw["dlat"], gv[pre + ".proj_down.bias"], sc, BN, Lt, accumulate=bool(acc))
+        ops.reduce_batch([(bw["dlat"], None, gv[pre + ".proj_down.bias"], acc)])
         ops.skinny_up(lat=bw["dlat"], w=wd, out=bw["dn"], M=BN, C=C, L=Lt, w_layout=1)
         ops.layernorm_bwd(bw["dn"], lin, m["mean"], m["rstd"], d(pre + ".norm.weight"), BN, C, dx=dLin, dres=dLout)
         ops.layernorm_bwd_affine(bw["dn"], lin, m["mean"], m["rstd"], gv[pre + ".norm.weight"], gv[pre + ".norm.bias"], sc, BN, C,

@@ -47,6 +47,7 @@ GpaDesc = _struct("GpaDesc",
                    "dcomb", "zx", "zl", "dimp", "dgw_part", "dqg", "dql", "dcg", "dcl", "delta_g", "delta_l", "dprm",
                    "dcls", "gate_partials", "dzx", "dzl"],
                   ["B", "T", "N", "P", "L"], ["scale"])
+ReduceJob = _struct("ReduceJob", ["a", "b", "out"], ["M", "J", "L", "accumulate"])
 HeadDesc = _struct("HeadDesc", ["g", "ln_gamma", "ln_beta", "wh", "bh", "logits", "pooled", "dlogits", "dg", "dwh", "dbh"],
                    ["B", "T", "C", "K", "r0", "R", "accumulate"])
 
@@ -70,6 +71,7 @@ SIGNATURES = {
     "gvk_outer_reduce": [C.POINTER(OuterDesc), _P],
     "gvk_small_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gvk_colsum": [_P, _P, _P, _I, _I, _I, _P],
+    "gvk_reduce_batch": [C.POINTER(ReduceJob), _I, _P],
     "gvk_window_attn_fwd": [C.POINTER(WindowAttnDesc), _P],
     "gvk_window_attn_bwd": [C.POINTER(WindowAttnDesc), _P],
     "gvk_gpa_fwd": [C.POINTER(GpaDesc), _P],
@@ -88,7 +90,7 @@ SIGNATURES = {
 NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, []), "gvk_abi_version": (C.c_int, []),
              "gvk_gpa_gate_param_count": (C.c_int, [C.c_int, C.c_int])}
 STRUCTS = {"gvk_gemm_desc": GemmDesc, "gvk_skinny_down_desc": SkinnyDownDesc, "gvk_skinny_up_desc": SkinnyUpDesc,
-           "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc}
+           "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob}
 
 _lib = None
 

@@ -292,3 +292,20 @@ def lora_merge(w, a_q, b_q, a_v, b_v, out, C_, r, s):
         raise L.GavikoHipError("lora_merge: shape mismatch")
     L.check(L.load().gvk_lora_merge_f32(L.ptr(w), L.ptr(a_q), L.ptr(b_q), L.ptr(a_v), L.ptr(b_v), L.ptr(out), C_, r, float(s), L.stream_ptr()),
             "gvk_lora_merge_f32")
+
+
+def reduce_batch(jobs):
+    """jobs: list of (a [M,J], b [M,L] or None, out, accumulate).  One launch for up to 8 small column-sum / J x L wgrad reductions."""
+    arr = (L.ReduceJob * len(jobs))()
+    for k, (a, b, out, acc) in enumerate(jobs):
+        _chk(a, torch.float32, "reduce_batch a")
+        _chk(b, torch.float32, "reduce_batch b")
+        _chk(out, torch.float32, "reduce_batch out")
+        M, J = a.shape[0], a.numel() // a.shape[0]
+        Lb = 0 if b is None else b.numel() // b.shape[0]
+        if b is not None and b.shape[0] != M:
+            raise L.GavikoHipError("reduce_batch: a and b must have the same number of rows")
+        if out.numel() < (J * Lb if b is not None else J):
+            raise L.GavikoHipError("reduce_batch: out too small")
+        arr[k] = L.ReduceJob(L.ptr(a), L.ptr(b), L.ptr(out), M, J, Lb, int(bool(acc)))
+    L.check(L.load().gvk_reduce_batch(arr, len(jobs), L.stream_ptr()), "gvk_reduce_batch")
