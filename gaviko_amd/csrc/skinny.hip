@@ -375,47 +375,50 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   scratch[(size_t)slab * C + c] = a;
 }
 
-// ---- batched small reductions: several independent column sums / (J x L) weight-gradient products in ONE launch.
-// Single stage and deterministic: a workgroup owns up to 64 outputs of one job, its 1024 threads are (output, row slice)
-// pairs, slices are combined through LDS in a fixed order.
+// ---- batched small reductions: several independent column sums / (J x L) weight-gradient products in TWO launches.
+// Deterministic: stage 1 = (job, 64-output chunk, row slab) workgroups whose 1024 threads are (output, row slice) pairs
+// combined through LDS in a fixed order; stage 2 sums the kRedSlabs partials of every output of every job.
 constexpr int kMaxJobs = 8;
-struct ReduceJob { const float* a; const float* b; float* out; int M, J, L, accumulate, wg0, nwg; };
-struct ReduceBatch { ReduceJob job[kMaxJobs]; int njobs; };
+constexpr int kRedSlabs = 32;
+struct ReduceJob { const float* a; const float* b; float* out; int M, J, L, accumulate, wg0, o_base; };
+struct ReduceBatch { ReduceJob job[kMaxJobs]; int njobs; float* scratch; int total_out; };
 
-__global__ __launch_bounds__(1024) void reduce_batch_kernel(ReduceBatch bt) {
+__global__ __launch_bounds__(1024) void reduce_batch_partial_kernel(ReduceBatch bt) {
   __shared__ float red[1024];
   int ji = 0;
 #pragma unroll
   for (int k = 1; k < kMaxJobs; ++k)
     if (k < bt.njobs && (int)blockIdx.x >= bt.job[k].wg0) ji = k;
   const ReduceJob jb = bt.job[ji];
+  const int slab = blockIdx.y;
   const int nout = jb.b ? jb.J * jb.L : jb.J;
   const int o0 = ((int)blockIdx.x - jb.wg0) * 64;
-  const int no = min(64, nout - o0);                 // outputs of this workgroup
-  const int nslice = 1024 / 64;                      // 16 row slices per output
-  const int oi = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int no = min(64, nout - o0);
+  const int rows_per = (jb.M + kRedSlabs - 1) / kRedSlabs;
+  const int r0 = slab * rows_per, r1 = min(jb.M, r0 + rows_per);
+  const int oi = threadIdx.x & 63, sl = threadIdx.x >> 6;     // 16 row slices
   float acc = 0.f;
   if (oi < no) {
     const int o = o0 + oi;
     if (jb.b != nullptr) {
       const int j = o / jb.L, l = o - j * jb.L;
-      for (int m = sl; m < jb.M; m += 4 * nslice) {
+      for (int m = r0 + sl; m < r1; m += 64) {
         float av[4], bv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int mm = m + u * nslice;
-          av[u] = mm < jb.M ? jb.a[(size_t)mm * jb.J + j] : 0.f;
-          bv[u] = mm < jb.M ? jb.b[(size_t)mm * jb.L + l] : 0.f;
+          const int mm = m + u * 16;
+          av[u] = mm < r1 ? jb.a[(size_t)mm * jb.J + j] : 0.f;
+          bv[u] = mm < r1 ? jb.b[(size_t)mm * jb.L + l] : 0.f;
         }
         acc += (av[0] * bv[0] + av[1] * bv[1]) + (av[2] * bv[2] + av[3] * bv[3]);
       }
     } else {
-      for (int m = sl; m < jb.M; m += 4 * nslice) {
+      for (int m = r0 + sl; m < r1; m += 64) {
         float av[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int mm = m + u * nslice;
-          av[u] = mm < jb.M ? jb.a[(size_t)mm * jb.J + o] : 0.f;
+          const int mm = m + u * 16;
+          av[u] = mm < r1 ? jb.a[(size_t)mm * jb.J + o] : 0.f;
         }
         acc += (av[0] + av[1]) + (av[2] + av[3]);
       }
@@ -426,10 +429,27 @@ __global__ __launch_bounds__(1024) void reduce_batch_kernel(ReduceBatch bt) {
   if (sl == 0 && oi < no) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < nslice; ++k) t += red[k * 64 + oi];
-    float* dst = jb.out + o0 + oi;
-    *dst = jb.accumulate ? *dst + t : t;
+    for (int k = 0; k < 16; ++k) t += red[k * 64 + oi];
+    bt.scratch[(size_t)slab * bt.total_out + jb.o_base + o0 + oi] = t;
   }
+}
+
+__global__ __launch_bounds__(256) void reduce_batch_final_kernel(ReduceBatch bt) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= bt.total_out) return;
+  int ji = 0;
+#pragma unroll
+  for (int k = 1; k < kMaxJobs; ++k)
+    if (k < bt.njobs && g >= bt.job[k].o_base) ji = k;
+  float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < kRedSlabs; s += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a4[u] += bt.scratch[(size_t)(s + u) * bt.total_out + g];
+  }
+  const float t = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  float* dst = bt.job[ji].out + (g - bt.job[ji].o_base);
+  *dst = bt.job[ji].accumulate ? *dst + t : t;
 }
 
 template <int L>
@@ -557,19 +577,26 @@ extern "C" int gvk_colsum(const float* x, float* out, float* scratch, int M, int
   return check_launch("colsum_final");
 }
 
-extern "C" int gvk_reduce_batch(const gvk_reduce_job* jobs, int njobs, void* stream) {
+extern "C" int gvk_reduce_batch(const gvk_reduce_job* jobs, int njobs, float* scratch, void* stream) {
   using namespace gvk;
-  GVK_REQUIRE(jobs && njobs > 0 && njobs <= kMaxJobs, "gvk_reduce_batch: 1..%d jobs per launch", kMaxJobs);
+  GVK_REQUIRE(jobs && scratch && njobs > 0 && njobs <= kMaxJobs, "gvk_reduce_batch: 1..%d jobs per launch, scratch required", kMaxJobs);
   ReduceBatch bt{};
   bt.njobs = njobs;
-  int wg = 0;
+  bt.scratch = scratch;
+  int wg = 0, ob = 0;
   for (int k = 0; k < njobs; ++k) {
     const gvk_reduce_job& j = jobs[k];
     GVK_REQUIRE(j.a && j.out && j.M > 0 && j.J > 0 && (j.b == nullptr || j.L > 0), "gvk_reduce_batch: job %d malformed", k);
     const int nout = j.b ? j.J * j.L : j.J;
-    bt.job[k] = ReduceJob{j.a, j.b, j.out, j.M, j.J, j.L, j.accumulate, wg, (nout + 63) / 64};
+    bt.job[k] = ReduceJob{j.a, j.b, j.out, j.M, j.J, j.L, j.accumulate, wg, ob};
     wg += (nout + 63) / 64;
+    ob += nout;
   }
-  hipLaunchKernelGGL(reduce_batch_kernel, dim3(wg), dim3(1024), 0, (hipStream_t)stream, bt);
-  return check_launch("reduce_batch");
+  bt.total_out = ob;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(reduce_batch_partial_kernel, dim3(wg, kRedSlabs), dim3(1024), 0, s, bt);
+  int rc = check_launch("reduce_batch/partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_batch_final_kernel, dim3((ob + 255) / 256), dim3(256), 0, s, bt);
+  return check_launch("reduce_batch/final");
 }

@@ -249,6 +249,7 @@ class Engine:
                                 gate_partials=mk(B, ng), dzx=mk(M, Lt), dzl=mk(BN, Lt),
                                 dctx=mk(BN, Lt), dqkv=mk(BN, 3 * Lt), wdelta=mk(BN), dlat=mk(BN, Lt), dn=mk(BN, C))
                 ws["scratch"] = mk(max(ops.outer_scratch_elems(Lt, C), 128 * C, 64 * 3 * Lt * Lt, 64 * ng))
+                ws["rscratch"] = mk(32 * (ng + 2 * Lt * Lt + 3 * Lt + 3 * Lt * Lt + 64))
             else:
                 lat = {"adaptformer": 64, "melo": getattr(self, "r", 4)}.get(self.kind, 1)
                 ws["scratch"] = torch.zeros(max(128 * C, ops.outer_scratch_elems(lat, C)), device=device)
@@ -642,8 +643,8 @@ class Engine:
         ops.reduce_batch([(bw["gate_partials"], None, gate_flat, acc),
                           (dqg, prm, gv[names["wgq"]], acc), (dqg, None, gv[names["bgq"]], acc),
                           (dql, prm, gv[names["wlq"]], acc), (dql, None, gv[names["blq"]], acc),
-                          (bw["dzx"], None, gbd, acc)])
-        ops.reduce_batch([(bw["dzl"], None, gbd, 1)])
+                          (bw["dzx"], None, gbd, acc)], ws["rscratch"])
+        ops.reduce_batch([(bw["dzl"], None, gbd, 1)], ws["rscratch"])
         # proj_down (shared by both streams): dWd = dzx^T.G1 + dzl^T.Lnew ; dbd
         ops.outer_reduce(narrow=bw["dzx"], wide=ws["G1"][i], scratch=sc, out=gwd, M=M, C=C, L=Lt, transposed=0, accumulate=acc)
         ops.outer_reduce(narrow=bw["dzl"], wide=ws["Lc"][i + 1], scratch=sc, out=gwd, M=B * N, C=C, L=Lt, transposed=0, accumulate=1)
@@ -757,13 +758,13 @@ class Engine:
                             D=self.grid[0], H=self.grid[1], W=self.grid[2], kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt,
                             scale=C ** -0.5, drop_p=sv["attn_drop"], seed=seed_a, seed_ptr=sp)
         wqkv = d(pre + ".qkv.weight")
-        ops.reduce_batch([(bw["dqkv"], m["lat"], gv[pre + ".qkv.weight"], acc)])
+        ops.reduce_batch([(bw["dqkv"], m["lat"], gv[pre + ".qkv.weight"], acc)], ws["rscratch"])
         ops.skinny_down(x=bw["dqkv"], w=wqkv, y=bw["dlat"], M=BN, C=3 * Lt, L=Lt, act=0, w_layout=1)
         wd = d(pre + ".proj_down.weight")
         ops.outer_reduce(narrow=bw["dlat"], wide=lin, mean=m["mean"], rstd=m["rstd"], ln_gamma=d(pre + ".norm.weight"),
                          ln_beta=d(pre + ".norm.bias"), scratch=sc, out=gv[pre + ".proj_down.weight"], M=BN, C=C, L=Lt, transposed=0,
                          accumulate=acc)
-        ops.reduce_batch([(bw["dlat"], None, gv[pre + ".proj_down.bias"], acc)])
+        ops.reduce_batch([(bw["dlat"], None, gv[pre + ".proj_down.bias"], acc)], ws["rscratch"])
         ops.skinny_up(lat=bw["dlat"], w=wd, out=bw["dn"], M=BN, C=C, L=Lt, w_layout=1)
         ops.layernorm_bwd(bw["dn"], lin, m["mean"], m["rstd"], d(pre + ".norm.weight"), BN, C, dx=dLin, dres=dLout)
         ops.layernorm_bwd_affine(bw["dn"], lin, m["mean"], m["rstd"], gv[pre + ".norm.weight"], gv[pre + ".norm.bias"], sc, BN, C,

@@ -71,7 +71,7 @@ SIGNATURES = {
     "gvk_outer_reduce": [C.POINTER(OuterDesc), _P],
     "gvk_small_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gvk_colsum": [_P, _P, _P, _I, _I, _I, _P],
-    "gvk_reduce_batch": [C.POINTER(ReduceJob), _I, _P],
+    "gvk_reduce_batch": [C.POINTER(ReduceJob), _I, _P, _P],
     "gvk_window_attn_fwd": [C.POINTER(WindowAttnDesc), _P],
     "gvk_window_attn_bwd": [C.POINTER(WindowAttnDesc), _P],
     "gvk_gpa_fwd": [C.POINTER(GpaDesc), _P],

@@ -294,9 +294,11 @@ def lora_merge(w, a_q, b_q, a_v, b_v, out, C_, r, s):
             "gvk_lora_merge_f32")
 
 
-def reduce_batch(jobs):
-    """jobs: list of (a [M,J], b [M,L] or None, out, accumulate).  One launch for up to 8 small column-sum / J x L wgrad reductions."""
+def reduce_batch(jobs, scratch):
+    """jobs: list of (a [M,J], b [M,L] or None, out, accumulate).  One launch pair for up to 8 small column-sum / J x L wgrad
+    reductions; scratch f32 >= 32 * total outputs."""
     arr = (L.ReduceJob * len(jobs))()
+    total = 0
     for k, (a, b, out, acc) in enumerate(jobs):
         _chk(a, torch.float32, "reduce_batch a")
         _chk(b, torch.float32, "reduce_batch b")
@@ -307,5 +309,7 @@ def reduce_batch(jobs):
             raise L.GavikoHipError("reduce_batch: a and b must have the same number of rows")
         if out.numel() < (J * Lb if b is not None else J):
             raise L.GavikoHipError("reduce_batch: out too small")
+        total += J * Lb if b is not None else J
         arr[k] = L.ReduceJob(L.ptr(a), L.ptr(b), L.ptr(out), M, J, Lb, int(bool(acc)))
-    L.check(L.load().gvk_reduce_batch(arr, len(jobs), L.stream_ptr()), "gvk_reduce_batch")
+    _chk(scratch, torch.float32, "reduce_batch scratch", 32 * total)
+    L.check(L.load().gvk_reduce_batch(arr, len(jobs), L.ptr(scratch), L.stream_ptr()), "gvk_reduce_batch")

@@ -138,13 +138,14 @@ typedef struct gvk_outer_desc {
 int gvk_outer_reduce(const gvk_outer_desc* d, void* stream);
 /* out[j][l] (+)= sum_m a[m][j] * b[m][l]  (J, L <= 64); scratch f32 [64*J*L] */
 int gvk_small_wgrad(const float* a, const float* b, float* out, float* scratch, int M, int J, int L, int accumulate, void* stream);
-/* Several small reductions in ONE launch (deterministic, single stage).  b == NULL: out[j] (+)= sum_m a[m][j], j < J.
- * b != NULL: out[j][l] (+)= sum_m a[m][j] * b[m][l].  Up to 8 jobs per call. */
+/* Several small reductions batched into one pair of launches (deterministic, two stages).  b == NULL: out[j] (+)= sum_m a[m][j],
+ * j < J.  b != NULL: out[j][l] (+)= sum_m a[m][j] * b[m][l].  Up to 8 jobs per call; jobs of one call must not share `out`.
+ * scratch: f32 [32 * total number of outputs]. */
 typedef struct gvk_reduce_job {
   const float* a; const float* b; float* out;
   int32_t M, J, L, accumulate;
 } gvk_reduce_job;
-int gvk_reduce_batch(const gvk_reduce_job* jobs, int njobs, void* stream);
+int gvk_reduce_batch(const gvk_reduce_job* jobs, int njobs, float* scratch, void* stream);
 /* out[c] (+)= sum_m x[m][c]; scratch f32 [64*C] */
 int gvk_colsum(const float* x, float* out, float* scratch, int M, int C, int accumulate, void* stream);
 
