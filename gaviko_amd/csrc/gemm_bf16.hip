@@ -27,12 +27,22 @@ struct GemmArgs {
   int nbm, nbn;
 };
 
-template <int BM, int BN, int EPI>
+// LDS swizzles (applied to the 16-byte chunk index of a tile row; conflict-free for the ds_read_b128 lane groups):
+//   BK = 64: 128-byte rows, chunk ^ ((row >> 1) & 7);   BK = 32: 64-byte rows, chunk ^ {0,2,3,1}[(row >> 2) & 3]
+template <int BK>
+__device__ __forceinline__ int swz_chunk(int row) {
+  if constexpr (BK == 64) return (row >> 1) & 7;
+  else return (0x78 >> (((row >> 2) & 3) * 2)) & 3;      // 0b01'11'10'00 -> 0,2,3,1
+}
+
+template <int BM, int BN, int EPI, int BK = 64>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
-  constexpr int BK = 64;
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NT = WN / 16;
-  constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+  constexpr int ROWB = BK * 2;                       // bytes per LDS tile row
+  constexpr int RPI = 1024 / ROWB;                   // rows covered by one 1-KiB wave LDS-DMA instruction
+  constexpr int CPR = ROWB / 16;                     // 16-byte chunks per row
+  constexpr int A_BYTES = BM * ROWB, W_BYTES = BN * ROWB, STAGE = A_BYTES + W_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // XCD-aware bijective remap: blocks b, b+8, ... share an XCD (own L2); give each XCD a contiguous run of tiles.
@@ -57,18 +67,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     char* sA = smem + buf * STAGE;
     char* sW = sA + A_BYTES;
     const int k0 = kt * BK;
-    const int rsub = lane >> 3, slot = lane & 7;
+    const int rsub = lane / CPR, slot = lane % CPR;
 #pragma unroll
-    for (int r = 0; r < BM / 32; ++r) {
-      const int row = r * 32 + wave * 8 + rsub;
-      const int chunk = slot ^ ((row >> 1) & 7);
-      glds16(Ag + (size_t)row * p.lda + k0 + chunk * 8, sA + (r * 32 + wave * 8) * 128);
+    for (int r = 0; r < BM / (4 * RPI); ++r) {
+      const int row = (r * 4 + wave) * RPI + rsub;
+      const int chunk = slot ^ swz_chunk<BK>(row);
+      glds16(Ag + (size_t)row * p.lda + k0 + chunk * 8, sA + (r * 4 + wave) * 1024);
     }
 #pragma unroll
-    for (int r = 0; r < BN / 32; ++r) {
-      const int row = r * 32 + wave * 8 + rsub;
-      const int chunk = slot ^ ((row >> 1) & 7);
-      glds16(Wg + (size_t)row * p.ldw + k0 + chunk * 8, sW + (r * 32 + wave * 8) * 128);
+    for (int r = 0; r < BN / (4 * RPI); ++r) {
+      const int row = (r * 4 + wave) * RPI + rsub;
+      const int chunk = slot ^ swz_chunk<BK>(row);
+      glds16(Wg + (size_t)row * p.ldw + k0 + chunk * 8, sW + (r * 4 + wave) * 1024);
     }
   };
 
@@ -87,18 +97,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     const char* sA = smem + buf * STAGE;
     const char* sW = sA + A_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8 xa[MT], wb[NT];
       const int chunk = ks * 4 + lq;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int row = wm * WM + i * 16 + l15;
-        xa[i] = *(const bf16x8*)(sA + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        xa[i] = *(const bf16x8*)(sA + row * ROWB + ((chunk ^ swz_chunk<BK>(row)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int row = wn * WN + j * 16 + l15;
-        wb[j] = *(const bf16x8*)(sW + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        wb[j] = *(const bf16x8*)(sW + row * ROWB + ((chunk ^ swz_chunk<BK>(row)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -172,12 +182,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int EPI>
+template <int BM, int BN, int EPI, int BK = 64>
 static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
-  constexpr int lds = 2 * (BM + BN) * 128;
+  constexpr int lds = 2 * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, EPI, BK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(gemm %dx%d): %s", BM, BN, hipGetErrorString(e));
     attr_set = true;
@@ -185,7 +195,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   GemmArgs p = a;
   p.nbm = (a.M + BM - 1) / BM;
   p.nbn = a.N / BN;
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, EPI>), dim3(p.nbm * p.nbn), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, EPI, BK>), dim3(p.nbm * p.nbn), dim3(256), lds, stream, p);
   return check_launch("gemm_nt_bf16");
 }
 
@@ -203,6 +213,9 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     case 128064: return launch_gemm<128, 64, EPI>(a, stream);
     case 64128: return launch_gemm<64, 128, EPI>(a, stream);
     case 64064: return launch_gemm<64, 64, EPI>(a, stream);
+    case 32128128: return launch_gemm<128, 128, EPI, 32>(a, stream);      // BK = 32 variants: half the LDS, ~2x the resident workgroups
+    case 32128064: return launch_gemm<128, 64, EPI, 32>(a, stream);
+    case 32064128: return launch_gemm<64, 128, EPI, 32>(a, stream);
     default: return set_error(-2, "gvk_gemm_nt_bf16: unsupported tile %d", tile);
   }
 }
@@ -220,6 +233,7 @@ extern "C" int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream) {
   GVK_REQUIRE(d->ldo % 4 == 0 && d->ldo >= d->N, "gvk_gemm_nt_bf16: ldo=%d must be >= N and a multiple of 4", d->ldo);
   if (d->tile != 0) {
     const int bn = d->tile % 1000;
+    GVK_REQUIRE(d->tile < 1000000 || d->K % 32 == 0, "gvk_gemm_nt_bf16: K not a multiple of 32");
     GVK_REQUIRE(bn > 0 && d->N % bn == 0, "gvk_gemm_nt_bf16: N=%d not a multiple of the tile's BN", d->N);
   }
   GemmArgs a{};

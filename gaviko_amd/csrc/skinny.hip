@@ -254,54 +254,96 @@ constexpr int kSlabs = 64;          // row slabs of the small two-stage reductio
 constexpr int kOuterSlabs = 128;    // row slabs of the outer-product reduction
 constexpr int kOuterMaxRows = 80;   // rows of one slab staged in LDS (M <= kOuterSlabs * kOuterMaxRows)
 
+// Partial outer products on the fp32 matrix cores: D[l][c] += sum over a slab of rows m of narrow'[m][l] * wide'[m][c], where
+// narrow' has an extra column of ones (row L of D is the column sum of wide').  A wave owns 64 columns of one row slab:
+// per k-step of 4 rows a lane (j = lane&15, kq = lane>>4) loads wide[m0+kq][c0 + 4j .. +3] as one float4 and feeds element e to
+// MFMA e, so accumulator tile e holds the interleaved columns c0 + 4j + e.  The slab's narrow rows / LN statistics sit in LDS.
 template <int L>
 __global__ __launch_bounds__(256) void outer_partial_kernel(OuterArgs p) {
   if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
-  __shared__ float nar[kOuterMaxRows][L];
+  constexpr int NT = (L + 1 + 15) / 16;              // 16-row tiles of the (L+1)-row result
+  __shared__ float nar[kOuterMaxRows][NT * 16];
   __shared__ float st[kOuterMaxRows][2];
-  const int C = p.C, c = blockIdx.x * 256 + threadIdx.x, slab = blockIdx.y;
+  const int C = p.C, slab = blockIdx.y;
+  const int lane = lane_id(), wave = wave_id();
+  const int j = lane & 15, kq = lane >> 4;
+  const int c0 = (blockIdx.x * 4 + wave) * 64, c = c0 + 4 * j;
   const int rows_per = (p.M + kOuterSlabs - 1) / kOuterSlabs;
   const int r0 = slab * rows_per, r1 = min(p.M, r0 + rows_per);
   const int nr = max(0, r1 - r0);
-  for (int i = threadIdx.x; i < nr * L; i += 256) {
-    const int r = i / L, l = i - r * L, m = r0 + r;
-    const float* src = p.narrow + (size_t)m * L;
-    if (p.lat_override != nullptr) {
-      const int s = m / p.T, t = m - s * p.T;
-      if (t < p.P) src = p.lat_override + ((size_t)s * p.P + t) * L;
+  for (int i = threadIdx.x; i < nr * NT * 16; i += 256) {
+    const int r = i / (NT * 16), l = i - r * (NT * 16), m = r0 + r;
+    float v = 0.f;
+    if (l < L) {
+      const float* src = p.narrow + (size_t)m * L;
+      if (p.lat_override != nullptr) {
+        const int s = m / p.T, t = m - s * p.T;
+        if (t < p.P) src = p.lat_override + ((size_t)s * p.P + t) * L;
+      }
+      v = src[l];
+    } else if (l == L) {
+      v = 1.f;
     }
-    nar[r][l] = src[l];
+    nar[r][l] = v;
   }
   if (p.mean != nullptr && (int)threadIdx.x < nr) {
     st[threadIdx.x][0] = p.mean[r0 + threadIdx.x];
     st[threadIdx.x][1] = p.rstd[r0 + threadIdx.x];
   }
   __syncthreads();
-  float acc[L + 1];
+  if (c0 >= C) return;
+  f32x4 acc[NT][4];
 #pragma unroll
-  for (int l = 0; l <= L; ++l) acc[l] = 0.f;
-  if (c < C) {
-    const float g = p.ln_g ? p.ln_g[c] : 1.f, bt = p.ln_b ? p.ln_b[c] : 0.f;
-    for (int rb = 0; rb < nr; rb += 8) {
-      float w[8];
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) w[u] = (rb + u < nr) ? p.wide[(size_t)(r0 + rb + u) * C + c] : 0.f;   // 8 loads in flight
+    for (int e = 0; e < 4; ++e) acc[t][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool cok = c < C;
+  f32x4 g4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.ln_g != nullptr && cok) { g4 = *(const f32x4*)(p.ln_g + c); b4 = *(const f32x4*)(p.ln_b + c); }
+  for (int rb = 0; rb < nr; rb += 16) {
+    f32x4 x[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (rb + u < nr) {
-          const int r = rb + u, m = r0 + r;
-          float x = w[u];
-          if (p.drop_thresh != 0u) x *= drop_scale(p.seed, (unsigned long long)m * C + c, p.drop_thresh, p.inv_keep);
-          if (p.mean != nullptr) x = (x - st[r][0]) * st[r][1] * g + bt;
+    for (int u = 0; u < 4; ++u) {                      // 4 k-steps (16 rows) of loads in flight
+      const int r = rb + 4 * u + kq;
+      x[u] = (r < nr && cok) ? *(const f32x4*)(p.wide + (size_t)(r0 + r) * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
-          for (int l = 0; l < L; ++l) acc[l] += nar[r][l] * x;
-          acc[L] += x;
+    for (int u = 0; u < 4; ++u) {
+      const int r = rb + 4 * u + kq;
+      const bool ok = r < nr && cok;
+      f32x4 xv = x[u];
+      if (ok) {
+        if (p.drop_thresh != 0u) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[e] *= drop_scale(p.seed, (unsigned long long)(r0 + r) * C + c + e, p.drop_thresh, p.inv_keep);
+        }
+        if (p.mean != nullptr) {
+          const float mu = st[r][0], rs = st[r][1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[e] = (xv[e] - mu) * rs * g4[e] + b4[e];
+        }
+      }
+      if (rb + 4 * u < nr) {                            // wave-uniform: skip k-steps entirely past the slab
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float a = (r < nr) ? nar[r][t * 16 + j] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xv[e], acc[t][e], 0, 0, 0);
         }
       }
     }
-#pragma unroll
-    for (int l = 0; l <= L; ++l) p.scratch[((size_t)slab * (L + 1) + l) * C + c] = acc[l];
   }
+  if (!cok) return;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int l = t * 16 + 4 * kq + q;               // D row = 4*(lane>>4) + reg
+      if (l <= L) {
+        f32x4 o = {acc[t][0][q], acc[t][1][q], acc[t][2][q], acc[t][3][q]};   // columns c .. c+3
+        *(f32x4*)(p.scratch + ((size_t)slab * (L + 1) + l) * C + c) = o;
+      }
+    }
 }
 
 // out[l][c] (transposed=0) or out[c][l] (transposed=1); colsum[c] optional
@@ -472,7 +514,7 @@ static int launch_up(const UpArgs& a, hipStream_t s) {
 }
 template <int L>
 static int launch_outer(const OuterArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL((outer_partial_kernel<L>), dim3((a.C + 255) / 256, kOuterSlabs), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((outer_partial_kernel<L>), dim3((a.C + 255) / 256, kOuterSlabs), dim3(256), 0, s, a);   // 4 waves x 64 columns
   return check_launch("outer_partial");
 }
 
@@ -531,7 +573,7 @@ extern "C" int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream) {
 extern "C" int gvk_outer_reduce(const gvk_outer_desc* d, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(d && d->narrow && d->wide && d->scratch && (d->out || d->colsum), "gvk_outer_reduce: null pointer");
-  GVK_REQUIRE(d->M > 0 && d->C > 0, "gvk_outer_reduce: empty shape");
+  GVK_REQUIRE(d->M > 0 && d->C > 0 && d->C % 4 == 0, "gvk_outer_reduce: C must be a positive multiple of 4");
   GVK_REQUIRE(d->M <= kOuterSlabs * kOuterMaxRows, "gvk_outer_reduce: M=%d exceeds %d rows", d->M, kOuterSlabs * kOuterMaxRows);
   GVK_REQUIRE((d->mean == nullptr) == (d->rstd == nullptr), "gvk_outer_reduce: mean/rstd must come together");
   OuterArgs a{};
