@@ -124,7 +124,7 @@ class Engine:
         self._graphs = {}
         self._calls = {}
         self._wss = {}
-        self._s2 = None
+        self._streams = {}
         self._ws = None
         self._step = 0
         self._flat_grad = None
@@ -250,6 +250,8 @@ class Engine:
                                 dctx=mk(BN, Lt), dqkv=mk(BN, 3 * Lt), wdelta=mk(BN), dlat=mk(BN, Lt), dn=mk(BN, C))
                 ws["scratch"] = mk(max(ops.outer_scratch_elems(Lt, C), 128 * C, 64 * 3 * Lt * Lt, 64 * ng))
                 ws["rscratch"] = mk(32 * (ng + 2 * Lt * Lt + 3 * Lt + 3 * Lt * Lt + 64))
+                ws["scratch_l"] = mk(max(ops.outer_scratch_elems(Lt, C), 128 * C))      # the MWSA chain runs on its own stream
+                ws["rscratch_l"] = mk(32 * (3 * Lt * Lt + Lt + 64))
             else:
                 lat = {"adaptformer": 64, "melo": getattr(self, "r", 4)}.get(self.kind, 1)
                 ws["scratch"] = torch.zeros(max(128 * C, ops.outer_scratch_elems(lat, C)), device=device)
@@ -260,22 +262,20 @@ class Engine:
     # GAViKO's local branch (MWSA) and the latent-space GPA core are independent of the backbone's attention / MLP GEMMs within
     # a layer; they run on a side stream and meet the main stream only where the dataflow does (gaviko.py:301-304).  Inside
     # a HIP-graph capture these waits become graph edges, so the replayed graph has two parallel branches.
-    def _side(self):
-        if self._s2 is None:
-            self._s2 = torch.cuda.Stream()
-        return self._s2
+    def _stream(self, name):
+        st = self._streams.get(name)
+        if st is None:
+            st = self._streams[name] = torch.cuda.Stream()
+        return st
 
-    def _after_main(self):
-        """side stream waits for everything enqueued on the main stream so far"""
+    def _wait(self, waiter, on):
+        """stream `waiter` waits for everything enqueued so far on stream `on` (None = the current/main stream)."""
+        cur = torch.cuda.current_stream()
+        src = cur if on is None else self._stream(on)
+        dst = cur if waiter is None else self._stream(waiter)
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self._side().wait_event(ev)
-
-    def _after_side(self):
-        """main stream waits for everything enqueued on the side stream so far"""
-        ev = torch.cuda.Event()
-        ev.record(self._side())
-        torch.cuda.current_stream().wait_event(ev)
+        ev.record(src)
+        dst.wait_event(ev)
 
     # ------------------------------------------------------------------ graphs
     def _run(self, tag, key, fn):
@@ -348,22 +348,26 @@ class Engine:
             self._adapter_shadows(train)
         # ---- layers.  main stream: attention block -> MLP block;  side stream: MWSA -> GPA latents / gates / cross-attention
         gaviko = self.kind == "gaviko"
-        side = self._side() if gaviko else None
         if gaviko:
-            self._after_main()
+            loc, gpa = self._stream("loc"), self._stream("gpa")
+            self._wait("loc", None)                                  # Lc[0] written by the patch GEMM
+            self._wait("gpa", None)
         for i in range(self.depth):
             si = i if train else 0
             gi, go = (i, i + 1) if train else (i & 1, (i + 1) & 1)
-            if gaviko:
-                with torch.cuda.stream(side):
-                    self._mwsa_fwd(ws, sv, i, si, ws["Lc"][gi], ws["Lc"][go])
             Mi = B * self.Ts[i]
             repack = self.kind == "vpt" and self.deep
             gout = ws["Go"] if repack else ws["G"][go]
+            if gaviko:
+                if not train and i > 0:
+                    self._wait("loc", "gpa")                         # eval ping-pongs Lc: the GPA of layer i-1 must be done with it
+                with torch.cuda.stream(loc):
+                    self._mwsa_fwd(ws, sv, i, si, ws["Lc"][gi], ws["Lc"][go])
             self._attn_block_fwd(ws, i, si, ws["G"][gi], ws["G1"][si], Mi)
             if gaviko:
-                self._after_main()                                   # G1 ready
-                with torch.cuda.stream(side):
+                self._wait("gpa", None)                              # G1 ready
+                self._wait("gpa", "loc")                             # L' ready
+                with torch.cuda.stream(gpa):
                     self._gpa_fwd_latents(ws, i, si, ws["G1"][si], ws["Lc"][go], M, B)
             if self.kind == "adaptformer":
                 self._adapter_fwd_down(ws, i, si, ws["G1"][si], Mi)
@@ -371,11 +375,13 @@ class Engine:
             if self.kind == "adaptformer":
                 self._adapter_fwd_up(ws, i, si, gout, Mi)
             if gaviko:
-                self._after_side()                                   # enh ready
+                self._wait(None, "gpa")                              # enh ready
                 self._gpa_fwd_up(ws, i, si, ws["G"][go], M)
             if repack and i + 1 < self.depth:
                 ops.vpt_repack_fwd(gout, ws["vproj"][(i + 1) * self.P: (i + 2) * self.P], ws["G"][go], B, self.Ts[i], self.Ts[i + 1],
                                    self.P, self.pd, C)
+        if gaviko:
+            self._wait(None, "loc")                                  # join the local chain (capture needs every fork joined)
         gfin = self._final_stream(ws, train)
         r0, R = self._pool_rows()
         ops.head_fwd(g=gfin, ln_gamma=d(nm.root + "transformer.norm.weight"), ln_beta=d(nm.root + "transformer.norm.bias"),
@@ -539,9 +545,10 @@ class Engine:
         vpt_deep = self.kind == "vpt" and self.deep
         if vpt_deep and ((self.depth - 1 - hi) & 1):           # the un-repack alternates two buffers with the layer parity
             dGout = ws["dGv"]
-        side = self._side() if gaviko else None
         if gaviko:
-            self._after_main()
+            loc, gpa = self._stream("loc"), self._stream("gpa")
+            self._wait("gpa", None)
+            self._wait("loc", None)
         for i in range(hi, lo - 1, -1):
             M = B * self.Ts[i]
             T = self.Ts[i]
@@ -550,7 +557,7 @@ class Engine:
             st = ws["stat"][i]
             # side stream: GPA backward up to (not including) its writes into dG1 / dL
             if gaviko:
-                with torch.cuda.stream(side):
+                with torch.cuda.stream(gpa):
                     self._gpa_bwd_core(ws, sv, gv, i, dGout, M, B)
             # main stream, MLP block: dG1 = dGout + LN'(fc1^T(GELU'(pre) * fc2^T(dGout)))
             self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i])
@@ -561,10 +568,11 @@ class Engine:
             if adapter:
                 self._adapter_bwd(ws, gv, i, dGout, dGin, M)                 # adds LN_a'(...) into dG1 and refreshes dG16
             if gaviko:
-                self._after_side()
+                self._wait(None, "gpa")                                      # dzx / dzl ready
+                self._wait(None, "loc")                                      # dL[par] written by the MWSA backward of layer i+1
                 self._gpa_bwd_scatter(ws, i, dGin, ws["dL"][par], M, B)      # dG1 += dzx.Wd (refreshes dG16), dL += dzl.Wd
-                self._after_main()
-                with torch.cuda.stream(side):
+                self._wait("loc", None)
+                with torch.cuda.stream(loc):
                     self._mwsa_bwd(ws, sv, gv, i, ws["dL"][par], ws["dL"][par ^ 1], B)
             # main stream, attention block: dG0 = dG1 + LN'(qkv^T(attn'(out^T(dG1))))
             self._gemm(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
@@ -574,7 +582,8 @@ class Engine:
             self._gemm(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
             ops.layernorm_bwd(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGout, dres=dGin, dx16=ws["dG16"])
             if gaviko:
-                self._after_main()                                           # next layer's GPA needs this dG[i]
+                self._wait("gpa", None)                                      # next layer's GPA backward needs this dG[i] (and the
+                                                                             # scatter above is done with bw["dzx"/"dzl"])
             if self.kind == "vpt" and (i == 0 or self.deep):
                 # prompt rows 1..P of this layer's input are this layer's projected prompts (vpt.py:127-131,147-153)
                 ops.rows_batch_sum(dGout, ws["dvproj"][i * self.P: (i + 1) * self.P], None, B, T, 1, self.P, C)
@@ -584,7 +593,8 @@ class Engine:
                 dGout = other
                 ops.cast_bf16(dGout, ws["dG16"])
         if gaviko:
-            self._after_side()
+            self._wait(None, "gpa")
+            self._wait(None, "loc")
         if last and self.kind == "vpt":
             emb_name = "deep_prompt_embeddings" if self.deep else "prompt_embeddings"
             emb = d(emb_name).reshape(-1, self.pd)
@@ -746,7 +756,7 @@ class Engine:
         pre = f"transformer.local_attns.{s}"
         d, C, Lt, N = self._d, self.C, self.Lat, self.N
         BN = B * N
-        m, bw, sc = ws["mw"][i], ws["bw"], ws["scratch"]
+        m, bw, sc = ws["mw"][i], ws["bw"], ws["scratch_l"]
         lin = ws["Lc"][i]
         acc = self._acc(i)
         pd, seed_p, seed_a, sp = sv["proj_drop"], 2 * i + 1, 2 * i, ws["seed"]
@@ -758,13 +768,13 @@ class Engine:
                             D=self.grid[0], H=self.grid[1], W=self.grid[2], kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt,
                             scale=C ** -0.5, drop_p=sv["attn_drop"], seed=seed_a, seed_ptr=sp)
         wqkv = d(pre + ".qkv.weight")
-        ops.reduce_batch([(bw["dqkv"], m["lat"], gv[pre + ".qkv.weight"], acc)], ws["rscratch"])
+        ops.reduce_batch([(bw["dqkv"], m["lat"], gv[pre + ".qkv.weight"], acc)], ws["rscratch_l"])
         ops.skinny_down(x=bw["dqkv"], w=wqkv, y=bw["dlat"], M=BN, C=3 * Lt, L=Lt, act=0, w_layout=1)
         wd = d(pre + ".proj_down.weight")
         ops.outer_reduce(narrow=bw["dlat"], wide=lin, mean=m["mean"], rstd=m["rstd"], ln_gamma=d(pre + ".norm.weight"),
                          ln_beta=d(pre + ".norm.bias"), scratch=sc, out=gv[pre + ".proj_down.weight"], M=BN, C=C, L=Lt, transposed=0,
                          accumulate=acc)
-        ops.reduce_batch([(bw["dlat"], None, gv[pre + ".proj_down.bias"], acc)], ws["rscratch"])
+        ops.reduce_batch([(bw["dlat"], None, gv[pre + ".proj_down.bias"], acc)], ws["rscratch_l"])
         ops.skinny_up(lat=bw["dlat"], w=wd, out=bw["dn"], M=BN, C=C, L=Lt, w_layout=1)
         ops.layernorm_bwd(bw["dn"], lin, m["mean"], m["rstd"], d(pre + ".norm.weight"), BN, C, dx=dLin, dres=dLout)
         ops.layernorm_bwd_affine(bw["dn"], lin, m["mean"], m["rstd"], gv[pre + ".norm.weight"], gv[pre + ".norm.bias"], sc, BN, C,
