@@ -174,68 +174,163 @@ struct UpArgs {
   const float* lat; const float* w; const float* bias;    // lat [M][L]; w [C][L] (layout 0) or [L][C] (layout 1)
   const float* res; float* out;                           // out = res + (...)  (res may be NULL / alias out); accumulate: out += (...)
   const float* lat_override; int T, P;                    // rows with (m % T) < P read lat_override[(m / T) * P + m % T][:]
+  const float* ln_x; const float* ln_mean; const float* ln_rstd; const float* ln_g;   // optional LayerNorm-backward epilogue
+  bf16* out16;                                            // optional bf16 copy of `out` (the next dgrad GEMM's operand)
   int M, C, w_layout, accumulate;
   unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;   // dropout on the projected value (proj_drop)
 };
 
-constexpr int kUpRows = 8;      // rows per workgroup; every row's read-modify-write operand is prefetched up front
+constexpr int kUpRows = 16;     // one 16-row MFMA tile per workgroup; 4 waves x up to 4 chunks of 64 columns
 
-template <int L>
-__global__ __launch_bounds__(256) void skinny_up_kernel(UpArgs p) {
-  __shared__ float lat_s[kUpRows][L];
+// v[16 rows][C] = lat[16][L] . W^T on the fp32 matrix cores (K = L in steps of 4).  A wave owns column chunks ch = wave + 4u;
+// with the interleaved column map c = 64 ch + 4 j + e (tile e, lane column j) a lane ends up with float4s of 4 consecutive
+// columns for its 4 rows, so the read-modify-write of the [M][C] stream is fully coalesced 16-byte traffic.
+// Epilogues: out = base + drop(v + bias)   or, with ln_x set,   out = base + LayerNorm'(v)  (dx of a LayerNorm whose output
+// gradient is the rank-L product v: fuses `dn = dlat . Wd` with the LN backward of the MWSA branch, gaviko.py:231).
+template <int L, int NW, int MAXU>
+__global__ __launch_bounds__(NW * 64) void skinny_up_kernel(UpArgs p) {
+  static_assert(L % 4 == 0, "latent width must be a multiple of 4");
+  constexpr int KS = L / 4;
+  __shared__ float red[NW][16][2];
   if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
   const int C = p.C;
-  const int r0 = blockIdx.x * kUpRows, nr = min(kUpRows, p.M - r0);
-  // prefetch the residual / accumulation operand of all rows (independent loads in flight together)
-  float base[kUpRows][4];
-  const float* src_add = p.accumulate ? p.out : p.res;
+  const int lane = lane_id(), wave = wave_id();
+  const int j = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.x * kUpRows;
+  const int nch = (C + 63) / 64;
+  const float* base = p.accumulate ? p.out : p.res;
+  // ---- prefetch the stream operands of this lane: rows m0 + 4kq + q, columns 64 ch + 4 j .. +3
+  f32x4 bs[MAXU][4], xs[MAXU][4];
 #pragma unroll
-  for (int r = 0; r < kUpRows; ++r)
+  for (int u = 0; u < MAXU; ++u) {
+    const int c = (wave + NW * u) * 64 + 4 * j;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = k * 256 + threadIdx.x;
-      base[r][k] = (src_add != nullptr && r < nr && c < C) ? src_add[(size_t)(r0 + r) * C + c] : 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0 + 4 * kq + q;
+      const bool ok = wave + NW * u < nch && c < C && m < p.M;
+      bs[u][q] = (ok && base != nullptr) ? *(const f32x4*)(base + (size_t)m * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      xs[u][q] = (ok && p.ln_x != nullptr) ? *(const f32x4*)(p.ln_x + (size_t)m * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  for (int i = threadIdx.x; i < nr * L; i += 256) {
-    const int r = i / L, l = i - r * L, m = r0 + r;
-    const float* src = p.lat + (size_t)m * L;
-    if (p.lat_override != nullptr) {
-      const int s = m / p.T, t = m - s * p.T;
-      if (t < p.P) src = p.lat_override + ((size_t)s * p.P + t) * L;
-    }
-    lat_s[r][l] = src[l];
   }
-  float wr[4][L];
-  float br[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = k * 256 + threadIdx.x;
-    br[k] = (c < C && p.bias) ? p.bias[c] : 0.f;
-    if (p.w_layout == 0 && (L % 4) == 0) {
-#pragma unroll
-      for (int l4 = 0; l4 < L / 4; ++l4) {
-        const f32x4 t = (c < C) ? *(const f32x4*)(p.w + (size_t)c * L + 4 * l4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        wr[k][4 * l4] = t[0]; wr[k][4 * l4 + 1] = t[1]; wr[k][4 * l4 + 2] = t[2]; wr[k][4 * l4 + 3] = t[3];
-      }
-    } else {
-#pragma unroll
-      for (int l = 0; l < L; ++l) wr[k][l] = (c < C) ? (p.w_layout == 0 ? p.w[(size_t)c * L + l] : p.w[(size_t)l * C + c]) : 0.f;
+  // ---- A operand: lat[m0 + j][4s + kq]
+  float a[KS];
+  {
+    const int m = m0 + j;
+    const float* src = p.lat + (size_t)min(m, p.M - 1) * L;
+    if (p.lat_override != nullptr && m < p.M) {
+      const int sidx = m / p.T, t = m - sidx * p.T;
+      if (t < p.P) src = p.lat_override + ((size_t)sidx * p.P + t) * L;
     }
+#pragma unroll
+    for (int sk = 0; sk < KS; ++sk) a[sk] = (m < p.M) ? src[4 * sk + kq] : 0.f;
+  }
+  // ---- MFMA per chunk
+  f32x4 acc[MAXU][4];
+#pragma unroll
+  for (int u = 0; u < MAXU; ++u) {
+    const int ch = wave + NW * u;
+    const int c = ch * 64 + 4 * j;
+    const bool cok = ch < nch && c < C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[u][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ch < nch) {                                       // wave-uniform
+#pragma unroll
+      for (int sk = 0; sk < KS; ++sk) {
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (cok) {
+          if (p.w_layout == 1) b4 = *(const f32x4*)(p.w + (size_t)(4 * sk + kq) * C + c);
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b4[e] = p.w[(size_t)(c + e) * L + 4 * sk + kq];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[u][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sk], b4[e], acc[u][e], 0, 0, 0);
+      }
+    }
+  }
+  if (p.ln_x == nullptr) {
+    // ---- plain epilogue: out = base + drop(v + bias)
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) {
+      const int c = (wave + NW * u) * 64 + 4 * j;
+      if (wave + NW * u < nch && c < C) {
+        const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = m0 + 4 * kq + q;
+          if (m < p.M) {
+            f32x4 v = {acc[u][0][q] + b4[0], acc[u][1][q] + b4[1], acc[u][2][q] + b4[2], acc[u][3][q] + b4[3]};
+            if (p.drop_thresh != 0u) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= drop_scale(p.seed, (unsigned long long)m * C + c + e, p.drop_thresh, p.inv_keep);
+            }
+            v += bs[u][q];
+            *(f32x4*)(p.out + (size_t)m * C + c) = v;
+            if (p.out16 != nullptr) {
+              bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+              *(bf16x4*)(p.out16 + (size_t)m * C + c) = h;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+  // ---- LayerNorm-backward epilogue: dx = base + rstd * (g*v - mean(g*v) - xhat * mean(g*v*xhat))
+  float mu[4], rs[4], s1[4], s2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int m = min(m0 + 4 * kq + q, p.M - 1);
+    mu[q] = p.ln_mean[m]; rs[q] = p.ln_rstd[m];
+    s1[q] = 0.f; s2[q] = 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < MAXU; ++u) {
+    const int c = (wave + NW * u) * 64 + 4 * j;
+    if (wave + NW * u < nch && c < C) {
+      const f32x4 g4 = *(const f32x4*)(p.ln_g + c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dh = acc[u][e][q] * g4[e];
+          const float xh = (xs[u][q][e] - mu[q]) * rs[q];
+          acc[u][e][q] = dh;            // keep g*v
+          xs[u][q][e] = xh;             // keep xhat
+          s1[q] += dh; s2[q] += dh * xh;
+        }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { s1[q] += __shfl_xor(s1[q], o, 64); s2[q] += __shfl_xor(s2[q], o, 64); }
+    if (j == 0) { red[wave][4 * kq + q][0] = s1[q]; red[wave][4 * kq + q][1] = s2[q]; }
   }
   __syncthreads();
 #pragma unroll
-  for (int r = 0; r < kUpRows; ++r) {
-    if (r >= nr) break;
-    const int m = r0 + r;
+  for (int q = 0; q < 4; ++q) {
+    const int i = 4 * kq + q;
+    float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = k * 256 + threadIdx.x;
-      if (c < C) {
-        float a = br[k];
+    for (int w = 0; w < NW; ++w) { t1 += red[w][i][0]; t2 += red[w][i][1]; }
+    s1[q] = t1 / (float)C;
+    s2[q] = t2 / (float)C;
+  }
 #pragma unroll
-        for (int l = 0; l < L; ++l) a += lat_s[r][l] * wr[k][l];
-        if (p.drop_thresh != 0u) a *= drop_scale(p.seed, (unsigned long long)m * C + c, p.drop_thresh, p.inv_keep);
-        p.out[(size_t)m * C + c] = a + base[r][k];
+  for (int u = 0; u < MAXU; ++u) {
+    const int c = (wave + NW * u) * 64 + 4 * j;
+    if (wave + NW * u < nch && c < C) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + 4 * kq + q;
+        if (m < p.M) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = rs[q] * (acc[u][e][q] - s1[q] - xs[u][q][e] * s2[q]) + bs[u][q][e];
+          *(f32x4*)(p.out + (size_t)m * C + c) = o;
+        }
       }
     }
   }
@@ -494,6 +589,31 @@ __global__ __launch_bounds__(256) void reduce_batch_final_kernel(ReduceBatch bt)
   *dst = bt.job[ji].accumulate ? *dst + t : t;
 }
 
+// Affine / weight gradients of  y = LN(x) . Wd^T  from Q[l][c] = sum_m dlat[m][l] xhat[m][c] and S[l] = sum_m dlat[m][l]:
+//   dWd[l][c] = g_c Q[l][c] + b_c S[l],  dgamma_c = sum_l Wd[l][c] Q[l][c],  dbeta_c = sum_l Wd[l][c] S[l],  dbias_l = S[l]
+// (replaces materialising dn = dlat . Wd for a separate LayerNorm-affine reduction).
+__global__ __launch_bounds__(256) void ln_lowrank_affine_kernel(const float* __restrict__ Q, const float* __restrict__ S, const float* __restrict__ W,
+                                                                const float* __restrict__ g, const float* __restrict__ b, float* __restrict__ dW,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias,
+                                                                int L, int C, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
+    const float gc = g[c], bc = b[c];
+    float dg = 0.f, db = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const float q = Q[(size_t)l * C + c], sl = S[l], w = W[(size_t)l * C + c];
+      const float v = gc * q + bc * sl;
+      float* o = dW + (size_t)l * C + c;
+      *o = accumulate ? *o + v : v;
+      dg += w * q;
+      db += w * sl;
+    }
+    dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+    dbeta[c] = accumulate ? dbeta[c] + db : db;
+  }
+  if (c < L && dbias != nullptr) dbias[c] = accumulate ? dbias[c] + S[c] : S[c];
+}
+
 template <int L>
 static int launch_down(const DownArgs& a, hipStream_t s) {
   const int lds_w = L * (a.C + 4), lds_p = 16 * 16 * 32 + 16 * 32;      // floats: staged W  vs  partial tiles + finished rows
@@ -509,7 +629,12 @@ static int launch_down(const DownArgs& a, hipStream_t s) {
 }
 template <int L>
 static int launch_up(const UpArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL((skinny_up_kernel<L>), dim3((a.M + kUpRows - 1) / kUpRows), dim3(256), 0, s, a);
+  const int nch = (a.C + 63) / 64;
+  const dim3 grid((a.M + kUpRows - 1) / kUpRows);
+  if (nch > 12) hipLaunchKernelGGL((skinny_up_kernel<L, 8, 2>), grid, dim3(512), 0, s, a);        // C <= 1024
+  else if (nch > 8) hipLaunchKernelGGL((skinny_up_kernel<L, 4, 3>), grid, dim3(256), 0, s, a);    // C <= 768
+  else if (nch > 4) hipLaunchKernelGGL((skinny_up_kernel<L, 4, 2>), grid, dim3(256), 0, s, a);    // C <= 512
+  else hipLaunchKernelGGL((skinny_up_kernel<L, 4, 1>), grid, dim3(256), 0, s, a);                 // C <= 256
   return check_launch("skinny_up");
 }
 template <int L>
@@ -553,11 +678,14 @@ extern "C" int gvk_skinny_down(const gvk_skinny_down_desc* d, void* stream) {
 extern "C" int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(d && d->lat && d->w && d->out, "gvk_skinny_up: null pointer");
-  GVK_REQUIRE(d->M > 0 && d->C > 0 && d->C <= 1024, "gvk_skinny_up: C=%d must be <= 1024", d->C);
+  GVK_REQUIRE(d->M > 0 && d->C > 0 && d->C <= 1024 && d->C % 4 == 0, "gvk_skinny_up: C=%d must be a multiple of 4 and <= 1024", d->C);
+  GVK_REQUIRE(d->ln_x == nullptr || (d->ln_mean && d->ln_rstd && d->ln_gamma && d->bias == nullptr && d->drop_p <= 0.f),
+              "gvk_skinny_up: the LayerNorm-backward epilogue needs mean/rstd/gamma and takes no bias / dropout");
   GVK_REQUIRE(d->lat_override == nullptr || (d->T > 0 && d->P > 0 && d->P <= d->T), "gvk_skinny_up: override needs 0 < P <= T");
   UpArgs a{};
   a.lat = d->lat; a.w = d->w; a.bias = d->bias; a.res = d->res; a.out = d->out; a.lat_override = d->lat_override; a.T = d->T; a.P = d->P;
   a.M = d->M; a.C = d->C; a.w_layout = d->w_layout; a.accumulate = d->accumulate;
+  a.ln_x = d->ln_x; a.ln_mean = d->ln_mean; a.ln_rstd = d->ln_rstd; a.ln_g = d->ln_gamma; a.out16 = (bf16*)d->out_bf16;
   a.seed = d->seed; a.seed_ptr = (const unsigned long long*)d->seed_ptr; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
   hipStream_t s = (hipStream_t)stream;
   switch (d->L) {
@@ -641,4 +769,13 @@ extern "C" int gvk_reduce_batch(const gvk_reduce_job* jobs, int njobs, float* sc
   if (rc) return rc;
   hipLaunchKernelGGL(reduce_batch_final_kernel, dim3((ob + 255) / 256), dim3(256), 0, s, bt);
   return check_launch("reduce_batch/final");
+}
+
+extern "C" int gvk_ln_lowrank_affine(const float* Q, const float* S, const float* W, const float* gamma, const float* beta, float* dW,
+                                     float* dgamma, float* dbeta, float* dbias, int L, int C, int accumulate, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(Q && S && W && gamma && beta && dW && dgamma && dbeta && L > 0 && C >= L, "gvk_ln_lowrank_affine: bad arguments");
+  hipLaunchKernelGGL(ln_lowrank_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, Q, S, W, gamma, beta, dW, dgamma,
+                     dbeta, dbias, L, C, accumulate);
+  return check_launch("ln_lowrank_affine");
 }

@@ -247,7 +247,7 @@ class Engine:
                 ws["bw"] = dict(dcomb=mk(M, Lt), dimp=mk(B, P), dgw_part=mk(B, P), dqg=mk(B, P, Lt), dql=mk(B, P, Lt), dcg=mk(B, P, Lt),
                                 dcl=mk(B, P, Lt), delta_g=mk(B, P), delta_l=mk(B, P), dprm=mk(B, P, Lt), dcls=mk(B, Lt),
                                 gate_partials=mk(B, ng), dzx=mk(M, Lt), dzl=mk(BN, Lt),
-                                dctx=mk(BN, Lt), dqkv=mk(BN, 3 * Lt), wdelta=mk(BN), dlat=mk(BN, Lt), dn=mk(BN, C))
+                                dctx=mk(BN, Lt), dqkv=mk(BN, 3 * Lt), wdelta=mk(BN), dlat=mk(BN, Lt), Q=mk(Lt, C), S=mk(Lt))
                 ws["scratch"] = mk(max(ops.outer_scratch_elems(Lt, C), 128 * C, 64 * 3 * Lt * Lt, 64 * ng))
                 ws["rscratch"] = mk(32 * (ng + 2 * Lt * Lt + 3 * Lt + 3 * Lt * Lt + 64))
                 ws["scratch_l"] = mk(max(ops.outer_scratch_elems(Lt, C), 128 * C))      # the MWSA chain runs on its own stream
@@ -663,9 +663,8 @@ class Engine:
         """dG1 += dzx . Wd ; dLnew += dzl . Wd ; bf16 copy of dG1 for the out-proj dgrad."""
         pre, _ = self._gpa_names(i)
         wd, bw = self._d(pre + ".proj_down.0.weight"), ws["bw"]
-        ops.skinny_up(lat=bw["dzx"], w=wd, out=dG1, M=M, C=self.C, L=self.Lat, w_layout=1, accumulate=1)
+        ops.skinny_up(lat=bw["dzx"], w=wd, out=dG1, out_bf16=ws["dG16"], M=M, C=self.C, L=self.Lat, w_layout=1, accumulate=1)
         ops.skinny_up(lat=bw["dzl"], w=wd, out=dLnew, M=B * self.N, C=self.C, L=self.Lat, w_layout=1, accumulate=1)
-        ops.cast_bf16(dG1, ws["dG16"])
 
     # ---- AdaptFormer (adaptformer.py:58-78, 93-97): r = up(ReLU(down(LN_a(x)))), x_out = ff(x) + x + r -----------------------
     def _adapter_prefix(self, i):
@@ -771,11 +770,13 @@ class Engine:
         ops.reduce_batch([(bw["dqkv"], m["lat"], gv[pre + ".qkv.weight"], acc)], ws["rscratch_l"])
         ops.skinny_down(x=bw["dqkv"], w=wqkv, y=bw["dlat"], M=BN, C=3 * Lt, L=Lt, act=0, w_layout=1)
         wd = d(pre + ".proj_down.weight")
-        ops.outer_reduce(narrow=bw["dlat"], wide=lin, mean=m["mean"], rstd=m["rstd"], ln_gamma=d(pre + ".norm.weight"),
-                         ln_beta=d(pre + ".norm.bias"), scratch=sc, out=gv[pre + ".proj_down.weight"], M=BN, C=C, L=Lt, transposed=0,
-                         accumulate=acc)
-        ops.reduce_batch([(bw["dlat"], None, gv[pre + ".proj_down.bias"], acc)], ws["rscratch_l"])
-        ops.skinny_up(lat=bw["dlat"], w=wd, out=bw["dn"], M=BN, C=C, L=Lt, w_layout=1)
-        ops.layernorm_bwd(bw["dn"], lin, m["mean"], m["rstd"], d(pre + ".norm.weight"), BN, C, dx=dLin, dres=dLout)
-        ops.layernorm_bwd_affine(bw["dn"], lin, m["mean"], m["rstd"], gv[pre + ".norm.weight"], gv[pre + ".norm.bias"], sc, BN, C,
-                                 accumulate=bool(acc))
+        g_, b_ = d(pre + ".norm.weight"), d(pre + ".norm.bias")
+        # Q[l][c] = sum_m dlat[m][l] xhat[m][c], S[l] = sum_m dlat[m][l]  ->  dWd, dbd, dgamma, dbeta in one tiny kernel
+        ops.outer_reduce(narrow=bw["dlat"], wide=lin, mean=m["mean"], rstd=m["rstd"], scratch=sc, out=bw["Q"], M=BN, C=C, L=Lt, transposed=0,
+                         accumulate=0)
+        ops.reduce_batch([(bw["dlat"], None, bw["S"], 0)], ws["rscratch_l"])
+        ops.ln_lowrank_affine(bw["Q"], bw["S"], wd, g_, b_, gv[pre + ".proj_down.weight"], gv[pre + ".norm.weight"], gv[pre + ".norm.bias"],
+                              gv[pre + ".proj_down.bias"], Lt, C, accumulate=bool(acc))
+        # dL_in = dL_out + LN'(dlat . Wd): the rank-L product never touches HBM
+        ops.skinny_up(lat=bw["dlat"], w=wd, res=dLout, out=dLin, ln_x=lin, ln_mean=m["mean"], ln_rstd=m["rstd"], ln_gamma=g_, M=BN, C=C, L=Lt,
+                      w_layout=1)

@@ -35,7 +35,7 @@ def _struct(name, ptrs, ints, floats=(), u64=()):
 SkinnyDownDesc = _struct("SkinnyDownDesc",
                          ["x", "w", "bias", "ln_gamma", "ln_beta", "mean", "rstd", "z", "y", "w2", "y2", "seed_ptr"],
                          ["M", "C", "L", "L2", "act", "w_layout"], ["eps", "drop_p"], ["seed"])
-SkinnyUpDesc = _struct("SkinnyUpDesc", ["lat", "w", "bias", "res", "out", "lat_override", "seed_ptr"],
+SkinnyUpDesc = _struct("SkinnyUpDesc", ["lat", "w", "bias", "res", "out", "lat_override", "seed_ptr", "ln_x", "ln_mean", "ln_rstd", "ln_gamma", "out_bf16"],
                        ["M", "C", "L", "T", "P", "w_layout", "accumulate"], ["drop_p"], ["seed"])
 OuterDesc = _struct("OuterDesc", ["narrow", "wide", "lat_override", "mean", "rstd", "ln_gamma", "ln_beta", "scratch", "out", "colsum", "seed_ptr"],
                     ["M", "C", "L", "T", "P", "transposed", "accumulate"], ["drop_p"], ["seed"])
@@ -70,6 +70,7 @@ SIGNATURES = {
     "gvk_skinny_up": [C.POINTER(SkinnyUpDesc), _P],
     "gvk_outer_reduce": [C.POINTER(OuterDesc), _P],
     "gvk_small_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "gvk_ln_lowrank_affine": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gvk_colsum": [_P, _P, _P, _I, _I, _I, _P],
     "gvk_reduce_batch": [C.POINTER(ReduceJob), _I, _P, _P],
     "gvk_window_attn_fwd": [C.POINTER(WindowAttnDesc), _P],

@@ -145,7 +145,7 @@ def _desc(cls, what, **kw):
         v = kw.pop(name, None)
         if ctype is C.c_void_p:
             if v is not None:
-                _chk(v, torch.int64 if name == "seed_ptr" else torch.float32, f"{what}.{name}")
+                _chk(v, torch.int64 if name == "seed_ptr" else torch.bfloat16 if name == "out_bf16" else torch.float32, f"{what}.{name}")
             setattr(d, name, L.ptr(v))
         elif v is not None:
             setattr(d, name, v)
@@ -313,3 +313,12 @@ def reduce_batch(jobs, scratch):
         arr[k] = L.ReduceJob(L.ptr(a), L.ptr(b), L.ptr(out), M, J, Lb, int(bool(acc)))
     _chk(scratch, torch.float32, "reduce_batch scratch", 32 * total)
     L.check(L.load().gvk_reduce_batch(arr, len(jobs), L.ptr(scratch), L.stream_ptr()), "gvk_reduce_batch")
+
+
+def ln_lowrank_affine(Q, S, W, gamma, beta, dW, dgamma, dbeta, dbias, Lat, C_, accumulate=False):
+    for t, n in ((Q, "Q"), (S, "S"), (W, "W"), (gamma, "gamma"), (beta, "beta"), (dW, "dW"), (dgamma, "dgamma"), (dbeta, "dbeta"), (dbias, "dbias")):
+        _chk(t, torch.float32, "ln_lowrank_affine " + n)
+    if Q.numel() < Lat * C_ or W.numel() < Lat * C_ or dW.numel() < Lat * C_ or S.numel() < Lat:
+        raise L.GavikoHipError("ln_lowrank_affine: buffer too small")
+    L.check(L.load().gvk_ln_lowrank_affine(L.ptr(Q), L.ptr(S), L.ptr(W), L.ptr(gamma), L.ptr(beta), L.ptr(dW), L.ptr(dgamma), L.ptr(dbeta),
+                                           L.ptr(dbias), Lat, C_, int(bool(accumulate)), L.stream_ptr()), "gvk_ln_lowrank_affine")

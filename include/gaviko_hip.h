@@ -117,6 +117,9 @@ int gvk_skinny_down(const gvk_skinny_down_desc* d, void* stream);
 typedef struct gvk_skinny_up_desc {
   const float* lat; const float* w; const float* bias; const float* res; float* out; const float* lat_override;
   const uint64_t* seed_ptr;
+  /* optional LayerNorm-backward epilogue: out = base + LN'(v) with v = lat . W^T as the LN output gradient (no bias/dropout) */
+  const float* ln_x; const float* ln_mean; const float* ln_rstd; const float* ln_gamma;
+  void* out_bf16;                   /* optional bf16 copy of out (plain epilogue only) */
   int32_t M, C, L, T, P, w_layout, accumulate;
   float drop_p;
   uint64_t seed;
@@ -136,6 +139,10 @@ typedef struct gvk_outer_desc {
   uint64_t seed;
 } gvk_outer_desc;
 int gvk_outer_reduce(const gvk_outer_desc* d, void* stream);
+/* Gradients of y = LN(x) . W^T (W [L][C]) from Q[l][c] = sum_m dy[m][l] xhat[m][c] (gvk_outer_reduce with mean/rstd but no gamma/beta)
+ * and S[l] = sum_m dy[m][l]:  dW (+)= gamma*Q + beta (x) S,  dgamma (+)= sum_l W*Q,  dbeta (+)= sum_l W*S,  dbias (+)= S (may be NULL). */
+int gvk_ln_lowrank_affine(const float* Q, const float* S, const float* W, const float* gamma, const float* beta, float* dW, float* dgamma,
+                          float* dbeta, float* dbias, int L, int C, int accumulate, void* stream);
 /* out[j][l] (+)= sum_m a[m][j] * b[m][l]  (J, L <= 64); scratch f32 [64*J*L] */
 int gvk_small_wgrad(const float* a, const float* b, float* out, float* scratch, int M, int J, int L, int accumulate, void* stream);
 /* Several small reductions batched into one pair of launches (deterministic, two stages).  b == NULL: out[j] (+)= sum_m a[m][j],

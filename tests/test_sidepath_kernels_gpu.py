@@ -294,3 +294,36 @@ def test_rows_broadcast_and_sum(dev):
     a = torch.zeros((R, C_), device=dev); b2 = torch.ones((R, C_), device=dev)
     ops.rows_batch_sum(f(dg.reshape(B * T, C_)), a, None, B, T, off, R, C_)
     _close(a, dg[:, off:off + R].sum(0), 1e-5, "rows_batch_sum")
+
+
+@pytest.mark.parametrize("M,C_,Lat", [(1000, 768, 20), (333, 192, 20), (100, 1024, 8)])
+def test_skinny_up_ln_backward_epilogue_and_lowrank_affine(dev, M, C_, Lat):
+    """y = LN(x) . Wd^T with upstream gradient dlat: dx, dWd, dgamma, dbeta, dbias via the fused kernels vs autograd."""
+    from gaviko_amd import ops
+    x = (_rand((M, C_), 141, 1.5) + 0.2).requires_grad_(True)
+    g = (1 + _rand((C_,), 142, 0.2)).requires_grad_(True)
+    b = _rand((C_,), 143, 0.1).requires_grad_(True)
+    wd = _rand((Lat, C_), 144, 1 / math.sqrt(C_)).requires_grad_(True)
+    bd = _rand((Lat,), 145, 0.1).requires_grad_(True)
+    dlat = _rand((M, Lat), 146)
+    dres = _rand((M, C_), 147)
+    y = F.linear(F.layer_norm(x, (C_,), g, b, 1e-5), wd, bd)
+    y.backward(dlat)
+    f = lambda t: t.detach().float().to(dev).contiguous()
+    X = f(x)
+    mu = X.mean(1).contiguous()
+    rstd = (X.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    dx = torch.zeros((M, C_), device=dev)
+    ops.skinny_up(lat=f(dlat), w=f(wd), res=f(dres), out=dx, ln_x=X, ln_mean=mu, ln_rstd=rstd, ln_gamma=f(g), M=M, C=C_, L=Lat, w_layout=1)
+    _close(dx, x.grad + dres, 3e-5, "dx (LN' epilogue)")
+    scratch = torch.zeros(ops.outer_scratch_elems(Lat, C_), device=dev)
+    Q = torch.zeros((Lat, C_), device=dev)
+    ops.outer_reduce(narrow=f(dlat), wide=X, mean=mu, rstd=rstd, scratch=scratch, out=Q, M=M, C=C_, L=Lat, transposed=0, accumulate=0)
+    S = torch.zeros(Lat, device=dev)
+    ops.reduce_batch([(f(dlat), None, S, 0)], torch.zeros(32 * (Lat + 64), device=dev))
+    dW = torch.zeros((Lat, C_), device=dev); dg = torch.zeros(C_, device=dev); db = torch.zeros(C_, device=dev); dbias = torch.zeros(Lat, device=dev)
+    ops.ln_lowrank_affine(Q, S, f(wd), f(g), f(b), dW, dg, db, dbias, Lat, C_)
+    _close(dW, wd.grad, 5e-5, "dWd")
+    _close(dg, g.grad, 5e-5, "dgamma")
+    _close(db, b.grad, 5e-5, "dbeta")
+    _close(dbias, bd.grad, 5e-5, "dbias")
