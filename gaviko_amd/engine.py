@@ -555,10 +555,14 @@ class Engine:
             par = (self.depth - 1 - i) & 1
             m, a = nm.mlp(i), nm.attn(i)
             st = ws["stat"][i]
-            # side stream: GPA backward up to (not including) its writes into dG1 / dL
+            # GPA stream: the critical kernels (-> dzx, dzl) first, then the parameter gradients; the other streams wait only
+            # for the event between the two
             if gaviko:
                 with torch.cuda.stream(gpa):
                     self._gpa_bwd_core(ws, sv, gv, i, dGout, M, B)
+                    dz_ready = torch.cuda.Event()
+                    dz_ready.record(gpa)
+                    self._gpa_bwd_params(ws, sv, gv, i, dGout, M, B)
             # main stream, MLP block: dG1 = dGout + LN'(fc1^T(GELU'(pre) * fc2^T(dGout)))
             self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i])
             self._gemm(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
@@ -568,11 +572,11 @@ class Engine:
             if adapter:
                 self._adapter_bwd(ws, gv, i, dGout, dGin, M)                 # adds LN_a'(...) into dG1 and refreshes dG16
             if gaviko:
-                self._wait(None, "gpa")                                      # dzx / dzl ready
-                self._wait(None, "loc")                                      # dL[par] written by the MWSA backward of layer i+1
-                self._gpa_bwd_scatter(ws, i, dGin, ws["dL"][par], M, B)      # dG1 += dzx.Wd (refreshes dG16), dL += dzl.Wd
-                self._wait("loc", None)
+                torch.cuda.current_stream().wait_event(dz_ready)
+                self._gpa_bwd_scatter_g(ws, i, dGin, M)                      # dG1 += dzx.Wd (+ bf16 copy)
+                loc.wait_event(dz_ready)
                 with torch.cuda.stream(loc):
+                    self._gpa_bwd_scatter_l(ws, i, ws["dL"][par], B)         # dL += dzl.Wd (dL[par] was written on this stream)
                     self._mwsa_bwd(ws, sv, gv, i, ws["dL"][par], ws["dL"][par ^ 1], B)
             # main stream, attention block: dG0 = dG1 + LN'(qkv^T(attn'(out^T(dG1))))
             self._gemm(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
@@ -580,10 +584,13 @@ class Engine:
             if self.kind == "melo":
                 self._melo_bwd(ws, gv, i, M)
             self._gemm(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
+            if gaviko:
+                self._wait(None, "gpa")                                      # the GPA parameter gradients still read dGout
             ops.layernorm_bwd(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGout, dres=dGin, dx16=ws["dG16"])
             if gaviko:
-                self._wait("gpa", None)                                      # next layer's GPA backward needs this dG[i] (and the
-                                                                             # scatter above is done with bw["dzx"/"dzl"])
+                self._wait(None, "loc")                                      # the MWSA chain has consumed dzl ...
+                self._wait("gpa", None)                                      # ... so the next layer's GPA backward, which needs this
+                                                                             # dG[i], may also overwrite bw["dzx"/"dzl"]
             if self.kind == "vpt" and (i == 0 or self.deep):
                 # prompt rows 1..P of this layer's input are this layer's projected prompts (vpt.py:127-131,147-153)
                 ops.rows_batch_sum(dGout, ws["dvproj"][i * self.P: (i + 1) * self.P], None, B, T, 1, self.P, C)
@@ -627,21 +634,26 @@ class Engine:
         return 0 if i == top else 1
 
     def _gpa_bwd_core(self, ws, sv, gv, i, dGout, M, B):
-        """Everything of the GPA backward that only READS dGout / saved activations: parameter gradients and dzx / dzl."""
+        """Critical part of the GPA backward: dcomb = dGout . Wup and the latent-space backward -> dzx / dzl
+        (what the main stream's dG1 update and the MWSA chain wait for)."""
         pre, names = self._gpa_names(i)
         d, C, Lt, P, T, N = self._d, self.C, self.Lat, self.P, self.T, self.N
-        g, bw, sc = ws["gp"][i], ws["bw"], ws["scratch"]
-        wup = d(pre + ".proj_up.weight")
-        acc = self._acc(i)
-        # proj_up: dcomb = dGout . Wup ; dWup = dGout^T . comb ; dbup = colsum(dGout)
-        ops.skinny_down(x=dGout, w=wup, y=bw["dcomb"], M=M, C=C, L=Lt, act=0, w_layout=1)
-        ops.outer_reduce(narrow=g["xl"], wide=dGout, lat_override=g["enh"], scratch=sc, out=gv[pre + ".proj_up.weight"],
-                         colsum=gv[pre + ".proj_up.bias"], M=M, C=C, L=Lt, T=T, P=P, transposed=1, accumulate=acc)
+        g, bw = ws["gp"][i], ws["bw"]
+        ops.skinny_down(x=dGout, w=d(pre + ".proj_up.weight"), y=bw["dcomb"], M=M, C=C, L=Lt, act=0, w_layout=1)
         ops.gpa_bwd(xl=g["xl"], ll=g["ll"], B=B, T=T, N=N, P=P, L=Lt, scale=Lt ** -0.5, imp=g["imp"], gw=g["gw"], enh=g["enh"], prm=g["prm"],
                     qg=g["qg"], ql=g["ql"], cg=g["cg"], cl=g["cl"], lse_g=g["lse_g"], lse_l=g["lse_l"], dcomb=bw["dcomb"], zx=g["zx"], zl=g["zl"],
                     dimp=bw["dimp"], dgw_part=bw["dgw_part"], dqg=bw["dqg"], dql=bw["dql"], dcg=bw["dcg"], dcl=bw["dcl"],
                     delta_g=bw["delta_g"], delta_l=bw["delta_l"], dprm=bw["dprm"], dcls=bw["dcls"], gate_partials=bw["gate_partials"],
                     dzx=bw["dzx"], dzl=bw["dzl"], **{k: d(v) for k, v in names.items()})
+
+    def _gpa_bwd_params(self, ws, sv, gv, i, dGout, M, B):
+        """Off the critical path: every parameter gradient of the GPA module (reads dGout, dzx, dzl, saved activations)."""
+        pre, names = self._gpa_names(i)
+        d, C, Lt, P, T, N = self._d, self.C, self.Lat, self.P, self.T, self.N
+        g, bw, sc = ws["gp"][i], ws["bw"], ws["scratch"]
+        acc = self._acc(i)
+        ops.outer_reduce(narrow=g["xl"], wide=dGout, lat_override=g["enh"], scratch=sc, out=gv[pre + ".proj_up.weight"],
+                         colsum=gv[pre + ".proj_up.bias"], M=M, C=C, L=Lt, T=T, P=P, transposed=1, accumulate=acc)
         # gate parameters: one contiguous slice of the flat gradient buffer, in the kernel's order
         ng = ops.gpa_gate_param_count(Lt, P)
         first = gv[names["ca0_g"]]
@@ -655,16 +667,21 @@ class Engine:
                           (dql, prm, gv[names["wlq"]], acc), (dql, None, gv[names["blq"]], acc),
                           (bw["dzx"], None, gbd, acc)], ws["rscratch"])
         ops.reduce_batch([(bw["dzl"], None, gbd, 1)], ws["rscratch"])
-        # proj_down (shared by both streams): dWd = dzx^T.G1 + dzl^T.Lnew ; dbd
+        # proj_down (shared by both streams): dWd = dzx^T.G1 + dzl^T.Lnew
         ops.outer_reduce(narrow=bw["dzx"], wide=ws["G1"][i], scratch=sc, out=gwd, M=M, C=C, L=Lt, transposed=0, accumulate=acc)
         ops.outer_reduce(narrow=bw["dzl"], wide=ws["Lc"][i + 1], scratch=sc, out=gwd, M=B * N, C=C, L=Lt, transposed=0, accumulate=1)
 
-    def _gpa_bwd_scatter(self, ws, i, dG1, dLnew, M, B):
-        """dG1 += dzx . Wd ; dLnew += dzl . Wd ; bf16 copy of dG1 for the out-proj dgrad."""
+    def _gpa_bwd_scatter_g(self, ws, i, dG1, M):
+        """main stream: dG1 += dzx . Wd, with the bf16 copy for the out-proj dgrad."""
         pre, _ = self._gpa_names(i)
-        wd, bw = self._d(pre + ".proj_down.0.weight"), ws["bw"]
-        ops.skinny_up(lat=bw["dzx"], w=wd, out=dG1, out_bf16=ws["dG16"], M=M, C=self.C, L=self.Lat, w_layout=1, accumulate=1)
-        ops.skinny_up(lat=bw["dzl"], w=wd, out=dLnew, M=B * self.N, C=self.C, L=self.Lat, w_layout=1, accumulate=1)
+        ops.skinny_up(lat=ws["bw"]["dzx"], w=self._d(pre + ".proj_down.0.weight"), out=dG1, out_bf16=ws["dG16"], M=M, C=self.C, L=self.Lat,
+                      w_layout=1, accumulate=1)
+
+    def _gpa_bwd_scatter_l(self, ws, i, dLnew, B):
+        """MWSA chain: dL += dzl . Wd."""
+        pre, _ = self._gpa_names(i)
+        ops.skinny_up(lat=ws["bw"]["dzl"], w=self._d(pre + ".proj_down.0.weight"), out=dLnew, M=B * self.N, C=self.C, L=self.Lat, w_layout=1,
+                      accumulate=1)
 
     # ---- AdaptFormer (adaptformer.py:58-78, 93-97): r = up(ReLU(down(LN_a(x)))), x_out = ff(x) + x + r -----------------------
     def _adapter_prefix(self, i):
