@@ -40,7 +40,8 @@ def collect_gemm_timing():
     out = {}
     for key, rec in (GEMM_TIMING or {}).items():
         ms = [a.elapsed_time(b) for a, b in rec["events"]]
-        out[key] = {"avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "n": len(ms), "flops_per_launch": rec["flops"], "shape": rec["shape"]}
+        out[key] = {"avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "n": len(ms), "flops_per_launch": rec["flops"], "shape": rec["shape"],
+                    "bytes": rec.get("bytes")}
     return out
 
 
@@ -327,11 +328,20 @@ class Engine:
         nm, w, d = self.names, self._w16, self._d
         ws["seed"].add_(7919)                               # device-side dropout epoch (HIP-graph safe)
         # ---- embedding: patch GEMM (+bias +pos, scattered to rows row_off..) and the broadcast rows
+        pe0 = pe1 = None
+        if GEMM_TIMING is not None:                          # bench.py: time the whole patch-embed stage (im2col + GEMM + scatter)
+            pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            pe0.record()
         ops.patchify(ws["img"], ws["cols"], self.patch)
         pos = d(nm.root + "pos_embedding")[0]
         G0 = ws["G"][0]
         self._gemm(ws["cols"], w["conv"], B * N, G0, epilogue=ops.EPI_PATCH_F32, out1=ws["Lc"][0] if self.kind == "gaviko" else None,
                    bias=d(nm.root + "conv_proj.0.bias"), pos=pos[1:], rows_in=N, rows_out=T, row_off=self.row_off)
+        if pe0 is not None:
+            pe1.record()
+            nout = 2 if self.kind == "gaviko" else 1
+            GEMM_TIMING.setdefault("__patch_embed__", {"events": [], "flops": 2.0 * B * N * self.Kp * C, "shape": [B * N, C, self.Kp],
+                                                       "bytes": B * (self.Kp * N * 4 + nout * N * C * 4)})["events"].append((pe0, pe1))
         cls = d(nm.root + "cls_token")[0]
         if self.kind == "gaviko":
             ops.rows_broadcast(G0, d("prompt_embeddings")[0], d("prompt_positional_embedding")[0], B, T, 0, self.P, C)
