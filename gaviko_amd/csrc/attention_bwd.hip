@@ -36,15 +36,16 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
   delta[((size_t)b * H + h) * T + t] = s;
 }
 
-constexpr int kTile32 = 32 * 128;   // bytes of a [32][64] bf16 tile
+constexpr int kQT = 64;                 // query rows staged per barrier pair (two 32-row MFMA sub-blocks)
+constexpr int kTileQ = kQT * 128;       // bytes of a [kQT][64] bf16 tile
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             bf16* __restrict__ dqkv, int T, int H, int ld_qkv, int ld_o, float scale,
                                                             float scale_log2e) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][Q tile 4K | dO tile 4K | lse' 128 B | delta 128 B]
-  constexpr int kBuf = 2 * kTile32 + 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][Q tile | dO tile | lse' kQT f32 | delta kQT f32]
+  constexpr int kBuf = 2 * kTileQ + 2 * kQT * 4;
   const int b = blockIdx.z, head = blockIdx.y, k0 = blockIdx.x * 128;
   const int lane = lane_id(), wave = wave_id();
   const int r31 = lane & 31, hh = lane >> 5;
@@ -67,17 +68,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
   const float inv_scale = 1.0f / scale;
   auto stage = [&](int buf, int qt) {
     char* sQ = smem + buf * kBuf;
-    char* sD = sQ + kTile32;
-    float* sL = (float*)(sD + kTile32);
-    const int row = wave * 8 + (lane >> 3), slot = lane & 7;
-    const int q = min(qt * 32 + row, T - 1);
-    const int chunk = slot ^ swz_b(row);
-    glds16(qbase + (size_t)q * ld_qkv + chunk * 8, sQ + wave * 8 * 128);
-    glds16(dobase + (size_t)q * ld_o + chunk * 8, sD + wave * 8 * 128);
-    if (wave == 0) {
-      const int qq = qt * 32 + r31;
-      if (hh == 0) sL[r31] = (qq < T) ? -lse_b[qq] * inv_scale : -INFINITY;   // rows >= T: P = exp2(-inf) = 0
-      else sL[32 + r31] = (qq < T) ? del_b[qq] : 0.f;
+    char* sD = sQ + kTileQ;
+    float* sL = (float*)(sD + kTileQ);
+#pragma unroll
+    for (int r = 0; r < kQT / 32; ++r) {
+      const int row = r * 32 + wave * 8 + (lane >> 3), slot = lane & 7;
+      const int q = min(qt * kQT + row, T - 1);
+      const int chunk = slot ^ swz_b(row);
+      glds16(qbase + (size_t)q * ld_qkv + chunk * 8, sQ + (r * 32 + wave * 8) * 128);
+      glds16(dobase + (size_t)q * ld_o + chunk * 8, sD + (r * 32 + wave * 8) * 128);
+    }
+    if (wave < kQT / 32) {                                 // wave w stages the row constants of sub-block w
+      const int qq = qt * kQT + wave * 32 + r31;
+      if (hh == 0) sL[wave * 32 + r31] = (qq < T) ? -lse_b[qq] * inv_scale : -INFINITY;   // rows >= T: P = exp2(-inf) = 0
+      else sL[kQT + wave * 32 + r31] = (qq < T) ? del_b[qq] : 0.f;
     }
   };
 
@@ -85,63 +89,70 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
 #pragma unroll
   for (int i = 0; i < 2; ++i) { dkt[i] = f32x16{}; dvt[i] = f32x16{}; }
 
-  const int nqt = (T + 31) / 32;
+  const int nqt = (T + kQT - 1) / kQT;
   const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
   stage(0, 0);
   __syncthreads();
   for (int qt = 0; qt < nqt; ++qt) {
     const int buf = qt & 1;
     if (qt + 1 < nqt) stage(buf ^ 1, qt + 1);
-    const char* sQ = smem + buf * kBuf;
-    const char* sD = sQ + kTile32;
-    const float* sL = (const float*)(sD + kTile32);
-    // S'[q][key] = Q.K^T - lse/scale ;  dP[q][key] = dO.V^T
-    f32x16 s, dp;
+    const char* sQ0 = smem + buf * kBuf;
+    const char* sD0 = sQ0 + kTileQ;
+    const float* sL0 = (const float*)(sD0 + kTileQ);
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const f32x4 l4 = *(const f32x4*)(sL + 8 * g4 + 4 * hh);
+    for (int sub = 0; sub < kQT / 32; ++sub) {
+      if (qt * kQT + sub * 32 >= T) break;                 // wave-uniform: sub-block entirely past the sequence
+      const char* sQ = sQ0 + sub * 32 * 128;               // (32 rows = a multiple of the swizzle period 16)
+      const char* sD = sD0 + sub * 32 * 128;
+      const float* sL = sL0 + sub * 32;
+      // S'[q][key] = Q.K^T - lse/scale ;  dP[q][key] = dO.V^T
+      f32x16 s, dp;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s[4 * g4 + e] = l4[e];
-    }
-    dp = f32x16{};
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 l4 = *(const f32x4*)(sL + 8 * g4 + 4 * hh);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int chunk = 2 * ks + hh;
-      const bf16x8 qa = *(const bf16x8*)(sQ + r31 * 128 + ((chunk ^ swz_b(r31)) << 4));
-      const bf16x8 da = *(const bf16x8*)(sD + r31 * 128 + ((chunk ^ swz_b(r31)) << 4));
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
-    }
-    // P = exp2(c * S');  dS = P * (dP - delta[q])
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const f32x4 d4 = *(const f32x4*)(sL + 32 + 8 * g4 + 4 * hh);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float pr = __builtin_amdgcn_exp2f(s[4 * g4 + e] * scale_log2e);
-        s[4 * g4 + e] = pr;
-        dp[4 * g4 + e] = pr * (dp[4 * g4 + e] - d4[e]);
+        for (int e = 0; e < 4; ++e) s[4 * g4 + e] = l4[e];
       }
-    }
-    // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]   (k = q, accumulator row order)
+      dp = f32x16{};
 #pragma unroll
-    for (int sk = 0; sk < 2; ++sk) {
-      bf16x8 pf, dsf;
+      for (int ks = 0; ks < 4; ++ks) {
+        const int chunk = 2 * ks + hh;
+        const bf16x8 qa = *(const bf16x8*)(sQ + r31 * 128 + ((chunk ^ swz_b(r31)) << 4));
+        const bf16x8 da = *(const bf16x8*)(sD + r31 * 128 + ((chunk ^ swz_b(r31)) << 4));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
+      }
+      // P = exp2(c * S');  dS = P * (dP - delta[q])
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { pf[j] = (bf16)s[8 * sk + j]; dsf[j] = (bf16)dp[8 * sk + j]; }
-      const int q0r = 16 * sk + 4 * (g >> 1);
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 d4 = *(const f32x4*)(sL + kQT + 8 * g4 + 4 * hh);
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
-        const int ra = q0r + tq, rb = q0r + 8 + tq;
-        const int oa = ra * 128 + ((chunk ^ swz_b(ra)) << 4) + (tp & 1) * 8;
-        const int ob = rb * 128 + ((chunk ^ swz_b(rb)) << 4) + (tp & 1) * 8;
-        const bf16x4 da0 = lds_read_tr16(sD + oa), da1 = lds_read_tr16(sD + ob);
-        const bf16x4 qa0 = lds_read_tr16(sQ + oa), qa1 = lds_read_tr16(sQ + ob);
-        const bf16x8 dof = {da0[0], da0[1], da0[2], da0[3], da1[0], da1[1], da1[2], da1[3]};
-        const bf16x8 qf = {qa0[0], qa0[1], qa0[2], qa0[3], qa1[0], qa1[1], qa1[2], qa1[3]};
-        dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dvt[db], 0, 0, 0);
-        dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, dsf, dkt[db], 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+          const float pr = __builtin_amdgcn_exp2f(s[4 * g4 + e] * scale_log2e);
+          s[4 * g4 + e] = pr;
+          dp[4 * g4 + e] = pr * (dp[4 * g4 + e] - d4[e]);
+        }
+      }
+      // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]   (k = q, accumulator row order)
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {
+        bf16x8 pf, dsf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pf[j] = (bf16)s[8 * sk + j]; dsf[j] = (bf16)dp[8 * sk + j]; }
+        const int q0r = 16 * sk + 4 * (g >> 1);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
+          const int ra = q0r + tq, rb = q0r + 8 + tq;
+          const int oa = ra * 128 + ((chunk ^ swz_b(ra)) << 4) + (tp & 1) * 8;
+          const int ob = rb * 128 + ((chunk ^ swz_b(rb)) << 4) + (tp & 1) * 8;
+          const bf16x4 da0 = lds_read_tr16(sD + oa), da1 = lds_read_tr16(sD + ob);
+          const bf16x4 qa0 = lds_read_tr16(sQ + oa), qa1 = lds_read_tr16(sQ + ob);
+          const bf16x8 dof = {da0[0], da0[1], da0[2], da0[3], da1[0], da1[1], da1[2], da1[3]};
+          const bf16x8 qf = {qa0[0], qa0[1], qa0[2], qa0[3], qa1[0], qa1[1], qa1[2], qa1[3]};
+          dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dvt[db], 0, 0, 0);
+          dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, dsf, dkt[db], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -232,12 +243,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], st, 0, 0, 0);
         dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dpt, 0, 0, 0);
       }
+      if (kt == nkt - 1) {                                 // wave-uniform: only the last tile holds keys >= T
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * kKB2 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const float pr = (key < T) ? __builtin_amdgcn_exp2f(st[r] * scale_log2e) : 0.f;
-        st[r] = pr * (dpt[r] - del);     // dS^T
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * kKB2 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          st[r] = (key < T) ? st[r] : -INFINITY;
+        }
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r] * scale_log2e) * (dpt[r] - del);     // dS^T
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         bf16x8 dsf;
@@ -286,7 +300,7 @@ extern "C" int gvk_attention_bwd_bf16(const void* qkv, const void* out, const vo
   int rc = check_launch("attention_bwd/delta");
   if (rc) return rc;
   const float sl2 = scale * 1.44269504088896340736f;
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((T + 127) / 128, H, B), dim3(256), 2 * (2 * kTile32 + 256), s, (const bf16*)qkv,
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((T + 127) / 128, H, B), dim3(256), 2 * (2 * kTileQ + 2 * kQT * 4), s, (const bf16*)qkv,
                      (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H, ld_qkv, ld_out, scale, sl2);
   rc = check_launch("attention_bwd/dkdv");
   if (rc) return rc;

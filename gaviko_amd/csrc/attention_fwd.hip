@@ -18,7 +18,7 @@ namespace gvk {
 __device__ __forceinline__ int swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
 constexpr int kQB = 128;   // queries per workgroup
-constexpr int kKB = 64;    // keys per tile
+constexpr int kKB = 128;   // keys per staged tile (4 MFMA key blocks of 32): one barrier pair per 128 keys
 constexpr int kTileBytes = kKB * 128;
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse,
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     char* sV = sK + kTileBytes;
     const int rsub = lane >> 3, slot = lane & 7;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < kKB / 32; ++r) {
       const int row = r * 32 + wave * 8 + rsub;
       const int key = min(kt * kKB + row, T - 1);
       const int chunk = slot ^ swz(row);
@@ -66,10 +66,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     const char* sK = smem + buf * 2 * kTileBytes;
     const char* sV = sK + kTileBytes;
 
-    // ---- S^T = K . Q^T   (two 32-key blocks)
-    f32x16 st[2];
+    // ---- S^T = K . Q^T   (kKB/32 key blocks of 32)
+    constexpr int NKB = kKB / 32;
+    f32x16 st[NKB];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb) {
       st[kb] = f32x16{};
       const int row = kb * 32 + r31;
 #pragma unroll
@@ -79,28 +80,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
       }
     }
-    // ---- scale (log2 domain), mask keys >= T, running max
+    // ---- online softmax in the log2 domain.  VALU budget per score: max, fma, exp2, add (the scale is folded into the fma,
+    //      the key mask is applied on the last tile only) -- this block, not the MFMAs, was the largest share of the kernel.
+    if (kt == nkt - 1) {                                  // wave-uniform: only the last tile can contain keys >= T
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * kKB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          st[kb][r] = (key < T) ? st[kb][r] : -INFINITY;
+        }
+    }
     float mx = -INFINITY;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * kKB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        float s = st[kb][r] * scale_log2e;
-        s = (key < T) ? s : -INFINITY;
-        st[kb][r] = s;
-        mx = fmaxf(mx, s);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;   // scale > 0 commutes with max
     const float m_new = fmaxf(m_run, mx);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
     m_run = m_new;
     float psum = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(st[kb][r] - m_new);
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], scale_log2e, -m_new));
         st[kb][r] = p;
         psum += p;
       }
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     // ---- O^T += V^T . P^T : P^T straight from the accumulator registers as the B operand
     const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         bf16x8 pf;
@@ -161,6 +166,12 @@ extern "C" int gvk_attention_fwd_bf16(const void* qkv, void* out, float* lse, in
   GVK_REQUIRE(ld_qkv >= 3 * H * 64 && ld_qkv % 8 == 0 && ld_out >= H * 64 && ld_out % 4 == 0,
               "gvk_attention_fwd_bf16: head dim is fixed at 64; ld_qkv=%d ld_out=%d inconsistent with H=%d", ld_qkv, ld_out, H);
   const int lds = 2 * 2 * kTileBytes;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(attn_fwd): %s", hipGetErrorString(e));
+    attr = true;
+  }
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((T + kQB - 1) / kQB, H, B), dim3(256), lds, (hipStream_t)stream, (const bf16*)qkv,
                      (bf16*)out, lse, T, H, ld_qkv, ld_out, scale * 1.44269504088896340736f);
   return check_launch("attention_fwd_bf16");
