@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -65,6 +66,31 @@ def cpu_baseline(backbone, batch):
     dt = time.perf_counter() - t0
     return {"value": batch / dt, "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"1 step (fwd + CE + bwd) of the same {batch}-volume batch, fp32 torch oracle, {dt:.1f}s"}
+
+
+def pmc_traffic(name, stats):
+    """HBM-side bytes per launch of the dominant GEMM from the committed PMC passes (profiles/r01_pmc_traffic.json, produced
+    by tools/pmc_traffic.py from two `rocprofv3 --pmc` runs of this same command: FETCH_SIZE and WRITE_SIZE, KiB units, reads
+    x2 on gfx950).  PMC counters cannot be read from inside the process, so the figure is the last profiled one; it is only
+    attached when the kernel instantiation (epilogue id) is used by exactly one GEMM shape of this run, else traffic stays null."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    m = re.match(r"gemm_nt_bf16\[(\w+)\]", name)
+    if not (m and os.path.exists(path)):
+        return {}
+    from gaviko_amd import engine as eng_mod
+    epi = {v: k for k, v in eng_mod._EPI_NAMES.items()}[m.group(1)]
+    if sum(1 for k in stats if k.startswith(f"gemm_nt_bf16[{m.group(1)}]")) != 1:
+        return {}
+    with open(path) as f:
+        ker = json.load(f)["kernels"]
+    hits = [v for k, v in ker.items() if re.match(rf"gemm_nt_kernel<\d+, \d+, {epi}, \d+>", k)]
+    if len(hits) != 1:
+        return {}
+    M, N, K = stats[name]["shape"]
+    return {"traffic": hits[0]["total_bytes"], "traffic_source": "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB)",
+            # bf16 operands in + (aux in, out) per epilogue: 0 bf16 out; 2 bias+gelu -> pre-act + act bf16 out; 4 pre-act in, bf16 out;
+            # 1 fp32 residual read-modify-write; 5 fp32 out
+            "algorithmic_bytes": 2 * (M * K + N * K) + M * N * {0: 2, 1: 8, 2: 4, 4: 4, 5: 4, 6: 10}.get(epi, 4)}
 
 
 def main():
@@ -170,6 +196,7 @@ def main():
                                "frac": round(s["flops_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                                "traffic": None, "avg_launch_us": round(s["avg_ms"] * 1e3, 2), "launches": s["n"],
                                "flop_per_launch": s["flops_per_launch"], "shape": s["shape"]}
+            out["roofline"].update(pmc_traffic(name, stats))
             out["gemm_classes"] = {k: {"avg_us": round(v["avg_ms"] * 1e3, 2), "n": v["n"], "tflops": round(v["flops_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12, 1)}
                                    for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])}
     elif world > 1 and not args.no_roofline:

@@ -295,16 +295,16 @@ extern "C" int gvk_attention_bwd_bf16(const void* qkv, const void* out, const vo
               "gvk_attention_bwd_bf16: head dim is fixed at 64; ld_qkv=%d ld_out=%d inconsistent with H=%d", ld_qkv, ld_out, H);
   hipStream_t s = (hipStream_t)stream;
   const int64_t n = (int64_t)B * T * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)out, (const bf16*)dout, delta, B, T, H,
+  GVK_LAUNCH(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)out, (const bf16*)dout, delta, B, T, H,
                      ld_out);
   int rc = check_launch("attention_bwd/delta");
   if (rc) return rc;
   const float sl2 = scale * 1.44269504088896340736f;
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((T + 127) / 128, H, B), dim3(256), 2 * (2 * kTileQ + 2 * kQT * 4), s, (const bf16*)qkv,
+  GVK_LAUNCH(attn_bwd_dkdv_kernel, dim3((T + 127) / 128, H, B), dim3(256), 2 * (2 * kTileQ + 2 * kQT * 4), s, (const bf16*)qkv,
                      (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H, ld_qkv, ld_out, scale, sl2);
   rc = check_launch("attention_bwd/dkdv");
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((T + 127) / 128, H, B), dim3(256), 2 * 2 * kTile64, s, (const bf16*)qkv, (const bf16*)dout, lse,
+  GVK_LAUNCH(attn_bwd_dq_kernel, dim3((T + 127) / 128, H, B), dim3(256), 2 * 2 * kTile64, s, (const bf16*)qkv, (const bf16*)dout, lse,
                      delta, (bf16*)dqkv, T, H, ld_qkv, ld_out, scale, sl2);
   return check_launch("attention_bwd/dq");
 }

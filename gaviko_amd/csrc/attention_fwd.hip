@@ -172,7 +172,7 @@ extern "C" int gvk_attention_fwd_bf16(const void* qkv, void* out, float* lse, in
     if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(attn_fwd): %s", hipGetErrorString(e));
     attr = true;
   }
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((T + kQB - 1) / kQB, H, B), dim3(256), lds, (hipStream_t)stream, (const bf16*)qkv,
+  GVK_LAUNCH(attn_fwd_kernel, dim3((T + kQB - 1) / kQB, H, B), dim3(256), lds, (hipStream_t)stream, (const bf16*)qkv,
                      (bf16*)out, lse, T, H, ld_qkv, ld_out, scale * 1.44269504088896340736f);
   return check_launch("attention_fwd_bf16");
 }

@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels.  wave = 64 lanes everywhere.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <functional>
 #include <stdint.h>
 
 namespace gvk {
@@ -83,6 +84,23 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
 extern "C" const char* gvk_last_error(void);
 namespace gvk {
 int set_error(int code, const char* fmt, ...);
+
+// ---- launch plans (runtime.hip) -----------------------------------------------------------------------------------------
+// Every kernel launch of the library goes through gvk::launch.  While a plan is being recorded on the calling thread the
+// launch is also stored as a closure (kernel, grid, block, LDS bytes, stream, by-value arguments) so gvk_plan_replay can
+// re-issue the whole step from one C loop: no Python, no validation, and -- unlike a captured hipGraph, whose executor
+// serialises three forked branches on this runtime (tools/probe/probe_streams.hip) -- exact stream/event semantics.
+bool plan_recording();
+void plan_push(std::function<void()>&& node);
+
+template <typename... KArgs, typename... Args>
+inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned lds, hipStream_t stream, Args... args) {
+  if (plan_recording())
+    plan_push([=]() { hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...); });
+  hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...);
+}
+#define GVK_LAUNCH(kernel, grid, block, lds, stream, ...) ::gvk::launch(kernel, grid, block, lds, stream, __VA_ARGS__)
+
 int check_launch(const char* what);
 }  // namespace gvk
 

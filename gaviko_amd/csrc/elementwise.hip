@@ -80,7 +80,7 @@ extern "C" int gvk_lora_merge_f32(const float* w, const float* a_q, const float*
                                   float s, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(w && a_q && b_q && a_v && b_v && out && C > 0 && r > 0, "gvk_lora_merge_f32: bad arguments");
-  hipLaunchKernelGGL(lora_merge_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, w, a_q, b_q, a_v, b_v, out, C, r, s);
+  GVK_LAUNCH(lora_merge_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, w, a_q, b_q, a_v, b_v, out, C, r, s);
   return check_launch("lora_merge_f32");
 }
 
@@ -91,14 +91,14 @@ extern "C" int gvk_cast_f32_bf16(const float* in, void* out, int64_t n, void* st
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, (bf16*)out, n);
+  GVK_LAUNCH(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, (bf16*)out, n);
   return check_launch("cast_f32_bf16");
 }
 
 extern "C" int gvk_transpose_cast_f32_bf16(const float* in, void* out, int rows, int cols, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(in && out && rows > 0 && cols > 0, "gvk_transpose_cast_f32_bf16: bad arguments");
-  hipLaunchKernelGGL(transpose_cast_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, in,
+  GVK_LAUNCH(transpose_cast_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, in,
                      (bf16*)out, rows, cols);
   return check_launch("transpose_cast_f32_bf16");
 }
@@ -111,6 +111,6 @@ extern "C" int gvk_patchify_bf16(const float* img, void* out, int B, int D, int 
   const int64_t total = (int64_t)B * D * H * (W / 4);
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img, (bf16*)out, B, D, H, W, pd, ph, pw);
+  GVK_LAUNCH(patchify_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img, (bf16*)out, B, D, H, W, pd, ph, pw);
   return check_launch("patchify_bf16");
 }

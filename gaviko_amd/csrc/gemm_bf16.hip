@@ -203,7 +203,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   GemmArgs p = a;
   p.nbm = (a.M + BM - 1) / BM;
   p.nbn = a.N / BN;
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, EPI, BK>), dim3(p.nbm * p.nbn), dim3(256), lds, stream, p);
+  GVK_LAUNCH((gemm_nt_kernel<BM, BN, EPI, BK>), dim3(p.nbm * p.nbn), dim3(256), lds, stream, p);
   return check_launch("gemm_nt_bf16");
 }
 

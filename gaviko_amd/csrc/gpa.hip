@@ -431,11 +431,11 @@ static void fill_gpa(GpaArgs& a, const gvk_gpa_desc* d) {
 
 #define GVK_GPA_LAUNCH(KERNEL, grid, block, lds)                                                        \
   switch (d->L) {                                                                                       \
-    case 4: hipLaunchKernelGGL((KERNEL<4>), grid, block, lds, s, a); break;                            \
-    case 8: hipLaunchKernelGGL((KERNEL<8>), grid, block, lds, s, a); break;                            \
-    case 16: hipLaunchKernelGGL((KERNEL<16>), grid, block, lds, s, a); break;                          \
-    case 20: hipLaunchKernelGGL((KERNEL<20>), grid, block, lds, s, a); break;                          \
-    case 32: hipLaunchKernelGGL((KERNEL<32>), grid, block, lds, s, a); break;                          \
+    case 4: GVK_LAUNCH((KERNEL<4>), grid, block, lds, s, a); break;                            \
+    case 8: GVK_LAUNCH((KERNEL<8>), grid, block, lds, s, a); break;                            \
+    case 16: GVK_LAUNCH((KERNEL<16>), grid, block, lds, s, a); break;                          \
+    case 20: GVK_LAUNCH((KERNEL<20>), grid, block, lds, s, a); break;                          \
+    case 32: GVK_LAUNCH((KERNEL<32>), grid, block, lds, s, a); break;                          \
     default: return set_error(-2, "gvk_gpa: L=%d unsupported (4, 8, 16, 20, 32)", d->L);               \
   }
 

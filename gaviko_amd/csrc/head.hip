@@ -202,7 +202,7 @@ extern "C" int gvk_rows_broadcast(float* out, const float* src, const float* add
   GVK_REQUIRE(out && src && B > 0 && R > 0 && C > 0 && row_off >= 0 && row_off + R <= T, "gvk_rows_broadcast: bad arguments");
   int64_t blocks = ((int64_t)B * R * C + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(rows_broadcast_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, src, add, B, T, row_off, R, C);
+  GVK_LAUNCH(rows_broadcast_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, src, add, B, T, row_off, R, C);
   return check_launch("rows_broadcast");
 }
 
@@ -211,7 +211,7 @@ extern "C" int gvk_rows_batch_sum(const float* dg, float* out, float* out2, int 
   GVK_REQUIRE(dg && out && B > 0 && R > 0 && C > 0 && row_off >= 0 && row_off + R <= T, "gvk_rows_batch_sum: bad arguments");
   int64_t blocks = ((int64_t)R * C + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(rows_batch_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dg, out, out2, B, T, row_off, R, C, accumulate);
+  GVK_LAUNCH(rows_batch_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dg, out, out2, B, T, row_off, R, C, accumulate);
   return check_launch("rows_batch_sum");
 }
 
@@ -232,7 +232,7 @@ extern "C" int gvk_head_fwd(const gvk_head_desc* d, void* stream) {
   int rc = head_fill(a, d);
   if (rc) return rc;
   GVK_REQUIRE(d->logits, "gvk_head_fwd: logits null");
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(d->B), dim3(256), 4 * d->C * 4, (hipStream_t)stream, a);
+  GVK_LAUNCH(head_fwd_kernel, dim3(d->B), dim3(256), 4 * d->C * 4, (hipStream_t)stream, a);
   return check_launch("head_fwd");
 }
 
@@ -244,11 +244,11 @@ extern "C" int gvk_head_bwd(const gvk_head_desc* d, void* stream) {
   GVK_REQUIRE(d->dlogits && d->pooled && d->dwh && d->dbh, "gvk_head_bwd: null pointer");
   hipStream_t s = (hipStream_t)stream;
   if (d->dg != nullptr) {
-    hipLaunchKernelGGL(head_bwd_rows_kernel, dim3(d->B), dim3(256), d->C * 4, s, a);
+    GVK_LAUNCH(head_bwd_rows_kernel, dim3(d->B), dim3(256), d->C * 4, s, a);
     rc = check_launch("head_bwd_rows");
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(head_bwd_w_kernel, dim3((d->K * d->C + 255) / 256), dim3(256), 0, s, a);
+  GVK_LAUNCH(head_bwd_w_kernel, dim3((d->K * d->C + 255) / 256), dim3(256), 0, s, a);
   return check_launch("head_bwd_w");
 }
 
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_strided_kernel(const bf16* 
 extern "C" int gvk_small_linear_fwd(const float* x, const float* w, const float* b, float* out, int R, int K, int C, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(x && w && out && R > 0 && K > 0 && C > 0, "gvk_small_linear_fwd: bad arguments");
-  hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((R * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, w, b, out, R, K, C);
+  GVK_LAUNCH(small_linear_fwd_kernel, dim3((R * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, w, b, out, R, K, C);
   return check_launch("small_linear_fwd");
 }
 extern "C" int gvk_small_linear_bwd(const float* x, const float* w, const float* dout, float* dw, float* db, float* dx, int R, int K, int C,
@@ -350,12 +350,12 @@ extern "C" int gvk_small_linear_bwd(const float* x, const float* w, const float*
   hipStream_t s = (hipStream_t)stream;
   if (dw != nullptr) {
     const int n = C * K > C ? C * K : C;
-    hipLaunchKernelGGL(small_linear_bwd_w_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, dout, dw, db, R, K, C, accumulate);
+    GVK_LAUNCH(small_linear_bwd_w_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, dout, dw, db, R, K, C, accumulate);
     int rc = check_launch("small_linear_bwd_w");
     if (rc) return rc;
   }
   if (dx != nullptr) {
-    hipLaunchKernelGGL(small_linear_bwd_x_kernel, dim3(R * K), dim3(64), 0, s, w, dout, dx, R, K, C, accumulate);
+    GVK_LAUNCH(small_linear_bwd_x_kernel, dim3(R * K), dim3(64), 0, s, w, dout, dx, R, K, C, accumulate);
     return check_launch("small_linear_bwd_x");
   }
   return 0;
@@ -366,7 +366,7 @@ extern "C" int gvk_vpt_repack_fwd(const float* in, const float* prompt, float* o
   GVK_REQUIRE(Tout == Tin - skip + P && Tout > 1 + P && skip >= 0, "gvk_vpt_repack_fwd: Tout=%d must equal Tin-skip+P (%d-%d+%d)", Tout, Tin, skip, P);
   int64_t blocks = ((int64_t)B * Tout * (C / 4) + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(vpt_repack_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, prompt, out, B, Tin, Tout, P, skip, C);
+  GVK_LAUNCH(vpt_repack_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, prompt, out, B, Tin, Tout, P, skip, C);
   return check_launch("vpt_repack_fwd");
 }
 extern "C" int gvk_vpt_repack_bwd(const float* dout, float* din, int B, int Tin, int Tout, int P, int skip, int C, void* stream) {
@@ -375,7 +375,7 @@ extern "C" int gvk_vpt_repack_bwd(const float* dout, float* din, int B, int Tin,
   GVK_REQUIRE(Tout == Tin - skip + P && skip >= 0, "gvk_vpt_repack_bwd: Tout=%d must equal Tin-skip+P", Tout);
   int64_t blocks = ((int64_t)B * Tin * (C / 4) + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(vpt_repack_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, din, B, Tin, Tout, P, skip, C);
+  GVK_LAUNCH(vpt_repack_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, din, B, Tin, Tout, P, skip, C);
   return check_launch("vpt_repack_bwd");
 }
 extern "C" int gvk_cast_bf16_f32_strided(const void* in, float* out, int M, int C, int ld_in, void* stream) {
@@ -383,6 +383,6 @@ extern "C" int gvk_cast_bf16_f32_strided(const void* in, float* out, int M, int 
   GVK_REQUIRE(in && out && M > 0 && C > 0 && C % 4 == 0 && ld_in % 4 == 0 && ld_in >= C, "gvk_cast_bf16_f32_strided: bad arguments");
   int64_t blocks = ((int64_t)M * (C / 4) + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(cast_bf16_f32_strided_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, out, M, C, ld_in);
+  GVK_LAUNCH(cast_bf16_f32_strided_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, out, M, C, ld_in);
   return check_launch("cast_bf16_f32_strided");
 }

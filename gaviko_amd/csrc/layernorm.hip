@@ -153,7 +153,7 @@ extern "C" int gvk_layernorm_fwd(const float* x, const float* gamma, const float
   using namespace gvk;
   GVK_REQUIRE(x && gamma && beta && (y_bf16 || y_f32), "gvk_layernorm_fwd: null pointer");
   GVK_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 256 * kMaxChunks, "gvk_layernorm_fwd: C=%d must be a multiple of 4 and <= 1024", C);
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16*)y_bf16, y_f32, mean,
+  GVK_LAUNCH(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16*)y_bf16, y_f32, mean,
                      rstd, M, C, eps);
   return check_launch("layernorm_fwd");
 }
@@ -163,7 +163,7 @@ extern "C" int gvk_layernorm_bwd(const float* dy, const float* x, const float* m
   using namespace gvk;
   GVK_REQUIRE(dy && x && mean && rstd && gamma && dx, "gvk_layernorm_bwd: null pointer");
   GVK_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 256 * kMaxChunks, "gvk_layernorm_bwd: C=%d must be a multiple of 4 and <= 1024", C);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dres, dx,
+  GVK_LAUNCH(ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dres, dx,
                      (bf16*)dx_bf16, M, C);
   return check_launch("layernorm_bwd");
 }
@@ -173,11 +173,11 @@ extern "C" int gvk_layernorm_bwd_affine(const float* dy, const float* x, const f
   using namespace gvk;
   GVK_REQUIRE(dy && x && mean && rstd && dgamma && dbeta && scratch, "gvk_layernorm_bwd_affine: null pointer");
   GVK_REQUIRE(M > 0 && C > 0, "gvk_layernorm_bwd_affine: empty shape");
-  hipLaunchKernelGGL(ln_affine_partial_kernel, dim3((C + 255) / 256, 64), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd,
+  GVK_LAUNCH(ln_affine_partial_kernel, dim3((C + 255) / 256, 64), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd,
                      scratch, M, C);
   int rc = check_launch("layernorm_bwd_affine/partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(ln_affine_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, dgamma, dbeta, C,
+  GVK_LAUNCH(ln_affine_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, dgamma, dbeta, C,
                      accumulate);
   return check_launch("layernorm_bwd_affine/final");
 }

@@ -4,6 +4,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <vector>
 
 namespace gvk {
 static thread_local char g_err[512] = "";
@@ -21,10 +24,133 @@ int check_launch(const char* what) {
   if (e != hipSuccess) return set_error(-1, "%s: launch failed: %s", what, hipGetErrorString(e));
   return 0;
 }
+
+// ---- launch plans ---------------------------------------------------------------------------------------------------------
+struct Plan {
+  std::vector<std::function<void()>> nodes;
+  std::vector<hipEvent_t> events;
+  ~Plan() {
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
+  }
+};
+static thread_local Plan* g_rec = nullptr;
+static std::mutex g_plans_mu;
+static std::vector<std::unique_ptr<Plan>> g_plans;
+
+bool plan_recording() { return g_rec != nullptr; }
+void plan_push(std::function<void()>&& node) { g_rec->nodes.push_back(std::move(node)); }
+
+__global__ void seed_advance_kernel(unsigned long long* seed, unsigned long long inc) { seed[0] += inc; }
+__global__ void scale_kernel(float* x, float alpha, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= alpha;
+}
 }  // namespace gvk
 
+extern "C" int gvk_plan_begin(void) {
+  using namespace gvk;
+  GVK_REQUIRE(g_rec == nullptr, "gvk_plan_begin: a plan is already being recorded on this thread");
+  g_rec = new Plan();
+  return 0;
+}
+
+extern "C" int gvk_plan_abort(void) {
+  delete gvk::g_rec;
+  gvk::g_rec = nullptr;
+  return 0;
+}
+
+extern "C" int gvk_plan_end(void) {
+  using namespace gvk;
+  GVK_REQUIRE(g_rec != nullptr, "gvk_plan_end: no plan is being recorded");
+  std::lock_guard<std::mutex> lk(g_plans_mu);
+  g_plans.emplace_back(g_rec);
+  g_rec = nullptr;
+  return (int)g_plans.size() - 1;
+}
+
+extern "C" int gvk_plan_size(int plan) {
+  using namespace gvk;
+  std::lock_guard<std::mutex> lk(g_plans_mu);
+  GVK_REQUIRE(plan >= 0 && plan < (int)g_plans.size() && g_plans[plan], "gvk_plan_size: no such plan %d", plan);
+  return (int)g_plans[plan]->nodes.size();
+}
+
+extern "C" int gvk_plan_replay(int plan) {
+  using namespace gvk;
+  Plan* p = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    GVK_REQUIRE(plan >= 0 && plan < (int)g_plans.size() && g_plans[plan], "gvk_plan_replay: no such plan %d", plan);
+    p = g_plans[plan].get();
+  }
+  GVK_REQUIRE(g_rec == nullptr, "gvk_plan_replay: cannot replay while recording");
+  for (auto& node : p->nodes) node();
+  return check_launch("plan_replay");
+}
+
+extern "C" int gvk_plan_free(int plan) {
+  using namespace gvk;
+  std::lock_guard<std::mutex> lk(g_plans_mu);
+  GVK_REQUIRE(plan >= 0 && plan < (int)g_plans.size() && g_plans[plan], "gvk_plan_free: no such plan %d", plan);
+  g_plans[plan].reset();
+  return 0;
+}
+
+extern "C" int gvk_plan_event_record(void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(g_rec != nullptr, "gvk_plan_event_record: only valid while a plan is being recorded");
+  hipEvent_t ev;
+  hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  if (e != hipSuccess) return set_error(-1, "hipEventCreate: %s", hipGetErrorString(e));
+  g_rec->events.push_back(ev);
+  hipStream_t s = (hipStream_t)stream;
+  g_rec->nodes.push_back([=]() { (void)hipEventRecord(ev, s); });
+  e = hipEventRecord(ev, s);
+  if (e != hipSuccess) return set_error(-1, "hipEventRecord: %s", hipGetErrorString(e));
+  return (int)g_rec->events.size() - 1;
+}
+
+extern "C" int gvk_plan_event_wait(void* stream, int event) {
+  using namespace gvk;
+  GVK_REQUIRE(g_rec != nullptr, "gvk_plan_event_wait: only valid while a plan is being recorded");
+  GVK_REQUIRE(event >= 0 && event < (int)g_rec->events.size(), "gvk_plan_event_wait: no such event %d", event);
+  hipEvent_t ev = g_rec->events[event];
+  hipStream_t s = (hipStream_t)stream;
+  g_rec->nodes.push_back([=]() { (void)hipStreamWaitEvent(s, ev, 0); });
+  hipError_t e = hipStreamWaitEvent(s, ev, 0);
+  if (e != hipSuccess) return set_error(-1, "hipStreamWaitEvent: %s", hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int gvk_memset_async(void* ptr, int value, size_t bytes, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(ptr != nullptr || bytes == 0, "gvk_memset_async: null pointer");
+  if (bytes == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (plan_recording()) plan_push([=]() { (void)hipMemsetAsync(ptr, value, bytes, s); });
+  hipError_t e = hipMemsetAsync(ptr, value, bytes, s);
+  if (e != hipSuccess) return set_error(-1, "hipMemsetAsync: %s", hipGetErrorString(e));
+  return 0;
+}
+
+extern "C" int gvk_seed_advance(void* seed, uint64_t inc, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(seed != nullptr, "gvk_seed_advance: null pointer");
+  GVK_LAUNCH(seed_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)seed, (unsigned long long)inc);
+  return check_launch("seed_advance");
+}
+
+extern "C" int gvk_scale_f32(float* x, float alpha, long n, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(x != nullptr && n >= 0, "gvk_scale_f32: bad arguments");
+  if (n == 0) return 0;
+  GVK_LAUNCH(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, alpha, n);
+  return check_launch("scale_f32");
+}
+
 extern "C" const char* gvk_last_error(void) { return gvk::g_err; }
-extern "C" int gvk_abi_version(void) { return 1; }
+extern "C" int gvk_abi_version(void) { return 2; }
 
 extern "C" int gvk_device_check(void) {
   int dev = 0;

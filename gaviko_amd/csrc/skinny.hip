@@ -624,22 +624,22 @@ static int launch_down(const DownArgs& a, hipStream_t s) {
     if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(skinny_down): %s", hipGetErrorString(e));
     attr = true;
   }
-  hipLaunchKernelGGL((skinny_down_kernel<L>), dim3((a.M + kDownRows - 1) / kDownRows), dim3(1024), lds, s, a);
+  GVK_LAUNCH((skinny_down_kernel<L>), dim3((a.M + kDownRows - 1) / kDownRows), dim3(1024), lds, s, a);
   return check_launch("skinny_down");
 }
 template <int L>
 static int launch_up(const UpArgs& a, hipStream_t s) {
   const int nch = (a.C + 63) / 64;
   const dim3 grid((a.M + kUpRows - 1) / kUpRows);
-  if (nch > 12) hipLaunchKernelGGL((skinny_up_kernel<L, 8, 2>), grid, dim3(512), 0, s, a);        // C <= 1024
-  else if (nch > 8) hipLaunchKernelGGL((skinny_up_kernel<L, 4, 3>), grid, dim3(256), 0, s, a);    // C <= 768
-  else if (nch > 4) hipLaunchKernelGGL((skinny_up_kernel<L, 4, 2>), grid, dim3(256), 0, s, a);    // C <= 512
-  else hipLaunchKernelGGL((skinny_up_kernel<L, 4, 1>), grid, dim3(256), 0, s, a);                 // C <= 256
+  if (nch > 12) GVK_LAUNCH((skinny_up_kernel<L, 8, 2>), grid, dim3(512), 0, s, a);        // C <= 1024
+  else if (nch > 8) GVK_LAUNCH((skinny_up_kernel<L, 4, 3>), grid, dim3(256), 0, s, a);    // C <= 768
+  else if (nch > 4) GVK_LAUNCH((skinny_up_kernel<L, 4, 2>), grid, dim3(256), 0, s, a);    // C <= 512
+  else GVK_LAUNCH((skinny_up_kernel<L, 4, 1>), grid, dim3(256), 0, s, a);                 // C <= 256
   return check_launch("skinny_up");
 }
 template <int L>
 static int launch_outer(const OuterArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL((outer_partial_kernel<L>), dim3((a.C + 255) / 256, kOuterSlabs), dim3(256), 0, s, a);   // 4 waves x 64 columns
+  GVK_LAUNCH((outer_partial_kernel<L>), dim3((a.C + 255) / 256, kOuterSlabs), dim3(256), 0, s, a);   // 4 waves x 64 columns
   return check_launch("outer_partial");
 }
 
@@ -720,7 +720,7 @@ extern "C" int gvk_outer_reduce(const gvk_outer_desc* d, void* stream) {
     default: return set_error(-2, "gvk_outer_reduce: L=%d unsupported (4, 8, 16, 20, 32, 64)", d->L);
   }
   if (rc) return rc;
-  hipLaunchKernelGGL(outer_final_kernel, dim3((d->C + 255) / 256, d->L + 1), dim3(256), 0, s, d->scratch, d->out, d->colsum, d->L, d->C,
+  GVK_LAUNCH(outer_final_kernel, dim3((d->C + 255) / 256, d->L + 1), dim3(256), 0, s, d->scratch, d->out, d->colsum, d->L, d->C,
                      d->transposed, d->accumulate);
   return check_launch("outer_final");
 }
@@ -729,10 +729,10 @@ extern "C" int gvk_small_wgrad(const float* a, const float* b, float* out, float
   using namespace gvk;
   GVK_REQUIRE(a && b && out && scratch && M > 0 && J > 0 && L > 0, "gvk_small_wgrad: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(small_wgrad_partial_kernel, dim3(kSlabs), dim3(256), 0, s, a, b, scratch, M, J, L);
+  GVK_LAUNCH(small_wgrad_partial_kernel, dim3(kSlabs), dim3(256), 0, s, a, b, scratch, M, J, L);
   int rc = check_launch("small_wgrad_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((J * L + 255) / 256), dim3(256), 0, s, scratch, out, J * L, kSlabs, accumulate);
+  GVK_LAUNCH(slab_sum_kernel, dim3((J * L + 255) / 256), dim3(256), 0, s, scratch, out, J * L, kSlabs, accumulate);
   return check_launch("small_wgrad_final");
 }
 
@@ -740,10 +740,10 @@ extern "C" int gvk_colsum(const float* x, float* out, float* scratch, int M, int
   using namespace gvk;
   GVK_REQUIRE(x && out && scratch && M > 0 && C > 0, "gvk_colsum: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 255) / 256, kSlabs), dim3(256), 0, s, x, scratch, M, C);
+  GVK_LAUNCH(colsum_partial_kernel, dim3((C + 255) / 256, kSlabs), dim3(256), 0, s, x, scratch, M, C);
   int rc = check_launch("colsum_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, s, scratch, out, C, kSlabs, accumulate);
+  GVK_LAUNCH(slab_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, s, scratch, out, C, kSlabs, accumulate);
   return check_launch("colsum_final");
 }
 
@@ -764,10 +764,10 @@ extern "C" int gvk_reduce_batch(const gvk_reduce_job* jobs, int njobs, float* sc
   }
   bt.total_out = ob;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(reduce_batch_partial_kernel, dim3(wg, kRedSlabs), dim3(1024), 0, s, bt);
+  GVK_LAUNCH(reduce_batch_partial_kernel, dim3(wg, kRedSlabs), dim3(1024), 0, s, bt);
   int rc = check_launch("reduce_batch/partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_batch_final_kernel, dim3((ob + 255) / 256), dim3(256), 0, s, bt);
+  GVK_LAUNCH(reduce_batch_final_kernel, dim3((ob + 255) / 256), dim3(256), 0, s, bt);
   return check_launch("reduce_batch/final");
 }
 
@@ -775,7 +775,7 @@ extern "C" int gvk_ln_lowrank_affine(const float* Q, const float* S, const float
                                      float* dgamma, float* dbeta, float* dbias, int L, int C, int accumulate, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(Q && S && W && gamma && beta && dW && dgamma && dbeta && L > 0 && C >= L, "gvk_ln_lowrank_affine: bad arguments");
-  hipLaunchKernelGGL(ln_lowrank_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, Q, S, W, gamma, beta, dW, dgamma,
+  GVK_LAUNCH(ln_lowrank_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, Q, S, W, gamma, beta, dW, dgamma,
                      dbeta, dbias, L, C, accumulate);
   return check_launch("ln_lowrank_affine");
 }

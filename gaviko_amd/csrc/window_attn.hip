@@ -222,11 +222,11 @@ static int fill(WinArgs& a, const gvk_window_attn_desc* d) {
 
 #define GVK_WIN_DISPATCH(KERNEL, what)                                                                             \
   switch (d->L) {                                                                                                  \
-    case 4: hipLaunchKernelGGL((KERNEL<4>), dim3(grid), dim3(256), 0, s, a); break;                               \
-    case 8: hipLaunchKernelGGL((KERNEL<8>), dim3(grid), dim3(256), 0, s, a); break;                               \
-    case 16: hipLaunchKernelGGL((KERNEL<16>), dim3(grid), dim3(256), 0, s, a); break;                             \
-    case 20: hipLaunchKernelGGL((KERNEL<20>), dim3(grid), dim3(256), 0, s, a); break;                             \
-    case 32: hipLaunchKernelGGL((KERNEL<32>), dim3(grid), dim3(256), 0, s, a); break;                             \
+    case 4: GVK_LAUNCH((KERNEL<4>), dim3(grid), dim3(256), 0, s, a); break;                               \
+    case 8: GVK_LAUNCH((KERNEL<8>), dim3(grid), dim3(256), 0, s, a); break;                               \
+    case 16: GVK_LAUNCH((KERNEL<16>), dim3(grid), dim3(256), 0, s, a); break;                             \
+    case 20: GVK_LAUNCH((KERNEL<20>), dim3(grid), dim3(256), 0, s, a); break;                             \
+    case 32: GVK_LAUNCH((KERNEL<32>), dim3(grid), dim3(256), 0, s, a); break;                             \
     default: return set_error(-2, what ": L=%d unsupported (4, 8, 16, 20, 32)", d->L);                            \
   }
 

@@ -27,11 +27,21 @@ from . import ops
 
 import os
 
-USE_GRAPHS = os.environ.get("GAVIKO_HIP_GRAPHS", "1") != "0"   # capture forward / backward into HIP graphs after warm-up
+# How a step is issued after the GRAPH_WARMUP eager passes (env GAVIKO_HIP_GRAPHS):
+#   "plan"  (default, also "1") -- the library's launch plan: recorded once, replayed from one C loop on the real streams
+#   "graph"                     -- one captured hipGraph per pass (kept for comparison: its executor serialises three forked
+#                                  branches on this runtime, tools/probe/probe_streams.hip: 7.6 ms vs 3.9 ms eager)
+#   "0" / "eager"               -- every launch from Python
+_MODE = os.environ.get("GAVIKO_HIP_GRAPHS", "plan")
+STEP_MODE = {"1": "plan", "0": "eager"}.get(_MODE, _MODE)
+USE_GRAPHS = STEP_MODE != "eager"
 GRAPH_WARMUP = 2
 
 # bench.py instrumentation: when a dict, every GEMM launch is bracketed by HIP events recorded on the launch stream
 GEMM_TIMING = None
+# Dispatch priority of the side-chain streams (negative = higher).  Measured: -1 drops the step rate from 448 to 274 volumes/s
+# (priority queues serialise against the captured graph's main queue on this runtime), so the default stays 0.
+SIDE_STREAM_PRIORITY = int(os.environ.get("GAVIKO_HIP_SIDE_PRIORITY", "0"))
 _EPI_NAMES = {0: "store_bf16", 1: "bias_res_f32", 2: "bias_gelu_bf16", 3: "patch_f32", 4: "gelu_bwd_bf16", 5: "store_f32", 6: "bias_res_f32_bf16"}
 
 
@@ -126,6 +136,7 @@ class Engine:
         self._calls = {}
         self._wss = {}
         self._streams = {}
+        self._recording = False
         self._ws = None
         self._step = 0
         self._flat_grad = None
@@ -247,7 +258,7 @@ class Engine:
                 ws["dL"] = [mk(BN, C), mk(BN, C)]
                 ws["bw"] = dict(dcomb=mk(M, Lt), dimp=mk(B, P), dgw_part=mk(B, P), dqg=mk(B, P, Lt), dql=mk(B, P, Lt), dcg=mk(B, P, Lt),
                                 dcl=mk(B, P, Lt), delta_g=mk(B, P), delta_l=mk(B, P), dprm=mk(B, P, Lt), dcls=mk(B, Lt),
-                                gate_partials=mk(B, ng), dzx=mk(M, Lt), dzl=mk(BN, Lt),
+                                gate_partials=mk(B, ng), dzx=mk(M, Lt), dzl=[mk(BN, Lt), mk(BN, Lt)],
                                 dctx=mk(BN, Lt), dqkv=mk(BN, 3 * Lt), wdelta=mk(BN), dlat=mk(BN, Lt), Q=mk(Lt, C), S=mk(Lt))
                 ws["scratch"] = mk(max(ops.outer_scratch_elems(Lt, C), 128 * C, 64 * 3 * Lt * Lt, 64 * ng))
                 ws["rscratch"] = mk(32 * (ng + 2 * Lt * Lt + 3 * Lt + 3 * Lt * Lt + 64))
@@ -266,17 +277,32 @@ class Engine:
     def _stream(self, name):
         st = self._streams.get(name)
         if st is None:
-            st = self._streams[name] = torch.cuda.Stream()
+            st = self._streams[name] = torch.cuda.Stream(priority=SIDE_STREAM_PRIORITY)
         return st
+
+    def _ev_record(self, stream):
+        """Record an event on `stream`; while a launch plan is being recorded the event belongs to the plan."""
+        if self._recording:
+            rc = L.load().gvk_plan_event_record(stream.cuda_stream)
+            if rc < 0:
+                L.check(rc, "gvk_plan_event_record")
+            return rc
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        return ev
+
+    def _ev_wait(self, stream, ev):
+        if self._recording:
+            L.check(L.load().gvk_plan_event_wait(stream.cuda_stream, ev), "gvk_plan_event_wait")
+        else:
+            stream.wait_event(ev)
 
     def _wait(self, waiter, on):
         """stream `waiter` waits for everything enqueued so far on stream `on` (None = the current/main stream)."""
         cur = torch.cuda.current_stream()
         src = cur if on is None else self._stream(on)
         dst = cur if waiter is None else self._stream(waiter)
-        ev = torch.cuda.Event()
-        ev.record(src)
-        dst.wait_event(ev)
+        self._ev_wait(dst, self._ev_record(src))
 
     # ------------------------------------------------------------------ graphs
     def _run(self, tag, key, fn):
@@ -285,15 +311,35 @@ class Engine:
         if GEMM_TIMING is not None:                         # instrumented (event-per-launch) pass: always eager
             fn()
             return
-        k = (tag,) + key
+        k = (tag,) + key + (torch.cuda.current_stream().cuda_stream,)
         g = self._graphs.get(k)
         if g is not None:
-            g.replay()
+            if isinstance(g, int):
+                L.check(L.load().gvk_plan_replay(g), "gvk_plan_replay")
+            else:
+                g.replay()
             return
         n = self._calls.get(k, 0)
         self._calls[k] = n + 1
         if not USE_GRAPHS or n < GRAPH_WARMUP:
             fn()
+            return
+        if STEP_MODE == "plan":
+            # this pass both executes and records; every launch inside fn goes through the library (no torch kernels)
+            lib = L.load()
+            L.check(lib.gvk_plan_begin(), "gvk_plan_begin")
+            self._recording = True
+            try:
+                fn()
+            except BaseException:
+                lib.gvk_plan_abort()
+                raise
+            finally:
+                self._recording = False
+            pid = lib.gvk_plan_end()
+            if pid < 0:
+                L.check(pid, "gvk_plan_end")
+            self._graphs[k] = pid
             return
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -326,7 +372,7 @@ class Engine:
         B, C, T, N, train = sv["B"], self.C, self.T, self.N, sv["train"]
         M = B * T
         nm, w, d = self.names, self._w16, self._d
-        ws["seed"].add_(7919)                               # device-side dropout epoch (HIP-graph safe)
+        ops.seed_advance(ws["seed"], 7919)                  # device-side dropout epoch (replay safe)
         # ---- embedding: patch GEMM (+bias +pos, scattered to rows row_off..) and the broadcast rows
         pe0 = pe1 = None
         if GEMM_TIMING is not None:                          # bench.py: time the whole patch-embed stage (im2col + GEMM + scatter)
@@ -532,7 +578,7 @@ class Engine:
         r0, R = self._pool_rows()
         dG = ws["dG"][0] if backbone_bwd else None
         if backbone_bwd:
-            dG.zero_()
+            ops.memset_zero(dG)
         ops.head_bwd(g=self._final_stream(ws, True), ln_gamma=d(nm.root + "transformer.norm.weight"),
                      ln_beta=d(nm.root + "transformer.norm.bias"), wh=d(nm.head() + ".weight"), bh=d(nm.head() + ".bias"), pooled=ws["pooled"],
                      dlogits=ws["dlogits"], dg=dG, dwh=gv[nm.head() + ".weight"], dbh=gv[nm.head() + ".bias"], B=B, T=self.Ts[-1], C=C,
@@ -540,7 +586,7 @@ class Engine:
         if backbone_bwd:
             ops.cast_bf16(dG, ws["dG16"])
             if self.kind == "gaviko":
-                ws["dL"][0].zero_()
+                ops.memset_zero(ws["dL"][0])
 
     def _backward_segment(self, ws, sv, gv, hi, lo, first, last):
         """Layers hi, hi-1, ..., lo of the backward sweep (+ the head when `first`, + the embedding rows when `last`).
@@ -559,6 +605,7 @@ class Engine:
             loc, gpa = self._stream("loc"), self._stream("gpa")
             self._wait("gpa", None)
             self._wait("loc", None)
+        prev_scl = None
         for i in range(hi, lo - 1, -1):
             M = B * self.Ts[i]
             T = self.Ts[i]
@@ -569,10 +616,9 @@ class Engine:
             # for the event between the two
             if gaviko:
                 with torch.cuda.stream(gpa):
-                    self._gpa_bwd_core(ws, sv, gv, i, dGout, M, B)
-                    dz_ready = torch.cuda.Event()
-                    dz_ready.record(gpa)
-                    self._gpa_bwd_params(ws, sv, gv, i, dGout, M, B)
+                    self._gpa_bwd_core(ws, sv, gv, i, dGout, M, B, par)
+                    dz_ready = self._ev_record(gpa)
+                    self._gpa_bwd_params(ws, sv, gv, i, dGout, M, B, par)
             # main stream, MLP block: dG1 = dGout + LN'(fc1^T(GELU'(pre) * fc2^T(dGout)))
             self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i])
             self._gemm(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
@@ -582,11 +628,12 @@ class Engine:
             if adapter:
                 self._adapter_bwd(ws, gv, i, dGout, dGin, M)                 # adds LN_a'(...) into dG1 and refreshes dG16
             if gaviko:
-                torch.cuda.current_stream().wait_event(dz_ready)
+                self._ev_wait(torch.cuda.current_stream(), dz_ready)
                 self._gpa_bwd_scatter_g(ws, i, dGin, M)                      # dG1 += dzx.Wd (+ bf16 copy)
-                loc.wait_event(dz_ready)
+                self._ev_wait(loc, dz_ready)
                 with torch.cuda.stream(loc):
-                    self._gpa_bwd_scatter_l(ws, i, ws["dL"][par], B)         # dL += dzl.Wd (dL[par] was written on this stream)
+                    self._gpa_bwd_scatter_l(ws, i, ws["dL"][par], B, par)    # dL += dzl.Wd (dL[par] was written on this stream)
+                    scl_done = self._ev_record(loc)
                     self._mwsa_bwd(ws, sv, gv, i, ws["dL"][par], ws["dL"][par ^ 1], B)
             # main stream, attention block: dG0 = dG1 + LN'(qkv^T(attn'(out^T(dG1))))
             self._gemm(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
@@ -598,9 +645,13 @@ class Engine:
                 self._wait(None, "gpa")                                      # the GPA parameter gradients still read dGout
             ops.layernorm_bwd(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGout, dres=dGin, dx16=ws["dG16"])
             if gaviko:
-                self._wait(None, "loc")                                      # the MWSA chain has consumed dzl ...
-                self._wait("gpa", None)                                      # ... so the next layer's GPA backward, which needs this
-                                                                             # dG[i], may also overwrite bw["dzx"/"dzl"]
+                # The MWSA chain never feeds the global stream in the backward, so the main stream does not join it per layer: dzl
+                # is double-buffered by layer parity and the only cross-stream hazard left is layer i-1's GPA rewriting the buffer
+                # layer i+1's scatter read -- ordered by waiting for THAT (long finished) kernel, one layer late.
+                if prev_scl is not None:
+                    self._ev_wait(torch.cuda.current_stream(), prev_scl)
+                prev_scl = scl_done
+                self._wait("gpa", None)                                      # the next layer's GPA backward needs this dG[i]
             if self.kind == "vpt" and (i == 0 or self.deep):
                 # prompt rows 1..P of this layer's input are this layer's projected prompts (vpt.py:127-131,147-153)
                 ops.rows_batch_sum(dGout, ws["dvproj"][i * self.P: (i + 1) * self.P], None, B, T, 1, self.P, C)
@@ -643,7 +694,7 @@ class Engine:
         top = min(self.depth - 1, s * self.share + self.share - 1)
         return 0 if i == top else 1
 
-    def _gpa_bwd_core(self, ws, sv, gv, i, dGout, M, B):
+    def _gpa_bwd_core(self, ws, sv, gv, i, dGout, M, B, par):
         """Critical part of the GPA backward: dcomb = dGout . Wup and the latent-space backward -> dzx / dzl
         (what the main stream's dG1 update and the MWSA chain wait for)."""
         pre, names = self._gpa_names(i)
@@ -654,9 +705,9 @@ class Engine:
                     qg=g["qg"], ql=g["ql"], cg=g["cg"], cl=g["cl"], lse_g=g["lse_g"], lse_l=g["lse_l"], dcomb=bw["dcomb"], zx=g["zx"], zl=g["zl"],
                     dimp=bw["dimp"], dgw_part=bw["dgw_part"], dqg=bw["dqg"], dql=bw["dql"], dcg=bw["dcg"], dcl=bw["dcl"],
                     delta_g=bw["delta_g"], delta_l=bw["delta_l"], dprm=bw["dprm"], dcls=bw["dcls"], gate_partials=bw["gate_partials"],
-                    dzx=bw["dzx"], dzl=bw["dzl"], **{k: d(v) for k, v in names.items()})
+                    dzx=bw["dzx"], dzl=bw["dzl"][par], **{k: d(v) for k, v in names.items()})
 
-    def _gpa_bwd_params(self, ws, sv, gv, i, dGout, M, B):
+    def _gpa_bwd_params(self, ws, sv, gv, i, dGout, M, B, par):
         """Off the critical path: every parameter gradient of the GPA module (reads dGout, dzx, dzl, saved activations)."""
         pre, names = self._gpa_names(i)
         d, C, Lt, P, T, N = self._d, self.C, self.Lat, self.P, self.T, self.N
@@ -676,10 +727,10 @@ class Engine:
                           (dqg, prm, gv[names["wgq"]], acc), (dqg, None, gv[names["bgq"]], acc),
                           (dql, prm, gv[names["wlq"]], acc), (dql, None, gv[names["blq"]], acc),
                           (bw["dzx"], None, gbd, acc)], ws["rscratch"])
-        ops.reduce_batch([(bw["dzl"], None, gbd, 1)], ws["rscratch"])
+        ops.reduce_batch([(bw["dzl"][par], None, gbd, 1)], ws["rscratch"])
         # proj_down (shared by both streams): dWd = dzx^T.G1 + dzl^T.Lnew
         ops.outer_reduce(narrow=bw["dzx"], wide=ws["G1"][i], scratch=sc, out=gwd, M=M, C=C, L=Lt, transposed=0, accumulate=acc)
-        ops.outer_reduce(narrow=bw["dzl"], wide=ws["Lc"][i + 1], scratch=sc, out=gwd, M=B * N, C=C, L=Lt, transposed=0, accumulate=1)
+        ops.outer_reduce(narrow=bw["dzl"][par], wide=ws["Lc"][i + 1], scratch=sc, out=gwd, M=B * N, C=C, L=Lt, transposed=0, accumulate=1)
 
     def _gpa_bwd_scatter_g(self, ws, i, dG1, M):
         """main stream: dG1 += dzx . Wd, with the bf16 copy for the out-proj dgrad."""
@@ -687,10 +738,10 @@ class Engine:
         ops.skinny_up(lat=ws["bw"]["dzx"], w=self._d(pre + ".proj_down.0.weight"), out=dG1, out_bf16=ws["dG16"], M=M, C=self.C, L=self.Lat,
                       w_layout=1, accumulate=1)
 
-    def _gpa_bwd_scatter_l(self, ws, i, dLnew, B):
+    def _gpa_bwd_scatter_l(self, ws, i, dLnew, B, par):
         """MWSA chain: dL += dzl . Wd."""
         pre, _ = self._gpa_names(i)
-        ops.skinny_up(lat=ws["bw"]["dzl"], w=self._d(pre + ".proj_down.0.weight"), out=dLnew, M=B * self.N, C=self.C, L=self.Lat, w_layout=1,
+        ops.skinny_up(lat=ws["bw"]["dzl"][par], w=self._d(pre + ".proj_down.0.weight"), out=dLnew, M=B * self.N, C=self.C, L=self.Lat, w_layout=1,
                       accumulate=1)
 
     # ---- AdaptFormer (adaptformer.py:58-78, 93-97): r = up(ReLU(down(LN_a(x)))), x_out = ff(x) + x + r -----------------------
@@ -771,8 +822,8 @@ class Engine:
             ops.outer_reduce(narrow=du, wide=x, mean=st[0], rstd=st[1], ln_gamma=g1, ln_beta=b1, scratch=sc, out=gv[na], M=M, C=C, L=r,
                              transposed=0, accumulate=0)
             if self.lora_s != 1:
-                gv[na].mul_(float(self.lora_s))
-                gv[nb].mul_(float(self.lora_s))
+                ops.scale_(gv[na], float(self.lora_s))
+                ops.scale_(gv[nb], float(self.lora_s))
 
     def _offset_of(self, name) -> int:
         return (self._flat_grad["views"][name].data_ptr() - self._flat_grad["buf"].data_ptr()) // 4

@@ -85,11 +85,17 @@ SIGNATURES = {
     "gvk_vpt_repack_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gvk_cast_bf16_f32_strided": [_P, _P, _I, _I, _I, _P],
     "gvk_lora_merge_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "gvk_memset_async": [_P, _I, C.c_size_t, _P],
+    "gvk_seed_advance": [_P, C.c_uint64, _P],
+    "gvk_scale_f32": [_P, _F, C.c_long, _P],
     "gvk_head_fwd": [C.POINTER(HeadDesc), _P],
     "gvk_head_bwd": [C.POINTER(HeadDesc), _P],
 }
 NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, []), "gvk_abi_version": (C.c_int, []),
-             "gvk_gpa_gate_param_count": (C.c_int, [C.c_int, C.c_int])}
+             "gvk_gpa_gate_param_count": (C.c_int, [C.c_int, C.c_int]),
+             "gvk_plan_begin": (C.c_int, []), "gvk_plan_end": (C.c_int, []), "gvk_plan_abort": (C.c_int, []),
+             "gvk_plan_size": (C.c_int, [C.c_int]), "gvk_plan_replay": (C.c_int, [C.c_int]), "gvk_plan_free": (C.c_int, [C.c_int]),
+             "gvk_plan_event_record": (C.c_int, [_P]), "gvk_plan_event_wait": (C.c_int, [_P, C.c_int])}
 STRUCTS = {"gvk_gemm_desc": GemmDesc, "gvk_skinny_down_desc": SkinnyDownDesc, "gvk_skinny_up_desc": SkinnyUpDesc,
            "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob}
 

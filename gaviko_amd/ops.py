@@ -72,6 +72,24 @@ def cast_bf16(x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     return out
 
 
+def memset_zero(t: torch.Tensor) -> None:
+    """Stream-ordered zero fill (hipMemsetAsync through the library so that it is part of a recorded launch plan)."""
+    if not t.is_contiguous():
+        raise L.GavikoHipError("memset_zero: tensor must be contiguous")
+    L.check(L.load().gvk_memset_async(L.ptr(t), 0, t.numel() * t.element_size(), L.stream_ptr()), "gvk_memset_async")
+
+
+def seed_advance(seed: torch.Tensor, inc: int) -> None:
+    if seed.dtype != torch.int64 or seed.numel() != 1:
+        raise L.GavikoHipError("seed_advance: the dropout epoch is one int64 device word")
+    L.check(L.load().gvk_seed_advance(L.ptr(seed), inc, L.stream_ptr()), "gvk_seed_advance")
+
+
+def scale_(t: torch.Tensor, alpha: float) -> None:
+    _chk(t, torch.float32, "scale_")
+    L.check(L.load().gvk_scale_f32(L.ptr(t), alpha, t.numel(), L.stream_ptr()), "gvk_scale_f32")
+
+
 def transpose_cast_bf16(x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     """x f32 [rows, cols] -> bf16 [cols, rows]."""
     _chk(x, torch.float32, "transpose_cast in")

@@ -13,6 +13,7 @@
  */
 #ifndef GAVIKO_HIP_H
 #define GAVIKO_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -22,6 +23,27 @@ const char* gvk_last_error(void);
 /* returns 950 when the code object loaded on the current device is gfx950, else <0 */
 int gvk_device_check(void);
 int gvk_abi_version(void);
+
+/* ------------------------------------------------------------------ launch plans
+ * The reference drives its step from the Python interpreter (train.py:296-319: one autograd node per op).  Here one
+ * training step is ~670 launches on three streams; a plan records them once (kernel, grid, by-value arguments, stream,
+ * and the event record/wait edges between streams) and gvk_plan_replay re-issues them from a single C loop.
+ * Recording is per host thread: between gvk_plan_begin and gvk_plan_end every gvk_* launch made by that thread both
+ * executes and is appended to the plan.  Pointers are baked in: replay is valid while the buffers passed at record
+ * time stay allocated (the engine's static workspace).  Events used for cross-stream edges inside a plan must come
+ * from gvk_plan_event_record.  gvk_plan_end returns the plan id (>= 0).                                              */
+int gvk_plan_begin(void);
+int gvk_plan_end(void);
+int gvk_plan_abort(void);
+int gvk_plan_size(int plan);                       /* number of recorded nodes */
+int gvk_plan_replay(int plan);
+int gvk_plan_free(int plan);
+int gvk_plan_event_record(void* stream);           /* -> event id within the plan being recorded */
+int gvk_plan_event_wait(void* stream, int event);
+/* small stream-ordered utilities the step needs between kernels (recorded into a plan like any launch) */
+int gvk_memset_async(void* ptr, int value, size_t bytes, void* stream);
+int gvk_seed_advance(void* seed_u64, uint64_t inc, void* stream);   /* device-side dropout epoch += inc */
+int gvk_scale_f32(float* x, float alpha, long n, void* stream);
 
 /* ------------------------------------------------------------------ bf16 MFMA GEMM  Y = A . W^T (+ epilogue)
  * A [M][lda] bf16 (K contiguous), W [N][ldw] bf16 (K contiguous, i.e. nn.Linear.weight layout), fp32 accumulate.
