@@ -18,6 +18,9 @@ LIB = os.path.join(HERE, "libgaviko_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
+# Per-file additions.  gemm_bf16: keep the MFMA accumulators in the VGPR half of gfx950's unified register file -- with the
+# default AGPR form the software-pipelined main loop came out with ~100 v_accvgpr_read/write/mov copies per k-tile.
+FILE_FLAGS = {"gemm_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def hipcc() -> str:
@@ -42,12 +45,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     jobs = []
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
-        if force or _newer([s] + hdrs, o):
+        if force or _newer([s] + hdrs + [os.path.abspath(__file__)], o):
             jobs.append((s, o))
 
     def compile_one(job):
         s, o = job
-        cmd = [cc, *FLAGS, "-c", s, "-o", o]
+        cmd = [cc, *FLAGS, *FILE_FLAGS.get(os.path.basename(s), []), "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return s, r.returncode, r.stdout + r.stderr
 

@@ -97,6 +97,62 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nt = p.K / BK;
+  if constexpr (BK == 64) {
+    // Software-pipelined main loop.  Fragments of the next 32-wide k sub-step are read from LDS while the 16 MFMAs of the
+    // current one run, so no MFMA ever waits on an LDS read it was issued behind; the single barrier per tile sits between
+    // the two sub-steps.  After that barrier every wave holds tile t entirely in registers, so the LDS-DMA of tile t+2 can
+    // already overwrite tile t's buffer: two buffers, two tiles of prefetch distance.
+#define GVK_LOAD_FRAGS(SA, SW, KS, XA, WB)                                                                  \
+  {                                                                                                         \
+    const int chunk_ = (KS) * 4 + lq;                                                                       \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                        \
+      const int row = wm * WM + i * 16 + l15;                                                               \
+      XA[i] = *(const bf16x8*)((SA) + row * ROWB + ((chunk_ ^ swz_chunk<BK>(row)) << 4));                   \
+    }                                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                        \
+      const int row = wn * WN + j * 16 + l15;                                                               \
+      WB[j] = *(const bf16x8*)((SW) + row * ROWB + ((chunk_ ^ swz_chunk<BK>(row)) << 4));                   \
+    }                                                                                                       \
+  }
+#define GVK_MMA(XA, WB)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                            \
+  _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB[j], XA[i], acc[i][j], 0, 0, 0);
+    bf16x8 xa0[MT], wb0[NT], xa1[MT], wb1[NT];
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    // tile 0 must have landed; tile 1 may still be in flight (PER_TILE LDS-DMA instructions per wave and tile)
+    constexpr int PER_TILE = BM / (4 * RPI) + BN / (4 * RPI);
+    if (nt > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (PER_TILE & 0xF) | ((PER_TILE >> 4) << 14));   // vmcnt(PER_TILE)
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                                                        // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    GVK_LOAD_FRAGS(smem, smem + A_BYTES, 0, xa0, wb0)
+    __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): the loop is entered with nothing outstanding on LDS
+    // the last two tiles prefetch nothing: peeled, so that the steady-state body is one branch-free block
+#define GVK_TILE(T, PREFETCH)                                                                               \
+    {                                                                                                       \
+      const int buf = (T) & 1;                                                                              \
+      const char* sA = smem + buf * STAGE;                                                                  \
+      const char* sW = sA + A_BYTES;                                                                        \
+      GVK_LOAD_FRAGS(sA, sW, 1, xa1, wb1)                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      GVK_MMA(xa0, wb0)                                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      __syncthreads(); /* vmcnt(0): tile T+1 landed; lgkmcnt(0): this wave's reads of tile T are done */    \
+      if (PREFETCH) stage(buf, (T) + 2);                                                                    \
+      GVK_LOAD_FRAGS(smem + (buf ^ 1) * STAGE, smem + (buf ^ 1) * STAGE + A_BYTES, 0, xa0, wb0)             \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      GVK_MMA(xa1, wb1)                                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) -- free: those reads were issued 16 MFMAs ago */    \
+    }
+    int t = 0;
+    for (; t < nt - 2; ++t) GVK_TILE(t, true)
+    for (; t < nt; ++t) GVK_TILE(t, false)
+#undef GVK_TILE
+#undef GVK_LOAD_FRAGS
+#undef GVK_MMA
+  } else {
   stage(0, 0);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
@@ -125,6 +181,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
     }
     __syncthreads();   // drains the LDS-DMA of tile t+1 (vmcnt(0)) and fences reads of buf before it is restaged
+  }
   }
 
   // ---- epilogue: lane owns rows m (one per i) x 4 consecutive columns n (per j)

@@ -3,6 +3,7 @@
 #include "../../include/gaviko_hip.h"
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -97,11 +98,23 @@ extern "C" int gvk_plan_free(int plan) {
   return 0;
 }
 
+extern "C" int gvk_plan_event_elapsed(int plan, int e0, int e1, float* ms) {
+  using namespace gvk;
+  std::lock_guard<std::mutex> lk(g_plans_mu);
+  GVK_REQUIRE(plan >= 0 && plan < (int)g_plans.size() && g_plans[plan], "gvk_plan_event_elapsed: no such plan %d", plan);
+  Plan* p = g_plans[plan].get();
+  GVK_REQUIRE(e0 >= 0 && e1 >= 0 && e0 < (int)p->events.size() && e1 < (int)p->events.size() && ms, "gvk_plan_event_elapsed: bad event ids");
+  hipError_t e = hipEventElapsedTime(ms, p->events[e0], p->events[e1]);
+  if (e != hipSuccess) return set_error(-1, "hipEventElapsedTime: %s (timing needs GAVIKO_HIP_PLAN_TIMING=1 at record time)", hipGetErrorString(e));
+  return 0;
+}
+
 extern "C" int gvk_plan_event_record(void* stream) {
   using namespace gvk;
   GVK_REQUIRE(g_rec != nullptr, "gvk_plan_event_record: only valid while a plan is being recorded");
+  static const bool timing = getenv("GAVIKO_HIP_PLAN_TIMING") != nullptr;      // diagnostics: tools/plan_marks.py
   hipEvent_t ev;
-  hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  hipError_t e = hipEventCreateWithFlags(&ev, timing ? hipEventDefault : hipEventDisableTiming);
   if (e != hipSuccess) return set_error(-1, "hipEventCreate: %s", hipGetErrorString(e));
   g_rec->events.push_back(ev);
   hipStream_t s = (hipStream_t)stream;

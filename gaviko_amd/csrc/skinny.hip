@@ -9,32 +9,11 @@
 // Replaces: gaviko.py:231 (norm + proj_down), :232 (qkv), :242 (proj_up), :155-156 (GPA proj_down + QuickGELU),
 //           :187 (GPA proj_up) and the autograd wgrad/dgrad of each.
 #include "common.hpp"
+#include <cstdlib>
+#include "skinny_args.hpp"
 #include "../../include/gaviko_hip.h"
 
 namespace gvk {
-
-// counter-based dropout mask: keep iff hash(seed, idx) >= p * 2^32
-__device__ __forceinline__ unsigned int hash_u32(unsigned long long seed, unsigned long long idx) {
-  unsigned long long x = idx * 0x9E3779B97F4A7C15ull + seed;
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  return (unsigned int)x;
-}
-__device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned long long idx, unsigned int thresh, float inv_keep) {
-  return (hash_u32(seed, idx) >= thresh) ? inv_keep : 0.f;
-}
-
-struct DownArgs {
-  const float* x; const float* w; const float* bias;      // x [M][C]; w [L][C] (layout 0) or [C][L] (layout 1)
-  const float* ln_g; const float* ln_b;                   // optional LayerNorm on the input row (eps 1e-5)
-  float* mean; float* rstd;                               // saved LN statistics (optional)
-  float* z; float* y;                                     // pre-activation (optional) / activated output [M][L]
-  const float* w2; float* y2; int L2;                     // optional second stage y2[m][0:L2] = y . w2^T, w2 [L2][L]
-  int M, C, act, w_layout;
-  float eps;
-  unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;   // dropout mask on the INPUT (bwd of proj_drop)
-};
 
 constexpr int kDownRows = 16;      // one 16-row MFMA tile per workgroup; the 16 waves split the C (reduction) dimension
 
@@ -169,16 +148,6 @@ __global__ __launch_bounds__(1024) void skinny_down_kernel(DownArgs p) {
     }
   }
 }
-
-struct UpArgs {
-  const float* lat; const float* w; const float* bias;    // lat [M][L]; w [C][L] (layout 0) or [L][C] (layout 1)
-  const float* res; float* out;                           // out = res + (...)  (res may be NULL / alias out); accumulate: out += (...)
-  const float* lat_override; int T, P;                    // rows with (m % T) < P read lat_override[(m / T) * P + m % T][:]
-  const float* ln_x; const float* ln_mean; const float* ln_rstd; const float* ln_g;   // optional LayerNorm-backward epilogue
-  bf16* out16;                                            // optional bf16 copy of `out` (the next dgrad GEMM's operand)
-  int M, C, w_layout, accumulate;
-  unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;   // dropout on the projected value (proj_drop)
-};
 
 constexpr int kUpRows = 16;     // one 16-row MFMA tile per workgroup; 4 waves x up to 4 chunks of 64 columns
 
@@ -665,6 +634,11 @@ extern "C" int gvk_skinny_down(const gvk_skinny_down_desc* d, void* stream) {
   a.eps = d->eps > 0.f ? d->eps : 1e-5f;
   a.seed = d->seed; a.seed_ptr = (const unsigned long long*)d->seed_ptr; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
   hipStream_t s = (hipStream_t)stream;
+  static const bool mfma_only = getenv("GAVIKO_HIP_SKINNY_MFMA") != nullptr;     // A/B switch: force the MFMA-tile kernels
+  if (!mfma_only) {
+    const int rc = launch_row_down(a, d->L, s);                                   // row-per-wave form for the wide shapes
+    if (rc != 1) return rc;
+  }
   switch (d->L) {
     case 4: return launch_down<4>(a, s);
     case 8: return launch_down<8>(a, s);
@@ -688,6 +662,11 @@ extern "C" int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream) {
   a.ln_x = d->ln_x; a.ln_mean = d->ln_mean; a.ln_rstd = d->ln_rstd; a.ln_g = d->ln_gamma; a.out16 = (bf16*)d->out_bf16;
   a.seed = d->seed; a.seed_ptr = (const unsigned long long*)d->seed_ptr; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
   hipStream_t s = (hipStream_t)stream;
+  static const bool mfma_only = getenv("GAVIKO_HIP_SKINNY_MFMA") != nullptr;
+  if (!mfma_only) {
+    const int rc = launch_row_up(a, d->L, s);
+    if (rc != 1) return rc;
+  }
   switch (d->L) {
     case 4: return launch_up<4>(a, s);
     case 8: return launch_up<8>(a, s);

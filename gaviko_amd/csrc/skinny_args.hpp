@@ -1,0 +1,44 @@
+// Argument blocks and the dropout hash shared by the rank-L side-path kernels (skinny.hip, rowwise.hip).
+#pragma once
+#include "common.hpp"
+
+namespace gvk {
+
+// counter-based dropout mask: keep iff hash(seed, idx) >= p * 2^32
+__device__ __forceinline__ unsigned int hash_u32(unsigned long long seed, unsigned long long idx) {
+  unsigned long long x = idx * 0x9E3779B97F4A7C15ull + seed;
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  return (unsigned int)x;
+}
+__device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned long long idx, unsigned int thresh, float inv_keep) {
+  return (hash_u32(seed, idx) >= thresh) ? inv_keep : 0.f;
+}
+
+struct DownArgs {
+  const float* x; const float* w; const float* bias;      // x [M][C]; w [L][C] (layout 0) or [C][L] (layout 1)
+  const float* ln_g; const float* ln_b;                   // optional LayerNorm on the input row (eps 1e-5)
+  float* mean; float* rstd;                               // saved LN statistics (optional)
+  float* z; float* y;                                     // pre-activation (optional) / activated output [M][L]
+  const float* w2; float* y2; int L2;                     // optional second stage y2[m][0:L2] = y . w2^T, w2 [L2][L]
+  int M, C, act, w_layout;
+  float eps;
+  unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;   // dropout mask on the INPUT (bwd of proj_drop)
+};
+
+struct UpArgs {
+  const float* lat; const float* w; const float* bias;    // lat [M][L]; w [C][L] (layout 0) or [L][C] (layout 1)
+  const float* res; float* out;                           // out = res + (...)  (res may be NULL / alias out); accumulate: out += (...)
+  const float* lat_override; int T, P;                    // rows with (m % T) < P read lat_override[(m / T) * P + m % T][:]
+  const float* ln_x; const float* ln_mean; const float* ln_rstd; const float* ln_g;   // optional LayerNorm-backward epilogue
+  bf16* out16;                                            // optional bf16 copy of `out` (the next dgrad GEMM's operand)
+  int M, C, w_layout, accumulate;
+  unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;   // dropout on the projected value (proj_drop)
+};
+
+
+int launch_row_down(const DownArgs& a, int L, hipStream_t s);   // rowwise.hip; returns 1 when the shape is not covered
+int launch_row_up(const UpArgs& a, int L, hipStream_t s);
+
+}  // namespace gvk

@@ -36,6 +36,7 @@ _MODE = os.environ.get("GAVIKO_HIP_GRAPHS", "plan")
 STEP_MODE = {"1": "plan", "0": "eager"}.get(_MODE, _MODE)
 USE_GRAPHS = STEP_MODE != "eager"
 GRAPH_WARMUP = 2
+PLAN_TIMING = os.environ.get("GAVIKO_HIP_PLAN_TIMING") is not None
 
 # bench.py instrumentation: when a dict, every GEMM launch is bracketed by HIP events recorded on the launch stream
 GEMM_TIMING = None
@@ -137,6 +138,11 @@ class Engine:
         self._wss = {}
         self._streams = {}
         self._recording = False
+        # GPA projections of backbone rows ride along in the backbone's LayerNorm kernels (gvk_layernorm_*_proj)
+        self._fuse_proj = (kind == "gaviko" and ops.rowproj_supported(self.Lat, dim)
+                           and os.environ.get("GAVIKO_HIP_FUSE_PROJ", "1") != "0")
+        self._marks = []
+        self.plan_marks = {}                # plan id -> [(name, event id)]
         self._ws = None
         self._step = 0
         self._flat_grad = None
@@ -256,6 +262,7 @@ class Engine:
                 mk = lambda *s: torch.zeros(s, device=device)
                 ng = ops.gpa_gate_param_count(Lt, P)
                 ws["dL"] = [mk(BN, C), mk(BN, C)]
+                ws["dGb"] = ops.act_zeros(M, C, torch.float32, device)       # second layer-boundary gradient buffer (parity ping-pong)
                 ws["bw"] = dict(dcomb=mk(M, Lt), dimp=mk(B, P), dgw_part=mk(B, P), dqg=mk(B, P, Lt), dql=mk(B, P, Lt), dcg=mk(B, P, Lt),
                                 dcl=mk(B, P, Lt), delta_g=mk(B, P), delta_l=mk(B, P), dprm=mk(B, P, Lt), dcls=mk(B, Lt),
                                 gate_partials=mk(B, ng), dzx=mk(M, Lt), dzl=[mk(BN, Lt), mk(BN, Lt)],
@@ -290,6 +297,11 @@ class Engine:
         ev = torch.cuda.Event()
         ev.record(stream)
         return ev
+
+    def _mark(self, name):
+        """Diagnostics (GAVIKO_HIP_PLAN_TIMING=1): a timestamped plan event on the current stream, read by tools/plan_marks.py."""
+        if self._recording and PLAN_TIMING:
+            self._marks.append((name, self._ev_record(torch.cuda.current_stream())))
 
     def _ev_wait(self, stream, ev):
         if self._recording:
@@ -329,6 +341,7 @@ class Engine:
             lib = L.load()
             L.check(lib.gvk_plan_begin(), "gvk_plan_begin")
             self._recording = True
+            self._marks = []
             try:
                 fn()
             except BaseException:
@@ -340,6 +353,7 @@ class Engine:
             if pid < 0:
                 L.check(pid, "gvk_plan_end")
             self._graphs[k] = pid
+            self.plan_marks[pid] = (tag, self._marks)
             return
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -419,20 +433,33 @@ class Engine:
                     self._wait("loc", "gpa")                         # eval ping-pongs Lc: the GPA of layer i-1 must be done with it
                 with torch.cuda.stream(loc):
                     self._mwsa_fwd(ws, sv, i, si, ws["Lc"][gi], ws["Lc"][go])
+                    if self._fuse_proj:
+                        self._gpa_down_local(ws, i, si, ws["Lc"][go], B)
+            self._mark(f"f{i}:start")
             self._attn_block_fwd(ws, i, si, ws["G"][gi], ws["G1"][si], Mi)
-            if gaviko:
+            self._mark(f"f{i}:attn")
+            fused = gaviko and self._fuse_proj
+            if gaviko and not fused:
                 self._wait("gpa", None)                              # G1 ready
                 self._wait("gpa", "loc")                             # L' ready
                 with torch.cuda.stream(gpa):
-                    self._gpa_fwd_latents(ws, i, si, ws["G1"][si], ws["Lc"][go], M, B)
+                    self._gpa_fwd_latents(ws, i, si, ws["G1"][si], ws["Lc"][go], M, B, True)
             if self.kind == "adaptformer":
                 self._adapter_fwd_down(ws, i, si, ws["G1"][si], Mi)
+            self._mlp_ln_fwd(ws, i, si, ws["G1"][si], Mi, fused)     # fused: also zx / xl = GPA proj_down(G1), same pass
+            if fused:
+                self._wait("gpa", None)                              # xl ready
+                self._wait("gpa", "loc")                             # ll ready (the MWSA chain projects its own L')
+                with torch.cuda.stream(gpa):
+                    self._gpa_fwd_latents(ws, i, si, ws["G1"][si], ws["Lc"][go], M, B, False)
             self._mlp_block_fwd(ws, i, si, ws["G1"][si], gout, Mi, train)
             if self.kind == "adaptformer":
                 self._adapter_fwd_up(ws, i, si, gout, Mi)
+            self._mark(f"f{i}:mlp")
             if gaviko:
                 self._wait(None, "gpa")                              # enh ready
                 self._gpa_fwd_up(ws, i, si, ws["G"][go], M)
+            self._mark(f"f{i}:end")
             if repack and i + 1 < self.depth:
                 ops.vpt_repack_fwd(gout, ws["vproj"][(i + 1) * self.P: (i + 2) * self.P], ws["G"][go], B, self.Ts[i], self.Ts[i + 1],
                                    self.P, self.pd, C)
@@ -463,11 +490,21 @@ class Engine:
         ops.attention_fwd(ws["qkv"][si], ws["ctx"][si], ws["lse"][si], ws["B"], self.Ts[i], self.heads, 64 ** -0.5)
         self._gemm(ws["ctx"][si], w[f"out{i}"], M, g1, epilogue=ops.EPI_BIAS_RES_F32, bias=d(a + ".to_out.0.bias"), res=gin)
 
+    def _mlp_ln_fwd(self, ws, i, si, g1, M, fused):
+        nm, d, C = self.names, self._d, self.C
+        m = nm.mlp(i)
+        st = ws["stat"][si]
+        if fused:
+            pre, _ = self._gpa_names(i)
+            g = ws["gp"][si]
+            ops.layernorm_fwd_proj(g1, d(m + ".net.0.weight"), d(m + ".net.0.bias"), M, C, y16=ws["xn"], mean=st[2], rstd=st[3],
+                                   w=d(pre + ".proj_down.0.weight"), bias=d(pre + ".proj_down.0.bias"), z=g["zx"], y=g["xl"], act=1, w_layout=0)
+        else:
+            ops.layernorm_fwd(g1, d(m + ".net.0.weight"), d(m + ".net.0.bias"), M, C, y16=ws["xn"], mean=st[2], rstd=st[3])
+
     def _mlp_block_fwd(self, ws, i, si, g1, gout, M, train):
         nm, w, d, C = self.names, self._w16, self._d, self.C
         m = nm.mlp(i)
-        st = ws["stat"][si]
-        ops.layernorm_fwd(g1, d(m + ".net.0.weight"), d(m + ".net.0.bias"), M, C, y16=ws["xn"], mean=st[2], rstd=st[3])
         self._gemm(ws["xn"], w[f"fc1{i}"], M, ws["pre"][si] if train else None, epilogue=ops.EPI_BIAS_GELU_BF16, out1=ws["act"],
                     bias=d(m + ".net.1.bias"))           # inference keeps no pre-activation (out0 = NULL)
         self._gemm(ws["act"], w[f"fc2{i}"], M, gout, epilogue=ops.EPI_BIAS_RES_F32, bias=d(m + ".net.4.bias"), res=g1)
@@ -497,13 +534,21 @@ class Engine:
                          wgq=pre + ".global_attention.query_proj.weight", bgq=pre + ".global_attention.query_proj.bias",
                          wlq=pre + ".local_attention.query_proj.weight", blq=pre + ".local_attention.query_proj.bias")
 
-    def _gpa_fwd_latents(self, ws, i, si, g1, lnew, M, B):
+    def _gpa_down_local(self, ws, i, si, lnew, B):
+        """ll = QuickGELU(proj_down(L')) (gaviko.py:156): depends on the MWSA chain only, so it runs at its tail."""
+        pre, _ = self._gpa_names(i)
+        d, g = self._d, ws["gp"][si]
+        ops.skinny_down(x=lnew, w=d(pre + ".proj_down.0.weight"), bias=d(pre + ".proj_down.0.bias"), z=g["zl"], y=g["ll"], M=B * self.N,
+                        C=self.C, L=self.Lat, act=1, w_layout=0)
+
+    def _gpa_fwd_latents(self, ws, i, si, g1, lnew, M, B, project):
         pre, names = self._gpa_names(i)
         d, C, Lt = self._d, self.C, self.Lat
         g = ws["gp"][si]
-        wd, bd = d(pre + ".proj_down.0.weight"), d(pre + ".proj_down.0.bias")
-        ops.skinny_down(x=g1, w=wd, bias=bd, z=g["zx"], y=g["xl"], M=M, C=C, L=Lt, act=1, w_layout=0)
-        ops.skinny_down(x=lnew, w=wd, bias=bd, z=g["zl"], y=g["ll"], M=B * self.N, C=C, L=Lt, act=1, w_layout=0)
+        if project:
+            ops.skinny_down(x=g1, w=d(pre + ".proj_down.0.weight"), bias=d(pre + ".proj_down.0.bias"), z=g["zx"], y=g["xl"], M=M, C=C, L=Lt,
+                            act=1, w_layout=0)
+            self._gpa_down_local(ws, i, si, lnew, B)
         ops.gpa_fwd(xl=g["xl"], ll=g["ll"], B=B, T=self.T, N=self.N, P=self.P, L=Lt, scale=Lt ** -0.5,
                     imp=g["imp"], gw=g["gw"], enh=g["enh"], prm=g["prm"], qg=g["qg"], ql=g["ql"], cg=g["cg"], cl=g["cl"],
                     lse_g=g["lse_g"], lse_l=g["lse_l"], **{k: d(v) for k, v in names.items()})
@@ -598,6 +643,8 @@ class Engine:
         if first:
             self._backward_head(ws, sv, gv, True)
         dGout, dGin = ws["dG"][0], ws["dG"][1]
+        if gaviko and ((self.depth - 1 - hi) & 1):
+            dGout = ws["dGb"]                                  # the boundary gradient ping-pongs with the layer parity (see below)
         vpt_deep = self.kind == "vpt" and self.deep
         if vpt_deep and ((self.depth - 1 - hi) & 1):           # the un-repack alternates two buffers with the layer parity
             dGout = ws["dGv"]
@@ -605,7 +652,7 @@ class Engine:
             loc, gpa = self._stream("loc"), self._stream("gpa")
             self._wait("gpa", None)
             self._wait("loc", None)
-        prev_scl = None
+        prev_scl = prev_par = None
         for i in range(hi, lo - 1, -1):
             M = B * self.Ts[i]
             T = self.Ts[i]
@@ -616,10 +663,13 @@ class Engine:
             # for the event between the two
             if gaviko:
                 with torch.cuda.stream(gpa):
-                    self._gpa_bwd_core(ws, sv, gv, i, dGout, M, B, par)
+                    # dcomb = dGout . W_up was produced by the LayerNorm backward that wrote dGout, except for the top layer
+                    self._gpa_bwd_core(ws, sv, gv, i, dGout, M, B, par, project=not (self._fuse_proj and i < self.depth - 1))
                     dz_ready = self._ev_record(gpa)
                     self._gpa_bwd_params(ws, sv, gv, i, dGout, M, B, par)
+                    par_done = self._ev_record(gpa)
             # main stream, MLP block: dG1 = dGout + LN'(fc1^T(GELU'(pre) * fc2^T(dGout)))
+            self._mark(f"b{i}:start")
             self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i])
             self._gemm(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
             adapter = self.kind == "adaptformer"
@@ -627,9 +677,11 @@ class Engine:
                               dx16=None if (gaviko or adapter) else ws["dG16"])
             if adapter:
                 self._adapter_bwd(ws, gv, i, dGout, dGin, M)                 # adds LN_a'(...) into dG1 and refreshes dG16
+            self._mark(f"b{i}:ln2")
             if gaviko:
                 self._ev_wait(torch.cuda.current_stream(), dz_ready)
                 self._gpa_bwd_scatter_g(ws, i, dGin, M)                      # dG1 += dzx.Wd (+ bf16 copy)
+                self._mark(f"b{i}:scatter")
                 self._ev_wait(loc, dz_ready)
                 with torch.cuda.stream(loc):
                     self._gpa_bwd_scatter_l(ws, i, ws["dL"][par], B, par)    # dL += dzl.Wd (dL[par] was written on this stream)
@@ -641,9 +693,24 @@ class Engine:
             if self.kind == "melo":
                 self._melo_bwd(ws, gv, i, M)
             self._gemm(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
+            self._mark(f"b{i}:qkvd")
             if gaviko:
-                self._wait(None, "gpa")                                      # the GPA parameter gradients still read dGout
-            ops.layernorm_bwd(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGout, dres=dGin, dx16=ws["dG16"])
+                # The new boundary gradient goes to the OTHER parity buffer: the GPA parameter kernels of this layer keep reading
+                # dGout off the critical path.  The buffer being overwritten was last read by layer i+1's parameter kernels.
+                if prev_par is not None:
+                    self._ev_wait(torch.cuda.current_stream(), prev_par)
+                prev_par = par_done
+                dGnext = ws["dGb"] if dGout is ws["dG"][0] else ws["dG"][0]
+                if self._fuse_proj and i > 0:
+                    pre_lo, _ = self._gpa_names(i - 1)
+                    ops.layernorm_bwd_proj(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGnext, dres=dGin,
+                                           dx16=ws["dG16"], w=d(pre_lo + ".proj_up.weight"), y=ws["bw"]["dcomb"], w_layout=1)
+                else:
+                    ops.layernorm_bwd(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGnext, dres=dGin,
+                                      dx16=ws["dG16"])
+                dGout = dGnext
+            else:
+                ops.layernorm_bwd(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGout, dres=dGin, dx16=ws["dG16"])
             if gaviko:
                 # The MWSA chain never feeds the global stream in the backward, so the main stream does not join it per layer: dzl
                 # is double-buffered by layer parity and the only cross-stream hazard left is layer i-1's GPA rewriting the buffer
@@ -652,6 +719,7 @@ class Engine:
                     self._ev_wait(torch.cuda.current_stream(), prev_scl)
                 prev_scl = scl_done
                 self._wait("gpa", None)                                      # the next layer's GPA backward needs this dG[i]
+            self._mark(f"b{i}:end")
             if self.kind == "vpt" and (i == 0 or self.deep):
                 # prompt rows 1..P of this layer's input are this layer's projected prompts (vpt.py:127-131,147-153)
                 ops.rows_batch_sum(dGout, ws["dvproj"][i * self.P: (i + 1) * self.P], None, B, T, 1, self.P, C)
@@ -694,13 +762,14 @@ class Engine:
         top = min(self.depth - 1, s * self.share + self.share - 1)
         return 0 if i == top else 1
 
-    def _gpa_bwd_core(self, ws, sv, gv, i, dGout, M, B, par):
+    def _gpa_bwd_core(self, ws, sv, gv, i, dGout, M, B, par, project=True):
         """Critical part of the GPA backward: dcomb = dGout . Wup and the latent-space backward -> dzx / dzl
         (what the main stream's dG1 update and the MWSA chain wait for)."""
         pre, names = self._gpa_names(i)
         d, C, Lt, P, T, N = self._d, self.C, self.Lat, self.P, self.T, self.N
         g, bw = ws["gp"][i], ws["bw"]
-        ops.skinny_down(x=dGout, w=d(pre + ".proj_up.weight"), y=bw["dcomb"], M=M, C=C, L=Lt, act=0, w_layout=1)
+        if project:
+            ops.skinny_down(x=dGout, w=d(pre + ".proj_up.weight"), y=bw["dcomb"], M=M, C=C, L=Lt, act=0, w_layout=1)
         ops.gpa_bwd(xl=g["xl"], ll=g["ll"], B=B, T=T, N=N, P=P, L=Lt, scale=Lt ** -0.5, imp=g["imp"], gw=g["gw"], enh=g["enh"], prm=g["prm"],
                     qg=g["qg"], ql=g["ql"], cg=g["cg"], cl=g["cl"], lse_g=g["lse_g"], lse_l=g["lse_l"], dcomb=bw["dcomb"], zx=g["zx"], zl=g["zl"],
                     dimp=bw["dimp"], dgw_part=bw["dgw_part"], dqg=bw["dqg"], dql=bw["dql"], dcg=bw["dcg"], dcl=bw["dcl"],

@@ -47,6 +47,7 @@ GpaDesc = _struct("GpaDesc",
                    "dcomb", "zx", "zl", "dimp", "dgw_part", "dqg", "dql", "dcg", "dcl", "delta_g", "delta_l", "dprm",
                    "dcls", "gate_partials", "dzx", "dzl"],
                   ["B", "T", "N", "P", "L"], ["scale"])
+RowProjDesc = _struct("RowProjDesc", ["w", "bias", "y", "z"], ["L", "w_layout", "act"])
 ReduceJob = _struct("ReduceJob", ["a", "b", "out"], ["M", "J", "L", "accumulate"])
 HeadDesc = _struct("HeadDesc", ["g", "ln_gamma", "ln_beta", "wh", "bh", "logits", "pooled", "dlogits", "dg", "dwh", "dbh"],
                    ["B", "T", "C", "K", "r0", "R", "accumulate"])
@@ -85,6 +86,8 @@ SIGNATURES = {
     "gvk_vpt_repack_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gvk_cast_bf16_f32_strided": [_P, _P, _I, _I, _I, _P],
     "gvk_lora_merge_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "gvk_layernorm_fwd_proj": [_P, _P, _P, _P, _P, _P, _I, _I, _F, C.POINTER(RowProjDesc), _P],
+    "gvk_layernorm_bwd_proj": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, C.POINTER(RowProjDesc), _P],
     "gvk_memset_async": [_P, _I, C.c_size_t, _P],
     "gvk_seed_advance": [_P, C.c_uint64, _P],
     "gvk_scale_f32": [_P, _F, C.c_long, _P],
@@ -95,9 +98,10 @@ NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, [
              "gvk_gpa_gate_param_count": (C.c_int, [C.c_int, C.c_int]),
              "gvk_plan_begin": (C.c_int, []), "gvk_plan_end": (C.c_int, []), "gvk_plan_abort": (C.c_int, []),
              "gvk_plan_size": (C.c_int, [C.c_int]), "gvk_plan_replay": (C.c_int, [C.c_int]), "gvk_plan_free": (C.c_int, [C.c_int]),
-             "gvk_plan_event_record": (C.c_int, [_P]), "gvk_plan_event_wait": (C.c_int, [_P, C.c_int])}
+             "gvk_plan_event_record": (C.c_int, [_P]), "gvk_plan_event_wait": (C.c_int, [_P, C.c_int]),
+             "gvk_plan_event_elapsed": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)])}
 STRUCTS = {"gvk_gemm_desc": GemmDesc, "gvk_skinny_down_desc": SkinnyDownDesc, "gvk_skinny_up_desc": SkinnyUpDesc,
-           "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob}
+           "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob, "gvk_rowproj_desc": RowProjDesc}
 
 _lib = None
 

@@ -124,6 +124,48 @@ def layernorm_fwd(x, gamma, beta, M, C_, *, y16=None, y32=None, mean=None, rstd=
                                        M, C_, eps, L.stream_ptr()), "gvk_layernorm_fwd")
 
 
+ROWPROJ_L = 20      # latent width the fused LayerNorm+projection kernels are built for
+
+
+def rowproj_supported(L_: int, C_: int) -> bool:
+    return L_ == ROWPROJ_L and C_ % 4 == 0 and C_ <= 1024
+
+
+def _rowproj(M, C_, w, y, bias, z, L_, w_layout, act):
+    _chk(w, torch.float32, "rowproj w", L_ * C_)
+    _chk(y, torch.float32, "rowproj y", M * L_)
+    _chk(bias, torch.float32, "rowproj bias", L_)
+    _chk(z, torch.float32, "rowproj z", M * L_)
+    return L.RowProjDesc(w=L.ptr(w), bias=L.ptr(bias), y=L.ptr(y), z=L.ptr(z), L=L_, w_layout=w_layout, act=act)
+
+
+def layernorm_fwd_proj(x, gamma, beta, M, C_, *, y16, mean=None, rstd=None, eps=1e-5, w, y, bias=None, z=None, L_=ROWPROJ_L, w_layout=0, act=0):
+    """LayerNorm forward + rank-L projection of the raw input rows (one pass over x)."""
+    _chk(x, torch.float32, "ln x", M * C_)
+    _chk(gamma, torch.float32, "ln gamma", C_)
+    _chk(beta, torch.float32, "ln beta", C_)
+    _chk(y16, torch.bfloat16, "ln y16", M * C_)
+    _chk(mean, torch.float32, "ln mean", M)
+    _chk(rstd, torch.float32, "ln rstd", M)
+    d = _rowproj(M, C_, w, y, bias, z, L_, w_layout, act)
+    L.check(L.load().gvk_layernorm_fwd_proj(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y16), L.ptr(mean), L.ptr(rstd), M, C_, eps,
+                                            C.byref(d), L.stream_ptr()), "gvk_layernorm_fwd_proj")
+
+
+def layernorm_bwd_proj(dy, x, mean, rstd, gamma, M, C_, *, dx, dres=None, dx16=None, w, y, L_=ROWPROJ_L, w_layout=1):
+    """LayerNorm backward + rank-L projection of the output rows dx (one pass)."""
+    for t, n in ((dy, "dy"), (x, "x"), (dx, "dx")):
+        _chk(t, torch.float32, "ln_bwd " + n, M * C_)
+    _chk(dres, torch.float32, "ln_bwd dres", M * C_)
+    _chk(dx16, torch.bfloat16, "ln_bwd dx16", M * C_)
+    _chk(mean, torch.float32, "ln_bwd mean", M)
+    _chk(rstd, torch.float32, "ln_bwd rstd", M)
+    _chk(gamma, torch.float32, "ln_bwd gamma", C_)
+    d = _rowproj(M, C_, w, y, None, None, L_, w_layout, 0)
+    L.check(L.load().gvk_layernorm_bwd_proj(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dres), L.ptr(dx),
+                                            L.ptr(dx16), M, C_, C.byref(d), L.stream_ptr()), "gvk_layernorm_bwd_proj")
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, M, C_, *, dx, dres=None, dx16=None):
     for t, n in ((dy, "dy"), (x, "x"), (dx, "dx")):
         _chk(t, torch.float32, "ln_bwd " + n, M * C_)

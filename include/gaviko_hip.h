@@ -40,6 +40,9 @@ int gvk_plan_replay(int plan);
 int gvk_plan_free(int plan);
 int gvk_plan_event_record(void* stream);           /* -> event id within the plan being recorded */
 int gvk_plan_event_wait(void* stream, int event);
+/* diagnostics: milliseconds between two events of a replayed plan (events carry timestamps only when the process was
+ * started with GAVIKO_HIP_PLAN_TIMING set) */
+int gvk_plan_event_elapsed(int plan, int e0, int e1, float* ms);
 /* small stream-ordered utilities the step needs between kernels (recorded into a plan like any launch) */
 int gvk_memset_async(void* ptr, int value, size_t bytes, void* stream);
 int gvk_seed_advance(void* seed_u64, uint64_t inc, void* stream);   /* device-side dropout epoch += inc */
@@ -100,6 +103,22 @@ int gvk_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
  * scratch: f32 [2*64*C]. */
 int gvk_layernorm_bwd_affine(const float* dy, const float* x, const float* mean, const float* rstd, float* dgamma,
                              float* dbeta, float* scratch, int M, int C, int accumulate, void* stream);
+
+/* LayerNorm with a fused rank-L projection of the rows it already holds (L = 20 = configs/gaviko.yaml prompt_latent_dim):
+ *   fwd_proj:  y_bf16 = LN(x) as gvk_layernorm_fwd, and   proj->y = act(x . W^T + bias)        of the RAW input rows
+ *              (gaviko.py:155-156: GPA proj_down + QuickGELU of the post-attention stream; proj->z = pre-activation);
+ *   bwd_proj:  dx as gvk_layernorm_bwd, and               proj->y = dx . W                      of the OUTPUT rows
+ *              (autograd of gaviko.py:187 proj_up: the next-lower layer's dcomb = dG . W_up).
+ * w_layout 0: w [L][C]; 1: w [C][L].  Other L: use the separate gvk_skinny_down. */
+typedef struct gvk_rowproj_desc {
+  const float* w; const float* bias;       /* bias [L] or NULL */
+  float* y; float* z;                      /* y [M][L]; z [M][L] pre-activation or NULL */
+  int32_t L, w_layout, act;                /* act: 0 none, 1 QuickGELU */
+} gvk_rowproj_desc;
+int gvk_layernorm_fwd_proj(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean, float* rstd,
+                           int M, int C, float eps, const gvk_rowproj_desc* proj, void* stream);
+int gvk_layernorm_bwd_proj(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                           const float* dres, float* dx, void* dx_bf16, int M, int C, const gvk_rowproj_desc* proj, void* stream);
 
 /* ------------------------------------------------------------------ multi-head self-attention, head dim 64
  * qkv bf16 [B*T (padded)][ld_qkv]: columns [q | k | v], each (head, 64) -- the to_qkv output as is

@@ -327,3 +327,59 @@ def test_skinny_up_ln_backward_epilogue_and_lowrank_affine(dev, M, C_, Lat):
     _close(dg, g.grad, 5e-5, "dgamma")
     _close(db, b.grad, 5e-5, "dbeta")
     _close(dbias, bd.grad, 5e-5, "dbias")
+
+
+@pytest.mark.parametrize("M,C", [(4132, 768), (258, 192), (1033, 1024)])
+def test_layernorm_fwd_with_fused_projection(dev, M, C):
+    from gaviko_amd import ops
+    _g = torch.Generator(device=dev).manual_seed(M * 7 + C)
+    rnd = lambda *sh, device: torch.randn(*sh, device=device, generator=_g)
+    """gvk_layernorm_fwd_proj = LayerNorm (bf16 out, stats) + QuickGELU(x.Wd^T + b) of the raw rows (gaviko.py:155-156)."""
+    L_ = 20
+    x = rnd(M, C, device=dev)
+    g, b = 1 + 0.2 * rnd(C, device=dev), 0.1 * rnd(C, device=dev)
+    wd, bd = rnd(L_, C, device=dev) * C ** -0.5, 0.1 * rnd(L_, device=dev)
+    y16 = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    z, y = torch.empty(M, L_, device=dev), torch.empty(M, L_, device=dev)
+    ops.layernorm_fwd_proj(x, g, b, M, C, y16=y16, mean=mean, rstd=rstd, w=wd, bias=bd, z=z, y=y, act=1, w_layout=0)
+    want = torch.nn.functional.layer_norm(x, (C,), g, b)
+    assert (y16.float() - want).abs().max() < 3e-2
+    assert torch.allclose(mean, x.mean(-1), atol=1e-5) and torch.allclose(rstd, (x.var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-5)
+    zz = (x.double() @ wd.double().t() + bd.double()).float()
+    assert torch.allclose(z, zz, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(y, zz * torch.sigmoid(1.702 * zz), atol=2e-5, rtol=1e-5)
+    # and the unfused pair produces the same numbers
+    z2, y2 = torch.empty_like(z), torch.empty_like(y)
+    ops.skinny_down(x=x, w=wd, bias=bd, z=z2, y=y2, M=M, C=C, L=L_, act=1, w_layout=0)
+    assert torch.allclose(y, y2, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,C", [(4132, 768), (258, 192)])
+def test_layernorm_bwd_with_fused_projection(dev, M, C):
+    from gaviko_amd import ops
+    _g = torch.Generator(device=dev).manual_seed(M + C)
+    rnd = lambda *sh, device: torch.randn(*sh, device=device, generator=_g)
+    """gvk_layernorm_bwd_proj = LayerNorm backward (dx, bf16 copy) + dx . W_up ([C][L] weight, autograd of gaviko.py:187)."""
+    L_ = 20
+    x, dy, dres = rnd(M, C, device=dev), rnd(M, C, device=dev), rnd(M, C, device=dev)
+    g = 1 + 0.2 * rnd(C, device=dev)
+    wup = rnd(C, L_, device=dev) * C ** -0.5
+    mean, rstd = x.mean(-1).contiguous(), (x.var(-1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    dx, dx2 = torch.empty(M, C, device=dev), torch.empty(M, C, device=dev)
+    dx16 = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
+    y = torch.empty(M, L_, device=dev)
+    ops.layernorm_bwd_proj(dy, x, mean, rstd, g, M, C, dx=dx, dres=dres, dx16=dx16, w=wup, y=y, w_layout=1)
+    ops.layernorm_bwd(dy, x, mean, rstd, g, M, C, dx=dx2, dres=dres)
+    assert torch.equal(dx, dx2)
+    assert (dx16.float() - dx).abs().max() <= dx.abs().max() * 2 ** -8
+    assert torch.allclose(y, (dx.double() @ wup.double()).float(), atol=3e-5, rtol=1e-5)
+
+
+def test_fused_projection_rejects_other_latent_widths(dev):
+    from gaviko_amd import ops
+    rnd = lambda *sh, device: torch.randn(*sh, device=device)
+    x = rnd(64, 768, device=dev)
+    with pytest.raises(ops.L.GavikoHipError, match="L=20"):
+        ops.layernorm_fwd_proj(x, x[0], x[0], 64, 768, y16=torch.empty(64, 768, dtype=torch.bfloat16, device=dev),
+                               w=rnd(16, 768, device=dev), y=torch.empty(64, 16, device=dev), L_=16)

@@ -8,7 +8,8 @@ import glob
 import re
 import sys
 
-f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
+import os
+f = max(glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"), key=os.path.getmtime)
 rows = [r for r in csv.DictReader(open(f))]
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
