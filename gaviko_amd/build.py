@@ -20,7 +20,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
          "-ffp-contract=off"]
 # Per-file additions.  gemm_bf16: keep the MFMA accumulators in the VGPR half of gfx950's unified register file -- with the
 # default AGPR form the software-pipelined main loop came out with ~100 v_accvgpr_read/write/mov copies per k-tile.
-FILE_FLAGS = {"gemm_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# attention_*: the score accumulator is re-used in place as the next MFMA's B operand, which the AGPR form can only do through
+# v_accvgpr_read copies (352 / 688 of them in the forward / backward kernels).
+_VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+FILE_FLAGS = {"gemm_bf16.hip": _VGPR_FORM, "attention_fwd.hip": _VGPR_FORM, "attention_bwd.hip": _VGPR_FORM, "skinny.hip": _VGPR_FORM}
 
 
 def hipcc() -> str:
