@@ -10,8 +10,9 @@ is outside the metric (BASELINE.json: fwd+bwd).  Inputs are resident in HBM befo
 Weak scaling: 4 volumes per GPU (BASELINE.json configs[1]).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- the dominant kernel (the bf16 MFMA GEMM instantiation with the largest total time), HIP-event timed
-                  per launch on the launch stream in a second, instrumented pass of K steps
+  roofline     -- the dominant kernel (the bf16 MFMA GEMM class with the largest total time), timed per launch by HIP event
+                  pairs on its launch stream inside a second, instrumented copy of the step's launch plans (same
+                  three-stream schedule as the timed region; the bracket's own cost is calibrated and subtracted)
   cpu_baseline -- the oracle (CPU restatement of the reference, fp32 torch) timed on this host's cores on one batch.
 """
 from __future__ import annotations
@@ -118,6 +119,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from gaviko_amd import engine as eng_mod
+    from gaviko_amd import lib as L
     from gaviko_amd.utils import synth
     model = build(args.backbone, dev)
     if world > 1:
@@ -176,13 +178,26 @@ def main():
         out["mfma_roofline_frac_whole_step"] = round(vps / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)
 
     if rank == 0 and not args.no_roofline:
-        # second, instrumented pass: HIP events around every GEMM launch on the launch stream
-        eng_mod.GEMM_TIMING = {}
-        for _ in range(args.steps):
-            step()
+        # Second, instrumented pass: the step is re-recorded as launch plans in which every GEMM launch (and the patch-embed
+        # stage) is bracketed by timestamped HIP events on its launch stream, then replayed like the timed region -- same
+        # three-stream schedule, same neighbours on the other queues.  An empty event pair per plan calibrates the bracket's
+        # own cost, which is subtracted.
+        eng = model._engine()
+        L.load().gvk_plan_set_timing(1)
+        eng_mod.GEMM_MARKS = {}
+        eng._graphs.clear()
+        step()                                              # records (and runs) the instrumented plans
         torch.cuda.synchronize(dev)
-        stats = eng_mod.collect_gemm_timing()
-        eng_mod.GEMM_TIMING = None
+        acc = {}
+        for _ in range(min(args.steps, 10)):
+            step()
+            torch.cuda.synchronize(dev)
+            eng.collect_gemm_marks(acc)
+        eng_mod.GEMM_MARKS = None
+        L.load().gvk_plan_set_timing(0)
+        eng._graphs.clear()
+        stats = {k: {"avg_ms": sum(v["ms"]) / len(v["ms"]), "total_ms": sum(v["ms"]), "n": len(v["ms"]), "flops_per_launch": v["flops"],
+                     "shape": v["shape"], "bytes": v["bytes"], "overhead_ms": v["overhead_ms"]} for k, v in acc.items()}
         pe = stats.pop("__patch_embed__", None)
         if pe:
             # HBM-bound stage: algorithmic bytes = fp32 volume in + fp32 token rows out (global + local stream), per launch
@@ -195,7 +210,9 @@ def main():
                                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(s["flops_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                                "traffic": None, "avg_launch_us": round(s["avg_ms"] * 1e3, 2), "launches": s["n"],
-                               "flop_per_launch": s["flops_per_launch"], "shape": s["shape"]}
+                               "flop_per_launch": s["flops_per_launch"], "shape": s["shape"],
+                               "timing": f"HIP event pairs on the launch stream inside the replayed plan, bracket cost "
+                                         f"{s['overhead_ms'] * 1e3:.1f} us subtracted"}
             out["roofline"].update(pmc_traffic(name, stats))
             out["gemm_classes"] = {k: {"avg_us": round(v["avg_ms"] * 1e3, 2), "n": v["n"], "tflops": round(v["flops_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12, 1)}
                                    for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])}

@@ -38,6 +38,7 @@ static thread_local Plan* g_rec = nullptr;
 static std::mutex g_plans_mu;
 static std::vector<std::unique_ptr<Plan>> g_plans;
 
+static bool g_plan_timing = false;      // gvk_plan_set_timing: events of plans recorded from now on carry timestamps
 bool plan_recording() { return g_rec != nullptr; }
 void plan_push(std::function<void()>&& node) { g_rec->nodes.push_back(std::move(node)); }
 
@@ -98,6 +99,11 @@ extern "C" int gvk_plan_free(int plan) {
   return 0;
 }
 
+extern "C" int gvk_plan_set_timing(int on) {
+  gvk::g_plan_timing = on != 0;
+  return 0;
+}
+
 extern "C" int gvk_plan_event_elapsed(int plan, int e0, int e1, float* ms) {
   using namespace gvk;
   std::lock_guard<std::mutex> lk(g_plans_mu);
@@ -112,9 +118,9 @@ extern "C" int gvk_plan_event_elapsed(int plan, int e0, int e1, float* ms) {
 extern "C" int gvk_plan_event_record(void* stream) {
   using namespace gvk;
   GVK_REQUIRE(g_rec != nullptr, "gvk_plan_event_record: only valid while a plan is being recorded");
-  static const bool timing = getenv("GAVIKO_HIP_PLAN_TIMING") != nullptr;      // diagnostics: tools/plan_marks.py
+  static const bool env_timing = getenv("GAVIKO_HIP_PLAN_TIMING") != nullptr;  // diagnostics: tools/plan_marks.py
   hipEvent_t ev;
-  hipError_t e = hipEventCreateWithFlags(&ev, timing ? hipEventDefault : hipEventDisableTiming);
+  hipError_t e = hipEventCreateWithFlags(&ev, (env_timing || g_plan_timing) ? hipEventDefault : hipEventDisableTiming);
   if (e != hipSuccess) return set_error(-1, "hipEventCreate: %s", hipGetErrorString(e));
   g_rec->events.push_back(ev);
   hipStream_t s = (hipStream_t)stream;

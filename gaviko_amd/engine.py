@@ -39,21 +39,14 @@ GRAPH_WARMUP = 2
 PLAN_TIMING = os.environ.get("GAVIKO_HIP_PLAN_TIMING") is not None
 
 # bench.py instrumentation: when a dict, every GEMM launch is bracketed by HIP events recorded on the launch stream
-GEMM_TIMING = None
+# bench.py instrumentation: when set to a dict, plans recorded from then on bracket every GEMM launch (and the patch-embed
+# stage) with timestamped plan events, so the kernels are timed inside the real three-stream schedule of a replayed step.
+GEMM_MARKS = None
 # Dispatch priority of the side-chain streams (negative = higher).  Measured: -1 drops the step rate from 448 to 274 volumes/s
 # (priority queues serialise against the captured graph's main queue on this runtime), so the default stays 0.
 SIDE_STREAM_PRIORITY = int(os.environ.get("GAVIKO_HIP_SIDE_PRIORITY", "0"))
-_EPI_NAMES = {0: "store_bf16", 1: "bias_res_f32", 2: "bias_gelu_bf16", 3: "patch_f32", 4: "gelu_bwd_bf16", 5: "store_f32", 6: "bias_res_f32_bf16"}
-
-
-def collect_gemm_timing():
-    """-> {class name: {avg_ms, total_ms, n, flops_per_launch, shape}} from the recorded event pairs (call after a sync)."""
-    out = {}
-    for key, rec in (GEMM_TIMING or {}).items():
-        ms = [a.elapsed_time(b) for a, b in rec["events"]]
-        out[key] = {"avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "n": len(ms), "flops_per_launch": rec["flops"], "shape": rec["shape"],
-                    "bytes": rec.get("bytes")}
-    return out
+_EPI_NAMES = {0: "store_bf16", 1: "bias_res_f32", 2: "bias_gelu_bf16", 3: "patch_f32", 4: "gelu_bwd_bf16", 5: "store_f32", 6: "bias_res_f32_bf16",
+              7: "bias_relu_bf16", 8: "relu_bwd_bf16"}
 
 
 class Names:
@@ -143,22 +136,41 @@ class Engine:
                            and os.environ.get("GAVIKO_HIP_FUSE_PROJ", "1") != "0")
         self._marks = []
         self.plan_marks = {}                # plan id -> [(name, event id)]
+        self._gemm_marks = []
+        self.plan_gemm_marks = {}           # plan id -> [(class, flops, shape, bytes, e0, e1)]
         self._ws = None
         self._step = 0
         self._flat_grad = None
         self._saved = None
 
     def _gemm(self, a, w, M, out0, **kw):
-        if GEMM_TIMING is None:
+        if GEMM_MARKS is None or not self._recording:
             return ops.gemm_nt(a, w, M, out0, **kw)
         N, K = w.shape
         key = f"gemm_nt_bf16[{_EPI_NAMES[kw['epilogue']]}] M={M} N={N} K={K}"
-        rec = GEMM_TIMING.setdefault(key, {"events": [], "flops": 2.0 * M * N * K, "shape": [M, N, K]})
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        cur = torch.cuda.current_stream()
+        e0 = self._ev_record(cur)
         ops.gemm_nt(a, w, M, out0, **kw)
-        e1.record()
-        rec["events"].append((e0, e1))
+        e1 = self._ev_record(cur)
+        self._gemm_marks.append((key, 2.0 * M * N * K, [M, N, K], None, e0, e1))
+
+    def collect_gemm_marks(self, acc=None):
+        """After a sync: add the event-pair durations of the last replay of every instrumented plan to `acc`
+        ({class: {"ms": [...], "flops", "shape", "bytes"}}).  An empty event pair recorded at the head of each plan measures the
+        cost of the bracketing itself, which is subtracted."""
+        import ctypes
+        acc = {} if acc is None else acc
+        lib, ms = L.load(), ctypes.c_float()
+        for pid, marks in self.plan_gemm_marks.items():
+            overhead = 0.0
+            for key, flops, shape, nbytes, e0, e1 in marks:
+                L.check(lib.gvk_plan_event_elapsed(pid, e0, e1, ctypes.byref(ms)), "gvk_plan_event_elapsed")
+                if key == "__empty__":
+                    overhead = ms.value
+                    continue
+                rec = acc.setdefault(key, {"ms": [], "flops": flops, "shape": shape, "bytes": nbytes, "overhead_ms": overhead})
+                rec["ms"].append(max(ms.value - overhead, 0.0))
+        return acc
 
     # ------------------------------------------------------------------ weights
     def _d(self, name) -> torch.Tensor:
@@ -320,9 +332,6 @@ class Engine:
     def _run(self, tag, key, fn):
         """Run `fn` eagerly the first GRAPH_WARMUP times, then capture it into a HIP graph and replay that.
         Everything `fn` launches reads/writes workspace buffers only, so a replay is exactly one more step."""
-        if GEMM_TIMING is not None:                         # instrumented (event-per-launch) pass: always eager
-            fn()
-            return
         k = (tag,) + key + (torch.cuda.current_stream().cuda_stream,)
         g = self._graphs.get(k)
         if g is not None:
@@ -341,8 +350,11 @@ class Engine:
             lib = L.load()
             L.check(lib.gvk_plan_begin(), "gvk_plan_begin")
             self._recording = True
-            self._marks = []
+            self._marks, self._gemm_marks = [], []
             try:
+                if GEMM_MARKS is not None:               # calibration: an empty event pair on the launch stream
+                    cur = torch.cuda.current_stream()
+                    self._gemm_marks.append(("__empty__", 0.0, None, None, self._ev_record(cur), self._ev_record(cur)))
                 fn()
             except BaseException:
                 lib.gvk_plan_abort()
@@ -354,6 +366,8 @@ class Engine:
                 L.check(pid, "gvk_plan_end")
             self._graphs[k] = pid
             self.plan_marks[pid] = (tag, self._marks)
+            if self._gemm_marks:
+                self.plan_gemm_marks[pid] = self._gemm_marks
             return
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -388,20 +402,18 @@ class Engine:
         nm, w, d = self.names, self._w16, self._d
         ops.seed_advance(ws["seed"], 7919)                  # device-side dropout epoch (replay safe)
         # ---- embedding: patch GEMM (+bias +pos, scattered to rows row_off..) and the broadcast rows
-        pe0 = pe1 = None
-        if GEMM_TIMING is not None:                          # bench.py: time the whole patch-embed stage (im2col + GEMM + scatter)
-            pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            pe0.record()
+        marking = GEMM_MARKS is not None and self._recording  # bench.py: time the whole patch-embed stage (im2col + GEMM + scatter)
+        cur = torch.cuda.current_stream()
+        pe0 = self._ev_record(cur) if marking else None
         ops.patchify(ws["img"], ws["cols"], self.patch)
         pos = d(nm.root + "pos_embedding")[0]
         G0 = ws["G"][0]
-        self._gemm(ws["cols"], w["conv"], B * N, G0, epilogue=ops.EPI_PATCH_F32, out1=ws["Lc"][0] if self.kind == "gaviko" else None,
-                   bias=d(nm.root + "conv_proj.0.bias"), pos=pos[1:], rows_in=N, rows_out=T, row_off=self.row_off)
-        if pe0 is not None:
-            pe1.record()
+        ops.gemm_nt(ws["cols"], w["conv"], B * N, G0, epilogue=ops.EPI_PATCH_F32, out1=ws["Lc"][0] if self.kind == "gaviko" else None,
+                    bias=d(nm.root + "conv_proj.0.bias"), pos=pos[1:], rows_in=N, rows_out=T, row_off=self.row_off)
+        if marking:
             nout = 2 if self.kind == "gaviko" else 1
-            GEMM_TIMING.setdefault("__patch_embed__", {"events": [], "flops": 2.0 * B * N * self.Kp * C, "shape": [B * N, C, self.Kp],
-                                                       "bytes": B * (self.Kp * N * 4 + nout * N * C * 4)})["events"].append((pe0, pe1))
+            self._gemm_marks.append(("__patch_embed__", 2.0 * B * N * self.Kp * C, [B * N, C, self.Kp],
+                                     B * (self.Kp * N * 4 + nout * N * C * 4), pe0, self._ev_record(cur)))
         cls = d(nm.root + "cls_token")[0]
         if self.kind == "gaviko":
             ops.rows_broadcast(G0, d("prompt_embeddings")[0], d("prompt_positional_embedding")[0], B, T, 0, self.P, C)

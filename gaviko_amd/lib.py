@@ -99,6 +99,7 @@ NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, [
              "gvk_plan_begin": (C.c_int, []), "gvk_plan_end": (C.c_int, []), "gvk_plan_abort": (C.c_int, []),
              "gvk_plan_size": (C.c_int, [C.c_int]), "gvk_plan_replay": (C.c_int, [C.c_int]), "gvk_plan_free": (C.c_int, [C.c_int]),
              "gvk_plan_event_record": (C.c_int, [_P]), "gvk_plan_event_wait": (C.c_int, [_P, C.c_int]),
+             "gvk_plan_set_timing": (C.c_int, [C.c_int]),
              "gvk_plan_event_elapsed": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)])}
 STRUCTS = {"gvk_gemm_desc": GemmDesc, "gvk_skinny_down_desc": SkinnyDownDesc, "gvk_skinny_up_desc": SkinnyUpDesc,
            "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob, "gvk_rowproj_desc": RowProjDesc}

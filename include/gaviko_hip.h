@@ -40,8 +40,10 @@ int gvk_plan_replay(int plan);
 int gvk_plan_free(int plan);
 int gvk_plan_event_record(void* stream);           /* -> event id within the plan being recorded */
 int gvk_plan_event_wait(void* stream, int event);
-/* diagnostics: milliseconds between two events of a replayed plan (events carry timestamps only when the process was
- * started with GAVIKO_HIP_PLAN_TIMING set) */
+/* measurement: milliseconds between two events of a replayed plan.  Events carry timestamps only in plans recorded after
+ * gvk_plan_set_timing(1) (or with GAVIKO_HIP_PLAN_TIMING set in the environment); bench.py brackets the GEMM launches
+ * of an instrumented copy of the step this way, so the kernels are timed inside the real three-stream schedule. */
+int gvk_plan_set_timing(int on);
 int gvk_plan_event_elapsed(int plan, int e0, int e1, float* ms);
 /* small stream-ordered utilities the step needs between kernels (recorded into a plan like any launch) */
 int gvk_memset_async(void* ptr, int value, size_t bytes, void* stream);
