@@ -50,11 +50,20 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const void* p) {
 
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_rcp, one v_exp, 6 FMAs -- libdevice erff costs ~10x that and
 // dominated the fused GELU epilogues.  The fp32 side paths that need the libm-grade value call erff directly.
+// Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7), written with explicit FMAs (the library builds with -ffp-contract=off) and the
+// exponential straight on v_exp_f32: exp(-a^2) = exp2(-a^2 * log2 e).
+__device__ __forceinline__ float as_poly(float t) {
+  float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+  p = __builtin_fmaf(t, p, 1.421413741f);
+  p = __builtin_fmaf(t, p, -0.284496736f);
+  p = __builtin_fmaf(t, p, 0.254829592f);
+  return t * p;
+}
 __device__ __forceinline__ float erf_fast(float x) {
   const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float r = 1.0f - poly * __expf(-ax * ax);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(ax * ax * -1.44269504088896340736f);
+  const float r = __builtin_fmaf(-as_poly(t), e, 1.0f);
   return copysignf(r, x);
 }
 // exact-erf GELU of nn.GELU() (vision_transformer.py:32); `fast` variants feed bf16 outputs only
@@ -62,15 +71,17 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
-__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float h = 0.5f * x;
+  return __builtin_fmaf(h, erf_fast(x * 0.70710678118654752440f), h);
+}
 __device__ __forceinline__ float gelu_fast_grad(float x) {
   // Phi(x) + x phi(x); e = exp(-x^2/2) is shared by the erf tail and the density
   const float ax = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float e = __expf(-0.5f * x * x);
-  const float erfv = copysignf(1.0f - poly * e, x);
-  return 0.5f * (1.0f + erfv) + x * 0.39894228040143267794f * e;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);
+  const float erfv = copysignf(__builtin_fmaf(-as_poly(t), e, 1.0f), x);
+  return __builtin_fmaf(x * 0.39894228040143267794f, e, __builtin_fmaf(0.5f, erfv, 0.5f));
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float quick_gelu(float x) { return x * sigmoidf_(1.702f * x); }

@@ -6,8 +6,12 @@
 // applied on the per-lane SOURCE address because the DMA destination is lane-linear) so that the 16 rows a
 // ds_read_b128 lane group touches land on 16 distinct 16-B slots of the 256-B bank row.
 // MFMA: v_mfma_f32_16x16x32_bf16 with the WEIGHT fragment as the A operand and the ACTIVATION fragment as the B
-// operand, i.e. each wave computes D[n][m]; a lane then owns 4 consecutive n of one row m, which makes every
-// epilogue a 8/16-byte contiguous access of the row-major output.
+// operand, i.e. each wave computes D[n][m]; a lane owns 4 consecutive n of one row m per 16x16 tile.  The weight rows
+// fed to tiles 2p and 2p+1 are interleaved (tile j, A row a  <->  n = 32(j>>1) + 8(a>>2) + 4(j&1) + (a&3)), so across the
+// pair a lane owns EIGHT consecutive n: every epilogue access is a 16-byte (bf16) or 32-byte (fp32) contiguous piece of
+// the row-major output.  (With 4-wide pieces the two-output GELU epilogue took 44 us against 31 us for the same GEMM
+// with one output: store-instruction bound, not byte bound.)  The weight tile has its own swizzle key so that the
+// interleaved rows stay conflict-free.
 #include "common.hpp"
 #include "../../include/gaviko_hip.h"
 
@@ -35,8 +39,13 @@ __device__ __forceinline__ int swz_chunk(int row) {
   else return (0x78 >> (((row >> 2) & 3) * 2)) & 3;      // 0b01'11'10'00 -> 0,2,3,1
 }
 
+// Weight tile (BK = 64): a fragment read touches rows base + 8q + 4b + r (q, r = 0..3, b fixed); the key takes row bits 1, 3, 4
+// so those 16 rows again hit 16 distinct (parity, slot) pairs.
+__device__ __forceinline__ int swz_w(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
+
 template <int BM, int BN, int EPI, int BK = 64>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+  static_assert(BK == 64, "the interleaved weight-row mapping is built for 128-byte tile rows");
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NT = WN / 16;
   constexpr int ROWB = BK * 2;                       // bytes per LDS tile row
@@ -85,7 +94,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
     for (int r = 0; r < BN / (4 * RPI); ++r) {
       const int row = (r * 4 + wave) * RPI + rsub;
-      const int chunk = slot ^ swz_chunk<BK>(row);
+      const int chunk = slot ^ swz_w(row);
       glds16(Wg + (size_t)row * p.ldw + k0 + chunk * 8, sW + (r * 4 + wave) * 1024);
     }
   };
@@ -110,8 +119,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
       XA[i] = *(const bf16x8*)((SA) + row * ROWB + ((chunk_ ^ swz_chunk<BK>(row)) << 4));                   \
     }                                                                                                       \
     _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                        \
-      const int row = wn * WN + j * 16 + l15;                                                               \
-      WB[j] = *(const bf16x8*)((SW) + row * ROWB + ((chunk_ ^ swz_chunk<BK>(row)) << 4));                   \
+      const int row = wn * WN + 32 * (j >> 1) + 8 * (l15 >> 2) + 4 * (j & 1) + (l15 & 3);                   \
+      WB[j] = *(const bf16x8*)((SW) + row * ROWB + ((chunk_ ^ swz_w(row)) << 4));                           \
     }                                                                                                       \
   }
 #define GVK_MMA(XA, WB)                                                                                      \
@@ -152,39 +161,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 #undef GVK_TILE
 #undef GVK_LOAD_FRAGS
 #undef GVK_MMA
-  } else {
-  stage(0, 0);
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nt) stage(buf ^ 1, t + 1);
-    const char* sA = smem + buf * STAGE;
-    const char* sW = sA + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 xa[MT], wb[NT];
-      const int chunk = ks * 4 + lq;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int row = wm * WM + i * 16 + l15;
-        xa[i] = *(const bf16x8*)(sA + row * ROWB + ((chunk ^ swz_chunk<BK>(row)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int row = wn * WN + j * 16 + l15;
-        wb[j] = *(const bf16x8*)(sW + row * ROWB + ((chunk ^ swz_chunk<BK>(row)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j], xa[i], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();   // drains the LDS-DMA of tile t+1 (vmcnt(0)) and fences reads of buf before it is restaged
-  }
   }
 
-  // ---- epilogue: lane owns rows m (one per i) x 4 consecutive columns n (per j)
+  // ---- epilogue: lane owns rows m (one per i) x 8 consecutive columns n (per tile pair jp)
+  static_assert(NT % 2 == 0, "tile pairs");
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = m0 + wm * WM + i * 16 + l15;
@@ -197,51 +177,63 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
       orow = (size_t)s * p.rows_out + p.row_off + prow;
     }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + wn * WN + j * 16 + lq * 4;
-      f32x4 v = acc[i][j];
+    for (int jp = 0; jp < NT / 2; ++jp) {
+      const int n = n0 + wn * WN + 32 * jp + 8 * lq;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jp][e]; v[4 + e] = acc[i][2 * jp + 1][e]; }
       if (p.bias != nullptr) {
-        const f32x4 b = *(const f32x4*)(p.bias + n);
-        v += b;
+        const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
       }
+      auto store_f32 = [&](float* dst) {
+        *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      };
+      auto store_bf16 = [&](bf16* dst) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+        *(bf16x8*)dst = o;
+      };
       if constexpr (EPI == GVK_EPI_STORE_BF16) {
-        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-        *(bf16x4*)((bf16*)p.out0 + (size_t)m * p.ldo + n) = o;
+        store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
       } else if constexpr (EPI == GVK_EPI_BIAS_RES_F32 || EPI == GVK_EPI_BIAS_RES_F32_BF16) {
-        const f32x4 r = *(const f32x4*)(p.res + (size_t)m * p.ldres + n);
-        v += r;
-        *(f32x4*)((float*)p.out0 + (size_t)m * p.ldo + n) = v;
-        if constexpr (EPI == GVK_EPI_BIAS_RES_F32_BF16) {
-          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-          *(bf16x4*)((bf16*)p.out1 + (size_t)m * p.ldo + n) = o;
-        }
+        const float* rp = p.res + (size_t)m * p.ldres + n;
+        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+        store_f32((float*)p.out0 + (size_t)m * p.ldo + n);
+        if constexpr (EPI == GVK_EPI_BIAS_RES_F32_BF16) store_bf16((bf16*)p.out1 + (size_t)m * p.ldo + n);
       } else if constexpr (EPI == GVK_EPI_BIAS_GELU_BF16) {
-        if (p.out0 != nullptr) {
-          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-          *(bf16x4*)((bf16*)p.out0 + (size_t)m * p.ldo + n) = o;
-        }
-        bf16x4 g = {(bf16)gelu_fast(v[0]), (bf16)gelu_fast(v[1]), (bf16)gelu_fast(v[2]), (bf16)gelu_fast(v[3])};
-        *(bf16x4*)((bf16*)p.out1 + (size_t)m * p.ldo + n) = g;
+        if (p.out0 != nullptr) store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+        store_bf16((bf16*)p.out1 + (size_t)m * p.ldo + n);
       } else if constexpr (EPI == GVK_EPI_PATCH_F32) {
-        const f32x4 pe = *(const f32x4*)(p.pos + (size_t)prow * p.N + n);
-        v += pe;
-        *(f32x4*)((float*)p.out0 + orow * p.ldo + n) = v;
-        if (p.out1 != nullptr) *(f32x4*)((float*)p.out1 + (size_t)m * p.ldo + n) = v;
+        const float* pp = p.pos + (size_t)prow * p.N + n;
+        const f32x4 q0 = *(const f32x4*)pp, q1 = *(const f32x4*)(pp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += q0[e]; v[4 + e] += q1[e]; }
+        store_f32((float*)p.out0 + orow * p.ldo + n);
+        if (p.out1 != nullptr) store_f32((float*)p.out1 + (size_t)m * p.ldo + n);
       } else if constexpr (EPI == GVK_EPI_GELU_BWD_BF16) {
-        const bf16x4 a = *(const bf16x4*)(p.aux + (size_t)m * p.ldaux + n);
-        bf16x4 o = {(bf16)(v[0] * gelu_fast_grad((float)a[0])), (bf16)(v[1] * gelu_fast_grad((float)a[1])),
-                    (bf16)(v[2] * gelu_fast_grad((float)a[2])), (bf16)(v[3] * gelu_fast_grad((float)a[3]))};
-        *(bf16x4*)((bf16*)p.out0 + (size_t)m * p.ldo + n) = o;
+        const bf16x8 a8 = *(const bf16x8*)(p.aux + (size_t)m * p.ldaux + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_fast_grad((float)a8[e]);
+        store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
       } else if constexpr (EPI == GVK_EPI_STORE_F32) {
-        *(f32x4*)((float*)p.out0 + (size_t)m * p.ldo + n) = v;
+        store_f32((float*)p.out0 + (size_t)m * p.ldo + n);
       } else if constexpr (EPI == GVK_EPI_BIAS_RELU_BF16) {
-        bf16x4 o = {(bf16)fmaxf(v[0], 0.f), (bf16)fmaxf(v[1], 0.f), (bf16)fmaxf(v[2], 0.f), (bf16)fmaxf(v[3], 0.f)};
-        *(bf16x4*)((bf16*)p.out0 + (size_t)m * p.ldo + n) = o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
       } else if constexpr (EPI == GVK_EPI_RELU_BWD_BF16) {
-        const bf16x4 a = *(const bf16x4*)(p.aux + (size_t)m * p.ldaux + n);
-        bf16x4 o = {(bf16)((float)a[0] > 0.f ? v[0] : 0.f), (bf16)((float)a[1] > 0.f ? v[1] : 0.f), (bf16)((float)a[2] > 0.f ? v[2] : 0.f),
-                    (bf16)((float)a[3] > 0.f ? v[3] : 0.f)};
-        *(bf16x4*)((bf16*)p.out0 + (size_t)m * p.ldo + n) = o;
+        const bf16x8 a8 = *(const bf16x8*)(p.aux + (size_t)m * p.ldaux + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)a8[e] > 0.f ? v[e] : 0.f;
+        store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
       }
     }
   }
@@ -278,9 +270,6 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     case 128064: return launch_gemm<128, 64, EPI>(a, stream);
     case 64128: return launch_gemm<64, 128, EPI>(a, stream);
     case 64064: return launch_gemm<64, 64, EPI>(a, stream);
-    case 32128128: return launch_gemm<128, 128, EPI, 32>(a, stream);      // BK = 32 variants: half the LDS, ~2x the resident workgroups
-    case 32128064: return launch_gemm<128, 64, EPI, 32>(a, stream);
-    case 32064128: return launch_gemm<64, 128, EPI, 32>(a, stream);
     default: return set_error(-2, "gvk_gemm_nt_bf16: unsupported tile %d", tile);
   }
 }
@@ -295,7 +284,7 @@ extern "C" int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream) {
   GVK_REQUIRE(d->N % 64 == 0, "gvk_gemm_nt_bf16: N=%d must be a multiple of 64", d->N);
   GVK_REQUIRE(d->lda >= d->K && d->ldw >= d->K && d->lda % 8 == 0 && d->ldw % 8 == 0,
               "gvk_gemm_nt_bf16: lda/ldw must be >= K and multiples of 8");
-  GVK_REQUIRE(d->ldo % 4 == 0 && d->ldo >= d->N, "gvk_gemm_nt_bf16: ldo=%d must be >= N and a multiple of 4", d->ldo);
+  GVK_REQUIRE(d->ldo % 8 == 0 && d->ldo >= d->N, "gvk_gemm_nt_bf16: ldo=%d must be >= N and a multiple of 8 (16-byte row pieces)", d->ldo);
   if (d->tile != 0) {
     const int bn = d->tile % 1000;
     GVK_REQUIRE(d->tile < 1000000 || d->K % 32 == 0, "gvk_gemm_nt_bf16: K not a multiple of 32");
@@ -325,7 +314,7 @@ extern "C" int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream) {
                   "gemm PATCH_F32: out0/pos/rows_in/rows_out/row_off inconsistent (ldo must equal N)");
       return dispatch_tile<GVK_EPI_PATCH_F32>(a, d->tile, s);
     case GVK_EPI_GELU_BWD_BF16:
-      GVK_REQUIRE(d->out0 && d->aux && d->ldaux >= d->N && d->ldaux % 4 == 0, "gemm GELU_BWD_BF16: out0/aux");
+      GVK_REQUIRE(d->out0 && d->aux && d->ldaux >= d->N && d->ldaux % 8 == 0, "gemm GELU_BWD_BF16: out0/aux");
       return dispatch_tile<GVK_EPI_GELU_BWD_BF16>(a, d->tile, s);
     case GVK_EPI_STORE_F32:
       GVK_REQUIRE(d->out0, "gemm STORE_F32: out0 null");
@@ -334,7 +323,7 @@ extern "C" int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream) {
       GVK_REQUIRE(d->out0, "gemm BIAS_RELU_BF16: out0 null");
       return dispatch_tile<GVK_EPI_BIAS_RELU_BF16>(a, d->tile, s);
     case GVK_EPI_RELU_BWD_BF16:
-      GVK_REQUIRE(d->out0 && d->aux && d->ldaux >= d->N && d->ldaux % 4 == 0, "gemm RELU_BWD_BF16: out0/aux");
+      GVK_REQUIRE(d->out0 && d->aux && d->ldaux >= d->N && d->ldaux % 8 == 0, "gemm RELU_BWD_BF16: out0/aux");
       return dispatch_tile<GVK_EPI_RELU_BWD_BF16>(a, d->tile, s);
     default:
       return set_error(-2, "gvk_gemm_nt_bf16: unknown epilogue %d", d->epilogue);
