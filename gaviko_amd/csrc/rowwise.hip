@@ -3,14 +3,16 @@
 //   row_up     out[m][:] = base[m][:] + drop?( lat[m][0:L] . W + b )   or   base + LN'(lat . W)   gaviko.py:242, 187 and dgrads
 // Both are single passes over a [M][C] fp32 stream with 2*L flop per element -- HBM-bound, so they are laid out like the
 // LayerNorm kernels (one 64-lane wave per token row, the row in registers as float4s: lane owns columns k*256 + 4*lane .. +3)
-// instead of as small GEMMs: 16 rows per 512-thread workgroup (one workgroup per CU, two waves per SIMD), so the weight is
-// staged once per CU.  The weight sits in LDS as Ws[l][c] (L*C*4 bytes, 60 KiB at L=20, C=768); a lane reads the
-// float4 of its own columns for each l (conflict-free ds_read_b128), shared between the wave's two rows.
-//   down: 4*L FMAs per float4, then L cross-lane sums per row: one DPP add, a 32-entry LDS line per l, L lanes finish.
-//   up:   lat[m][l] is broadcast from lane l with v_readlane (an SGPR operand of the FMA); no reduction at all; the
-//         LayerNorm-backward epilogue's two row sums are plain wave reductions in this layout.
+// instead of as small GEMMs.  At most one 512-thread workgroup per CU, rows split evenly over them.  The weight is staged
+// through LDS one 256-column chunk at a time as Wc[l][0:256) (20 KB at L = 20, so the workgroup fits beside the backbone's
+// GEMM / attention workgroups on a CU); a lane reads the float4 of its own columns for each l (conflict-free ds_read_b128),
+// shared between the wave's rows.
+//   down: 4*L FMAs per float4 as v_pk_fma_f32, then L cross-lane sums per row: four DPP adds give 16-lane row sums, a 4-entry
+//         LDS line per l joins the four rows of the wave, L lanes finish (bias, activation, optional second projection).
+//   up:   lat[m][l] is a wave-uniform LDS broadcast operand of the FMAs; no reduction at all; the LayerNorm-backward
+//         epilogue's two row sums are plain wave reductions in this layout.
 // fp32 VALU throughout (these feed trainable parameters); same arguments, masks and results as skinny.hip's MFMA kernels,
-// which remain for the shapes this layout does not cover (C < 128, L*C too large for LDS).
+// which remain for the shapes this layout does not cover (C < 128, L = 32).
 #include "common.hpp"
 #include "skinny_args.hpp"
 
@@ -27,23 +29,30 @@ __device__ long long g_stamps[4][16];
 
 constexpr int kNW = 8;                 // waves per workgroup
 
-constexpr int kRS = 36;                // floats per reduction line (32 used; 16-byte aligned rows)
 constexpr int kKC = 4;                 // C <= 1024: up to four float4 per lane
 
-// Ws[l][c] <- weight; src_lc: source is [L][C] (straight copy), else [C][L] (transposed on the way in: consecutive lanes take
-// consecutive c, so the LDS stores are conflict-free and the 16-byte global reads stay inside L2-resident lines).
+// Wc[l][0:256) <- columns 256k .. 256k+255 of the weight.  src_lc: the source is [L][C] (straight copy), else [C][L]
+// (transposed on the way in: consecutive lanes take consecutive c, so the LDS stores are conflict-free and the 16-byte global
+// reads stay inside L2-resident lines).  Only ONE 256-column chunk of the weight is resident at a time (20 KB at L = 20):
+// with the whole weight in LDS (60 KB) these workgroups could not share a CU with the backbone's GEMM / attention
+// workgroups (2 x 64 KB) and waited for them to retire -- in the running step the kernels took twice their isolated time.
 template <int L>
-__device__ __forceinline__ void stage_weight(float* Ws, const float* __restrict__ w, int C, bool src_lc) {
+__device__ __forceinline__ void stage_chunk(float* Wc, const float* __restrict__ w, int C, int k, bool src_lc) {
+  const int cols = min(256, C - 256 * k);
   if (src_lc) {
-    const int n4 = L * C / 4;
-    for (int i = threadIdx.x; i < n4; i += 64 * kNW) *(f32x4*)(Ws + 4 * i) = *(const f32x4*)(w + 4 * i);
+    for (int i = threadIdx.x; i < L * 64; i += 64 * kNW) {
+      const int l = i >> 6, c = (i & 63) * 4;
+      if (c < cols) *(f32x4*)(Wc + l * 256 + c) = *(const f32x4*)(w + (size_t)l * C + 256 * k + c);
+    }
   } else {
     constexpr int L4 = L / 4;
-    for (int i = threadIdx.x; i < C * L4; i += 64 * kNW) {
-      const int q = i / C, c = i - q * C;
-      const f32x4 v = *(const f32x4*)(w + (size_t)c * L + 4 * q);
+    for (int i = threadIdx.x; i < 256 * L4; i += 64 * kNW) {
+      const int q = i >> 8, c = i & 255;
+      if (c < cols) {
+        const f32x4 v = *(const f32x4*)(w + (size_t)(256 * k + c) * L + 4 * q);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) Ws[(4 * q + e) * C + c] = v[e];
+        for (int e = 0; e < 4; ++e) Wc[(4 * q + e) * 256 + c] = v[e];
+      }
     }
   }
 }
@@ -69,13 +78,23 @@ __device__ __forceinline__ Pass next_pass(int& cursor, int r1, int wave) {
   }
   return ps;
 }
-__device__ __forceinline__ float dpp_xor1(float v) {     // lane ^ 1 within a quad: one DPP move, no LDS crossbar
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum over each 16-lane row, left in all of its lanes: quad xor 1, quad xor 2, half-row mirror, row mirror -- four DPP adds,
+// no LDS crossbar
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v;
 }
 
 template <int L, int R>
-__device__ __forceinline__ void row_down_pass(const DownArgs& p, const float* Ws, float* red, const float (&w2r)[L], float bias_l,
-                                              int first, int n, bool stage, int lane) {
+__device__ __forceinline__ void row_down_pass(const DownArgs& p, float* Wc, float* red, const float* w2s, float bias_l,
+                                              int first, int n, int lane) {
   const int C = p.C;
   const bool ln = p.ln_g != nullptr;
   int rows[R];
@@ -89,7 +108,6 @@ __device__ __forceinline__ void row_down_pass(const DownArgs& p, const float* Ws
       const int c = k * 256 + lane * 4;
       v[r][k] = (c < C) ? *(const f32x4*)(p.x + (size_t)rows[r] * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  if (stage) stage_weight<L>(const_cast<float*>(Ws), p.w, C, p.w_layout == 0);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     if (p.drop_thresh != 0u) {
@@ -136,44 +154,44 @@ __device__ __forceinline__ void row_down_pass(const DownArgs& p, const float* Ws
       }
     }
   }
-  if (stage) __syncthreads();                            // Ws complete (workgroup-uniform branch)
-
-  // two-wide accumulators: the compiler packs them into v_pk_fma_f32 (half the VALU issue of scalar FMAs)
-  f32x2 a[R][L];
+  // accumulators per (row, l); the FMAs are issued two l at a time as v_pk_fma_f32 (x broadcast into both halves)
+  f32x2 a[R][L / 2];
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int l = 0; l < L; ++l) a[r][l] = f32x2{0.f, 0.f};
+    for (int l = 0; l < L / 2; ++l) a[r][l] = f32x2{0.f, 0.f};
+  const int nk = (C + 255) / 256;
 #pragma unroll
   for (int k = 0; k < kKC; ++k) {
-    const int c = k * 256 + lane * 4;
-    if (c < C) {
+    if (k < nk) {                                        // workgroup-uniform
+      if (k > 0) __syncthreads();                        // everyone is done with the previous chunk
+      stage_chunk<L>(Wc, p.w, C, k, p.w_layout == 0);
+      __syncthreads();
+      if (k * 256 + lane * 4 < C) {
 #pragma unroll
-      for (int l = 0; l < L; ++l) {
-        const f32x4 w = *(const f32x4*)(Ws + l * C + c);
-        const f32x2 wlo = {w[0], w[1]}, whi = {w[2], w[3]};
+        for (int l = 0; l < L / 2; ++l) {
+          const f32x4 w0 = *(const f32x4*)(Wc + (2 * l) * 256 + lane * 4);
+          const f32x4 w1 = *(const f32x4*)(Wc + (2 * l + 1) * 256 + lane * 4);
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const f32x2 xlo = {v[r][k][0], v[r][k][1]}, xhi = {v[r][k][2], v[r][k][3]};
-          a[r][l] = __builtin_elementwise_fma(xlo, wlo, a[r][l]);          // explicit: the library builds with -ffp-contract=off
-          a[r][l] = __builtin_elementwise_fma(xhi, whi, a[r][l]);
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              a[r][l] = __builtin_elementwise_fma(f32x2{v[r][k][e], v[r][k][e]}, f32x2{w0[e], w1[e]}, a[r][l]);
         }
       }
     }
   }
+  __syncthreads();                                       // the next pass (or nothing) may restage Wc
 #pragma unroll
   for (int r = 0; r < R; ++r) {
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-      float pr = a[r][l][0] + a[r][l][1];
-      pr += dpp_xor1(pr);
-      if (!(lane & 1)) red[l * kRS + (lane >> 1)] = pr;
+      const float pr = row16_sum(a[r][l >> 1][l & 1]);
+      if ((lane & 15) == 0) red[l * 4 + (lane >> 4)] = pr;
     }
     float yv = 0.f;
     if (lane < L) {                                      // a wave's own LDS traffic is in order: no barrier
-      f32x4 t = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 8; ++i) t += *(const f32x4*)(red + lane * kRS + 4 * i);
+      const f32x4 t = *(const f32x4*)(red + lane * 4);
       const float zz = (t[0] + t[1]) + (t[2] + t[3]) + bias_l;
       yv = p.act == 1 ? quick_gelu(zz) : zz;
       if (r < n) {
@@ -184,52 +202,45 @@ __device__ __forceinline__ void row_down_pass(const DownArgs& p, const float* Ws
     if (p.w2 != nullptr) {
       float acc = 0.f;
 #pragma unroll
-      for (int l = 0; l < L; ++l) acc = __builtin_fmaf(__shfl(yv, l, 64), w2r[l], acc);
+      for (int l = 0; l < L; ++l) acc = __builtin_fmaf(__shfl(yv, l, 64), w2s[lane * (L + 1) + l], acc);
       if (lane < p.L2 && r < n) p.y2[(size_t)rows[r] * p.L2 + lane] = acc;
     }
   }
 }
 
 template <int L>
-__global__ __launch_bounds__(64 * kNW) void row_down_kernel(DownArgs p) {
+__global__ __launch_bounds__(64 * kNW, 3) void row_down_kernel(DownArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lsm[];
   const int lane = lane_id(), wave = wave_id();
-  const float* Ws = lsm;
-  float* red = lsm + L * p.C + wave * L * kRS;
+  float* Wc = lsm;                                       // [L][256] weight chunk
+  float* red = lsm + L * 256 + wave * L * 4;             // [L][4] row-of-16 partial sums per wave
+  float* w2s = lsm + L * 256 + kNW * L * 4;              // [64][L+1] second-stage weight (rows >= L2 zero), padded rows
+  if (p.w2 != nullptr) {
+    for (int i = threadIdx.x; i < 64 * L; i += 64 * kNW) {
+      const int t = i / L, l = i - t * L;
+      w2s[t * (L + 1) + l] = t < p.L2 ? p.w2[t * L + l] : 0.f;
+    }
+  }                                                      // visible after the first staging barrier
   if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
   const float bias_l = (p.bias != nullptr && lane < L) ? p.bias[lane] : 0.f;
-  float w2r[L];                                          // second stage: lane t < L2 owns output t
-#pragma unroll
-  for (int l = 0; l < L; ++l) w2r[l] = (p.w2 != nullptr && lane < p.L2) ? p.w2[lane * L + l] : 0.f;
   int cursor = (int)((long long)blockIdx.x * p.M / gridDim.x);
   const int r1 = (int)((long long)(blockIdx.x + 1) * p.M / gridDim.x);
-  bool stage = true;
   while (cursor < r1) {                                  // workgroup-uniform loop
     const Pass ps = next_pass(cursor, r1, wave);
-    if (ps.R == 3) row_down_pass<L, 3>(p, Ws, red, w2r, bias_l, ps.first, ps.n, stage, lane);
-    else row_down_pass<L, 2>(p, Ws, red, w2r, bias_l, ps.first, ps.n, stage, lane);
-    stage = false;
+    if (ps.R == 3) row_down_pass<L, 3>(p, Wc, red, w2s, bias_l, ps.first, ps.n, lane);
+    else row_down_pass<L, 2>(p, Wc, red, w2s, bias_l, ps.first, ps.n, lane);
   }
 }
 
-template <int L, int R>
-__device__ __forceinline__ void row_up_pass(const UpArgs& p, const float* Ws, float* latrow, int first, int n, bool stage, int lane) {
+template <int L, int R, bool LNB>
+__device__ __forceinline__ void row_up_pass(const UpArgs& p, float* Wc, float* latrow, int first, int n, int lane) {
   const int C = p.C;
   const float* base = p.accumulate ? p.out : p.res;
-  const bool lnb = p.ln_x != nullptr;
   int rows[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) rows[r] = min(first + min(r, max(n - 1, 0)), p.M - 1);
-  f32x4 bs[R][kKC], xs[R][kKC];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-#pragma unroll
-    for (int k = 0; k < kKC; ++k) {
-      const int c = k * 256 + lane * 4;
-      const bool ok = c < C;
-      bs[r][k] = (ok && base != nullptr) ? *(const f32x4*)(base + (size_t)rows[r] * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-      xs[r][k] = (ok && lnb) ? *(const f32x4*)(p.ln_x + (size_t)rows[r] * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
     if (lane < L) {
       const float* src = p.lat + (size_t)rows[r] * L;
       if (p.lat_override != nullptr) {
@@ -239,52 +250,65 @@ __device__ __forceinline__ void row_up_pass(const UpArgs& p, const float* Ws, fl
       latrow[r * L + lane] = src[lane];
     }
   }
-  if (stage) {
-    stage_weight<L>(const_cast<float*>(Ws), p.w, C, p.w_layout == 1);
-    __syncthreads();
+  // LayerNorm-backward epilogue: the whole row of g*v and xhat is needed for the two row sums, so those stay in registers;
+  // the plain epilogue streams: each 256-column chunk is finished (bias, dropout, + base, store) before the next is staged.
+  f32x4 acc[LNB ? R : 1][LNB ? kKC : 1], xs[LNB ? R : 1][LNB ? kKC : 1];
+  if constexpr (LNB) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int k = 0; k < kKC; ++k) {
+        const int c = k * 256 + lane * 4;
+        xs[r][k] = (c < C) ? *(const f32x4*)(p.ln_x + (size_t)rows[r] * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
   }
-  f32x4 acc[R][kKC];
+  const int nk = (C + 255) / 256;
 #pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int k = 0; k < kKC; ++k) acc[r][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int l = 0; l < L; ++l) {
-    float sc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) sc[r] = latrow[r * L + l];             // wave-uniform LDS broadcast reads (own writes: in order)
-#pragma unroll
-    for (int k = 0; k < kKC; ++k) {
+  for (int k = 0; k < kKC; ++k) {
+    if (k < nk) {                                        // workgroup-uniform
       const int c = k * 256 + lane * 4;
-      if (c < C) {
-        const f32x4 w = *(const f32x4*)(Ws + l * C + c);
+      f32x4 bs[R];
+      if constexpr (!LNB) {                              // issue this chunk's stream loads before the staging barrier
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const f32x2 s2 = {sc[r], sc[r]};
-          const f32x2 lo = __builtin_elementwise_fma(s2, f32x2{w[0], w[1]}, f32x2{acc[r][k][0], acc[r][k][1]});
-          const f32x2 hi = __builtin_elementwise_fma(s2, f32x2{w[2], w[3]}, f32x2{acc[r][k][2], acc[r][k][3]});
-          acc[r][k] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+        for (int r = 0; r < R; ++r)
+          bs[r] = (c < C && base != nullptr) ? *(const f32x4*)(base + (size_t)rows[r] * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (k > 0) __syncthreads();                        // everyone is done with the previous chunk
+      stage_chunk<L>(Wc, p.w, C, k, p.w_layout == 1);
+      __syncthreads();
+      f32x4 a[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) a[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < C) {
+#pragma unroll 4
+        for (int l = 0; l < L; ++l) {
+          const f32x4 w = *(const f32x4*)(Wc + l * 256 + lane * 4);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float sc = latrow[r * L + l];          // wave-uniform LDS broadcast read (own writes: in order)
+            const f32x2 s2 = {sc, sc};
+            const f32x2 lo = __builtin_elementwise_fma(s2, f32x2{w[0], w[1]}, f32x2{a[r][0], a[r][1]});
+            const f32x2 hi = __builtin_elementwise_fma(s2, f32x2{w[2], w[3]}, f32x2{a[r][2], a[r][3]});
+            a[r] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+          }
         }
       }
-    }
-  }
+      if constexpr (LNB) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int row = rows[r];
-    if (!lnb) {
-      // ---- plain epilogue: out = base + drop(v + bias)
-      if (r < n) {
+        for (int r = 0; r < R; ++r) acc[r][k] = a[r];
+      } else if (c < C) {
+        // ---- plain epilogue of this chunk: out = base + drop(v + bias)
+        const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < kKC; ++k) {
-          const int c = k * 256 + lane * 4;
-          if (c < C) {
-            f32x4 vv = acc[r][k];
-            if (p.bias) vv += *(const f32x4*)(p.bias + c);
+        for (int r = 0; r < R; ++r) {
+          if (r < n) {
+            const int row = rows[r];
+            f32x4 vv = a[r] + b4;
             if (p.drop_thresh != 0u) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) vv[e] *= drop_scale(p.seed, (unsigned long long)row * C + c + e, p.drop_thresh, p.inv_keep);
             }
-            vv += bs[r][k];
+            vv += bs[r];
             *(f32x4*)(p.out + (size_t)row * C + c) = vv;
             if (p.out16 != nullptr) {
               bf16x4 h = {(bf16)vv[0], (bf16)vv[1], (bf16)vv[2], (bf16)vv[3]};
@@ -293,8 +317,14 @@ __device__ __forceinline__ void row_up_pass(const UpArgs& p, const float* Ws, fl
           }
         }
       }
-    } else {
-      // ---- LayerNorm-backward epilogue: dx = base + rstd * (g*v - mean(g*v) - xhat * mean(g*v*xhat))
+    }
+  }
+  __syncthreads();                                       // the next pass (or nothing) may restage Wc
+  if constexpr (LNB) {
+    // ---- LayerNorm-backward epilogue: dx = base + rstd * (g*v - mean(g*v) - xhat * mean(g*v*xhat))
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int row = rows[r];
       const float mu = p.ln_mean[row], rs = p.ln_rstd[row];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -320,9 +350,10 @@ __device__ __forceinline__ void row_up_pass(const UpArgs& p, const float* Ws, fl
         for (int k = 0; k < kKC; ++k) {
           const int c = k * 256 + lane * 4;
           if (c < C) {
+            const f32x4 b = base != nullptr ? *(const f32x4*)(base + (size_t)row * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = rs * (acc[r][k][e] - s1 - xs[r][k][e] * s2) + bs[r][k][e];
+            for (int e = 0; e < 4; ++e) o[e] = rs * (acc[r][k][e] - s1 - xs[r][k][e] * s2) + b[e];
             *(f32x4*)(p.out + (size_t)row * C + c) = o;
           }
         }
@@ -331,20 +362,18 @@ __device__ __forceinline__ void row_up_pass(const UpArgs& p, const float* Ws, fl
   }
 }
 
-template <int L>
-__global__ __launch_bounds__(64 * kNW) void row_up_kernel(UpArgs p) {
+template <int L, bool LNB>
+__global__ __launch_bounds__(64 * kNW, LNB ? 3 : 4) void row_up_kernel(UpArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lsm[];
   __shared__ float latrow[kNW][3 * L];
   const int lane = lane_id(), wave = wave_id();
   if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
   int cursor = (int)((long long)blockIdx.x * p.M / gridDim.x);
   const int r1 = (int)((long long)(blockIdx.x + 1) * p.M / gridDim.x);
-  bool stage = true;
   while (cursor < r1) {                                  // workgroup-uniform loop
     const Pass ps = next_pass(cursor, r1, wave);
-    if (ps.R == 3) row_up_pass<L, 3>(p, lsm, latrow[wave], ps.first, ps.n, stage, lane);
-    else row_up_pass<L, 2>(p, lsm, latrow[wave], ps.first, ps.n, stage, lane);
-    stage = false;
+    if (ps.R == 3) row_up_pass<L, 3, LNB>(p, lsm, latrow[wave], ps.first, ps.n, lane);
+    else row_up_pass<L, 2, LNB>(p, lsm, latrow[wave], ps.first, ps.n, lane);
   }
 }
 
@@ -372,7 +401,7 @@ static int ensure_lds(K kernel, size_t bytes, size_t& granted, const char* who) 
 template <int L>
 static int launch_down_t(const DownArgs& a, hipStream_t s) {
   static size_t granted = 0;
-  const size_t lds = (size_t)(L * a.C + kNW * L * kRS) * sizeof(float);
+  const size_t lds = (size_t)(L * 256 + kNW * L * 4 + 64 * (L + 1)) * sizeof(float);
   if (int rc = ensure_lds(&row_down_kernel<L>, lds, granted, "row_down")) return rc;
   GVK_LAUNCH((row_down_kernel<L>), dim3(row_grid(a.M)), dim3(64 * kNW), (unsigned)lds, s, a);
   return check_launch("skinny_down(row)");
@@ -380,15 +409,14 @@ static int launch_down_t(const DownArgs& a, hipStream_t s) {
 
 template <int L>
 static int launch_up_t(const UpArgs& a, hipStream_t s) {
-  static size_t granted = 0;
-  const size_t lds = (size_t)(L * a.C) * sizeof(float);
-  if (int rc = ensure_lds(&row_up_kernel<L>, lds, granted, "row_up")) return rc;
-  GVK_LAUNCH((row_up_kernel<L>), dim3(row_grid(a.M)), dim3(64 * kNW), (unsigned)lds, s, a);
+  const unsigned lds = (unsigned)(L * 256 * sizeof(float));       // < 64 KB: no attribute needed
+  if (a.ln_x != nullptr) GVK_LAUNCH((row_up_kernel<L, true>), dim3(row_grid(a.M)), dim3(64 * kNW), lds, s, a);
+  else GVK_LAUNCH((row_up_kernel<L, false>), dim3(row_grid(a.M)), dim3(64 * kNW), lds, s, a);
   return check_launch("skinny_up(row)");
 }
 
 static bool row_shape_ok(int L, int C, int L2) {
-  return C >= 128 && C % 4 == 0 && C <= 256 * kKC && L % 4 == 0 && L2 <= 64 && (size_t)(L * C + kNW * L * kRS) * sizeof(float) <= 150 * 1024;
+  return C >= 128 && C % 4 == 0 && C <= 256 * kKC && L % 4 == 0 && L2 <= 64 ;
 }
 
 int launch_row_down(const DownArgs& a, int L, hipStream_t s) {
