@@ -92,11 +92,11 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <int L, int R>
+template <int L, int R, int MODE>
 __device__ __forceinline__ void row_down_pass(const DownArgs& p, float* Wc, float* red, const float* w2s, float bias_l,
                                               int first, int n, int lane) {
   const int C = p.C;
-  const bool ln = p.ln_g != nullptr;
+  const bool ln = MODE == 0 && p.ln_g != nullptr;
   int rows[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) rows[r] = min(first + min(r, max(n - 1, 0)), p.M - 1);
@@ -108,9 +108,93 @@ __device__ __forceinline__ void row_down_pass(const DownArgs& p, float* Wc, floa
       const int c = k * 256 + lane * 4;
       v[r][k] = (c < C) ? *(const f32x4*)(p.x + (size_t)rows[r] * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  if constexpr (MODE == 2) {
+    // LayerNorm backward of the rows (as ln_bwd_kernel), leaving dx in v for the projection
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float mean = p.mean_in[rows[r]], rstd = p.rstd_in[rows[r]];
+      f32x4 dh[kKC];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < kKC; ++k) {
+        const int c = k * 256 + lane * 4;
+        dh[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < C) {
+          const f32x4 dv = *(const f32x4*)(p.dy + (size_t)rows[r] * C + c);
+          const f32x4 g = *(const f32x4*)(p.ln_g + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[r][k][e] = (v[r][k][e] - mean) * rstd;     // xhat
+            dh[k][e] = dv[e] * g[e];
+            s1 += dh[k][e];
+            s2 += dh[k][e] * v[r][k][e];
+          }
+        }
+      }
+      const float m1 = wave_sum(s1) / (float)C, m2 = wave_sum(s2) / (float)C;
+#pragma unroll
+      for (int k = 0; k < kKC; ++k) {
+        const int c = k * 256 + lane * 4;
+        if (c < C) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = rstd * (dh[k][e] - m1 - v[r][k][e] * m2);
+          if (p.dres) o += *(const f32x4*)(p.dres + (size_t)rows[r] * C + c);
+          v[r][k] = o;
+          if (r < n) {
+            *(f32x4*)(p.dx + (size_t)rows[r] * C + c) = o;
+            if (p.dx16) {
+              bf16x4 h = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+              *(bf16x4*)(p.dx16 + (size_t)rows[r] * C + c) = h;
+            }
+          }
+        }
+      }
+    }
+  }
+  if constexpr (MODE == 1) {
+    // LayerNorm forward of the rows (as ln_fwd_kernel: bf16 output, statistics saved); v stays raw for the projection
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < kKC; ++k) s += v[r][k][0] + v[r][k][1] + v[r][k][2] + v[r][k][3];
+      const float mean = wave_sum(s) / (float)C;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < kKC; ++k) {
+        if (k * 256 + lane * 4 < C) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = v[r][k][e] - mean;
+            q += d * d;
+          }
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(q) / (float)C + p.eps);
+      if (r < n) {
+        if (lane == 0) {
+          if (p.mean) p.mean[rows[r]] = mean;
+          if (p.rstd) p.rstd[rows[r]] = rstd;
+        }
+#pragma unroll
+        for (int k = 0; k < kKC; ++k) {
+          const int c = k * 256 + lane * 4;
+          if (c < C) {
+            const f32x4 g = *(const f32x4*)(p.ln_g + c);
+            const f32x4 b = *(const f32x4*)(p.ln_b + c);
+            bf16x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (bf16)((v[r][k][e] - mean) * rstd * g[e] + b[e]);
+            *(bf16x4*)(p.y16 + (size_t)rows[r] * C + c) = h;
+          }
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    if (p.drop_thresh != 0u) {
+    if (MODE == 0 && p.drop_thresh != 0u) {
 #pragma unroll
       for (int k = 0; k < kKC; ++k) {
         const int c = k * 256 + lane * 4;
@@ -208,7 +292,7 @@ __device__ __forceinline__ void row_down_pass(const DownArgs& p, float* Wc, floa
   }
 }
 
-template <int L>
+template <int L, int MODE>
 __global__ __launch_bounds__(64 * kNW, 3) void row_down_kernel(DownArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lsm[];
   const int lane = lane_id(), wave = wave_id();
@@ -227,8 +311,8 @@ __global__ __launch_bounds__(64 * kNW, 3) void row_down_kernel(DownArgs p) {
   const int r1 = (int)((long long)(blockIdx.x + 1) * p.M / gridDim.x);
   while (cursor < r1) {                                  // workgroup-uniform loop
     const Pass ps = next_pass(cursor, r1, wave);
-    if (ps.R == 3) row_down_pass<L, 3>(p, Wc, red, w2s, bias_l, ps.first, ps.n, lane);
-    else row_down_pass<L, 2>(p, Wc, red, w2s, bias_l, ps.first, ps.n, lane);
+    if (ps.R == 3) row_down_pass<L, 3, MODE>(p, Wc, red, w2s, bias_l, ps.first, ps.n, lane);
+    else row_down_pass<L, 2, MODE>(p, Wc, red, w2s, bias_l, ps.first, ps.n, lane);
   }
 }
 
@@ -402,8 +486,10 @@ template <int L>
 static int launch_down_t(const DownArgs& a, hipStream_t s) {
   static size_t granted = 0;
   const size_t lds = (size_t)(L * 256 + kNW * L * 4 + 64 * (L + 1)) * sizeof(float);
-  if (int rc = ensure_lds(&row_down_kernel<L>, lds, granted, "row_down")) return rc;
-  GVK_LAUNCH((row_down_kernel<L>), dim3(row_grid(a.M)), dim3(64 * kNW), (unsigned)lds, s, a);
+  (void)granted;                                         // < 64 KB: no attribute needed
+  if (a.mode == 1) GVK_LAUNCH((row_down_kernel<L, 1>), dim3(row_grid(a.M)), dim3(64 * kNW), (unsigned)lds, s, a);
+  else if (a.mode == 2) GVK_LAUNCH((row_down_kernel<L, 2>), dim3(row_grid(a.M)), dim3(64 * kNW), (unsigned)lds, s, a);
+  else GVK_LAUNCH((row_down_kernel<L, 0>), dim3(row_grid(a.M)), dim3(64 * kNW), (unsigned)lds, s, a);
   return check_launch("skinny_down(row)");
 }
 

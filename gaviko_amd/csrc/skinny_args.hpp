@@ -25,6 +25,12 @@ struct DownArgs {
   int M, C, act, w_layout;
   float eps;
   unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;   // dropout mask on the INPUT (bwd of proj_drop)
+  // row-per-wave kernel only (rowwise.hip): LayerNorm kernels that also project the rows they hold
+  //   mode 1: y16 = LN(x; ln_g, ln_b) (bf16), mean/rstd saved, and the projection is taken of the RAW row x
+  //   mode 2: dx = dres + LN'(dy; x, mean_in, rstd_in, ln_g) (+ bf16 copy dx16), and the projection is taken of dx
+  int mode;
+  bf16* y16;
+  const float* dy; const float* mean_in; const float* rstd_in; const float* dres; float* dx; bf16* dx16;
 };
 
 struct UpArgs {
@@ -38,7 +44,7 @@ struct UpArgs {
 };
 
 
-int launch_row_down(const DownArgs& a, int L, hipStream_t s);   // rowwise.hip; returns 1 when the shape is not covered
+int launch_row_down(const DownArgs& a, int L, hipStream_t s);   // rowwise.hip; returns 1 when the shape is not covered (all modes)
 int launch_row_up(const UpArgs& a, int L, hipStream_t s);
 
 }  // namespace gvk

@@ -124,11 +124,12 @@ def layernorm_fwd(x, gamma, beta, M, C_, *, y16=None, y32=None, mean=None, rstd=
                                        M, C_, eps, L.stream_ptr()), "gvk_layernorm_fwd")
 
 
-ROWPROJ_L = 20      # latent width the fused LayerNorm+projection kernels are built for
+ROWPROJ_L = 20      # default latent width (configs/gaviko.yaml prompt_latent_dim)
 
 
 def rowproj_supported(L_: int, C_: int) -> bool:
-    return L_ == ROWPROJ_L and C_ % 4 == 0 and C_ <= 1024
+    """Shapes the fused LayerNorm+projection kernels (row-per-wave form) cover."""
+    return L_ in (4, 8, 16, 20) and C_ % 4 == 0 and 128 <= C_ <= 1024
 
 
 def _rowproj(M, C_, w, y, bias, z, L_, w_layout, act):

@@ -111,7 +111,7 @@ int gvk_layernorm_bwd_affine(const float* dy, const float* x, const float* mean,
  *              (gaviko.py:155-156: GPA proj_down + QuickGELU of the post-attention stream; proj->z = pre-activation);
  *   bwd_proj:  dx as gvk_layernorm_bwd, and               proj->y = dx . W                      of the OUTPUT rows
  *              (autograd of gaviko.py:187 proj_up: the next-lower layer's dcomb = dG . W_up).
- * w_layout 0: w [L][C]; 1: w [C][L].  Other L: use the separate gvk_skinny_down. */
+ * w_layout 0: w [L][C]; 1: w [C][L].  Covers L in {4, 8, 16, 20} and 128 <= C <= 1024; otherwise use gvk_skinny_down. */
 typedef struct gvk_rowproj_desc {
   const float* w; const float* bias;       /* bias [L] or NULL */
   float* y; float* z;                      /* y [M][L]; z [M][L] pre-activation or NULL */

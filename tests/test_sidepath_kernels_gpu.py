@@ -380,6 +380,6 @@ def test_fused_projection_rejects_other_latent_widths(dev):
     from gaviko_amd import ops
     rnd = lambda *sh, device: torch.randn(*sh, device=device)
     x = rnd(64, 768, device=dev)
-    with pytest.raises(ops.L.GavikoHipError, match="L=20"):
+    with pytest.raises(ops.L.GavikoHipError, match="gvk_skinny_down"):
         ops.layernorm_fwd_proj(x, x[0], x[0], 64, 768, y16=torch.empty(64, 768, dtype=torch.bfloat16, device=dev),
-                               w=rnd(16, 768, device=dev), y=torch.empty(64, 16, device=dev), L_=16)
+                               w=rnd(32, 768, device=dev), y=torch.empty(64, 32, device=dev), L_=32)
