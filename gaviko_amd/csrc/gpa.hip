@@ -87,184 +87,168 @@ __global__ __launch_bounds__(64) void gpa_gates_fwd_kernel(GpaArgs p) {
   if (lane == 0) p.gw[b] = sigmoidf_(t);
 }
 
-// Token latents of one sample staged in LDS as [n][L+1] (the +1 pad makes the per-lane row reads conflict-free).
+// ---- cross attention of one prompt against one token set (global image tokens or local tokens of its sample) -----------
+// One wave per (prompt, token set): lanes over tokens, four tokens per lane in flight (their 80-byte latent rows are read
+// straight from global memory -- the per-sample sets are 80 KB and L2-resident -- as five 16-byte loads each), online
+// softmax per lane, merged across lanes at the end.  No LDS staging: the earlier form (8 prompts per 512-thread workgroup
+// around an 84 KB LDS copy of the tokens) put 16 fat workgroups on 16 CUs, where they had to wait for the backbone's
+// GEMM workgroups to retire; these 128-thread workgroups fit beside them anywhere.
 template <int L>
-__device__ __forceinline__ void stage_tokens(float* tok_s, const float* __restrict__ src, int n) {
-  static_assert(L % 4 == 0, "latent width must be a multiple of 4");
-  const int n4 = n * L / 4, nt = blockDim.x;
-  for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * nt) {        // 4 independent 16-byte loads in flight per thread
-    f32x4 v[4];
+__device__ __forceinline__ void load_tok(const float* __restrict__ src, int i, int n, float (&t)[L]) {
+  const f32x4* r = (const f32x4*)(src + (size_t)min(i, n - 1) * L);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * nt;
-      v[u] = (i < n4) ? *(const f32x4*)(src + 4 * (size_t)i) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * nt;
-      if (i < n4) {
-        const int e = 4 * i, r = e / L, l = e - r * L;
-        float* d = tok_s + r * (L + 1) + l;
-        d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
-      }
-    }
+  for (int v = 0; v < L / 4; ++v) {
+    const f32x4 x = r[v];
+    t[4 * v] = x[0]; t[4 * v + 1] = x[1]; t[4 * v + 2] = x[2]; t[4 * v + 3] = x[3];
   }
 }
 
-// softmax(q . tok^T) . tok over the n staged tokens; lanes over tokens; returns ctx (all lanes) and lse.
+// softmax(q . tok^T) . tok over n tokens; returns ctx (all lanes) and lse
 template <int L>
-__device__ __forceinline__ void cross_one(const float* q, const float* tok_s, int n, int lane, float* ctx, float& lse) {
-  float m = -INFINITY, s = 0.f;
-  for (int i = lane; i < n; i += 64) {
-    const float* t = tok_s + i * (L + 1);
-    float d = 0.f;
+__device__ __forceinline__ void cross_one(const float (&q)[L], const float* __restrict__ src, int n, int lane, float (&ctx)[L], float& lse) {
+  float m = -INFINITY, s = 0.f, c[L];
 #pragma unroll
-    for (int l = 0; l < L; ++l) d += q[l] * t[l];
-    const float mn = fmaxf(m, d);
-    s = s * __expf(m - mn) + __expf(d - mn);
+  for (int l = 0; l < L; ++l) c[l] = 0.f;
+  for (int i0 = lane; i0 < n; i0 += 256) {
+    float t[4][L], d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_tok<L>(src, i0 + 64 * u, n, t[u]);
+    float mb = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float a = 0.f;
+#pragma unroll
+      for (int l = 0; l < L; ++l) a = __builtin_fmaf(q[l], t[u][l], a);
+      d[u] = (i0 + 64 * u < n) ? a : -INFINITY;
+      mb = fmaxf(mb, d[u]);
+    }
+    const float mn = fmaxf(m, mb);                       // finite: token i0 itself is valid
+    const float sc = __expf(m - mn);                     // first batch: exp(-inf) = 0
+    s *= sc;
+#pragma unroll
+    for (int l = 0; l < L; ++l) c[l] *= sc;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float e = __expf(d[u] - mn);                 // invalid token: exp(-inf) = 0
+      s += e;
+#pragma unroll
+      for (int l = 0; l < L; ++l) c[l] = __builtin_fmaf(e, t[u][l], c[l]);
+    }
     m = mn;
   }
   const float mw = wave_max(m);
-  s = wave_sum(s * __expf(m - mw));
-  lse = mw + __logf(s);
-  float c[L];
+  const float f = (m == -INFINITY) ? 0.f : __expf(m - mw);          // lanes without tokens contribute nothing
+  const float st = wave_sum(s * f);
+  lse = mw + __logf(st);
+  const float inv = 1.f / st;
 #pragma unroll
-  for (int l = 0; l < L; ++l) c[l] = 0.f;
-  for (int i = lane; i < n; i += 64) {
-    const float* t = tok_s + i * (L + 1);
-    float d = 0.f;
-#pragma unroll
-    for (int l = 0; l < L; ++l) d += q[l] * t[l];
-    const float pr = __expf(d - lse);
-#pragma unroll
-    for (int l = 0; l < L; ++l) c[l] += pr * t[l];
-  }
-#pragma unroll
-  for (int l = 0; l < L; ++l) ctx[l] = wave_sum(c[l]);
+  for (int l = 0; l < L; ++l) ctx[l] = wave_sum(c[l] * f) * inv;
 }
 
-// ---- cross-attention forward: workgroup = up to 8 prompts of one sample (one wave each, 256-VGPR budget); the sample's global image
-// latents, then its local latents, are staged once in LDS and shared by the waves.
+// ---- cross-attention forward: workgroup = one prompt of one sample; wave 0 = global image tokens (gaviko.py:172-176, the
+// reference's double slice: tokens 2P+2..), wave 1 = local tokens (:177-181); wave 0 then fuses (:183-185).
 template <int L>
-__global__ __launch_bounds__(512) void gpa_cross_fwd_kernel(GpaArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* tok_s = (float*)smem;
-  const int b = blockIdx.y, wave = wave_id(), lane = lane_id();
-  const int pi = blockIdx.x * 8 + wave;
-  const bool live = pi < p.P;
-  const int pc = live ? pi : p.P - 1;
-  const size_t o = ((size_t)b * p.P + pc) * L;
-  // Per-prompt vectors are wave-uniform; they are kept in VGPRs on purpose (lane l owns element l, values are spread with
-  // lane shuffles): letting the compiler scalarise them overflows the SGPR file.
+__global__ __launch_bounds__(128) void gpa_cross_fwd_kernel(GpaArgs p) {
+  __shared__ float cl_s[L];
+  const int b = blockIdx.y, pi = blockIdx.x, wave = wave_id(), lane = lane_id();
+  const size_t o = ((size_t)b * p.P + pi) * L;
+  // lane l owns element l of the per-prompt vectors while they are formed; they are then spread with lane shuffles
   const int ll_ = lane < L ? lane : 0;
-  const float pr_l = p.xl[((size_t)b * p.T + pc) * L + ll_];
-  float qg_l = p.bgq[ll_], ql_l = p.blq[ll_];
+  const float pr_l = p.xl[((size_t)b * p.T + pi) * L + ll_];
+  const float* wq = wave == 0 ? p.wgq : p.wlq;
+  float q_l = (wave == 0 ? p.bgq : p.blq)[ll_];
 #pragma unroll
-  for (int l = 0; l < L; ++l) {
-    const float pv = __shfl(pr_l, l, 64);
-    qg_l += p.wgq[ll_ * L + l] * pv;
-    ql_l += p.wlq[ll_ * L + l] * pv;
+  for (int l = 0; l < L; ++l) q_l = __builtin_fmaf(wq[ll_ * L + l], __shfl(pr_l, l, 64), q_l);
+  q_l *= p.scale;                                        // scale folded into the query
+  float q[L], c[L], lse;
+#pragma unroll
+  for (int l = 0; l < L; ++l) q[l] = __shfl(q_l, l, 64);
+  if (wave == 0) cross_one<L>(q, p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L, p.T - (2 * p.P + 2), lane, c, lse);
+  else cross_one<L>(q, p.ll + (size_t)b * p.N * L, p.N, lane, c, lse);
+  float c_l = 0.f;
+#pragma unroll
+  for (int l = 0; l < L; ++l) c_l = (lane == l) ? c[l] : c_l;
+  if (wave == 1) {
+    if (lane < L) { cl_s[lane] = c_l; p.ql[o + lane] = q_l; p.cl[o + lane] = c_l; }
+    if (lane == 0) p.lse_l[b * p.P + pi] = lse;
   }
-  qg_l *= p.scale; ql_l *= p.scale;                 // scale folded into the query
-  float qg[L], ql[L], cg[L], cl[L];
-#pragma unroll
-  for (int l = 0; l < L; ++l) { qg[l] = __shfl(qg_l, l, 64); ql[l] = __shfl(ql_l, l, 64); }
-  float lg, lloc;
-  const int ng = p.T - (2 * p.P + 2);
-  stage_tokens<L>(tok_s, p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L, ng);
   __syncthreads();
-  cross_one<L>(qg, tok_s, ng, lane, cg, lg);
-  __syncthreads();
-  stage_tokens<L>(tok_s, p.ll + (size_t)b * p.N * L, p.N);
-  __syncthreads();
-  cross_one<L>(ql, tok_s, p.N, lane, cl, lloc);
-  if (!live) return;
-  const float gw = p.gw[b], im = p.imp[b * p.P + pi];
-#pragma unroll
-  for (int l = 0; l < L; ++l) {
-    if (lane == l) {
-      p.enh[o + l] = (gw * cg[l] + (1.f - gw) * cl[l]) * im;
-      p.prm[o + l] = pr_l; p.qg[o + l] = qg[l]; p.ql[o + l] = ql[l]; p.cg[o + l] = cg[l]; p.cl[o + l] = cl[l];
+  if (wave == 0) {
+    const float gw = p.gw[b], im = p.imp[b * p.P + pi];
+    if (lane < L) {
+      p.enh[o + lane] = (gw * c_l + (1.f - gw) * cl_s[lane]) * im;
+      p.prm[o + lane] = pr_l; p.qg[o + lane] = q_l; p.cg[o + lane] = c_l;
     }
+    if (lane == 0) p.lse_g[b * p.P + pi] = lse;
   }
-  if (lane == 0) { p.lse_g[b * p.P + pi] = lg; p.lse_l[b * p.P + pi] = lloc; }
 }
 
 // dq (already-scaled query space) of softmax cross attention: dq[l] = sum_n A_n (dA_n - delta) tok_n[l]
 template <int L>
-__device__ __forceinline__ void cross_dq(const float* q, const float* dc, const float* tok_s, int n, int lane, float lse, float delta, float* dq) {
+__device__ __forceinline__ void cross_dq(const float (&q)[L], const float (&dc)[L], const float* __restrict__ src, int n, int lane, float lse,
+                                         float delta, float (&dq)[L]) {
   float a[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) a[l] = 0.f;
-  for (int i = lane; i < n; i += 64) {
-    const float* t = tok_s + i * (L + 1);
-    float d = 0.f, da = 0.f;
+  for (int i0 = lane; i0 < n; i0 += 256) {
+    float t[4][L];
 #pragma unroll
-    for (int l = 0; l < L; ++l) { d += q[l] * t[l]; da += dc[l] * t[l]; }
-    const float ds = __expf(d - lse) * (da - delta);
+    for (int u = 0; u < 4; ++u) load_tok<L>(src, i0 + 64 * u, n, t[u]);
 #pragma unroll
-    for (int l = 0; l < L; ++l) a[l] += ds * t[l];
+    for (int u = 0; u < 4; ++u) {
+      float d = 0.f, da = 0.f;
+#pragma unroll
+      for (int l = 0; l < L; ++l) { d = __builtin_fmaf(q[l], t[u][l], d); da = __builtin_fmaf(dc[l], t[u][l], da); }
+      const float ds = (i0 + 64 * u < n) ? __expf(d - lse) * (da - delta) : 0.f;
+#pragma unroll
+      for (int l = 0; l < L; ++l) a[l] = __builtin_fmaf(ds, t[u][l], a[l]);
+    }
   }
 #pragma unroll
   for (int l = 0; l < L; ++l) dq[l] = wave_sum(a[l]);
 }
 
-// ---- backward, prompt side: same workgroup shape as the forward (tokens staged in LDS, one wave per prompt)
+// ---- backward, prompt side: same workgroup shape as the forward (wave 0 global, wave 1 local)
 template <int L>
-__global__ __launch_bounds__(512) void gpa_cross_bwd_p_kernel(GpaArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* tok_s = (float*)smem;
-  const int b = blockIdx.y, wave = wave_id(), lane = lane_id();
-  const int pi = blockIdx.x * 8 + wave;
-  const bool live = pi < p.P;
-  const int pc = live ? pi : p.P - 1;
-  const size_t o = ((size_t)b * p.P + pc) * L;
-  const float gw = p.gw[b], im = p.imp[b * p.P + pc];
-  // lane l owns element l of every per-prompt vector (see the forward kernel for why these stay out of SGPRs)
+__global__ __launch_bounds__(128) void gpa_cross_bwd_p_kernel(GpaArgs p) {
+  __shared__ float dpr_s[L];
+  const int b = blockIdx.y, pi = blockIdx.x, wave = wave_id(), lane = lane_id();
+  const size_t o = ((size_t)b * p.P + pi) * L;
+  const float gw = p.gw[b], im = p.imp[b * p.P + pi];
   const int ll_ = lane < L ? lane : 0;
   const bool in = lane < L;
-  const float denh_l = p.dcomb[((size_t)b * p.T + pc) * L + ll_];
+  const float denh_l = p.dcomb[((size_t)b * p.T + pi) * L + ll_];
   const float cg_l = p.cg[o + ll_], cl_l = p.cl[o + ll_];
   const float fused_l = gw * cg_l + (1.f - gw) * cl_l;
   const float df_l = denh_l * im;
   const float dcg_l = gw * df_l, dcl_l = (1.f - gw) * df_l;
-  const float dimp = wave_sum(in ? denh_l * fused_l : 0.f);
-  const float dgw = wave_sum(in ? df_l * (cg_l - cl_l) : 0.f);
-  const float delg = wave_sum(in ? dcg_l * cg_l : 0.f);
-  const float dell = wave_sum(in ? dcl_l * cl_l : 0.f);
-  const float qg_l = p.qg[o + ll_], ql_l = p.ql[o + ll_];
-  float dcg[L], dcl[L], qg[L], ql[L];
+  const float dc_l = wave == 0 ? dcg_l : dcl_l;
+  const float del = wave_sum(in ? dc_l * (wave == 0 ? cg_l : cl_l) : 0.f);
+  const float q_l = (wave == 0 ? p.qg : p.ql)[o + ll_];
+  float dc[L], q[L], dq[L];
 #pragma unroll
-  for (int l = 0; l < L; ++l) {
-    dcg[l] = __shfl(dcg_l, l, 64); dcl[l] = __shfl(dcl_l, l, 64);
-    qg[l] = __shfl(qg_l, l, 64); ql[l] = __shfl(ql_l, l, 64);
-  }
-  float dqg[L], dql[L];
-  const int ng = p.T - (2 * p.P + 2);
-  const float lsg = p.lse_g[b * p.P + pc], lsl = p.lse_l[b * p.P + pc];
-  stage_tokens<L>(tok_s, p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L, ng);
-  __syncthreads();
-  cross_dq<L>(qg, dcg, tok_s, ng, lane, lsg, delg, dqg);
-  __syncthreads();
-  stage_tokens<L>(tok_s, p.ll + (size_t)b * p.N * L, p.N);
-  __syncthreads();
-  cross_dq<L>(ql, dcl, tok_s, p.N, lane, lsl, dell, dql);
-  if (!live) return;
-  // unscaled-query gradients (q_scaled = scale * (W prompt + b)), and the prompt latent gradient through both query projections
-  float dpr_l = 0.f;
+  for (int l = 0; l < L; ++l) { dc[l] = __shfl(dc_l, l, 64); q[l] = __shfl(q_l, l, 64); }
+  if (wave == 0) cross_dq<L>(q, dc, p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L, p.T - (2 * p.P + 2), lane, p.lse_g[b * p.P + pi], del, dq);
+  else cross_dq<L>(q, dc, p.ll + (size_t)b * p.N * L, p.N, lane, p.lse_l[b * p.P + pi], del, dq);
+  // unscaled-query gradients (q_scaled = scale * (W prompt + b)), and this query path's share of the prompt latent gradient
+  const float* wq = wave == 0 ? p.wgq : p.wlq;
+  float dpr_l = 0.f, dq_l = 0.f;
 #pragma unroll
   for (int j = 0; j < L; ++j) {
-    dqg[j] *= p.scale; dql[j] *= p.scale;
-    dpr_l += p.wgq[j * L + ll_] * dqg[j] + p.wlq[j * L + ll_] * dql[j];
+    dq[j] *= p.scale;
+    dpr_l = __builtin_fmaf(wq[j * L + ll_], dq[j], dpr_l);
+    dq_l = (lane == j) ? dq[j] : dq_l;
   }
-#pragma unroll
-  for (int l = 0; l < L; ++l) {
-    if (lane == l) {
-      p.dqg[o + l] = dqg[l]; p.dql[o + l] = dql[l]; p.dcg[o + l] = dcg_l; p.dcl[o + l] = dcl_l; p.dprm[o + l] = dpr_l;
-    }
+  if (wave == 1) {
+    if (in) { dpr_s[lane] = dpr_l; p.dql[o + lane] = dq_l; p.dcl[o + lane] = dcl_l; }
+    if (lane == 0) p.delta_l[b * p.P + pi] = del;
   }
-  if (lane == 0) {
-    p.dimp[b * p.P + pi] = dimp; p.dgw_part[b * p.P + pi] = dgw; p.delta_g[b * p.P + pi] = delg; p.delta_l[b * p.P + pi] = dell;
+  __syncthreads();
+  if (wave == 0) {
+    if (in) { p.dqg[o + lane] = dq_l; p.dcg[o + lane] = dcg_l; p.dprm[o + lane] = dpr_l + dpr_s[lane]; }
+    const float dimp = wave_sum(in ? denh_l * fused_l : 0.f);
+    const float dgw = wave_sum(in ? df_l * (cg_l - cl_l) : 0.f);
+    if (lane == 0) { p.dimp[b * p.P + pi] = dimp; p.dgw_part[b * p.P + pi] = dgw; p.delta_g[b * p.P + pi] = del; }
   }
 }
 
@@ -439,28 +423,6 @@ static void fill_gpa(GpaArgs& a, const gvk_gpa_desc* d) {
     default: return set_error(-2, "gvk_gpa: L=%d unsupported (4, 8, 16, 20, 32)", d->L);               \
   }
 
-template <int L>
-static int gpa_set_attr() {
-  static bool done = false;
-  if (done) return 0;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gvk::gpa_cross_fwd_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gvk::gpa_cross_bwd_p_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return gvk::set_error(-3, "hipFuncSetAttribute(gpa_cross): %s", hipGetErrorString(e));
-  done = true;
-  return 0;
-}
-static int gpa_lds_attr(int L) {
-  switch (L) {
-    case 4: return gpa_set_attr<4>();
-    case 8: return gpa_set_attr<8>();
-    case 16: return gpa_set_attr<16>();
-    case 20: return gpa_set_attr<20>();
-    case 32: return gpa_set_attr<32>();
-    default: return gvk::set_error(-2, "gvk_gpa: L=%d unsupported (4, 8, 16, 20, 32)", L);
-  }
-}
-
 static int gpa_check(const gvk_gpa_desc* d, const char* what) {
   using namespace gvk;
   GVK_REQUIRE(d && d->xl && d->ll, "%s: null latents", what);
@@ -480,11 +442,7 @@ extern "C" int gvk_gpa_fwd(const gvk_gpa_desc* d, void* stream) {
   GVK_GPA_LAUNCH(gpa_gates_fwd_kernel, dim3(d->B), dim3(64), 0);
   rc = check_launch("gpa_gates_fwd");
   if (rc) return rc;
-  const int tok_lds = (d->N > d->T - 2 * d->P - 2 ? d->N : d->T - 2 * d->P - 2) * (d->L + 1) * 4;
-  GVK_REQUIRE(tok_lds <= 160 * 1024, "gvk_gpa_fwd: %d token latents do not fit the 160 KiB LDS", d->N);
-  rc = gpa_lds_attr(d->L);
-  if (rc) return rc;
-  GVK_GPA_LAUNCH(gpa_cross_fwd_kernel, dim3((d->P + 7) / 8, d->B), dim3(512), tok_lds);
+  GVK_GPA_LAUNCH(gpa_cross_fwd_kernel, dim3(d->P, d->B), dim3(128), 0);
   return check_launch("gpa_cross_fwd");
 }
 
@@ -498,11 +456,7 @@ extern "C" int gvk_gpa_bwd(const gvk_gpa_desc* d, void* stream) {
   GpaArgs a{};
   fill_gpa(a, d);
   hipStream_t s = (hipStream_t)stream;
-  const int tok_lds = (d->N > d->T - 2 * d->P - 2 ? d->N : d->T - 2 * d->P - 2) * (d->L + 1) * 4;
-  GVK_REQUIRE(tok_lds <= 160 * 1024, "gvk_gpa_bwd: %d token latents do not fit the 160 KiB LDS", d->N);
-  rc = gpa_lds_attr(d->L);
-  if (rc) return rc;
-  GVK_GPA_LAUNCH(gpa_cross_bwd_p_kernel, dim3((d->P + 7) / 8, d->B), dim3(512), tok_lds);
+  GVK_GPA_LAUNCH(gpa_cross_bwd_p_kernel, dim3(d->P, d->B), dim3(128), 0);
   rc = check_launch("gpa_cross_bwd_p");
   if (rc) return rc;
   GVK_GPA_LAUNCH(gpa_gates_bwd_kernel, dim3(d->B), dim3(64), 0);
