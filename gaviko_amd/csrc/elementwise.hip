@@ -17,7 +17,8 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
 }
 
 // out[c][r] = in[r][c]; 64x64 tile through LDS (+1 pad), coalesced both sides.
-__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ in, bf16* __restrict__ out, int rows, int cols) {
+template <typename OUT>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ in, OUT* __restrict__ out, int rows, int cols) {
   __shared__ float tile[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -28,13 +29,14 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;
-    if (c < cols && r < rows) out[(size_t)c * rows + r] = (bf16)tile[tx][i];
+    if (c < cols && r < rows) out[(size_t)c * rows + r] = (OUT)tile[tx][i];
   }
 }
 
 // One thread = 4 consecutive kw of one (patch, kd, kh): a float4 read, an 8-byte bf16x4 write.
 // out row = patch index (b, d, h, w), column = (kd*ph + kh)*pw + kw.
-__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16* __restrict__ out, int B, int D, int H,
+template <typename OUT>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, OUT* __restrict__ out, int B, int D, int H,
                                                        int W, int pd, int ph, int pw) {
   const int nd = D / pd, nh = H / ph, nw = W / pw;
   const int K = pd * ph * pw, kq = K / 4;
@@ -50,8 +52,13 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const f32x4 v = *(const f32x4*)(img + (((int64_t)b * D + z) * H + y) * W + x);
     const int d = z / pd, kd = z - d * pd, h = y / ph, kh = y - h * ph, w = x / pw, kw = x - w * pw;
     const int64_t row = (((int64_t)b * nd + d) * nh + h) * nw + w;
-    bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-    *(bf16x4*)(out + row * K + (kd * ph + kh) * pw + kw) = o;
+    OUT* dst = out + row * K + (kd * ph + kh) * pw + kw;
+    if constexpr (sizeof(OUT) == 2) {
+      bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+      *(bf16x4*)dst = o;
+    } else {
+      *(f32x4*)dst = v;
+    }
   }
 }
 
@@ -98,9 +105,40 @@ extern "C" int gvk_cast_f32_bf16(const float* in, void* out, int64_t n, void* st
 extern "C" int gvk_transpose_cast_f32_bf16(const float* in, void* out, int rows, int cols, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(in && out && rows > 0 && cols > 0, "gvk_transpose_cast_f32_bf16: bad arguments");
-  GVK_LAUNCH(transpose_cast_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, in,
+  GVK_LAUNCH(transpose_cast_kernel<bf16>, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, in,
                      (bf16*)out, rows, cols);
   return check_launch("transpose_cast_f32_bf16");
+}
+
+// ---- fp32 forms for the fp32 compute path (gemm_f32.hip / attention_f32.hip)
+extern "C" int gvk_transpose_f32(const float* in, float* out, int rows, int cols, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(in && out && rows > 0 && cols > 0, "gvk_transpose_f32: bad arguments");
+  GVK_LAUNCH(transpose_cast_kernel<float>, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols);
+  return check_launch("transpose_f32");
+}
+
+extern "C" int gvk_patchify_f32(const float* img, float* out, int B, int D, int H, int W, int pd, int ph, int pw, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(img && out && B > 0, "gvk_patchify_f32: null pointer");
+  GVK_REQUIRE(D % pd == 0 && H % ph == 0 && W % pw == 0 && pw % 4 == 0 && W % 4 == 0,
+              "gvk_patchify_f32: volume %dx%dx%d not divisible by patch %dx%dx%d (pw must be a multiple of 4)", D, H, W, pd, ph, pw);
+  const int64_t total = (int64_t)B * D * H * (W / 4);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  GVK_LAUNCH(patchify_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img, out, B, D, H, W, pd, ph, pw);
+  return check_launch("patchify_f32");
+}
+
+extern "C" int gvk_copy_async(void* dst, const void* src, size_t bytes, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE((dst && src) || bytes == 0, "gvk_copy_async: null pointer");
+  if (bytes == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (plan_recording()) plan_push([=]() { (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s); });
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return set_error(-1, "hipMemcpyAsync: %s", hipGetErrorString(e));
+  return 0;
 }
 
 extern "C" int gvk_patchify_bf16(const float* img, void* out, int B, int D, int H, int W, int pd, int ph, int pw, void* stream) {
@@ -111,6 +149,6 @@ extern "C" int gvk_patchify_bf16(const float* img, void* out, int B, int D, int 
   const int64_t total = (int64_t)B * D * H * (W / 4);
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  GVK_LAUNCH(patchify_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img, (bf16*)out, B, D, H, W, pd, ph, pw);
+  GVK_LAUNCH(patchify_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img, (bf16*)out, B, D, H, W, pd, ph, pw);
   return check_launch("patchify_bf16");
 }

@@ -324,14 +324,19 @@ __global__ __launch_bounds__(256) void vpt_repack_bwd_kernel(const float* __rest
   }
 }
 
-__global__ __launch_bounds__(256) void cast_bf16_f32_strided_kernel(const bf16* __restrict__ in, float* __restrict__ out, int M, int C, int ld_in) {
+template <typename IN>
+__global__ __launch_bounds__(256) void cast_bf16_f32_strided_kernel(const IN* __restrict__ in, float* __restrict__ out, int M, int C, int ld_in) {
   const int c4 = C / 4;
   const int64_t total = (int64_t)M * c4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c = (i % c4) * 4;
     const int64_t m = i / c4;
-    const bf16x4 v = *(const bf16x4*)(in + m * ld_in + c);
-    *(f32x4*)(out + m * C + c) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    if constexpr (sizeof(IN) == 2) {
+      const bf16x4 v = *(const bf16x4*)(in + m * ld_in + c);
+      *(f32x4*)(out + m * C + c) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    } else {
+      *(f32x4*)(out + m * C + c) = *(const f32x4*)(in + m * ld_in + c);
+    }
   }
 }
 
@@ -383,6 +388,14 @@ extern "C" int gvk_cast_bf16_f32_strided(const void* in, float* out, int M, int 
   GVK_REQUIRE(in && out && M > 0 && C > 0 && C % 4 == 0 && ld_in % 4 == 0 && ld_in >= C, "gvk_cast_bf16_f32_strided: bad arguments");
   int64_t blocks = ((int64_t)M * (C / 4) + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  GVK_LAUNCH(cast_bf16_f32_strided_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, out, M, C, ld_in);
+  GVK_LAUNCH(cast_bf16_f32_strided_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, out, M, C, ld_in);
   return check_launch("cast_bf16_f32_strided");
+}
+extern "C" int gvk_copy_f32_strided(const float* in, float* out, int M, int C, int ld_in, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(in && out && M > 0 && C > 0 && C % 4 == 0 && ld_in % 4 == 0 && ld_in >= C, "gvk_copy_f32_strided: bad arguments");
+  int64_t blocks = ((int64_t)M * (C / 4) + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  GVK_LAUNCH(cast_bf16_f32_strided_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, M, C, ld_in);
+  return check_launch("copy_f32_strided");
 }

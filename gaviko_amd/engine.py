@@ -84,6 +84,14 @@ class Engine:
         self.N = self.grid[0] * self.grid[1] * self.grid[2]
         self.Kp = fp * ip * ip
         self.K = cfg["num_classes"]
+        # Operand precision of the backbone GEMMs / attention: "bf16" = MFMA bf16 operands with fp32 accumulation (the headline
+        # path); "fp32" = exact fp32 arithmetic (gemm_f32.hip / attention_f32.hip) for the reference's fp32 configurations
+        # (train.py:157 keeps the model in float32 unless config['train']['fp16']; BASELINE cfg4 is pinned at 1e-5).
+        prec = str(cfg.get("precision") or os.environ.get("GAVIKO_HIP_PRECISION", "bf16")).lower()
+        if prec not in ("bf16", "fp32", "float32"):
+            raise L.GavikoHipError(f"precision={prec!r}: expected 'bf16' or 'fp32'")
+        self.fp32 = prec != "bf16"
+        self.adt = torch.float32 if self.fp32 else torch.bfloat16
         if cfg.get("dim_head", 64) != 64:
             raise L.GavikoHipError("the attention kernels are built for dim_head = 64")
         if cfg.get("channels", 1) != 1:
@@ -132,7 +140,7 @@ class Engine:
         self._streams = {}
         self._recording = False
         # GPA projections of backbone rows ride along in the backbone's LayerNorm kernels (gvk_layernorm_*_proj)
-        self._fuse_proj = (kind == "gaviko" and ops.rowproj_supported(self.Lat, dim)
+        self._fuse_proj = (kind == "gaviko" and not self.fp32 and ops.rowproj_supported(self.Lat, dim)
                            and os.environ.get("GAVIKO_HIP_FUSE_PROJ", "1") != "0")
         self._marks = []
         self.plan_marks = {}                # plan id -> [(name, event id)]
@@ -192,7 +200,7 @@ class Engine:
         w = self._w16
         if stale:
             conv = self._d(names[0]).reshape(self.C, self.Kp).contiguous()
-            w["conv"] = ops.cast_bf16(conv, w.get("conv"))
+            w["conv"] = ops.to_operand(conv, None if self.fp32 else w.get("conv"), self.adt)
         if not stale and (not need_dgrad or self._have_dgrad):
             return
         for i in range(self.depth):
@@ -200,9 +208,9 @@ class Engine:
                             ("fc1", self.names.mlp(i) + ".net.1.weight"), ("fc2", self.names.mlp(i) + ".net.4.weight")):
                 src = self._d(nm).contiguous()
                 if stale:
-                    w[f"{tag}{i}"] = ops.cast_bf16(src, w.get(f"{tag}{i}"))
+                    w[f"{tag}{i}"] = ops.to_operand(src, None if self.fp32 else w.get(f"{tag}{i}"), self.adt)   # fp32: the parameter itself
                 if need_dgrad and (stale or not self._have_dgrad):
-                    w[f"{tag}{i}_t"] = ops.transpose_cast_bf16(src, w.get(f"{tag}{i}_t"))
+                    w[f"{tag}{i}_t"] = ops.transpose_operand(src, w.get(f"{tag}{i}_t"), self.adt)
         self._have_dgrad = self._have_dgrad and not stale or need_dgrad
         self._w16_version = version
 
@@ -214,7 +222,7 @@ class Engine:
             return self._ws
         C, T, N, M = self.C, self.T, self.N, B * self.T
         z = lambda r, c, dt: ops.act_zeros(r, c, dt, device)
-        f32, bf16 = torch.float32, torch.bfloat16
+        f32, bf16 = torch.float32, self.adt                # "bf16" below = the GEMM-operand dtype (fp32 on the fp32 path)
         nsave = self.depth if train else 1
         ws = {"key": key, "B": B, "M": M}
         ws["img"] = torch.zeros((B, 1) + tuple(g * p for g, p in zip(self.grid, self.patch)), device=device)
@@ -641,7 +649,7 @@ class Engine:
                      dlogits=ws["dlogits"], dg=dG, dwh=gv[nm.head() + ".weight"], dbh=gv[nm.head() + ".bias"], B=B, T=self.Ts[-1], C=C,
                      K=self.K, r0=r0, R=R, accumulate=0)
         if backbone_bwd:
-            ops.cast_bf16(dG, ws["dG16"])
+            ops.to_operand(dG, ws["dG16"], self.adt)
             if self.kind == "gaviko":
                 ops.memset_zero(ws["dL"][0])
 
@@ -739,7 +747,7 @@ class Engine:
                 other = ws["dGv"] if dGout is ws["dG"][0] else ws["dG"][0]
                 ops.vpt_repack_bwd(dGout, other, B, self.Ts[i - 1], T, self.P, self.pd, C)
                 dGout = other
-                ops.cast_bf16(dGout, ws["dG16"])
+                ops.to_operand(dGout, ws["dG16"], self.adt)
         if gaviko:
             self._wait(None, "gpa")
             self._wait(None, "loc")
@@ -816,8 +824,10 @@ class Engine:
     def _gpa_bwd_scatter_g(self, ws, i, dG1, M):
         """main stream: dG1 += dzx . Wd, with the bf16 copy for the out-proj dgrad."""
         pre, _ = self._gpa_names(i)
-        ops.skinny_up(lat=ws["bw"]["dzx"], w=self._d(pre + ".proj_down.0.weight"), out=dG1, out_bf16=ws["dG16"], M=M, C=self.C, L=self.Lat,
-                      w_layout=1, accumulate=1)
+        ops.skinny_up(lat=ws["bw"]["dzx"], w=self._d(pre + ".proj_down.0.weight"), out=dG1, out_bf16=None if self.fp32 else ws["dG16"],
+                      M=M, C=self.C, L=self.Lat, w_layout=1, accumulate=1)
+        if self.fp32:
+            ops.copy_(ws["dG16"], dG1)
 
     def _gpa_bwd_scatter_l(self, ws, i, dLnew, B, par):
         """MWSA chain: dL += dzl . Wd."""
@@ -835,11 +845,11 @@ class Engine:
         for i in range(self.depth):
             p = self._adapter_prefix(i)
             wd, wu = self._d(p + ".down_adapter_proj.weight"), self._d(p + ".up_adapter_proj.weight")
-            w[f"ad_d{i}"] = ops.cast_bf16(wd, w.get(f"ad_d{i}"))
-            w[f"ad_u{i}"] = ops.cast_bf16(wu, w.get(f"ad_u{i}"))
+            w[f"ad_d{i}"] = ops.to_operand(wd, None if self.fp32 else w.get(f"ad_d{i}"), self.adt)
+            w[f"ad_u{i}"] = ops.to_operand(wu, None if self.fp32 else w.get(f"ad_u{i}"), self.adt)
             if train:
-                w[f"ad_dT{i}"] = ops.transpose_cast_bf16(wd, w.get(f"ad_dT{i}"))
-                w[f"ad_uT{i}"] = ops.transpose_cast_bf16(wu, w.get(f"ad_uT{i}"))
+                w[f"ad_dT{i}"] = ops.transpose_operand(wd, w.get(f"ad_dT{i}"), self.adt)
+                w[f"ad_uT{i}"] = ops.transpose_operand(wu, w.get(f"ad_uT{i}"), self.adt)
 
     def _adapter_fwd_down(self, ws, i, si, g1, M):
         p, d, ad = self._adapter_prefix(i), self._d, ws["ad"][si]
@@ -883,9 +893,11 @@ class Engine:
         for i in range(self.depth):
             aq, bq, av, bv = (self._d(n) for n in self._lora_names(i))
             ops.lora_merge(self._d(self.names.qkv_weight(i)), aq, bq, av, bv, ws["merge32"], C, self.r, self.lora_s)
-            w[f"qkv{i}"] = ops.cast_bf16(ws["merge32"], w.get(f"qkv{i}"))
+            if self.fp32 and not isinstance(w.get(f"qkv{i}_own"), torch.Tensor):
+                w[f"qkv{i}_own"] = torch.empty_like(ws["merge32"])     # the merged weight needs its own buffer per layer
+            w[f"qkv{i}"] = ops.to_operand(ws["merge32"], w[f"qkv{i}_own"] if self.fp32 else w.get(f"qkv{i}"), self.adt)
             if train:
-                w[f"qkv{i}_t"] = ops.transpose_cast_bf16(ws["merge32"], w.get(f"qkv{i}_t"))
+                w[f"qkv{i}_t"] = ops.transpose_operand(ws["merge32"], w.get(f"qkv{i}_t"), self.adt)
 
     def _melo_bwd(self, ws, gv, i, M):
         """dB = s dq^T u, dA = s (dq B)^T LN(x), u = LN(x) A^T -- all rank-r fp32 kernels over the bf16 dq / dv blocks."""

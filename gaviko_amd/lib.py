@@ -59,6 +59,13 @@ _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 # name -> argtypes (every function returns int and takes the stream last)
 SIGNATURES = {
     "gvk_gemm_nt_bf16": [C.POINTER(GemmDesc), _P],
+    "gvk_gemm_nt_f32": [C.POINTER(GemmDesc), _P],
+    "gvk_attention_fwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "gvk_attention_bwd_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "gvk_patchify_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "gvk_transpose_f32": [_P, _P, _I, _I, _P],
+    "gvk_copy_async": [_P, _P, C.c_size_t, _P],
+    "gvk_copy_f32_strided": [_P, _P, _I, _I, _I, _P],
     "gvk_cast_f32_bf16": [_P, _P, _L, _P],
     "gvk_transpose_cast_f32_bf16": [_P, _P, _I, _I, _P],
     "gvk_patchify_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

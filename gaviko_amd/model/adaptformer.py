@@ -80,6 +80,7 @@ class AdaptFormer(HotPathModule):
                     p.requires_grad = False
                 if "adapter" in k or "head" in k:
                     p.requires_grad = True
+        self.__dict__["_kw_precision"] = kwargs.get("precision")      # "bf16" (default) | "fp32": see HotPathModule.set_precision
         self._cfg = dict(image_size=ih, image_patch_size=ph, frames=frames, frame_patch_size=frame_patch_size, num_classes=num_classes,
                          pool=pool, channels=channels, dim_head=dim_head, backbone=backbone, dropout=dropout, emb_dropout=emb_dropout)
 

@@ -186,6 +186,7 @@ class Gaviko(HotPathModule):
                     p.requires_grad = True
         # (timm weight fetch of gaviko.py:436-441 is outside the hot path)
         self.init_weights()
+        self.__dict__["_kw_precision"] = kwargs.get("precision")      # "bf16" (default) | "fp32": see HotPathModule.set_precision
         self._cfg = dict(image_size=ih, image_patch_size=ph, frames=frames, frame_patch_size=frame_patch_size, num_classes=num_classes,
                          pool=pool, channels=channels, dim_head=dim_head, backbone=backbone, num_prompts=num_prompts,
                          prompt_latent_dim=prompt_latent_dim, local_dim=local_dim, local_k=tuple(local_k),

@@ -50,6 +50,7 @@ class MeLO(HotPathModule):
         self.lora_vit = vit
         if num_classes > 0:
             self.lora_vit.mlp_head = nn.Linear(self.dim, num_classes)
+        self.__dict__["_kw_precision"] = kwargs.get("precision")      # "bf16" (default) | "fp32": see HotPathModule.set_precision
         self._cfg = dict(vit._cfg, r=r, alpha=alpha)
 
     def forward(self, x):

@@ -104,7 +104,11 @@ class HotPathModule(nn.Module):
         eng = self.__dict__.get("_eng")
         if eng is None:
             depth, heads, dim, mlp_dim = mapping_vit(self._cfg["backbone"])
-            eng = Engine(self._kind, self._cfg, dict(self.named_parameters()), depth, heads, dim, mlp_dim)
+            cfg = dict(self._cfg)
+            prec = self.__dict__.get("_precision") or self.__dict__.get("_kw_precision")
+            if prec:
+                cfg["precision"] = prec
+            eng = Engine(self._kind, cfg, dict(self.named_parameters()), depth, heads, dim, mlp_dim)
             self.__dict__["_eng"] = eng
         return eng
 
@@ -115,6 +119,16 @@ class HotPathModule(nn.Module):
 
     def _drop_config(self) -> dict:
         return {}
+
+    def set_precision(self, precision):
+        """'bf16' (default): MFMA bf16 operands with fp32 accumulation / residual stream / statistics.  'fp32': exact fp32
+        arithmetic throughout -- what the reference computes when config['train']['fp16'] is false (train.py:157).
+        Parameters stay fp32 either way.  Also settable with a `precision=` constructor kwarg or GAVIKO_HIP_PRECISION."""
+        if precision is not None and str(precision).lower() not in ("bf16", "fp32", "float32"):
+            raise L.GavikoHipError(f"precision={precision!r}: expected 'bf16' or 'fp32'")
+        self.__dict__["_precision"] = None if precision is None else str(precision).lower()
+        self.__dict__.pop("_eng", None)
+        return self
 
     def attach_reducer(self, reducer) -> None:
         """Data parallelism: `reducer` (gaviko_amd.distributed.GradReducer) all-reduces the flat gradient buffer during backward."""
@@ -166,6 +180,7 @@ class VisionTransformer(HotPathModule):
         self.to_latent = nn.Identity()
         self.mlp_head = nn.Linear(dim, num_classes)
         # (the reference fetches timm weights here, vision_transformer.py:140-145: outside the hot path, needs network)
+        self.__dict__["_kw_precision"] = kwargs.get("precision")      # "bf16" (default) | "fp32": see HotPathModule.set_precision
         self._cfg = dict(image_size=ih, image_patch_size=ph, frames=frames, frame_patch_size=frame_patch_size, num_classes=num_classes,
                          pool=pool, channels=channels, dim_head=dim_head, backbone=backbone, dropout=dropout, emb_dropout=emb_dropout)
 

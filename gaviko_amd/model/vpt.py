@@ -46,6 +46,7 @@ class PromptedVisionTransformer(HotPathModule):
             for k, p in self.vision_transformer.named_parameters():
                 if "transformer" in k or "cls_token" in k or "conv_proj" in k or "pos_embedding" in k:
                     p.requires_grad = False
+        self.__dict__["_kw_precision"] = kwargs.get("precision")      # "bf16" (default) | "fp32": see HotPathModule.set_precision
         self._cfg = dict(self.vision_transformer._cfg, num_prompts=num_prompts, prompt_dim=prompt_dim, deep_prompt=deep_prompt,
                          prompt_dropout=prompt_dropout)
 

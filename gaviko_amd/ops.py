@@ -41,26 +41,33 @@ def _chk(t, dtype, what, min_elems=0):
 
 def gemm_nt(a, w, M, out0, *, epilogue, out1=None, bias=None, res=None, aux=None, pos=None,
             lda=None, ldo=None, ldres=None, ldaux=None, rows_in=0, rows_out=0, row_off=0, tile=0, N=None, K=None):
-    """Y[M,N] = A[M,K] . W[N,K]^T with a fused epilogue (gvk_gemm_nt_bf16)."""
+    """Y[M,N] = A[M,K] . W[N,K]^T with a fused epilogue.  The operand dtype picks the kernel: bf16 -> gvk_gemm_nt_bf16 (MFMA
+    bf16, fp32 accumulate), fp32 -> gvk_gemm_nt_f32 (every 16-bit slot of the epilogue table then carries fp32)."""
+    adt = a.dtype
+    if adt not in (torch.bfloat16, torch.float32):
+        raise L.GavikoHipError(f"gemm A: expected bf16 or fp32 operands, got {adt}")
     N = w.shape[0] if N is None else N
     K = w.shape[1] if K is None else K
     lda = a.shape[-1] if lda is None else lda
     ldw = w.shape[-1]
     ldo = N if ldo is None else ldo
-    _chk(a, torch.bfloat16, "gemm A", pad_rows(M) * lda if lda == a.shape[-1] else 0)
-    _chk(w, torch.bfloat16, "gemm W", N * ldw)
-    out_dt = torch.float32 if epilogue in (EPI_BIAS_RES_F32, EPI_PATCH_F32, EPI_STORE_F32, EPI_BIAS_RES_F32_BF16) else torch.bfloat16
+    _chk(a, adt, "gemm A", pad_rows(M) * lda if lda == a.shape[-1] else 0)
+    _chk(w, adt, "gemm W", N * ldw)
+    out_dt = torch.float32 if epilogue in (EPI_BIAS_RES_F32, EPI_PATCH_F32, EPI_STORE_F32, EPI_BIAS_RES_F32_BF16) else adt
     _chk(out0, out_dt, "gemm out0")
     if out1 is not None:
-        _chk(out1, torch.float32 if epilogue == EPI_PATCH_F32 else torch.bfloat16, "gemm out1")
+        _chk(out1, torch.float32 if epilogue == EPI_PATCH_F32 else adt, "gemm out1")
     _chk(bias, torch.float32, "gemm bias", N)
     _chk(res, torch.float32, "gemm res")
-    _chk(aux, torch.bfloat16, "gemm aux")
+    _chk(aux, adt, "gemm aux")
     _chk(pos, torch.float32, "gemm pos", rows_in * N)
     d = L.GemmDesc(L.ptr(a), L.ptr(w), L.ptr(out0), L.ptr(out1), L.ptr(bias), L.ptr(res), L.ptr(aux), L.ptr(pos),
                    M, N, K, lda, ldw, ldo, (N if ldres is None else ldres), (N if ldaux is None else ldaux),
                    epilogue, rows_in, rows_out, row_off, tile)
-    L.check(L.load().gvk_gemm_nt_bf16(C.byref(d), L.stream_ptr()), "gvk_gemm_nt_bf16")
+    if adt == torch.float32:
+        L.check(L.load().gvk_gemm_nt_f32(C.byref(d), L.stream_ptr()), "gvk_gemm_nt_f32")
+    else:
+        L.check(L.load().gvk_gemm_nt_bf16(C.byref(d), L.stream_ptr()), "gvk_gemm_nt_bf16")
 
 
 def cast_bf16(x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
@@ -69,6 +76,36 @@ def cast_bf16(x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     _chk(out, torch.bfloat16, "cast out", x.numel())
     L.check(L.load().gvk_cast_f32_bf16(L.ptr(x), L.ptr(out), x.numel(), L.stream_ptr()), "gvk_cast_f32_bf16")
+    return out
+
+
+def copy_(dst: torch.Tensor, src: torch.Tensor) -> None:
+    """Stream-ordered device copy of src into dst (same dtype, contiguous; dst may be larger)."""
+    if dst.dtype != src.dtype or not dst.is_contiguous() or not src.is_contiguous() or dst.numel() < src.numel():
+        raise L.GavikoHipError("copy_: need contiguous tensors of one dtype with dst at least as large as src")
+    L.check(L.load().gvk_copy_async(L.ptr(dst), L.ptr(src), src.numel() * src.element_size(), L.stream_ptr()), "gvk_copy_async")
+
+
+def to_operand(x: torch.Tensor, out: torch.Tensor = None, dtype=torch.bfloat16) -> torch.Tensor:
+    """GEMM-operand form of an fp32 matrix: a bf16 copy (MFMA path) or, on the fp32 path, the matrix itself / an fp32 copy."""
+    if dtype == torch.bfloat16:
+        return cast_bf16(x, out)
+    if out is None:
+        return x
+    copy_(out, x)
+    return out
+
+
+def transpose_operand(x: torch.Tensor, out: torch.Tensor = None, dtype=torch.bfloat16) -> torch.Tensor:
+    """x f32 [rows, cols] -> [cols, rows] in the operand dtype."""
+    if dtype == torch.bfloat16:
+        return transpose_cast_bf16(x, out)
+    _chk(x, torch.float32, "transpose in")
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((cols, rows), dtype=torch.float32, device=x.device)
+    _chk(out, torch.float32, "transpose out", rows * cols)
+    L.check(L.load().gvk_transpose_f32(L.ptr(x), L.ptr(out), rows, cols, L.stream_ptr()), "gvk_transpose_f32")
     return out
 
 
@@ -108,11 +145,17 @@ def patchify(img: torch.Tensor, out: torch.Tensor, patch) -> None:
         raise L.GavikoHipError("patchify: single-channel MRI volumes only (channels=1)")
     pd, ph, pw = patch
     n = (D // pd) * (H // ph) * (W // pw)
+    if out.dtype == torch.float32:
+        _chk(out, torch.float32, "patchify out", B * n * pd * ph * pw)
+        L.check(L.load().gvk_patchify_f32(L.ptr(img), L.ptr(out), B, D, H, W, pd, ph, pw, L.stream_ptr()), "gvk_patchify_f32")
+        return
     _chk(out, torch.bfloat16, "patchify out", B * n * pd * ph * pw)
     L.check(L.load().gvk_patchify_bf16(L.ptr(img), L.ptr(out), B, D, H, W, pd, ph, pw, L.stream_ptr()), "gvk_patchify_bf16")
 
 
 def layernorm_fwd(x, gamma, beta, M, C_, *, y16=None, y32=None, mean=None, rstd=None, eps=1e-5):
+    if y16 is not None and y16.dtype == torch.float32:       # fp32 compute path: the "operand" output is fp32
+        y16, y32 = None, y16
     _chk(x, torch.float32, "ln x", M * C_)
     _chk(gamma, torch.float32, "ln gamma", C_)
     _chk(beta, torch.float32, "ln beta", C_)
@@ -168,6 +211,10 @@ def layernorm_bwd_proj(dy, x, mean, rstd, gamma, M, C_, *, dx, dres=None, dx16=N
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, M, C_, *, dx, dres=None, dx16=None):
+    if dx16 is not None and dx16.dtype == torch.float32:     # fp32 compute path: the operand copy is a plain copy of dx
+        layernorm_bwd(dy, x, mean, rstd, gamma, M, C_, dx=dx, dres=dres)
+        copy_(dx16, dx)
+        return
     for t, n in ((dy, "dy"), (x, "x"), (dx, "dx")):
         _chk(t, torch.float32, "ln_bwd " + n, M * C_)
     _chk(dres, torch.float32, "ln_bwd dres", M * C_)
@@ -192,6 +239,13 @@ def layernorm_bwd_affine(dy, x, mean, rstd, dgamma, dbeta, scratch, M, C_, accum
 def attention_fwd(qkv, out, lse, B, T, H, scale):
     """qkv bf16 [pad(B*T), 3*H*64] -> out bf16 [pad(B*T), H*64], lse f32 [B,H,T]."""
     inner = H * 64
+    if qkv.dtype == torch.float32:
+        _chk(qkv, torch.float32, "attn qkv", B * T * 3 * inner)
+        _chk(out, torch.float32, "attn out", B * T * inner)
+        _chk(lse, torch.float32, "attn lse", B * H * T)
+        L.check(L.load().gvk_attention_fwd_f32(L.ptr(qkv), L.ptr(out), L.ptr(lse), B, T, H, 3 * inner, inner, scale, L.stream_ptr()),
+                "gvk_attention_fwd_f32")
+        return
     _chk(qkv, torch.bfloat16, "attn qkv", pad_rows(B * T) * 3 * inner)
     _chk(out, torch.bfloat16, "attn out", B * T * inner)
     _chk(lse, torch.float32, "attn lse", B * H * T)
@@ -301,6 +355,14 @@ def head_bwd(**kw):
 
 def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, scale):
     inner = H * 64
+    if qkv.dtype == torch.float32:
+        for t, n, k in ((qkv, "qkv", 3), (out, "out", 1), (dout, "dout", 1), (dqkv, "dqkv", 3)):
+            _chk(t, torch.float32, "attn_bwd " + n, B * T * k * inner)
+        _chk(lse, torch.float32, "attn_bwd lse", B * H * T)
+        _chk(delta, torch.float32, "attn_bwd delta", B * H * T)
+        L.check(L.load().gvk_attention_bwd_f32(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), B, T, H,
+                                               3 * inner, inner, scale, L.stream_ptr()), "gvk_attention_bwd_f32")
+        return
     _chk(qkv, torch.bfloat16, "attn_bwd qkv", pad_rows(B * T) * 3 * inner)
     _chk(out, torch.bfloat16, "attn_bwd out", pad_rows(B * T) * inner)
     _chk(dout, torch.bfloat16, "attn_bwd dout", pad_rows(B * T) * inner)
@@ -340,7 +402,12 @@ def vpt_repack_bwd(dout, din, B, Tin, Tout, P, skip, C_):
 
 
 def cast_bf16_f32_strided(inp, out, M, C_, ld_in, col0=0):
-    """f32 out[M][C] = bf16 inp[M][ld_in] columns col0 .. col0+C."""
+    """f32 out[M][C] = inp[M][ld_in] columns col0 .. col0+C (inp bf16, or fp32 on the fp32 compute path)."""
+    if inp.dtype == torch.float32:
+        _chk(inp, torch.float32, "copy_strided in", M * ld_in)
+        _chk(out, torch.float32, "copy_strided out", M * C_)
+        L.check(L.load().gvk_copy_f32_strided(inp.data_ptr() + 4 * col0, L.ptr(out), M, C_, ld_in, L.stream_ptr()), "gvk_copy_f32_strided")
+        return
     _chk(inp, torch.bfloat16, "cast_bf16_f32 in", M * ld_in)
     _chk(out, torch.float32, "cast_bf16_f32 out", M * C_)
     L.check(L.load().gvk_cast_bf16_f32_strided(inp.data_ptr() + 2 * col0, L.ptr(out), M, C_, ld_in, L.stream_ptr()), "gvk_cast_bf16_f32_strided")

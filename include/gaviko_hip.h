@@ -85,6 +85,23 @@ typedef struct gvk_gemm_desc {
 } gvk_gemm_desc;
 int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream);
 
+/* ------------------------------------------------------------------ fp32 compute path
+ * BASELINE cfg4 (adaptformer / melo) runs the reference in fp32 with a 1e-5 tolerance, which bf16 MFMA operands cannot
+ * meet.  These entry points mirror their bf16 namesakes argument for argument -- same descriptor, same epilogue table,
+ * same layouts -- with every 16-bit slot (A, W, bf16 outputs, aux) carrying float.  GELU is the exact erf form.
+ * gvk_gemm_nt_f32: v_mfma_f32_16x16x4_f32 (exact fp32 products), N % 64 == 0, K % 16 == 0.
+ * gvk_attention_*_f32: flash-style fp32 VALU kernels; delta f32 [B][H][T] is scratch written by the backward. */
+int gvk_gemm_nt_f32(const gvk_gemm_desc* d, void* stream);
+int gvk_attention_fwd_f32(const float* qkv, float* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale,
+                          void* stream);
+int gvk_attention_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv,
+                          int B, int T, int H, int ld_qkv, int ld_out, float scale, void* stream);
+int gvk_patchify_f32(const float* img, float* out, int B, int D, int H, int W, int pd, int ph, int pw, void* stream);
+int gvk_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
+int gvk_copy_f32_strided(const float* in, float* out, int M, int C, int ld_in, void* stream);   /* out[M][C] = in[M][ld_in] cols 0..C */
+/* stream-ordered device-to-device copy (recorded into a launch plan like any launch) */
+int gvk_copy_async(void* dst, const void* src, size_t bytes, void* stream);
+
 /* ------------------------------------------------------------------ casts / layout
  * fp32 -> bf16 copy of a [rows][cols] matrix (weights -> MFMA operand form), optionally transposed
  * (out [cols][rows]) for the dgrad operand of frozen weights. */

@@ -185,3 +185,62 @@ def test_attention_fwd_forced_rescale(dev):
     got = O[:T].view(1, T, 64).cpu().double()
     assert (got - ref).abs().max().item() < 1.5e-2 * max(1.0, ref.abs().max().item())
     assert (lse.cpu().double() - lse_ref).abs().max().item() < 5e-3
+
+
+# ---- fp32 compute path (BASELINE cfg4: fp32, tolerance 1e-5) ------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (1001, 192, 192), (130, 64, 3072)])
+def test_gemm_f32_epilogues(dev, M, N, K):
+    """gvk_gemm_nt_f32 (v_mfma_f32_16x16x4_f32) against float64, every epilogue the engine uses on the fp32 path."""
+    from gaviko_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    a = ops.act_zeros(M, K, torch.float32, dev)
+    a[:M] = torch.randn(M, K, device=dev, generator=g)
+    w = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+    bias = torch.randn(N, device=dev, generator=g)
+    res = ops.act_zeros(M, N, torch.float32, dev); res[:M] = torch.randn(M, N, device=dev, generator=g)
+    aux = ops.act_zeros(M, N, torch.float32, dev); aux[:M] = torch.randn(M, N, device=dev, generator=g)
+    ref = a[:M].double() @ w.double().t()
+    tol = dict(atol=2e-5, rtol=1e-5)
+    out0, out1 = ops.act_zeros(M, N, torch.float32, dev), ops.act_zeros(M, N, torch.float32, dev)
+    ops.gemm_nt(a, w, M, out0, epilogue=ops.EPI_STORE_BF16)
+    assert torch.allclose(out0[:M].double(), ref, **tol)
+    ops.gemm_nt(a, w, M, out0, epilogue=ops.EPI_BIAS_RES_F32, bias=bias, res=res)
+    assert torch.allclose(out0[:M].double(), ref + bias.double() + res[:M].double(), **tol)
+    ops.gemm_nt(a, w, M, out0, epilogue=ops.EPI_BIAS_GELU_BF16, bias=bias, out1=out1)
+    pre = ref + bias.double()
+    assert torch.allclose(out0[:M].double(), pre, **tol)
+    assert torch.allclose(out1[:M].double(), torch.nn.functional.gelu(pre), **tol)
+    ops.gemm_nt(a, w, M, out0, epilogue=ops.EPI_GELU_BWD_BF16, aux=aux)
+    x = aux[:M].double().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    assert torch.allclose(out0[:M].double(), ref * x.grad, **tol)
+    ops.gemm_nt(a, w, M, out0, epilogue=ops.EPI_BIAS_RELU_BF16, bias=bias)
+    assert torch.allclose(out0[:M].double(), pre.clamp_min(0), **tol)
+    ops.gemm_nt(a, w, M, out0, epilogue=ops.EPI_RELU_BWD_BF16, aux=aux)
+    assert torch.allclose(out0[:M].double(), ref * (aux[:M] > 0), **tol)
+    assert out0[M:].abs().max() == 0                      # rows beyond M are never stored
+
+
+@pytest.mark.parametrize("B,T,H", [(2, 197, 2), (1, 1001, 1), (2, 65, 3)])
+def test_attention_f32_fwd_bwd(dev, B, T, H):
+    """fp32 flash attention (vision_transformer.py:63-71 and its autograd) against float64 torch."""
+    from gaviko_amd import ops
+    inner = H * 64
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    qkv = torch.randn(B, T, 3 * inner, generator=g, dtype=torch.float64).requires_grad_(True)
+    dO = torch.randn(B, T, inner, generator=g, dtype=torch.float64)
+    q, k, v = (t.reshape(B, T, H, 64).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=-1))
+    s = q @ k.transpose(-1, -2) * 0.125
+    o = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B, T, inner)
+    o.backward(dO)
+    Q = qkv.detach().reshape(B * T, -1).float().to(dev).contiguous()
+    O = torch.zeros(B * T, inner, device=dev)
+    lse = torch.zeros(B, H, T, device=dev)
+    ops.attention_fwd(Q, O, lse, B, T, H, 0.125)
+    assert torch.allclose(O.cpu().double(), o.detach().reshape(B * T, -1), atol=2e-6, rtol=1e-5)
+    assert torch.allclose(lse.cpu().double(), torch.logsumexp(s.detach(), -1), atol=1e-5, rtol=1e-6)
+    dQ = torch.zeros_like(Q)
+    delta = torch.zeros(B, H, T, device=dev)
+    ops.attention_bwd(Q, O, dO.reshape(B * T, -1).float().to(dev).contiguous(), lse, delta, dQ, B, T, H, 0.125)
+    want = qkv.grad.reshape(B * T, -1)
+    assert (dQ.cpu().double() - want).abs().max() <= 1e-5 * want.abs().max()

@@ -245,3 +245,47 @@ def test_bucketed_backward_segments_match_single_graph(dev):
         assert torch.equal(o, ref)
     keys = [k for k in m._engine()._graphs if k[0].startswith("bwd")]
     assert {k[0] for k in keys} >= {"bwd0", "bwd1", "bwd2"}
+
+
+# ---- fp32 compute path: the reference's fp32 configurations at fp32 tolerances (BASELINE cfg4: 1e-5) ---------------------
+FP32_CASES = [("cfg1_linear_t16_b1", "linear", "vit-t16", 1, dict()),
+              ("adaptformer_t16_b2", "adaptformer", "vit-t16", 2, dict(freeze_vit=True)),
+              ("melo_t16_b2", "melo", "vit-t16", 2, dict(r=4, alpha=4)),
+              ("deep_vpt_t16_b2", "deep_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True)),
+              ("gaviko_t16_b2", "gaviko", "vit-t16", 2, dict(GAVIKO)),
+              ("cfg4_adaptformer_b16_b8", "adaptformer", "vit-b16", 8, dict(freeze_vit=True)),
+              ("cfg4_melo_b16_b8", "melo", "vit-b16", 8, dict(r=4, alpha=4))]
+
+
+@pytest.mark.parametrize("name,method,backbone,B,extra", FP32_CASES)
+def test_fp32_path_vs_golden(dev, name, method, backbone, B, extra):
+    """precision='fp32': fp32 MFMA GEMMs (exact products) + fp32 flash attention.  The reference's own fp32 CPU results
+    are reproduced to fp32 round-off: logits and loss to 1e-5 (BASELINE's fp32 tolerance), argmax exact, every gradient
+    norm and every stored full gradient to 1e-4 of its scale (sums over up to 8008 tokens in a different order)."""
+    from gaviko_amd.utils import synth
+    g = golden(name)
+    m, cfg = build(method, backbone, dict(extra, precision="fp32"), dev)
+    assert m._engine().fp32
+    x = torch.from_numpy(synth.volumes(0, B)).to(dev)
+    y = torch.from_numpy(synth.labels(0, B)).to(dev)
+    logits = m(x)
+    loss = torch.nn.functional.cross_entropy(logits, y)
+    lg = logits.detach().cpu().numpy()
+    want = g["logits"][:B]
+    assert rel(lg, want) < 1e-5, (lg, want)
+    assert (lg.argmax(-1) == want.argmax(-1)).all()
+    assert abs(loss.item() - float(g["loss_ce"])) < 1e-5
+    if not any(k.startswith("gradnorm/") for k in g.files):
+        return
+    loss.backward()
+    torch.cuda.synchronize()
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for k in g.files:
+        if k.startswith("gradnorm/"):
+            want_n = float(g[k])
+            worst = max(worst, abs(named[k[9:]].grad.norm().item() - want_n) / max(want_n, 1e-12))
+    assert worst < 1e-4, worst
+    for k in g.files:
+        if k.startswith("grad/"):
+            assert rel(named[k[5:]].grad.cpu().numpy(), g[k]) < 1e-4, k
