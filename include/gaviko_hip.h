@@ -296,6 +296,25 @@ int gvk_lora_merge_f32(const float* w, const float* a_q, const float* b_q, const
 /* bf16 [M][ld_in] column block -> dense f32 [M][C] (gradient blocks handed to the fp32 rank-r kernels) */
 int gvk_cast_bf16_f32_strided(const void* in, float* out, int M, int C, int ld_in, void* stream);
 
+/* ------------------------------------------------------------------ optimisation step
+ * Replaces train.py:315-319: torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step() over every
+ * trainable tensor, on the engine's flat fp32 gradient buffer (exp_avg / exp_avg_sq share its layout).
+ * gvk_sumsq: out[0] = sum x^2, two-stage deterministic; scratch f32 [256].
+ * gvk_adam_step: one workgroup per table row; blk_tab int32 [nblocks][4] = {tensor id, offset inside that tensor, offset
+ * into the flat buffers, element count (<= 1024)}; ptr_tab uint64 [ntensors] = parameter data pointers.  norm_sq (device
+ * scalar from gvk_sumsq over the same flat gradient) enables clipping: g *= min(1, max_norm / (sqrt(norm_sq) + 1e-6)),
+ * written back as torch does.  lr / beta1 are the OneCycleLR values of this step (train.py:197-206, host-side schedule);
+ * bias_c1 = 1 - beta1_product ... exactly torch's single-tensor Adam: p -= lr/bias_c1 * m / (sqrt(v)/sqrt(bias_c2) + eps). */
+typedef struct gvk_adam_desc {
+  const void* ptr_tab; const void* blk_tab;
+  float* grad; float* m; float* v;
+  const float* norm_sq;                    /* NULL: no clipping */
+  int32_t nblocks;
+  float lr, beta1, beta2, eps, bias_c1, bias_c2, max_norm;
+} gvk_adam_desc;
+int gvk_sumsq(const float* x, int64_t n, float* scratch, float* out, void* stream);
+int gvk_adam_step(const gvk_adam_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
