@@ -137,8 +137,10 @@ def main():
     else:
         criterion = torch.nn.functional.cross_entropy
 
+    params = list(model.parameters())                 # what optimizer.zero_grad() walks: a flat list, not the module tree
+
     def step():
-        for p in model.parameters():
+        for p in params:
             p.grad = None
         loss = criterion(model(x), y)
         loss.backward()
