@@ -130,15 +130,18 @@ extern "C" int gvk_patchify_f32(const float* img, float* out, int B, int D, int 
   return check_launch("patchify_f32");
 }
 
+namespace gvk { __global__ void copy_u32_kernel(unsigned* dst, const unsigned* src, long n4, long n); }   // runtime.hip
+
 extern "C" int gvk_copy_async(void* dst, const void* src, size_t bytes, void* stream) {
   using namespace gvk;
   GVK_REQUIRE((dst && src) || bytes == 0, "gvk_copy_async: null pointer");
   if (bytes == 0) return 0;
-  hipStream_t s = (hipStream_t)stream;
-  if (plan_recording()) plan_push([=]() { (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s); });
-  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
-  if (e != hipSuccess) return set_error(-1, "hipMemcpyAsync: %s", hipGetErrorString(e));
-  return 0;
+  GVK_REQUIRE((((uintptr_t)dst | (uintptr_t)src) & 15) == 0 && bytes % 4 == 0, "gvk_copy_async: pointers must be 16-byte aligned and the size a multiple of 4");
+  const long n = (long)(bytes / 4), n4 = n / 4;
+  long blocks = (n4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  GVK_LAUNCH(copy_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned*)dst, (const unsigned*)src, n4, n);
+  return check_launch("copy_async");
 }
 
 extern "C" int gvk_patchify_bf16(const float* img, void* out, int B, int D, int H, int W, int pd, int ph, int pw, void* stream) {

@@ -43,6 +43,19 @@ bool plan_recording() { return g_rec != nullptr; }
 void plan_push(std::function<void()>&& node) { g_rec->nodes.push_back(std::move(node)); }
 
 __global__ void seed_advance_kernel(unsigned long long* seed, unsigned long long inc) { seed[0] += inc; }
+// zero / copy as ordinary kernels: hipMemsetAsync issued inside a torch stream capture was executed immediately instead of
+// becoming a graph node on this runtime (the replayed hipGraph then ran on stale buffers), and kernels are recorded into a
+// launch plan like everything else.
+__global__ __launch_bounds__(256) void fill_u32_kernel(unsigned* p, unsigned v, long n4, long n) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) ((uint4*)p)[i] = uint4{v, v, v, v};
+  for (long i = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+__global__ __launch_bounds__(256) void copy_u32_kernel(unsigned* dst, const unsigned* src, long n4, long n) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+  for (long i = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
 __global__ void scale_kernel(float* x, float alpha, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] *= alpha;
@@ -146,11 +159,13 @@ extern "C" int gvk_memset_async(void* ptr, int value, size_t bytes, void* stream
   using namespace gvk;
   GVK_REQUIRE(ptr != nullptr || bytes == 0, "gvk_memset_async: null pointer");
   if (bytes == 0) return 0;
-  hipStream_t s = (hipStream_t)stream;
-  if (plan_recording()) plan_push([=]() { (void)hipMemsetAsync(ptr, value, bytes, s); });
-  hipError_t e = hipMemsetAsync(ptr, value, bytes, s);
-  if (e != hipSuccess) return set_error(-1, "hipMemsetAsync: %s", hipGetErrorString(e));
-  return 0;
+  GVK_REQUIRE(((uintptr_t)ptr & 15) == 0 && bytes % 4 == 0, "gvk_memset_async: pointer must be 16-byte aligned and the size a multiple of 4");
+  const unsigned b = (unsigned)value & 0xFFu, v = b | (b << 8) | (b << 16) | (b << 24);
+  const long n = (long)(bytes / 4), n4 = n / 4;
+  long blocks = (n4 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  GVK_LAUNCH(fill_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned*)ptr, v, n4, n);
+  return check_launch("memset_async");
 }
 
 extern "C" int gvk_seed_advance(void* seed, uint64_t inc, void* stream) {

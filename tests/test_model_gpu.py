@@ -243,8 +243,10 @@ def test_bucketed_backward_segments_match_single_graph(dev):
     outs = [step() for _ in range(4)]                   # eager, eager, capture, replay -- now 3 segments
     for o in outs:
         assert torch.equal(o, ref)
-    keys = [k for k in m._engine()._graphs if k[0].startswith("bwd")]
-    assert {k[0] for k in keys} >= {"bwd0", "bwd1", "bwd2"}
+    from gaviko_amd import engine as eng_mod
+    if eng_mod.USE_GRAPHS:                              # plan / hipGraph modes keep one recorded backward per segment
+        keys = [k for k in m._engine()._graphs if k[0].startswith("bwd")]
+        assert {k[0] for k in keys} >= {"bwd0", "bwd1", "bwd2"}
 
 
 # ---- fp32 compute path: the reference's fp32 configurations at fp32 tolerances (BASELINE cfg4: 1e-5) ---------------------
