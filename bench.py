@@ -111,12 +111,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # Rehearsal switches (not used by the driver): GAVIKO_BENCH_REHEARSAL=1 runs every rank on cuda:0 over gloo, so that the
+    # whole multi-rank flow (bucketed backward, all-reduce, instrumented pass) can be exercised on a one-GPU box.
+    rehearsal = os.environ.get("GAVIKO_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from gaviko_amd import engine as eng_mod
     from gaviko_amd import lib as L
@@ -179,7 +187,8 @@ def main():
     if gf:
         out["mfma_roofline_frac_whole_step"] = round(vps / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)
 
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # (every rank runs this pass -- its steps contain the gradient all-reduce -- but only rank 0 reports)
         # Second, instrumented pass: the step is re-recorded as launch plans in which every GEMM launch (and the patch-embed
         # stage) is bracketed by timestamped HIP events on its launch stream, then replayed like the timed region -- same
         # three-stream schedule, same neighbours on the other queues.  An empty event pair per plan calibrates the bracket's
@@ -201,6 +210,8 @@ def main():
         stats = {k: {"avg_ms": sum(v["ms"]) / len(v["ms"]), "total_ms": sum(v["ms"]), "n": len(v["ms"]), "flops_per_launch": v["flops"],
                      "shape": v["shape"], "bytes": v["bytes"], "overhead_ms": v["overhead_ms"]} for k, v in acc.items()}
         pe = stats.pop("__patch_embed__", None)
+        if rank != 0:
+            pe, stats = None, {}
         if pe:
             # HBM-bound stage: algorithmic bytes = fp32 volume in + fp32 token rows out (global + local stream), per launch
             out["patch_embed"] = {"bound": "hbm", "achieved": round(pe["bytes"] / (pe["avg_ms"] * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
@@ -218,8 +229,6 @@ def main():
             out["roofline"].update(pmc_traffic(name, stats))
             out["gemm_classes"] = {k: {"avg_us": round(v["avg_ms"] * 1e3, 2), "n": v["n"], "tflops": round(v["flops_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12, 1)}
                                    for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])}
-    elif world > 1 and not args.no_roofline:
-        pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.backbone, B)
     if rank == 0:
