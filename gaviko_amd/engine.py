@@ -139,6 +139,7 @@ class Engine:
         self._wss = {}
         self._streams = {}
         self._recording = False
+        self._eff: Dict[str, torch.Tensor] = {}
         # GPA projections of backbone rows ride along in the backbone's LayerNorm kernels (gvk_layernorm_*_proj)
         self._fuse_proj = (kind == "gaviko" and not self.fp32 and ops.rowproj_supported(self.Lat, dim)
                            and os.environ.get("GAVIKO_HIP_FUSE_PROJ", "1") != "0")
@@ -182,7 +183,8 @@ class Engine:
 
     # ------------------------------------------------------------------ weights
     def _d(self, name) -> torch.Tensor:
-        return self.p[name].detach()
+        eff = self._eff.get(name)                 # SSF: LayerNorm affines and biases are read in their effective (folded) form
+        return self.p[name].detach() if eff is None else eff
 
     def _backbone_weight_names(self) -> List[str]:
         n = [self.names.root + "conv_proj.0.weight"]
@@ -194,6 +196,8 @@ class Engine:
     def refresh_weights(self, need_dgrad: bool) -> None:
         """(Re)build the bf16 shadows when a source weight changed (load_state_dict, optimizer step on an unfrozen tensor).
         Shadows are rewritten IN PLACE so that captured HIP graphs keep pointing at valid operands."""
+        if self.kind == "ssf":
+            return                                  # every operand is re-folded from (W, scale) inside the recorded step (_ssf_fold)
         names = self._backbone_weight_names()
         version = tuple(self.p[n]._version for n in names) + tuple(self.p[n].data_ptr() for n in names)
         stale = version != self._w16_version
@@ -292,6 +296,10 @@ class Engine:
                 ws["scratch_l"] = mk(max(ops.outer_scratch_elems(Lt, C), 128 * C))      # the MWSA chain runs on its own stream
                 ws["rscratch_l"] = mk(32 * (3 * Lt * Lt + Lt + 64))
             else:
+                if self.kind == "ssf":
+                    ws["ssf_scratch"] = torch.zeros(64 * 2 * max(self.mlp, 3 * C), device=device)
+                    ws["ssf_tmp"] = torch.zeros(2 * C, device=device)
+                    ws["ssf_stat"] = [torch.zeros(M, device=device), torch.zeros(M, device=device)]
                 lat = {"adaptformer": 64, "melo": getattr(self, "r", 4)}.get(self.kind, 1)
                 ws["scratch"] = torch.zeros(max(128 * C, ops.outer_scratch_elems(lat, C)), device=device)
         self._ws = self._wss[key] = ws       # one workspace (and one set of captured graphs) per (batch, mode)
@@ -409,6 +417,8 @@ class Engine:
         M = B * T
         nm, w, d = self.names, self._w16, self._d
         ops.seed_advance(ws["seed"], 7919)                  # device-side dropout epoch (replay safe)
+        if self.kind == "ssf":
+            self._ssf_fold(train)
         # ---- embedding: patch GEMM (+bias +pos, scattered to rows row_off..) and the broadcast rows
         marking = GEMM_MARKS is not None and self._recording  # bench.py: time the whole patch-embed stage (im2col + GEMM + scatter)
         cur = torch.cuda.current_stream()
@@ -506,7 +516,7 @@ class Engine:
         a = nm.attn(i)
         st = ws["stat"][si]
         ops.layernorm_fwd(gin, d(a + ".norm.weight"), d(a + ".norm.bias"), M, C, y16=ws["xn"], mean=st[0], rstd=st[1])
-        self._gemm(ws["xn"], w[f"qkv{i}"], M, ws["qkv"][si], epilogue=ops.EPI_STORE_BF16)
+        self._gemm(ws["xn"], w[f"qkv{i}"], M, ws["qkv"][si], epilogue=ops.EPI_STORE_BF16, bias=self._eff.get(a + ".to_qkv.bias"))
         ops.attention_fwd(ws["qkv"][si], ws["ctx"][si], ws["lse"][si], ws["B"], self.Ts[i], self.heads, 64 ** -0.5)
         self._gemm(ws["ctx"][si], w[f"out{i}"], M, g1, epilogue=ops.EPI_BIAS_RES_F32, bias=d(a + ".to_out.0.bias"), res=gin)
 
@@ -648,6 +658,15 @@ class Engine:
                      ln_beta=d(nm.root + "transformer.norm.bias"), wh=d(nm.head() + ".weight"), bh=d(nm.head() + ".bias"), pooled=ws["pooled"],
                      dlogits=ws["dlogits"], dg=dG, dwh=gv[nm.head() + ".weight"], dbh=gv[nm.head() + ".bias"], B=B, T=self.Ts[-1], C=C,
                      K=self.K, r0=r0, R=R, accumulate=0)
+        if self.kind == "ssf" and backbone_bwd:
+            # final norm + ssf (ssf.py:138): statistics of the final stream, then the pooled rows' scale / shift gradients
+            g = self._final_stream(ws, True)
+            st = ws["ssf_stat"]
+            ops.layernorm_fwd(g, self.p["transformer.norm.weight"].detach(), self.p["transformer.norm.bias"].detach(), B * T, C, y16=ws["xn"],
+                              mean=st[0], rstd=st[1])
+            ops.ssf_head_grad(g, st[0], st[1], d(nm.head() + ".weight"), ws["dlogits"], self.p["transformer.norm.weight"].detach(),
+                              self.p["transformer.norm.bias"].detach(), gv["transformer.ssf_scale_1"], gv["transformer.ssf_shift_1"],
+                              B, T, C, self.K, r0, R)
         if backbone_bwd:
             ops.to_operand(dG, ws["dG16"], self.adt)
             if self.kind == "gaviko":
@@ -690,8 +709,15 @@ class Engine:
                     par_done = self._ev_record(gpa)
             # main stream, MLP block: dG1 = dGout + LN'(fc1^T(GELU'(pre) * fc2^T(dGout)))
             self._mark(f"b{i}:start")
+            ssf = self.kind == "ssf"
+            if ssf:                                                          # fc2 + ssf_2: dy = dGout, y = G[i+1] - G1[i]
+                self._ssf_linear_grad(ws, gv, m, 2, dGout, ws["G"][i + 1], M, C, y1=ws["G1"][i])
             self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i])
+            if ssf:                                                          # fc1 + ssf_1: dy = d(pre-activation), y = saved pre-activation
+                self._ssf_linear_grad(ws, gv, m, 1, ws["dpre"], ws["pre"][i], M, self.mlp)
             self._gemm(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
+            if ssf:                                                          # LN2 + ssf_0
+                self._ssf_ln_grad(ws, gv, m, ".net.0", ws["dx32"], ws["G1"][i], st[2], st[3], M)
             adapter = self.kind == "adaptformer"
             ops.layernorm_bwd(ws["dx32"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), M, C, dx=dGin, dres=dGout,
                               dx16=None if (gaviko or adapter) else ws["dG16"])
@@ -708,11 +734,17 @@ class Engine:
                     scl_done = self._ev_record(loc)
                     self._mwsa_bwd(ws, sv, gv, i, ws["dL"][par], ws["dL"][par ^ 1], B)
             # main stream, attention block: dG0 = dG1 + LN'(qkv^T(attn'(out^T(dG1))))
+            if ssf:                                                          # to_out + ssf_2: dy = dG1, y = G1[i] - G[i]
+                self._ssf_linear_grad(ws, gv, a, 2, dGin, ws["G1"][i], M, C, y1=ws["G"][i])
             self._gemm(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
             ops.attention_bwd(ws["qkv"][i], ws["ctx"][i], ws["dctx"], ws["lse"][i], ws["delta"], ws["dqkv"], B, T, self.heads, 64 ** -0.5)
             if self.kind == "melo":
                 self._melo_bwd(ws, gv, i, M)
+            if ssf:                                                          # to_qkv + ssf_1: dy = dqkv, y = saved qkv
+                self._ssf_linear_grad(ws, gv, a, 1, ws["dqkv"], ws["qkv"][i], M, 3 * C)
             self._gemm(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
+            if ssf:                                                          # LN1 + ssf_0
+                self._ssf_ln_grad(ws, gv, a, ".norm", ws["dx32"], ws["G"][i], st[0], st[1], M)
             self._mark(f"b{i}:qkvd")
             if gaviko:
                 # The new boundary gradient goes to the OTHER parity buffer: the GPA parameter kernels of this layer keep reading
@@ -751,6 +783,11 @@ class Engine:
         if gaviko:
             self._wait(None, "gpa")
             self._wait(None, "loc")
+        if last and self.kind == "ssf":
+            # patch embedding + ssf (ssf.py:229-232): dy = the patch rows of the input gradient, y = G[0] patch rows - pos[1:]
+            pos = self.p["pos_embedding"].detach()[0]
+            ops.ssf_colgrad(dGout, ws["G"][0], self.p["ssf_scale_1"].detach(), self.p["ssf_shift_1"].detach(), gv["ssf_scale_1"], gv["ssf_shift_1"],
+                            ws["ssf_scratch"], B * self.N, C, pos=pos[1:], rows_in=self.N, rows_out=T, row_off=1)
         if last and self.kind == "vpt":
             emb_name = "deep_prompt_embeddings" if self.deep else "prompt_embeddings"
             emb = d(emb_name).reshape(-1, self.pd)
@@ -771,6 +808,8 @@ class Engine:
             return "adapter" in name
         if self.kind == "melo":
             return ".linear_a_" in name or ".linear_b_" in name
+        if self.kind == "ssf":
+            return "ssf_scale_" in name or "ssf_shift_" in name
         return False
 
     def _needs_backbone_backward(self) -> bool:
@@ -917,6 +956,57 @@ class Engine:
             if self.lora_s != 1:
                 ops.scale_(gv[na], float(self.lora_s))
                 ops.scale_(gv[nb], float(self.lora_s))
+
+    # ---- SSF (ssf.py): effective parameters per step, scale / shift gradients per site -----------------------------------------
+    def _ssf_sites(self):
+        """(scale name, shift name, kind, target) for every ssf_ada of the model, in forward order."""
+        nm = self.names
+        sites = [("ssf_scale_1", "ssf_shift_1", "linear", ("conv", "conv_proj.0.weight", "conv_proj.0.bias"))]
+        for i in range(self.depth):
+            a, m = nm.attn(i), nm.mlp(i)
+            sites += [(a + ".ssf_scale_0", a + ".ssf_shift_0", "ln", (a + ".norm.weight", a + ".norm.bias")),
+                      (a + ".ssf_scale_1", a + ".ssf_shift_1", "linear", (f"qkv{i}", a + ".to_qkv.weight", a + ".to_qkv.bias")),
+                      (a + ".ssf_scale_2", a + ".ssf_shift_2", "linear", (f"out{i}", a + ".to_out.0.weight", a + ".to_out.0.bias")),
+                      (m + ".ssf_scale_0", m + ".ssf_shift_0", "ln", (m + ".net.0.weight", m + ".net.0.bias")),
+                      (m + ".ssf_scale_1", m + ".ssf_shift_1", "linear", (f"fc1{i}", m + ".net.1.weight", m + ".net.1.bias")),
+                      (m + ".ssf_scale_2", m + ".ssf_shift_2", "linear", (f"fc2{i}", m + ".net.4.weight", m + ".net.4.bias"))]
+        sites.append(("transformer.ssf_scale_1", "transformer.ssf_shift_1", "ln", ("transformer.norm.weight", "transformer.norm.bias")))
+        return sites
+
+    def _ssf_fold(self, train):
+        """gamma' = gamma*s, beta' = beta*s + t;  W' = s[:,None]*W (operand dtype, + transpose for the dgrad), b' = b*s + t.
+        Runs inside the recorded step: the scales and shifts are what the optimiser updates."""
+        w, eff, raw = self._w16, self._eff, (lambda n: self.p[n].detach())
+        for sn, tn, kind, tgt in self._ssf_sites():
+            s_, t_ = raw(sn), raw(tn)
+            if kind == "ln":
+                gname, bname = tgt
+                if gname not in eff:
+                    eff[gname], eff[bname] = torch.empty_like(s_), torch.empty_like(s_)
+                ops.ssf_fold_vec(raw(gname), s_, None, eff[gname])
+                ops.ssf_fold_vec(raw(bname), s_, t_, eff[bname])
+            else:
+                key, wname, bname = tgt
+                W = raw(wname)
+                W2 = W.reshape(W.shape[0], -1)
+                if key not in w:
+                    w[key] = torch.empty(W2.shape, dtype=self.adt, device=W.device)
+                    eff[bname] = torch.empty_like(s_)
+                need_t = train and key != "conv"
+                if need_t and key + "_t" not in w:
+                    w[key + "_t"] = torch.empty((W2.shape[1], W2.shape[0]), dtype=self.adt, device=W.device)
+                ops.ssf_fold_weight(W2, s_, w[key], w[key + "_t"] if need_t else None)
+                ops.ssf_fold_vec(self.p[bname].detach() if bname in self.p else None, s_, t_, eff[bname])
+
+    def _ssf_linear_grad(self, ws, gv, prefix, idx, dy, y0, M, N, y1=None):
+        sn, tn = f"{prefix}.ssf_scale_{idx}", f"{prefix}.ssf_shift_{idx}"
+        ops.ssf_colgrad(dy, y0, self.p[sn].detach(), self.p[tn].detach(), gv[sn], gv[tn], ws["ssf_scratch"], M, N, y1=y1)
+
+    def _ssf_ln_grad(self, ws, gv, prefix, ln, dy, x, mean, rstd, M):
+        C, tmp = self.C, ws["ssf_tmp"]
+        ops.layernorm_bwd_affine(dy, x, mean, rstd, tmp[:C], tmp[C:], ws["scratch"], M, C)
+        ops.ssf_ln_grad(tmp[:C], tmp[C:], self.p[prefix + ln + ".weight"].detach(), self.p[prefix + ln + ".bias"].detach(),
+                        gv[prefix + ".ssf_scale_0"], gv[prefix + ".ssf_shift_0"])
 
     def _offset_of(self, name) -> int:
         return (self._flat_grad["views"][name].data_ptr() - self._flat_grad["buf"].data_ptr()) // 4

@@ -47,6 +47,8 @@ GpaDesc = _struct("GpaDesc",
                    "dcomb", "zx", "zl", "dimp", "dgw_part", "dqg", "dql", "dcg", "dcl", "delta_g", "delta_l", "dprm",
                    "dcls", "gate_partials", "dzx", "dzl"],
                   ["B", "T", "N", "P", "L"], ["scale"])
+SsfColgradDesc = _struct("SsfColgradDesc", ["dy", "y0", "y1", "pos", "s", "t", "ds", "dt", "scratch"],
+                         ["M", "N", "ld_dy", "ld_y", "dy_f32", "y0_f32", "rows_in", "rows_out", "row_off"])
 AdamDesc = _struct("AdamDesc", ["ptr_tab", "blk_tab", "grad", "m", "v", "norm_sq"], ["nblocks"],
                    ["lr", "beta1", "beta2", "eps", "bias_c1", "bias_c2", "max_norm"])
 RowProjDesc = _struct("RowProjDesc", ["w", "bias", "y", "z"], ["L", "w_layout", "act"])
@@ -97,6 +99,11 @@ SIGNATURES = {
     "gvk_lora_merge_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "gvk_layernorm_fwd_proj": [_P, _P, _P, _P, _P, _P, _I, _I, _F, C.POINTER(RowProjDesc), _P],
     "gvk_layernorm_bwd_proj": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, C.POINTER(RowProjDesc), _P],
+    "gvk_ssf_fold_weight": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "gvk_ssf_fold_vec": [_P, _P, _P, _P, _I, _P],
+    "gvk_ssf_colgrad": [C.POINTER(SsfColgradDesc), _P],
+    "gvk_ssf_ln_grad": [_P, _P, _P, _P, _P, _P, _I, _P],
+    "gvk_ssf_head_grad": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gvk_sumsq": [_P, C.c_int64, _P, _P, _P],
     "gvk_adam_step": [C.POINTER(AdamDesc), _P],
     "gvk_memset_async": [_P, _I, C.c_size_t, _P],
@@ -113,7 +120,7 @@ NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, [
              "gvk_plan_set_timing": (C.c_int, [C.c_int]),
              "gvk_plan_event_elapsed": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)])}
 STRUCTS = {"gvk_gemm_desc": GemmDesc, "gvk_skinny_down_desc": SkinnyDownDesc, "gvk_skinny_up_desc": SkinnyUpDesc,
-           "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob, "gvk_rowproj_desc": RowProjDesc, "gvk_adam_desc": AdamDesc}
+           "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob, "gvk_rowproj_desc": RowProjDesc, "gvk_adam_desc": AdamDesc, "gvk_ssf_colgrad_desc": SsfColgradDesc}
 
 _lib = None
 

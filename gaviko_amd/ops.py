@@ -450,3 +450,56 @@ def ln_lowrank_affine(Q, S, W, gamma, beta, dW, dgamma, dbeta, dbias, Lat, C_, a
         raise L.GavikoHipError("ln_lowrank_affine: buffer too small")
     L.check(L.load().gvk_ln_lowrank_affine(L.ptr(Q), L.ptr(S), L.ptr(W), L.ptr(gamma), L.ptr(beta), L.ptr(dW), L.ptr(dgamma), L.ptr(dbeta),
                                            L.ptr(dbias), Lat, C_, int(bool(accumulate)), L.stream_ptr()), "gvk_ln_lowrank_affine")
+
+
+# ---- SSF (model/ssf.py): effective parameters and scale/shift gradients ---------------------------------------------------
+def ssf_fold_weight(w, s, out, out_t=None):
+    """out[n][k] = w[n][k] * s[n] in out's dtype (bf16 / fp32); out_t [K][N] = the transpose (optional)."""
+    _chk(w, torch.float32, "ssf_fold_weight w")
+    N = w.shape[0]
+    K = w.numel() // N
+    _chk(s, torch.float32, "ssf_fold_weight s", N)
+    if out.dtype not in (torch.bfloat16, torch.float32) or (out_t is not None and out_t.dtype != out.dtype):
+        raise L.GavikoHipError("ssf_fold_weight: outputs must be bf16 or fp32 (both the same)")
+    _chk(out, out.dtype, "ssf_fold_weight out", N * K)
+    _chk(out_t, out.dtype, "ssf_fold_weight out_t", N * K)
+    L.check(L.load().gvk_ssf_fold_weight(L.ptr(w), L.ptr(s), L.ptr(out), L.ptr(out_t), N, K, int(out.dtype == torch.float32), L.stream_ptr()),
+            "gvk_ssf_fold_weight")
+
+
+def ssf_fold_vec(a, s, t, out):
+    n = s.numel()
+    for x, nm in ((a, "a"), (s, "s"), (t, "t"), (out, "out")):
+        _chk(x, torch.float32, "ssf_fold_vec " + nm, n)
+    L.check(L.load().gvk_ssf_fold_vec(L.ptr(a), L.ptr(s), L.ptr(t), L.ptr(out), n, L.stream_ptr()), "gvk_ssf_fold_vec")
+
+
+def ssf_colgrad(dy, y0, s, t, ds, dt, scratch, M, N, *, y1=None, pos=None, ld_dy=None, ld_y=None, rows_in=0, rows_out=0, row_off=0):
+    for x, nm in ((s, "s"), (t, "t"), (ds, "ds"), (dt, "dt")):
+        _chk(x, torch.float32, "ssf_colgrad " + nm, N)
+    _chk(scratch, torch.float32, "ssf_colgrad scratch", 64 * 2 * N)
+    _chk(y1, torch.float32, "ssf_colgrad y1")
+    _chk(pos, torch.float32, "ssf_colgrad pos")
+    for x, nm in ((dy, "dy"), (y0, "y0")):
+        if x.dtype not in (torch.bfloat16, torch.float32) or not x.is_cuda or not x.is_contiguous():
+            raise L.GavikoHipError(f"ssf_colgrad {nm}: expected a contiguous bf16 / fp32 device tensor")
+    d = L.SsfColgradDesc(dy=L.ptr(dy), y0=L.ptr(y0), y1=L.ptr(y1), pos=L.ptr(pos), s=L.ptr(s), t=L.ptr(t), ds=L.ptr(ds), dt=L.ptr(dt),
+                         scratch=L.ptr(scratch), M=M, N=N, ld_dy=N if ld_dy is None else ld_dy, ld_y=N if ld_y is None else ld_y,
+                         dy_f32=int(dy.dtype == torch.float32), y0_f32=int(y0.dtype == torch.float32), rows_in=rows_in, rows_out=rows_out,
+                         row_off=row_off)
+    L.check(L.load().gvk_ssf_colgrad(C.byref(d), L.stream_ptr()), "gvk_ssf_colgrad")
+
+
+def ssf_ln_grad(dgamma_eff, dbeta_eff, gamma, beta, ds, dt):
+    n = gamma.numel()
+    for x, nm in ((dgamma_eff, "dgamma'"), (dbeta_eff, "dbeta'"), (gamma, "gamma"), (beta, "beta"), (ds, "ds"), (dt, "dt")):
+        _chk(x, torch.float32, "ssf_ln_grad " + nm, n)
+    L.check(L.load().gvk_ssf_ln_grad(L.ptr(dgamma_eff), L.ptr(dbeta_eff), L.ptr(gamma), L.ptr(beta), L.ptr(ds), L.ptr(dt), n, L.stream_ptr()),
+            "gvk_ssf_ln_grad")
+
+
+def ssf_head_grad(g, mean, rstd, wh, dlogits, gamma, beta, ds, dt, B, T, C_, K, r0, R):
+    for x, nm in ((g, "g"), (mean, "mean"), (rstd, "rstd"), (wh, "wh"), (dlogits, "dlogits"), (gamma, "gamma"), (beta, "beta"), (ds, "ds"), (dt, "dt")):
+        _chk(x, torch.float32, "ssf_head_grad " + nm)
+    L.check(L.load().gvk_ssf_head_grad(L.ptr(g), L.ptr(mean), L.ptr(rstd), L.ptr(wh), L.ptr(dlogits), L.ptr(gamma), L.ptr(beta), L.ptr(ds),
+                                       L.ptr(dt), B, T, C_, K, r0, R, L.stream_ptr()), "gvk_ssf_head_grad")

@@ -31,7 +31,10 @@ def build_model(model_cfg):
         from .model.melo import MeLO
         from .model.vision_transformer import VisionTransformer
         return MeLO(vit=VisionTransformer(**cfg), **cfg)
-    if method in ("dvpt", "evp", "ssf"):
+    if method == "ssf":
+        from .model.ssf import ScalingShiftingFeatures
+        return ScalingShiftingFeatures(**cfg)
+    if method in ("dvpt", "evp"):
         raise NotImplementedError(f"--method {method} resolves in the reference (train.py:139-146) but its kernels are not built yet "
                                   "(SURVEY.md 8(f)-2)")
     raise ValueError(f"unknown method {method!r}; expected one of {METHODS}")

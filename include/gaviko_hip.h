@@ -296,6 +296,30 @@ int gvk_lora_merge_f32(const float* w, const float* a_q, const float* b_q, const
 /* bf16 [M][ld_in] column block -> dense f32 [M][C] (gradient blocks handed to the fp32 rank-r kernels) */
 int gvk_cast_bf16_f32_strided(const void* in, float* out, int M, int C, int ld_in, void* stream);
 
+/* ------------------------------------------------------------------ SSF, `--method ssf` (model/ssf.py)
+ * ssf_ada(x, s, t) = x*s + t (ssf.py:24-31) always follows a LayerNorm or a Linear, so the forward runs the plain ViT
+ * kernels on effective parameters and the backward adds two column sums per site.
+ * gvk_ssf_fold_weight: out[n][k] = w[n][k]*s[n] (bf16, or fp32 when out_f32), out_t (may be NULL) = its transpose [K][N].
+ * gvk_ssf_fold_vec:    out = a*s + t   (a NULL -> t alone: the bias-free to_qkv; t NULL -> a*s: a LayerNorm gamma).
+ * gvk_ssf_colgrad:     dt[n] = sum_m dy[m][n];  ds[n] = sum_m dy[m][n]*z[m][n] with z = (y - t)/s the pre-ssf value,
+ *                      y = y0 (bf16 / fp32) [- y1 fp32] [- pos[m % rows_in][n]]; optional row mapping as GVK_EPI_PATCH_F32;
+ *                      scratch f32 [64*2*N].
+ * gvk_ssf_ln_grad:     LayerNorm+ssf site, from the effective-affine gradients (gvk_layernorm_bwd_affine):
+ *                      ds = gamma*dgamma' + beta*dbeta', dt = dbeta'.
+ * gvk_ssf_head_grad:   the final norm + ssf in front of the head (only the pooled rows r0..r0+R carry gradient). */
+typedef struct gvk_ssf_colgrad_desc {
+  const void* dy; const void* y0; const float* y1; const float* pos;
+  const float* s; const float* t; float* ds; float* dt; float* scratch;
+  int32_t M, N, ld_dy, ld_y, dy_f32, y0_f32, rows_in, rows_out, row_off;
+} gvk_ssf_colgrad_desc;
+int gvk_ssf_fold_weight(const float* w, const float* s, void* out, void* out_t, int N, int K, int out_f32, void* stream);
+int gvk_ssf_fold_vec(const float* a, const float* s, const float* t, float* out, int n, void* stream);
+int gvk_ssf_colgrad(const gvk_ssf_colgrad_desc* d, void* stream);
+int gvk_ssf_ln_grad(const float* dgamma_eff, const float* dbeta_eff, const float* gamma, const float* beta, float* ds, float* dt, int n,
+                    void* stream);
+int gvk_ssf_head_grad(const float* g, const float* mean, const float* rstd, const float* wh, const float* dlogits, const float* gamma,
+                      const float* beta, float* ds, float* dt, int B, int T, int C, int K, int r0, int R, void* stream);
+
 /* ------------------------------------------------------------------ optimisation step
  * Replaces train.py:315-319: torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step() over every
  * trainable tensor, on the engine's flat fp32 gradient buffer (exp_avg / exp_avg_sq share its layout).

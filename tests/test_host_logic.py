@@ -94,3 +94,22 @@ def test_synth_recipe_is_deterministic_and_bounded():
     w = synth.fill_param("transformer.attns.0.to_qkv.weight", (2304, 768))
     assert abs(float(w.std()) * np.sqrt(768) - 1.0) < 0.02
     assert np.array_equal(synth.labels(3, 4), np.array([3, 4, 0, 1]))
+
+
+def test_ssf_schema_and_freeze_rule():
+    """ScalingShiftingFeatures mirror: state_dict keys / shapes of the reference (checked against the fixture's trainable list, which
+    came from the reference class itself) and the freeze rule of ssf.py:192-197."""
+    from conftest import golden
+    cfg = dict(BASE, method="ssf", freeze_vit=True)
+    m = build_model(cfg)
+    assert type(m).__name__ == "ScalingShiftingFeatures"
+    sd = m.state_dict()
+    want = oracle.ssf_param_shapes(cfg)
+    assert list(sd) == list(want) and all(tuple(sd[k].shape) == tuple(want[k]) for k in sd)      # same registration order too
+    named = dict(m.named_parameters())
+    tr = sorted(k for k, p in named.items() if p.requires_grad)
+    assert tr == sorted(str(k) for k in golden("ssf_t16_b2")["meta/trainable"])
+    assert all(oracle.ssf_trainable(k) == named[k].requires_grad for k in named)
+    assert m.train() is None and not m.transformer.training and m.mlp_head.training
+    with pytest.raises(NotImplementedError):
+        build_model(dict(BASE, method="dvpt"))

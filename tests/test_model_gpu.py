@@ -141,7 +141,9 @@ PEFT_CASES = [("deep_vpt_t16_b2", "deep_vpt", "vit-t16", 2, dict(num_prompts=8, 
               ("adaptformer_t16_b2", "adaptformer", "vit-t16", 2, dict(freeze_vit=True)),
               ("melo_t16_b2", "melo", "vit-t16", 2, dict(r=4, alpha=4)),
               ("cfg4_adaptformer_b16_b8", "adaptformer", "vit-b16", 8, dict(freeze_vit=True)),
-              ("cfg4_melo_b16_b8", "melo", "vit-b16", 8, dict(r=4, alpha=4))]
+              ("cfg4_melo_b16_b8", "melo", "vit-b16", 8, dict(r=4, alpha=4)),
+              ("ssf_t16_b2", "ssf", "vit-t16", 2, dict(freeze_vit=True)),
+              ("ssf_b16_b4", "ssf", "vit-b16", 4, dict(freeze_vit=True))]
 
 
 def _check_against_golden(m, g, B, first=0, logit_tol=1e-2):
@@ -256,7 +258,9 @@ FP32_CASES = [("cfg1_linear_t16_b1", "linear", "vit-t16", 1, dict()),
               ("deep_vpt_t16_b2", "deep_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True)),
               ("gaviko_t16_b2", "gaviko", "vit-t16", 2, dict(GAVIKO)),
               ("cfg4_adaptformer_b16_b8", "adaptformer", "vit-b16", 8, dict(freeze_vit=True)),
-              ("cfg4_melo_b16_b8", "melo", "vit-b16", 8, dict(r=4, alpha=4))]
+              ("cfg4_melo_b16_b8", "melo", "vit-b16", 8, dict(r=4, alpha=4)),
+              ("ssf_t16_b2", "ssf", "vit-t16", 2, dict(freeze_vit=True)),
+              ("ssf_b16_b4", "ssf", "vit-b16", 4, dict(freeze_vit=True))]
 
 
 @pytest.mark.parametrize("name,method,backbone,B,extra", FP32_CASES)

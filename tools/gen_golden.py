@@ -50,6 +50,8 @@ CASES = {
     "cfg4_adaptformer_b16_b8": ("adaptformer", "vit-b16", 8, dict(freeze_vit=True)),
     "cfg4_melo_b16_b8": ("melo", "vit-b16", 8, dict(r=4, alpha=4)),
     "cfg5_gaviko_l16_b2": ("gaviko", "vit-l16", 2, dict(GAVIKO)),
+    "ssf_t16_b2": ("ssf", "vit-t16", 2, dict(freeze_vit=True)),
+    "ssf_b16_b4": ("ssf", "vit-b16", 4, dict(freeze_vit=True)),
 }
 
 
@@ -64,10 +66,11 @@ def import_reference():
     import model.vpt as vpt
     import model.adaptformer as af
     import model.melo as melo
+    import model.ssf as ssf
     import losses.focal_loss as fl
-    for m in (vt, gv, af):
+    for m in (vt, gv, af, ssf):
         m.load_pretrain = lp.load_pretrain
-    return dict(vt=vt, gv=gv, vpt=vpt, af=af, melo=melo, fl=fl)
+    return dict(vt=vt, gv=gv, vpt=vpt, af=af, melo=melo, ssf=ssf, fl=fl)
 
 
 def build_reference(mods, method, cfg):
@@ -88,6 +91,8 @@ def build_reference(mods, method, cfg):
         return mods["af"].AdaptFormer(**cfg)
     if method == "melo":
         return mods["melo"].MeLO(vit=mods["vt"].VisionTransformer(**cfg), **cfg)
+    if method == "ssf":
+        return mods["ssf"].ScalingShiftingFeatures(**cfg)
     raise ValueError(method)
 
 
@@ -154,7 +159,7 @@ def attach_hooks(model, method, taps):
 
 
 FULL_GRAD_PATTERNS = (
-    "mlp_head", "prompt_embeddings", "prompt_positional_embedding", "prompt_proj.",
+    "mlp_head", "ssf_s", "prompt_embeddings", "prompt_positional_embedding", "prompt_proj.",
     "prompt_projs.0.", "local_attns.0.", "layers.0.1.", "layers.0.0.to_qkv.linear_",
 )
 
