@@ -295,3 +295,48 @@ def test_fp32_path_vs_golden(dev, name, method, backbone, B, extra):
     for k in g.files:
         if k.startswith("grad/"):
             assert rel(named[k[5:]].grad.cpu().numpy(), g[k]) < 1e-4, k
+
+
+# ---- ragged batches and eval mode against the oracle run on the same inputs (no fixture: the oracle is the pinned restatement) ----
+@pytest.mark.parametrize("method,extra,B", [("gaviko", dict(GAVIKO), 3), ("gaviko", dict(GAVIKO), 1), ("adaptformer", dict(freeze_vit=True), 3),
+                                            ("ssf", dict(freeze_vit=True), 1), ("deep_vpt", dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True), 5)])
+def test_odd_batch_sizes_match_oracle(dev, method, extra, B):
+    """Batch sizes the fixtures do not cover (1, 3, 5 volumes; each gets its own workspace and launch plans): fp32 path against the
+    oracle at fp32 tolerances, bf16 path at the bf16 tolerance, forward in train and eval mode, and the head gradient."""
+    import oracle
+    from gaviko_amd.utils import synth
+    x = torch.from_numpy(synth.volumes(11, B))
+    y = torch.from_numpy(synth.labels(11, B))
+    m, cfg = build(method, "vit-t16", dict(extra, precision="fp32"), dev)
+    sd = {k: v.detach().cpu().clone().requires_grad_(oracle.trainable(method, k)) for k, v in m.state_dict().items()}
+    want = oracle.FORWARD[method](sd, x, cfg)
+    torch.nn.functional.cross_entropy(want, y).backward()
+    head = [k for k in sd if "head" in k and k.endswith("weight") and sd[k].grad is not None][0]
+    for precision, tol in (("fp32", 2e-5), ("bf16", 1e-2)):
+        m.set_precision(precision)
+        m.train()
+        lg = m(x.to(dev))
+        torch.nn.functional.cross_entropy(lg, y.to(dev)).backward()
+        assert rel(lg.detach().cpu().numpy(), want.detach().numpy()) < tol, precision
+        got = dict(m.named_parameters())[head].grad.cpu().numpy()
+        assert rel(got, sd[head].grad.numpy()) < (1e-4 if precision == "fp32" else 3e-2), precision
+        m.eval()
+        with torch.no_grad():
+            le = m(x.to(dev))
+        assert rel(le.cpu().numpy(), want.detach().numpy()) < tol, precision + " eval"
+        for p in m.parameters():
+            p.grad = None
+
+
+def test_wrong_volume_shape_and_unsupported_modes_fail_loudly(dev):
+    m, cfg = build("gaviko", "vit-t16", dict(GAVIKO), dev)
+    from gaviko_amd.lib import GavikoHipError
+    with pytest.raises(GavikoHipError, match="expected img"):
+        m(torch.zeros(2, 1, 120, 160, 128, device=dev))
+    with pytest.raises(GavikoHipError, match="expected img"):
+        m(torch.zeros(2, 3, 120, 160, 160, device=dev))
+    with pytest.raises(GavikoHipError, match="precision"):
+        m.set_precision("fp8")
+    from gaviko_amd.registry import build_model
+    with pytest.raises(NotImplementedError):
+        build_model(dict(BASE, backbone="vit-t16", method="evp"))
