@@ -80,18 +80,25 @@ def pmc_traffic(name, stats):
         return {}
     from gaviko_amd import engine as eng_mod
     epi = {v: k for k, v in eng_mod._EPI_NAMES.items()}[m.group(1)]
-    if sum(1 for k in stats if k.startswith(f"gemm_nt_bf16[{m.group(1)}]")) != 1:
-        return {}
     with open(path) as f:
         ker = json.load(f)["kernels"]
     hits = [v for k, v in ker.items() if re.match(rf"gemm_nt_kernel<\d+, \d+, {epi}, \d+>", k)]
     if len(hits) != 1:
         return {}
-    M, N, K = stats[name]["shape"]
-    return {"traffic": hits[0]["total_bytes"], "traffic_source": "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB)",
-            # bf16 operands in + (aux in, out) per epilogue: 0 bf16 out; 2 bias+gelu -> pre-act + act bf16 out; 4 pre-act in, bf16 out;
-            # 1 fp32 residual read-modify-write; 5 fp32 out
-            "algorithmic_bytes": 2 * (M * K + N * K) + M * N * {0: 2, 1: 8, 2: 4, 4: 4, 5: 4, 6: 10}.get(epi, 4)}
+
+    def alg_bytes(shape):
+        # bf16 operands in + (aux in, out) per epilogue: 0 bf16 out; 2 bias+gelu -> pre-act + act bf16 out; 4 pre-act in, bf16 out;
+        # 1 fp32 residual read-modify-write; 5 fp32 out
+        M, N, K = shape
+        return 2 * (M * K + N * K) + M * N * {0: 2, 1: 8, 2: 4, 4: 4, 5: 4, 6: 10}.get(epi, 4)
+
+    # the instantiation may serve several shapes of this run: match its traffic clusters to them by ascending algorithmic bytes
+    same = sorted((k for k in stats if k.startswith(f"gemm_nt_bf16[{m.group(1)}]")), key=lambda k: alg_bytes(stats[k]["shape"]))
+    cl = hits[0].get("clusters") or [hits[0]]
+    if len(cl) != len(same):
+        return {}
+    return {"traffic": cl[same.index(name)]["total_bytes"], "traffic_source": "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB)",
+            "algorithmic_bytes": alg_bytes(stats[name]["shape"])}
 
 
 def main():

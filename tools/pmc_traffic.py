@@ -18,22 +18,45 @@ import sys
 
 
 def load(d, counter):
-    f = glob.glob(f"{d}/*/*_counter_collection.csv")[0]
+    """-> {kernel: [per-dispatch values in dispatch order]}"""
+    import os
+    f = max(glob.glob(f"{d}/*/*_counter_collection.csv"), key=os.path.getmtime)
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter:
-            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    for r in rows:
+        acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def clusters(reads, writes):
+    """One kernel instantiation may serve several shapes (e.g. the bias+residual GEMM: out-proj K=768 and fc2 K=3072): split its
+    dispatches into groups whose read traffic differs by more than 1.5x."""
+    order = sorted(range(len(reads)), key=lambda i: reads[i])
+    groups = []
+    for i in order:
+        if groups and reads[i] <= 1.5 * groups[-1][0][0] + 1:
+            groups[-1].append((reads[i], writes[i] if i < len(writes) else 0.0))
+        else:
+            groups.append([(reads[i], writes[i] if i < len(writes) else 0.0)])
+    out = []
+    for g in groups:
+        rd, wr = sum(x[0] for x in g) / len(g), sum(x[1] for x in g) / len(g)
+        out.append({"launches": len(g), "read_bytes": round(2 * rd * 1024), "write_bytes": round(wr * 1024), "total_bytes": round(2 * rd * 1024 + wr * 1024)})
+    return out
 
 
 def main():
-    fetch, n = load(sys.argv[1], "FETCH_SIZE")
-    write, _ = load(sys.argv[2], "WRITE_SIZE")
-    out = {"note": "bytes per launch; read = 2*FETCH_SIZE*1024 (gfx950 half-count correction), write = WRITE_SIZE*1024", "kernels": {}}
-    for k in sorted(fetch, key=lambda k: -fetch[k] * n[k]):
+    fetch = load(sys.argv[1], "FETCH_SIZE")
+    write = load(sys.argv[2], "WRITE_SIZE")
+    out = {"note": "bytes per launch; read = 2*FETCH_SIZE*1024 (gfx950 half-count correction), write = WRITE_SIZE*1024; 'clusters' splits "
+                   "an instantiation that serves several shapes (ascending traffic)", "kernels": {}}
+    for k in sorted(fetch, key=lambda k: -sum(fetch[k])):
         short = k.replace("gvk::", "").replace("void ", "")
-        rd, wr = 2 * fetch[k] * 1024, write.get(k, 0.0) * 1024
-        out["kernels"][short] = {"launches": n[k], "read_bytes": round(rd), "write_bytes": round(wr), "total_bytes": round(rd + wr)}
+        n = len(fetch[k])
+        rd, wr = 2 * sum(fetch[k]) / n * 1024, (sum(write.get(k, [0.0])) / max(1, len(write.get(k, [0.0])))) * 1024
+        out["kernels"][short] = {"launches": n, "read_bytes": round(rd), "write_bytes": round(wr), "total_bytes": round(rd + wr),
+                                 "clusters": clusters(fetch[k], write.get(k, []))}
     pk = [k for k in out["kernels"] if k.startswith("patchify_kernel")]
     if pk:
         out["calibration"] = {"kernel": pk[0], "expected_read": 4 * 120 * 160 * 160 * 4, "expected_write": 4 * 1000 * 3072 * 2, **out["kernels"][pk[0]]}
