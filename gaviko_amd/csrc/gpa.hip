@@ -10,6 +10,7 @@
 // One wave per (sample, prompt) for the cross-attention (lanes over the ~1000 tokens); the token-side gradient is a
 // gather over the P prompts (no atomics).
 #include "common.hpp"
+#include "cross.hpp"
 #include "../../include/gaviko_hip.h"
 
 namespace gvk {
@@ -93,58 +94,6 @@ __global__ __launch_bounds__(64) void gpa_gates_fwd_kernel(GpaArgs p) {
 // softmax per lane, merged across lanes at the end.  No LDS staging: the earlier form (8 prompts per 512-thread workgroup
 // around an 84 KB LDS copy of the tokens) put 16 fat workgroups on 16 CUs, where they had to wait for the backbone's
 // GEMM workgroups to retire; these 128-thread workgroups fit beside them anywhere.
-template <int L>
-__device__ __forceinline__ void load_tok(const float* __restrict__ src, int i, int n, float (&t)[L]) {
-  const f32x4* r = (const f32x4*)(src + (size_t)min(i, n - 1) * L);
-#pragma unroll
-  for (int v = 0; v < L / 4; ++v) {
-    const f32x4 x = r[v];
-    t[4 * v] = x[0]; t[4 * v + 1] = x[1]; t[4 * v + 2] = x[2]; t[4 * v + 3] = x[3];
-  }
-}
-
-// softmax(q . tok^T) . tok over n tokens; returns ctx (all lanes) and lse
-template <int L>
-__device__ __forceinline__ void cross_one(const float (&q)[L], const float* __restrict__ src, int n, int lane, float (&ctx)[L], float& lse) {
-  float m = -INFINITY, s = 0.f, c[L];
-#pragma unroll
-  for (int l = 0; l < L; ++l) c[l] = 0.f;
-  for (int i0 = lane; i0 < n; i0 += 256) {
-    float t[4][L], d[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) load_tok<L>(src, i0 + 64 * u, n, t[u]);
-    float mb = -INFINITY;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float a = 0.f;
-#pragma unroll
-      for (int l = 0; l < L; ++l) a = __builtin_fmaf(q[l], t[u][l], a);
-      d[u] = (i0 + 64 * u < n) ? a : -INFINITY;
-      mb = fmaxf(mb, d[u]);
-    }
-    const float mn = fmaxf(m, mb);                       // finite: token i0 itself is valid
-    const float sc = __expf(m - mn);                     // first batch: exp(-inf) = 0
-    s *= sc;
-#pragma unroll
-    for (int l = 0; l < L; ++l) c[l] *= sc;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float e = __expf(d[u] - mn);                 // invalid token: exp(-inf) = 0
-      s += e;
-#pragma unroll
-      for (int l = 0; l < L; ++l) c[l] = __builtin_fmaf(e, t[u][l], c[l]);
-    }
-    m = mn;
-  }
-  const float mw = wave_max(m);
-  const float f = (m == -INFINITY) ? 0.f : __expf(m - mw);          // lanes without tokens contribute nothing
-  const float st = wave_sum(s * f);
-  lse = mw + __logf(st);
-  const float inv = 1.f / st;
-#pragma unroll
-  for (int l = 0; l < L; ++l) ctx[l] = wave_sum(c[l] * f) * inv;
-}
-
 // ---- cross-attention forward: workgroup = one prompt of one sample; wave 0 = global image tokens (gaviko.py:172-176, the
 // reference's double slice: tokens 2P+2..), wave 1 = local tokens (:177-181); wave 0 then fuses (:183-185).
 template <int L>
@@ -181,31 +130,6 @@ __global__ __launch_bounds__(128) void gpa_cross_fwd_kernel(GpaArgs p) {
     }
     if (lane == 0) p.lse_g[b * p.P + pi] = lse;
   }
-}
-
-// dq (already-scaled query space) of softmax cross attention: dq[l] = sum_n A_n (dA_n - delta) tok_n[l]
-template <int L>
-__device__ __forceinline__ void cross_dq(const float (&q)[L], const float (&dc)[L], const float* __restrict__ src, int n, int lane, float lse,
-                                         float delta, float (&dq)[L]) {
-  float a[L];
-#pragma unroll
-  for (int l = 0; l < L; ++l) a[l] = 0.f;
-  for (int i0 = lane; i0 < n; i0 += 256) {
-    float t[4][L];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) load_tok<L>(src, i0 + 64 * u, n, t[u]);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float d = 0.f, da = 0.f;
-#pragma unroll
-      for (int l = 0; l < L; ++l) { d = __builtin_fmaf(q[l], t[u][l], d); da = __builtin_fmaf(dc[l], t[u][l], da); }
-      const float ds = (i0 + 64 * u < n) ? __expf(d - lse) * (da - delta) : 0.f;
-#pragma unroll
-      for (int l = 0; l < L; ++l) a[l] = __builtin_fmaf(ds, t[u][l], a[l]);
-    }
-  }
-#pragma unroll
-  for (int l = 0; l < L; ++l) dq[l] = wave_sum(a[l]);
 }
 
 // ---- backward, prompt side: same workgroup shape as the forward (wave 0 global, wave 1 local)

@@ -108,6 +108,14 @@ __device__ __forceinline__ void row_down_pass(const DownArgs& p, float* Wc, floa
       const int c = k * 256 + lane * 4;
       v[r][k] = (c < C) ? *(const f32x4*)(p.x + (size_t)rows[r] * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  if constexpr (MODE == 3) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int k = 0; k < KC; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[r][k][e] = quick_gelu(v[r][k][e]);
+  }
   if constexpr (MODE == 2) {
     // LayerNorm backward of the rows (as ln_bwd_kernel), leaving dx in v for the projection
 #pragma unroll
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(64 * kNW, 3) void row_down_kernel(DownArgs p) {
   }
 }
 
-template <int L, int R, bool LNB>
+template <int L, int R, bool LNB, bool EXT>
 __device__ __forceinline__ void row_up_pass(const UpArgs& p, float* Wc, float* latrow, int first, int n, int lane) {
   const int C = p.C;
   const float* base = p.accumulate ? p.out : p.res;
@@ -388,6 +396,14 @@ __device__ __forceinline__ void row_up_pass(const UpArgs& p, float* Wc, float* l
           if (r < n) {
             const int row = rows[r];
             f32x4 vv = a[r] + b4;
+            if constexpr (EXT) {                         // DVPT: scalar gate and / or the input QuickGELU's derivative
+              if (p.alpha_ptr != nullptr) vv *= p.alpha_ptr[0];
+              if (p.gg_x != nullptr) {
+                const f32x4 xg = *(const f32x4*)(p.gg_x + (size_t)row * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vv[e] *= quick_gelu_grad(xg[e]);
+              }
+            }
             if (p.drop_thresh != 0u) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) vv[e] *= drop_scale(p.seed, (unsigned long long)row * C + c + e, p.drop_thresh, p.inv_keep);
@@ -446,7 +462,7 @@ __device__ __forceinline__ void row_up_pass(const UpArgs& p, float* Wc, float* l
   }
 }
 
-template <int L, bool LNB>
+template <int L, bool LNB, bool EXT>
 __global__ __launch_bounds__(64 * kNW, LNB ? 3 : 4) void row_up_kernel(UpArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lsm[];
   __shared__ float latrow[kNW][3 * L];
@@ -456,8 +472,8 @@ __global__ __launch_bounds__(64 * kNW, LNB ? 3 : 4) void row_up_kernel(UpArgs p)
   const int r1 = (int)((long long)(blockIdx.x + 1) * p.M / gridDim.x);
   while (cursor < r1) {                                  // workgroup-uniform loop
     const Pass ps = next_pass(cursor, r1, wave);
-    if (ps.R == 3) row_up_pass<L, 3, LNB>(p, lsm, latrow[wave], ps.first, ps.n, lane);
-    else row_up_pass<L, 2, LNB>(p, lsm, latrow[wave], ps.first, ps.n, lane);
+    if (ps.R == 3) row_up_pass<L, 3, LNB, EXT>(p, lsm, latrow[wave], ps.first, ps.n, lane);
+    else row_up_pass<L, 2, LNB, EXT>(p, lsm, latrow[wave], ps.first, ps.n, lane);
   }
 }
 
@@ -489,11 +505,13 @@ static int launch_down_t(const DownArgs& a, hipStream_t s) {
   (void)granted;                                         // < 64 KB: no attribute needed
   const dim3 grid(row_grid(a.M)), block(64 * kNW);
   if (a.C <= 768) {                                       // three float4 chunks per lane: 25 % fewer row registers than the C <= 1024 form
-    if (a.mode == 1) GVK_LAUNCH((row_down_kernel<L, 1, 3>), grid, block, (unsigned)lds, s, a);
+    if (a.mode == 3) GVK_LAUNCH((row_down_kernel<L, 3, 3>), grid, block, (unsigned)lds, s, a);
+    else if (a.mode == 1) GVK_LAUNCH((row_down_kernel<L, 1, 3>), grid, block, (unsigned)lds, s, a);
     else if (a.mode == 2) GVK_LAUNCH((row_down_kernel<L, 2, 3>), grid, block, (unsigned)lds, s, a);
     else GVK_LAUNCH((row_down_kernel<L, 0, 3>), grid, block, (unsigned)lds, s, a);
   } else {
-    if (a.mode == 1) GVK_LAUNCH((row_down_kernel<L, 1, 4>), grid, block, (unsigned)lds, s, a);
+    if (a.mode == 3) GVK_LAUNCH((row_down_kernel<L, 3, 4>), grid, block, (unsigned)lds, s, a);
+    else if (a.mode == 1) GVK_LAUNCH((row_down_kernel<L, 1, 4>), grid, block, (unsigned)lds, s, a);
     else if (a.mode == 2) GVK_LAUNCH((row_down_kernel<L, 2, 4>), grid, block, (unsigned)lds, s, a);
     else GVK_LAUNCH((row_down_kernel<L, 0, 4>), grid, block, (unsigned)lds, s, a);
   }
@@ -503,8 +521,9 @@ static int launch_down_t(const DownArgs& a, hipStream_t s) {
 template <int L>
 static int launch_up_t(const UpArgs& a, hipStream_t s) {
   const unsigned lds = (unsigned)(L * 256 * sizeof(float));       // < 64 KB: no attribute needed
-  if (a.ln_x != nullptr) GVK_LAUNCH((row_up_kernel<L, true>), dim3(row_grid(a.M)), dim3(64 * kNW), lds, s, a);
-  else GVK_LAUNCH((row_up_kernel<L, false>), dim3(row_grid(a.M)), dim3(64 * kNW), lds, s, a);
+  if (a.ln_x != nullptr) GVK_LAUNCH((row_up_kernel<L, true, false>), dim3(row_grid(a.M)), dim3(64 * kNW), lds, s, a);
+  else if (a.alpha_ptr != nullptr || a.gg_x != nullptr) GVK_LAUNCH((row_up_kernel<L, false, true>), dim3(row_grid(a.M)), dim3(64 * kNW), lds, s, a);
+  else GVK_LAUNCH((row_up_kernel<L, false, false>), dim3(row_grid(a.M)), dim3(64 * kNW), lds, s, a);
   return check_launch("skinny_up(row)");
 }
 

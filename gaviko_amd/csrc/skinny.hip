@@ -312,6 +312,7 @@ struct OuterArgs {
   float* scratch;                                         // [64][L+1][C]
   int M, C;
   unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;   // optional dropout mask on `wide`
+  int wide_act;                                           // 1: QuickGELU applied to `wide` on the fly (DVPT: dWd = dz^T . QuickGELU(x))
 };
 
 constexpr int kSlabs = 64;          // row slabs of the small two-stage reductions (colsum, small_wgrad)
@@ -385,6 +386,10 @@ __global__ __launch_bounds__(256) void outer_partial_kernel(OuterArgs p) {
           const float mu = st[r][0], rs = st[r][1];
 #pragma unroll
           for (int e = 0; e < 4; ++e) xv[e] = (xv[e] - mu) * rs * g4[e] + b4[e];
+        }
+        if (p.wide_act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[e] = quick_gelu(xv[e]);
         }
       }
       if (rb + 4 * u < nr) {                            // wave-uniform: skip k-steps entirely past the slab
@@ -635,6 +640,13 @@ extern "C" int gvk_skinny_down(const gvk_skinny_down_desc* d, void* stream) {
   a.seed = d->seed; a.seed_ptr = (const unsigned long long*)d->seed_ptr; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
   hipStream_t s = (hipStream_t)stream;
   static const bool mfma_only = getenv("GAVIKO_HIP_SKINNY_MFMA") != nullptr;     // A/B switch: force the MFMA-tile kernels
+  if (d->act_in != 0) {
+    GVK_REQUIRE(d->act_in == 1 && d->ln_gamma == nullptr && d->drop_p <= 0.f, "gvk_skinny_down: act_in=1 (QuickGELU on the input) takes no LN / dropout");
+    a.mode = 3;
+    const int rc = launch_row_down(a, d->L, s);
+    if (rc == 1) return set_error(-2, "gvk_skinny_down: act_in needs the row-per-wave kernel (L in {4,8,16,20}, C >= 128)");
+    return rc;
+  }
   if (!mfma_only) {
     const int rc = launch_row_down(a, d->L, s);                                   // row-per-wave form for the wide shapes
     if (rc != 1) return rc;
@@ -663,6 +675,13 @@ extern "C" int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream) {
   a.seed = d->seed; a.seed_ptr = (const unsigned long long*)d->seed_ptr; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
   hipStream_t s = (hipStream_t)stream;
   static const bool mfma_only = getenv("GAVIKO_HIP_SKINNY_MFMA") != nullptr;
+  a.alpha_ptr = d->alpha_ptr; a.gg_x = d->gg_x;
+  if (a.alpha_ptr != nullptr || a.gg_x != nullptr) {
+    GVK_REQUIRE(d->ln_x == nullptr, "gvk_skinny_up: alpha_ptr / gg_x do not combine with the LayerNorm-backward epilogue");
+    const int rc = launch_row_up(a, d->L, s);
+    if (rc == 1) return set_error(-2, "gvk_skinny_up: alpha_ptr / gg_x need the row-per-wave kernel (L in {4,8,16,20}, C >= 128)");
+    return rc;
+  }
   if (!mfma_only) {
     const int rc = launch_row_up(a, d->L, s);
     if (rc != 1) return rc;
@@ -686,6 +705,7 @@ extern "C" int gvk_outer_reduce(const gvk_outer_desc* d, void* stream) {
   OuterArgs a{};
   a.narrow = d->narrow; a.wide = d->wide; a.lat_override = d->lat_override; a.T = d->T; a.P = d->P;
   a.mean = d->mean; a.rstd = d->rstd; a.ln_g = d->ln_gamma; a.ln_b = d->ln_beta; a.scratch = d->scratch; a.M = d->M; a.C = d->C;
+  a.wide_act = d->wide_act;
   a.seed = d->seed; a.seed_ptr = (const unsigned long long*)d->seed_ptr; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
   hipStream_t s = (hipStream_t)stream;
   int rc;

@@ -28,6 +28,7 @@ struct DownArgs {
   // row-per-wave kernel only (rowwise.hip): LayerNorm kernels that also project the rows they hold
   //   mode 1: y16 = LN(x; ln_g, ln_b) (bf16), mean/rstd saved, and the projection is taken of the RAW row x
   //   mode 2: dx = dres + LN'(dy; x, mean_in, rstd_in, ln_g) (+ bf16 copy dx16), and the projection is taken of dx
+  //   mode 3: QuickGELU applied to the input rows before the projection (DVPT share_MLP, dvpt.py:38)
   int mode;
   bf16* y16;
   const float* dy; const float* mean_in; const float* rstd_in; const float* dres; float* dx; bf16* dx16;
@@ -39,6 +40,8 @@ struct UpArgs {
   const float* lat_override; int T, P;                    // rows with (m % T) < P read lat_override[(m / T) * P + m % T][:]
   const float* ln_x; const float* ln_mean; const float* ln_rstd; const float* ln_g;   // optional LayerNorm-backward epilogue
   bf16* out16;                                            // optional bf16 copy of `out` (the next dgrad GEMM's operand)
+  const float* alpha_ptr;                                 // optional device scalar: v = alpha * (lat . W + bias)   (DVPT prompt_gate)
+  const float* gg_x;                                      // optional [M][C]: v *= QuickGELU'(gg_x[m][c])           (DVPT dgrad through the input GELU)
   int M, C, w_layout, accumulate;
   unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;   // dropout on the projected value (proj_drop)
 };

@@ -59,11 +59,15 @@ class Names:
     def attn(self, i):
         if self.kind == "gaviko":
             return f"transformer.attns.{i}"
+        if self.kind == "dvpt":
+            return f"transformer.layers.{i}.0.attn"
         return f"{self.root}transformer.layers.{i}.0"
 
     def mlp(self, i):
         if self.kind == "gaviko":
             return f"transformer.mlps.{i}"
+        if self.kind == "dvpt":
+            return f"transformer.layers.{i}.0.mlp"
         return f"{self.root}transformer.layers.{i}." + ("2" if self.kind == "adaptformer" else "1")
 
     def qkv_weight(self, i):
@@ -112,6 +116,10 @@ class Engine:
                 if tuple(dhw) != self.grid:
                     raise L.GavikoHipError(f"DHW={tuple(dhw)} does not match the patch grid {self.grid}")
                 self.win = tuple(cfg.get("local_k", (3, 6, 6)))
+        elif kind == "dvpt":
+            self.P = cfg.get("num_prompts", 50)
+            self.Lat = 20                                                                  # share_MLP.latent_dim (dvpt.py:27)
+            self.T, self.row_off = self.P + 1 + self.N, self.P + 1
         elif kind == "vpt":
             self.P = cfg.get("num_prompts", 8)
             self.pd = cfg.get("prompt_dim", 64)
@@ -252,6 +260,9 @@ class Engine:
             ws["gp"] = [dict(zx=mk(M, Lt), xl=mk(M, Lt), zl=mk(BN, Lt), ll=mk(BN, Lt), imp=mk(B, P), gw=mk(B), enh=mk(B, P, Lt),
                              prm=mk(B, P, Lt), qg=mk(B, P, Lt), ql=mk(B, P, Lt), cg=mk(B, P, Lt), cl=mk(B, P, Lt), lse_g=mk(B, P),
                              lse_l=mk(B, P)) for _ in range(nsave)]
+        if self.kind == "dvpt":
+            mk = lambda *s_: torch.zeros(s_, device=device)
+            ws["dv"] = [dict(z=mk(M, self.Lat), enh=mk(B, self.P, self.Lat), lse=mk(B, self.P)) for _ in range(nsave)]
         if self.kind == "adaptformer":
             ws["xa"] = z(M, C, bf16)
             ws["ad"] = [dict(mean=torch.zeros(M, device=device), rstd=torch.zeros(M, device=device), h16=z(M, self.adim, bf16))
@@ -295,6 +306,12 @@ class Engine:
                 ws["rscratch"] = mk(32 * (ng + 2 * Lt * Lt + 3 * Lt + 3 * Lt * Lt + 64))
                 ws["scratch_l"] = mk(max(ops.outer_scratch_elems(Lt, C), 128 * C))      # the MWSA chain runs on its own stream
                 ws["rscratch_l"] = mk(32 * (3 * Lt * Lt + Lt + 64))
+            elif self.kind == "dvpt":
+                Lt, P = self.Lat, self.P
+                mk = lambda *s_: torch.zeros(s_, device=device)
+                ws["dvb"] = dict(dcomb=mk(M, Lt), dz=mk(M, Lt), delta=mk(B, P))
+                ws["scratch"] = mk(max(ops.outer_scratch_elems(Lt, C), 128 * C))
+                ws["rscratch"] = mk(32 * (Lt + 64))
             else:
                 if self.kind == "ssf":
                     ws["ssf_scratch"] = torch.zeros(64 * 2 * max(self.mlp, 3 * C), device=device)
@@ -433,7 +450,7 @@ class Engine:
             self._gemm_marks.append(("__patch_embed__", 2.0 * B * N * self.Kp * C, [B * N, C, self.Kp],
                                      B * (self.Kp * N * 4 + nout * N * C * 4), pe0, self._ev_record(cur)))
         cls = d(nm.root + "cls_token")[0]
-        if self.kind == "gaviko":
+        if self.kind in ("gaviko", "dvpt"):                   # [P prompts | cls | patches] (gaviko.py:536-548, dvpt.py:196-199)
             ops.rows_broadcast(G0, d("prompt_embeddings")[0], d("prompt_positional_embedding")[0], B, T, 0, self.P, C)
             ops.rows_broadcast(G0, cls, pos[0:1], B, T, self.P, 1, C)
         else:
@@ -476,6 +493,8 @@ class Engine:
                     self._gpa_fwd_latents(ws, i, si, ws["G1"][si], ws["Lc"][go], M, B, True)
             if self.kind == "adaptformer":
                 self._adapter_fwd_down(ws, i, si, ws["G1"][si], Mi)
+            if self.kind == "dvpt":
+                self._dvpt_fwd_latents(ws, i, si, ws["G1"][si], Mi, B)
             self._mlp_ln_fwd(ws, i, si, ws["G1"][si], Mi, fused)     # fused: also zx / xl = GPA proj_down(G1), same pass
             if fused:
                 self._wait("gpa", None)                              # xl ready
@@ -485,6 +504,8 @@ class Engine:
             self._mlp_block_fwd(ws, i, si, ws["G1"][si], gout, Mi, train)
             if self.kind == "adaptformer":
                 self._adapter_fwd_up(ws, i, si, gout, Mi)
+            if self.kind == "dvpt":
+                self._dvpt_fwd_up(ws, i, si, gout, Mi)
             self._mark(f"f{i}:mlp")
             if gaviko:
                 self._wait(None, "gpa")                              # enh ready
@@ -507,6 +528,8 @@ class Engine:
         return ws["G"][self.depth] if train else ws["G"][self.depth & 1]
 
     def _pool_rows(self):
+        if self.kind == "dvpt":                       # dvpt.py:80-83,205: 'cls' reads row 0 -- the FIRST PROMPT; 'mean' = prompts + cls
+            return (0, self.P + 1) if self.pool == "mean" else (0, 1)
         if self.kind == "gaviko":
             return 0, self.P + 1                      # gaviko.py:316 prompts + CLS
         return (0, self.Ts[-1]) if self.pool == "mean" else (0, 1)
@@ -709,6 +732,9 @@ class Engine:
                     par_done = self._ev_record(gpa)
             # main stream, MLP block: dG1 = dGout + LN'(fc1^T(GELU'(pre) * fc2^T(dGout)))
             self._mark(f"b{i}:start")
+            dvpt = self.kind == "dvpt"
+            if dvpt:
+                self._dvpt_bwd_latents(ws, gv, i, dGout, M, B)
             ssf = self.kind == "ssf"
             if ssf:                                                          # fc2 + ssf_2: dy = dGout, y = G[i+1] - G1[i]
                 self._ssf_linear_grad(ws, gv, m, 2, dGout, ws["G"][i + 1], M, C, y1=ws["G1"][i])
@@ -720,7 +746,9 @@ class Engine:
                 self._ssf_ln_grad(ws, gv, m, ".net.0", ws["dx32"], ws["G1"][i], st[2], st[3], M)
             adapter = self.kind == "adaptformer"
             ops.layernorm_bwd(ws["dx32"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), M, C, dx=dGin, dres=dGout,
-                              dx16=None if (gaviko or adapter) else ws["dG16"])
+                              dx16=None if (gaviko or adapter or dvpt) else ws["dG16"])
+            if dvpt:
+                self._dvpt_bwd_scatter(ws, i, dGin, M)                       # dG1 += (dz . Wd) * QuickGELU'(G1)  (+ operand copy)
             if adapter:
                 self._adapter_bwd(ws, gv, i, dGout, dGin, M)                 # adds LN_a'(...) into dG1 and refreshes dG16
             self._mark(f"b{i}:ln2")
@@ -793,7 +821,7 @@ class Engine:
             emb = d(emb_name).reshape(-1, self.pd)
             ops.small_linear_bwd(emb, d("prompt_proj.weight"), ws["dvproj"], gv["prompt_proj.weight"], gv["prompt_proj.bias"],
                                  gv[emb_name].view(-1, self.pd), emb.shape[0], self.pd, C)
-        if last and gaviko:
+        if last and (gaviko or self.kind == "dvpt"):
             ops.rows_batch_sum(dGout, gv["prompt_embeddings"].view(self.P, C), gv["prompt_positional_embedding"].view(self.P, C), B, T, 0,
                                self.P, C)
 
@@ -810,6 +838,8 @@ class Engine:
             return ".linear_a_" in name or ".linear_b_" in name
         if self.kind == "ssf":
             return "ssf_scale_" in name or "ssf_shift_" in name
+        if self.kind == "dvpt":
+            return "prompt" in name
         return False
 
     def _needs_backbone_backward(self) -> bool:
@@ -956,6 +986,45 @@ class Engine:
             if self.lora_s != 1:
                 ops.scale_(gv[na], float(self.lora_s))
                 ops.scale_(gv[nb], float(self.lora_s))
+
+    # ---- DVPT (dvpt.py:24-63): share_MLP beside the MLP block ------------------------------------------------------------------
+    def _dvpt_names(self, i):
+        p = f"transformer.layers.{i}.0.prompt_proj"
+        return p + ".prompt_key_proj_d", p + ".prompt_key_proj_u", p + ".prompt_gate"
+
+    def _dvpt_fwd_latents(self, ws, i, si, g1, M, B):
+        pd, pu, pg = self._dvpt_names(i)
+        d, v = self._d, ws["dv"][si]
+        ops.skinny_down(x=g1, w=d(pd + ".weight"), bias=d(pd + ".bias"), y=v["z"], M=M, C=self.C, L=self.Lat, act=0, w_layout=0, act_in=1)
+        ops.dvpt_fwd(z=v["z"], enh=v["enh"], lse=v["lse"], B=B, T=self.T, P=self.P, L=self.Lat, C=self.C, scale=self.C ** -0.5)
+
+    def _dvpt_fwd_up(self, ws, i, si, gout, M):
+        pd, pu, pg = self._dvpt_names(i)
+        d, v = self._d, ws["dv"][si]
+        ops.skinny_up(lat=v["z"], lat_override=v["enh"], w=d(pu + ".weight"), bias=d(pu + ".bias"), alpha_ptr=d(pg), out=gout, M=M, C=self.C,
+                      L=self.Lat, T=self.T, P=self.P, w_layout=0, accumulate=1)
+
+    def _dvpt_bwd_latents(self, ws, gv, i, dGout, M, B):
+        """dcomb = dGout . W_u;  dW_u, db_u (gate applied afterwards), dgate;  latent backward -> dz;  db_d, dW_d."""
+        pd, pu, pg = self._dvpt_names(i)
+        d, v, bw, C, Lt = self._d, ws["dv"][i], ws["dvb"], self.C, self.Lat
+        ops.skinny_down(x=dGout, w=d(pu + ".weight"), y=bw["dcomb"], M=M, C=C, L=Lt, act=0, w_layout=1)
+        ops.outer_reduce(narrow=v["z"], lat_override=v["enh"], wide=dGout, scratch=ws["scratch"], out=gv[pu + ".weight"], colsum=gv[pu + ".bias"],
+                         M=M, C=C, L=Lt, T=self.T, P=self.P, transposed=1, accumulate=0)
+        ops.dvpt_bwd(z=v["z"], enh=v["enh"], lse=v["lse"], dcomb=bw["dcomb"], gate=d(pg), bu=d(pu + ".bias"), colsum_dy=gv[pu + ".bias"],
+                     delta=bw["delta"], dz=bw["dz"], dgate=gv[pg], B=B, T=self.T, P=self.P, L=Lt, C=C, scale=C ** -0.5)
+        ops.scale_dev_(gv[pu + ".weight"], d(pg))
+        ops.scale_dev_(gv[pu + ".bias"], d(pg))
+        ops.reduce_batch([(bw["dz"], None, gv[pd + ".bias"], 0)], ws["rscratch"])
+        ops.outer_reduce(narrow=bw["dz"], wide=ws["G1"][i], scratch=ws["scratch"], out=gv[pd + ".weight"], M=M, C=C, L=Lt, transposed=0,
+                         accumulate=0, wide_act=1)
+
+    def _dvpt_bwd_scatter(self, ws, i, dG1, M):
+        pd, pu, pg = self._dvpt_names(i)
+        ops.skinny_up(lat=ws["dvb"]["dz"], w=self._d(pd + ".weight"), out=dG1, out_bf16=None if self.fp32 else ws["dG16"], gg_x=ws["G1"][i],
+                      M=M, C=self.C, L=self.Lat, w_layout=1, accumulate=1)
+        if self.fp32:
+            ops.copy_(ws["dG16"], dG1)
 
     # ---- SSF (ssf.py): effective parameters per step, scale / shift gradients per site -----------------------------------------
     def _ssf_sites(self):

@@ -34,11 +34,12 @@ def _struct(name, ptrs, ints, floats=(), u64=()):
 
 SkinnyDownDesc = _struct("SkinnyDownDesc",
                          ["x", "w", "bias", "ln_gamma", "ln_beta", "mean", "rstd", "z", "y", "w2", "y2", "seed_ptr"],
-                         ["M", "C", "L", "L2", "act", "w_layout"], ["eps", "drop_p"], ["seed"])
-SkinnyUpDesc = _struct("SkinnyUpDesc", ["lat", "w", "bias", "res", "out", "lat_override", "seed_ptr", "ln_x", "ln_mean", "ln_rstd", "ln_gamma", "out_bf16"],
+                         ["M", "C", "L", "L2", "act", "w_layout", "act_in"], ["eps", "drop_p"], ["seed"])
+SkinnyUpDesc = _struct("SkinnyUpDesc", ["lat", "w", "bias", "res", "out", "lat_override", "seed_ptr", "ln_x", "ln_mean", "ln_rstd", "ln_gamma", "out_bf16",
+                                        "alpha_ptr", "gg_x"],
                        ["M", "C", "L", "T", "P", "w_layout", "accumulate"], ["drop_p"], ["seed"])
 OuterDesc = _struct("OuterDesc", ["narrow", "wide", "lat_override", "mean", "rstd", "ln_gamma", "ln_beta", "scratch", "out", "colsum", "seed_ptr"],
-                    ["M", "C", "L", "T", "P", "transposed", "accumulate"], ["drop_p"], ["seed"])
+                    ["M", "C", "L", "T", "P", "transposed", "accumulate", "wide_act"], ["drop_p"], ["seed"])
 WindowAttnDesc = _struct("WindowAttnDesc", ["qkv", "ctx", "lse", "dctx", "delta", "dqkv", "seed_ptr"],
                          ["B", "D", "H", "W", "kd", "kh", "kw", "L"], ["scale", "drop_p"], ["seed"])
 GpaDesc = _struct("GpaDesc",
@@ -49,6 +50,7 @@ GpaDesc = _struct("GpaDesc",
                   ["B", "T", "N", "P", "L"], ["scale"])
 SsfColgradDesc = _struct("SsfColgradDesc", ["dy", "y0", "y1", "pos", "s", "t", "ds", "dt", "scratch"],
                          ["M", "N", "ld_dy", "ld_y", "dy_f32", "y0_f32", "rows_in", "rows_out", "row_off"])
+DvptDesc = _struct("DvptDesc", ["z", "enh", "lse", "dcomb", "gate", "bu", "colsum_dy", "delta", "dz", "dgate"], ["B", "T", "P", "L", "C"], ["scale"])
 AdamDesc = _struct("AdamDesc", ["ptr_tab", "blk_tab", "grad", "m", "v", "norm_sq"], ["nblocks"],
                    ["lr", "beta1", "beta2", "eps", "bias_c1", "bias_c2", "max_norm"])
 RowProjDesc = _struct("RowProjDesc", ["w", "bias", "y", "z"], ["L", "w_layout", "act"])
@@ -104,6 +106,9 @@ SIGNATURES = {
     "gvk_ssf_colgrad": [C.POINTER(SsfColgradDesc), _P],
     "gvk_ssf_ln_grad": [_P, _P, _P, _P, _P, _P, _I, _P],
     "gvk_ssf_head_grad": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gvk_dvpt_fwd": [C.POINTER(DvptDesc), _P],
+    "gvk_dvpt_bwd": [C.POINTER(DvptDesc), _P],
+    "gvk_scale_dev": [_P, _P, C.c_int64, _P],
     "gvk_sumsq": [_P, C.c_int64, _P, _P, _P],
     "gvk_adam_step": [C.POINTER(AdamDesc), _P],
     "gvk_memset_async": [_P, _I, C.c_size_t, _P],
@@ -120,7 +125,7 @@ NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, [
              "gvk_plan_set_timing": (C.c_int, [C.c_int]),
              "gvk_plan_event_elapsed": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)])}
 STRUCTS = {"gvk_gemm_desc": GemmDesc, "gvk_skinny_down_desc": SkinnyDownDesc, "gvk_skinny_up_desc": SkinnyUpDesc,
-           "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob, "gvk_rowproj_desc": RowProjDesc, "gvk_adam_desc": AdamDesc, "gvk_ssf_colgrad_desc": SsfColgradDesc}
+           "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob, "gvk_rowproj_desc": RowProjDesc, "gvk_adam_desc": AdamDesc, "gvk_ssf_colgrad_desc": SsfColgradDesc, "gvk_dvpt_desc": DvptDesc}
 
 _lib = None
 

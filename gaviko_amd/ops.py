@@ -503,3 +503,21 @@ def ssf_head_grad(g, mean, rstd, wh, dlogits, gamma, beta, ds, dt, B, T, C_, K, 
         _chk(x, torch.float32, "ssf_head_grad " + nm)
     L.check(L.load().gvk_ssf_head_grad(L.ptr(g), L.ptr(mean), L.ptr(rstd), L.ptr(wh), L.ptr(dlogits), L.ptr(gamma), L.ptr(beta), L.ptr(ds),
                                        L.ptr(dt), B, T, C_, K, r0, R, L.stream_ptr()), "gvk_ssf_head_grad")
+
+
+# ---- DVPT (model/dvpt.py) ------------------------------------------------------------------------------------------------
+def dvpt_fwd(**kw):
+    d = _desc(L.DvptDesc, "dvpt_fwd", **kw)
+    L.check(L.load().gvk_dvpt_fwd(C.byref(d), L.stream_ptr()), "gvk_dvpt_fwd")
+
+
+def dvpt_bwd(**kw):
+    d = _desc(L.DvptDesc, "dvpt_bwd", **kw)
+    L.check(L.load().gvk_dvpt_bwd(C.byref(d), L.stream_ptr()), "gvk_dvpt_bwd")
+
+
+def scale_dev_(t: torch.Tensor, alpha: torch.Tensor) -> None:
+    """t *= alpha[0] with alpha a device scalar (no host read)."""
+    _chk(t, torch.float32, "scale_dev_ x")
+    _chk(alpha, torch.float32, "scale_dev_ alpha", 1)
+    L.check(L.load().gvk_scale_dev(L.ptr(t), L.ptr(alpha), t.numel(), L.stream_ptr()), "gvk_scale_dev")

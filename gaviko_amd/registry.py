@@ -34,7 +34,10 @@ def build_model(model_cfg):
     if method == "ssf":
         from .model.ssf import ScalingShiftingFeatures
         return ScalingShiftingFeatures(**cfg)
-    if method in ("dvpt", "evp"):
-        raise NotImplementedError(f"--method {method} resolves in the reference (train.py:139-146) but its kernels are not built yet "
+    if method == "dvpt":
+        from .model.dvpt import DynamicVisualPromptTuning
+        return DynamicVisualPromptTuning(**cfg)
+    if method == "evp":
+        raise NotImplementedError(f"--method {method} resolves in the reference (train.py:139-146) but its kernels (slice-wise fft2 high-pass) are not built yet "
                                   "(SURVEY.md 8(f)-2)")
     raise ValueError(f"unknown method {method!r}; expected one of {METHODS}")

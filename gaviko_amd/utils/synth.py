@@ -78,6 +78,8 @@ def fill_param(name: str, shape, salt: int = 0) -> np.ndarray:
         if name.endswith("weight"):
             return 1.0 + symmetric(name, shape, 0.2, salt)
         return symmetric(name, shape, 0.1, salt)
+    if name.endswith("prompt_gate"):              # DVPT's scalar gate is zero-initialised (dvpt.py:31): make the adapter path count
+        return 0.5 + symmetric(name, shape, 0.2, salt)
     if "ssf_scale_" in name:                      # SSF per-channel scale ~ 1 +- .2 / shift ~ +- .1 (ssf.py:14-20 inits N(1,.02) / N(0,.02))
         return 1.0 + symmetric(name, shape, 0.2, salt)
     if "ssf_shift_" in name:

@@ -22,7 +22,7 @@ extern "C" {
 const char* gvk_last_error(void);
 /* returns 950 when the code object loaded on the current device is gfx950, else <0 */
 int gvk_device_check(void);
-int gvk_abi_version(void);
+int gvk_abi_version(void);   /* 3 */
 
 /* ------------------------------------------------------------------ launch plans
  * The reference drives its step from the Python interpreter (train.py:296-319: one autograd node per op).  Here one
@@ -166,6 +166,7 @@ typedef struct gvk_skinny_down_desc {
   const float* w2; float* y2;       /* second stage, W2 [L2][L] */
   const uint64_t* seed_ptr;          /* optional device word added to `seed` at run time (HIP-graph-safe dropout) */
   int32_t M, C, L, L2, act, w_layout;
+  int32_t act_in;                    /* 1: QuickGELU applied to the input rows before the projection (DVPT share_MLP, dvpt.py:38) */
   float eps, drop_p;
   uint64_t seed;
 } gvk_skinny_down_desc;
@@ -180,6 +181,8 @@ typedef struct gvk_skinny_up_desc {
   /* optional LayerNorm-backward epilogue: out = base + LN'(v) with v = lat . W^T as the LN output gradient (no bias/dropout) */
   const float* ln_x; const float* ln_mean; const float* ln_rstd; const float* ln_gamma;
   void* out_bf16;                   /* optional bf16 copy of out (plain epilogue only) */
+  const float* alpha_ptr;           /* optional device scalar: v = alpha * (lat . W^T + bias)          (DVPT prompt_gate, dvpt.py:46) */
+  const float* gg_x;                /* optional f32 [M][C]: v *= QuickGELU'(gg_x[m][c])                 (dgrad through DVPT's input GELU) */
   int32_t M, C, L, T, P, w_layout, accumulate;
   float drop_p;
   uint64_t seed;
@@ -195,6 +198,7 @@ typedef struct gvk_outer_desc {
   float* scratch; float* out; float* colsum;
   const uint64_t* seed_ptr;
   int32_t M, C, L, T, P, transposed, accumulate;
+  int32_t wide_act;                  /* 1: QuickGELU applied to `wide` on the fly (DVPT: dW_d = dz^T . QuickGELU(x)) */
   float drop_p;
   uint64_t seed;
 } gvk_outer_desc;
@@ -319,6 +323,24 @@ int gvk_ssf_ln_grad(const float* dgamma_eff, const float* dbeta_eff, const float
                     void* stream);
 int gvk_ssf_head_grad(const float* g, const float* mean, const float* rstd, const float* wh, const float* dlogits, const float* gamma,
                       const float* beta, float* ds, float* dt, int B, int T, int C, int K, int r0, int R, void* stream);
+
+/* ------------------------------------------------------------------ DVPT, `--method dvpt` (model/dvpt.py)
+ * Latent-space core of share_MLP (dvpt.py:37-47) on z = proj_d(QuickGELU(x)) f32 [B*T][L] (gvk_skinny_down with act_in = 1;
+ * rows per sample: P prompts | cls | T-P-1 patches):
+ *   gvk_dvpt_fwd: enh[b][p] = softmax(scale * z_p . z_patches^T) . z_patches, lse saved            (scale = d_model^-1/2)
+ *   gvk_dvpt_bwd: from dcomb = dy . W_u (NOT yet scaled by the gate) and colsum_dy = sum_m dy:
+ *                 dgate = <dcomb, lat'> + <bu, colsum_dy>;  dz (all rows) = backward of the attention and of the concatenation
+ * (the up-projection and the gate are gvk_skinny_up with lat_override / alpha_ptr; gvk_scale_dev applies the gate to dW_u, db_u). */
+typedef struct gvk_dvpt_desc {
+  const float* z; float* enh; float* lse;               /* z [B*T][L]; enh [B][P][L], lse [B][P]: written by fwd, read by bwd */
+  const float* dcomb; const float* gate; const float* bu; const float* colsum_dy;
+  float* delta; float* dz; float* dgate;                 /* delta [B][P] scratch; dz [B*T][L]; dgate [1] */
+  int32_t B, T, P, L, C;
+  float scale;
+} gvk_dvpt_desc;
+int gvk_dvpt_fwd(const gvk_dvpt_desc* d, void* stream);
+int gvk_dvpt_bwd(const gvk_dvpt_desc* d, void* stream);
+int gvk_scale_dev(float* x, const float* alpha, int64_t n, void* stream);   /* x[i] *= alpha[0], alpha on the device */
 
 /* ------------------------------------------------------------------ optimisation step
  * Replaces train.py:315-319: torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step() over every

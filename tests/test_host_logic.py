@@ -112,4 +112,19 @@ def test_ssf_schema_and_freeze_rule():
     assert all(oracle.ssf_trainable(k) == named[k].requires_grad for k in named)
     assert m.train() is None and not m.transformer.training and m.mlp_head.training
     with pytest.raises(NotImplementedError):
-        build_model(dict(BASE, method="dvpt"))
+        build_model(dict(BASE, method="evp"))
+
+
+def test_dvpt_schema_and_freeze_rule():
+    from conftest import golden
+    cfg = dict(BASE, method="dvpt", num_prompts=50, freeze_vit=True)
+    m = build_model(cfg)
+    assert type(m).__name__ == "DynamicVisualPromptTuning"
+    sd = m.state_dict()
+    want = oracle.dvpt_param_shapes(cfg)
+    assert list(sd) == list(want) and all(tuple(sd[k].shape) == tuple(want[k]) for k in sd)
+    named = dict(m.named_parameters())
+    tr = sorted(k for k, p in named.items() if p.requires_grad)
+    assert tr == sorted(str(k) for k in golden("dvpt_t16_b2")["meta/trainable"]) and len(tr) == 64
+    assert all(oracle.dvpt_trainable(k) == named[k].requires_grad for k in named)
+    assert m.train() is None and not m.transformer.layers[0][0].attn.training and m.transformer.layers[0][0].prompt_proj.training

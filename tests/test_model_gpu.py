@@ -143,7 +143,10 @@ PEFT_CASES = [("deep_vpt_t16_b2", "deep_vpt", "vit-t16", 2, dict(num_prompts=8, 
               ("cfg4_adaptformer_b16_b8", "adaptformer", "vit-b16", 8, dict(freeze_vit=True)),
               ("cfg4_melo_b16_b8", "melo", "vit-b16", 8, dict(r=4, alpha=4)),
               ("ssf_t16_b2", "ssf", "vit-t16", 2, dict(freeze_vit=True)),
-              ("ssf_b16_b4", "ssf", "vit-b16", 4, dict(freeze_vit=True))]
+              ("ssf_b16_b4", "ssf", "vit-b16", 4, dict(freeze_vit=True)),
+              ("dvpt_t16_b2", "dvpt", "vit-t16", 2, dict(num_prompts=50, freeze_vit=True)),
+              ("dvpt_t16_b2_mean_p8", "dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=True, pool="mean")),
+              ("dvpt_b16_b4", "dvpt", "vit-b16", 4, dict(num_prompts=50, freeze_vit=True))]
 
 
 def _check_against_golden(m, g, B, first=0, logit_tol=1e-2):
@@ -171,17 +174,21 @@ def test_peft_forward_backward_vs_golden(dev, name, method, backbone, B, extra):
     assert abs(loss.item() - float(g["loss_ce"])) < 1e-2
     named = dict(m.named_parameters())
     errs = []
+    # DVPT's scalar gates: each gradient is one signed sum over all M x 20 latents, so a layer whose sum nearly cancels carries the
+    # same absolute bf16 noise as the others on a much smaller value -- they are judged against the largest gate gradient.
+    gate_scale = max([float(g[k]) for k in g.files if k.startswith("gradnorm/") and k.endswith("prompt_gate")] or [0.0])
     for k in g.files:
         if k.startswith("gradnorm/"):
             want = float(g[k])
-            errs.append((abs(named[k[9:]].grad.norm().item() - want) / max(want, 1e-12), k[9:]))
+            denom = gate_scale if k.endswith("prompt_gate") else max(want, 1e-12)
+            errs.append((abs(named[k[9:]].grad.norm().item() - want) / denom, k[9:]))
     e = np.array([x[0] for x in errs])     # same criterion as the gaviko test: the smallest-norm tensors are noise-dominated
     # (AdaptFormer's whole trainable path runs on bf16 operands incl. the ReLU mask: p90 3.1 % at ViT-B, B=8 -- BASELINE cfg4
     #  asks for fp32 there; the f32-MFMA family is not built yet)
     p90 = 5e-2 if method == "adaptformer" else 3e-2
     assert np.median(e) < 1e-2 and np.percentile(e, 90) < p90 and e.max() < 0.15, sorted(errs, reverse=True)[:5]
     for k in g.files:
-        if k.startswith("grad/"):
+        if k.startswith("grad/") and not k.endswith("prompt_gate"):      # the scalar gates are judged above, against the largest one
             e = rel(named[k[5:]].grad.cpu().numpy(), g[k])
             # elementwise, relative to the tensor's max.  AdaptFormer's ReLU mask is taken from the bf16 hidden state, so units
             # whose pre-activation sits within bf16 noise of zero flip: isolated elements move, norms stay within 5 %.
@@ -260,7 +267,10 @@ FP32_CASES = [("cfg1_linear_t16_b1", "linear", "vit-t16", 1, dict()),
               ("cfg4_adaptformer_b16_b8", "adaptformer", "vit-b16", 8, dict(freeze_vit=True)),
               ("cfg4_melo_b16_b8", "melo", "vit-b16", 8, dict(r=4, alpha=4)),
               ("ssf_t16_b2", "ssf", "vit-t16", 2, dict(freeze_vit=True)),
-              ("ssf_b16_b4", "ssf", "vit-b16", 4, dict(freeze_vit=True))]
+              ("ssf_b16_b4", "ssf", "vit-b16", 4, dict(freeze_vit=True)),
+              ("dvpt_t16_b2", "dvpt", "vit-t16", 2, dict(num_prompts=50, freeze_vit=True)),
+              ("dvpt_t16_b2_mean_p8", "dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=True, pool="mean")),
+              ("dvpt_b16_b4", "dvpt", "vit-b16", 4, dict(num_prompts=50, freeze_vit=True))]
 
 
 @pytest.mark.parametrize("name,method,backbone,B,extra", FP32_CASES)

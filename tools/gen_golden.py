@@ -52,6 +52,9 @@ CASES = {
     "cfg5_gaviko_l16_b2": ("gaviko", "vit-l16", 2, dict(GAVIKO)),
     "ssf_t16_b2": ("ssf", "vit-t16", 2, dict(freeze_vit=True)),
     "ssf_b16_b4": ("ssf", "vit-b16", 4, dict(freeze_vit=True)),
+    "dvpt_t16_b2": ("dvpt", "vit-t16", 2, dict(num_prompts=50, freeze_vit=True)),
+    "dvpt_t16_b2_mean_p8": ("dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=True, pool="mean")),
+    "dvpt_b16_b4": ("dvpt", "vit-b16", 4, dict(num_prompts=50, freeze_vit=True)),
 }
 
 
@@ -67,10 +70,11 @@ def import_reference():
     import model.adaptformer as af
     import model.melo as melo
     import model.ssf as ssf
+    import model.dvpt as dvpt
     import losses.focal_loss as fl
-    for m in (vt, gv, af, ssf):
+    for m in (vt, gv, af, ssf, dvpt):
         m.load_pretrain = lp.load_pretrain
-    return dict(vt=vt, gv=gv, vpt=vpt, af=af, melo=melo, ssf=ssf, fl=fl)
+    return dict(vt=vt, gv=gv, vpt=vpt, af=af, melo=melo, ssf=ssf, dvpt=dvpt, fl=fl)
 
 
 def build_reference(mods, method, cfg):
@@ -93,6 +97,8 @@ def build_reference(mods, method, cfg):
         return mods["melo"].MeLO(vit=mods["vt"].VisionTransformer(**cfg), **cfg)
     if method == "ssf":
         return mods["ssf"].ScalingShiftingFeatures(**cfg)
+    if method == "dvpt":
+        return mods["dvpt"].DynamicVisualPromptTuning(**cfg)
     raise ValueError(method)
 
 
@@ -148,7 +154,7 @@ def attach_hooks(model, method, taps):
         if method == "melo":
             vit = model.lora_vit
         for i, layer in enumerate(vit.transformer.layers):
-            ff = layer[-1]
+            ff = layer[-1].mlp if method == "dvpt" else layer[-1]
 
             def h_ff(mod, inp, out, i=i):
                 taps[f"layer{i}.ff_out"] = tap(out)
@@ -159,7 +165,7 @@ def attach_hooks(model, method, taps):
 
 
 FULL_GRAD_PATTERNS = (
-    "mlp_head", "ssf_s", "prompt_embeddings", "prompt_positional_embedding", "prompt_proj.",
+    "mlp_head", "ssf_s", "layers.0.0.prompt_proj", "prompt_embeddings", "prompt_positional_embedding", "prompt_proj.",
     "prompt_projs.0.", "local_attns.0.", "layers.0.1.", "layers.0.0.to_qkv.linear_",
 )
 
