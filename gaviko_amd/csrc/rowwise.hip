@@ -538,6 +538,7 @@ int launch_row_down(const DownArgs& a, int L, hipStream_t s) {
     case 8: return launch_down_t<8>(a, s);
     case 16: return launch_down_t<16>(a, s);
     case 20: return launch_down_t<20>(a, s);
+    case 24: return launch_down_t<24>(a, s);                 // EVP at ViT-B: dim / 32
     default: return 1;                                   // L = 32 would spill (3 rows x 32 two-wide accumulators): MFMA-tile kernel
   }
 }
@@ -549,6 +550,7 @@ int launch_row_up(const UpArgs& a, int L, hipStream_t s) {
     case 8: return launch_up_t<8>(a, s);
     case 16: return launch_up_t<16>(a, s);
     case 20: return launch_up_t<20>(a, s);
+    case 24: return launch_up_t<24>(a, s);
     default: return 1;
   }
 }

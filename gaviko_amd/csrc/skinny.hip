@@ -714,6 +714,7 @@ extern "C" int gvk_outer_reduce(const gvk_outer_desc* d, void* stream) {
     case 8: rc = launch_outer<8>(a, s); break;
     case 16: rc = launch_outer<16>(a, s); break;
     case 20: rc = launch_outer<20>(a, s); break;
+    case 24: rc = launch_outer<24>(a, s); break;
     case 32: rc = launch_outer<32>(a, s); break;
     case 64: rc = launch_outer<64>(a, s); break;
     default: return set_error(-2, "gvk_outer_reduce: L=%d unsupported (4, 8, 16, 20, 32, 64)", d->L);

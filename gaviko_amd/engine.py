@@ -49,6 +49,27 @@ _EPI_NAMES = {0: "store_bf16", 1: "bias_res_f32", 2: "bias_gelu_bf16", 3: "patch
               7: "bias_relu_bf16", 8: "relu_bwd_bf16"}
 
 
+def evp_highpass_operator(D: int, H: int, W: int, rate: float):
+    """The linear operator behind PromptGenerator.fft (evp.py:126-147) as it executes on a [B, C, D, H, W] volume.
+    fft2 / ifft2 run over (H, W); fftshift / ifftshift run over EVERY axis; the mask `mask[:, :, w//2-line:w//2+line, h//2-line:h//2+line]`
+    (w, h = the last two sizes) is indexed on axes 2 and 3 = (D, H).  Net effect: on the depth slices whose shifted index falls in the
+    first range, the H-frequencies whose shifted index falls in the second range are zeroed for every W-frequency; all other slices pass.
+    Returns (Hp [H][H] float32 with Hp = I - Re(F^-1 diag(band) F), depth mask int32 [D]): out[b, d] = |Hp . x[b, d]| or |x[b, d]|."""
+    import numpy as np
+    w_, h_ = H, W                                            # the reference's names for x.shape[-2:]
+    line = int((w_ * h_ * rate) ** 0.5 // 2)
+    dlo, dhi = max(0, w_ // 2 - line), min(D, w_ // 2 + line)              # slice of axis 2 (depth), clipped like Python slicing
+    hlo, hhi = max(0, h_ // 2 - line), min(H, h_ // 2 + line)              # slice of axis 3 (H)
+    d_shift = (np.arange(D) + D // 2) % D                    # fftshift: original index d sits at shifted index (d + D//2) % D
+    dmask = ((d_shift >= dlo) & (d_shift < dhi)).astype(np.int32)
+    k_shift = (np.arange(H) + H // 2) % H
+    band = ((k_shift >= hlo) & (k_shift < hhi)).astype(np.float64)
+    idx = np.arange(H)
+    ph = np.exp(2j * np.pi * np.outer(idx, idx) / H)          # ph[i][k] = e^{2 pi i k i / H}
+    A = (ph * band[None, :]) @ ph.conj().T / H                # A[i][j] = 1/H sum_k band[k] e^{2 pi i k (i - j) / H}
+    return (np.eye(H) - A.real).astype(np.float32), dmask
+
+
 class Names:
     """Maps logical backbone tensors to the state_dict names of each reference class."""
 
@@ -69,6 +90,9 @@ class Names:
         if self.kind == "dvpt":
             return f"transformer.layers.{i}.0.mlp"
         return f"{self.root}transformer.layers.{i}." + ("2" if self.kind == "adaptformer" else "1")
+
+    def conv(self):
+        return "conv_proj.proj" if self.kind == "evp" else f"{self.root}conv_proj.0"      # evp.py:292: a PatchEmbed, not a Sequential
 
     def qkv_weight(self, i):
         return self.attn(i) + (".to_qkv.qkv.weight" if self.kind == "melo" else ".to_qkv.weight")
@@ -116,6 +140,14 @@ class Engine:
                 if tuple(dhw) != self.grid:
                     raise L.GavikoHipError(f"DHW={tuple(dhw)} does not match the patch grid {self.grid}")
                 self.win = tuple(cfg.get("local_k", (3, 6, 6)))
+        elif kind == "evp":
+            self.P, self.T, self.row_off = 0, 1 + self.N, 1
+            self.r = dim // int(cfg.get("scale_factor", 32))                              # rank of the prompt latents (evp.py:41-42)
+            widths = [w_ for w_ in (4, 8, 16, 20, 24, 32) if w_ >= self.r]
+            if not widths or self.r < 1:
+                raise L.GavikoHipError(f"EVP: prompt rank dim/scale_factor = {self.r} is outside the rank-L kernels' range (1..32)")
+            self.Lp = widths[0]                                                            # latents are zero-padded to this width
+            self.freq = float(cfg.get("freq_nums", 0.25))
         elif kind == "dvpt":
             self.P = cfg.get("num_prompts", 50)
             self.Lat = 20                                                                  # share_MLP.latent_dim (dvpt.py:27)
@@ -195,7 +227,7 @@ class Engine:
         return self.p[name].detach() if eff is None else eff
 
     def _backbone_weight_names(self) -> List[str]:
-        n = [self.names.root + "conv_proj.0.weight"]
+        n = [self.names.conv() + ".weight"]
         for i in range(self.depth):
             n += [self.names.qkv_weight(i), self.names.attn(i) + ".to_out.0.weight", self.names.mlp(i) + ".net.1.weight",
                   self.names.mlp(i) + ".net.4.weight"]
@@ -260,6 +292,19 @@ class Engine:
             ws["gp"] = [dict(zx=mk(M, Lt), xl=mk(M, Lt), zl=mk(BN, Lt), ll=mk(BN, Lt), imp=mk(B, P), gw=mk(B), enh=mk(B, P, Lt),
                              prm=mk(B, P, Lt), qg=mk(B, P, Lt), ql=mk(B, P, Lt), cg=mk(B, P, Lt), cl=mk(B, P, Lt), lse_g=mk(B, P),
                              lse_l=mk(B, P)) for _ in range(nsave)]
+        if self.kind == "evp":
+            mk = lambda *s_: torch.zeros(s_, device=device)
+            BN, Lp = B * N, self.Lp
+            ws["xc"] = z(BN, C, f32)
+            ws["hp"] = torch.zeros_like(ws["img"])
+            ws["hcols"] = z(BN, self.Kp, f32)
+            ws["hc"] = z(BN, 64, f32)
+            ws["ev"] = dict(e=mk(BN, Lp), s=mk(BN, Lp), pre=[mk(BN, Lp) for _ in range(nsave)], u=[mk(BN, Lp) for _ in range(nsave)],
+                            tmp=z(BN, C, f32))
+            if train:
+                ws["evb"] = dict(du=mk(BN, Lp), dpre=mk(BN, Lp), ds_tmp=mk(BN, Lp), ds=mk(BN, Lp))
+                ws["scratch"] = mk(max(ops.outer_scratch_elems(Lp, self.Kp), 128 * C))
+                ws["rscratch"] = mk(32 * (Lp * Lp + Lp + 64))
         if self.kind == "dvpt":
             mk = lambda *s_: torch.zeros(s_, device=device)
             ws["dv"] = [dict(z=mk(M, self.Lat), enh=mk(B, self.P, self.Lat), lse=mk(B, self.P)) for _ in range(nsave)]
@@ -312,6 +357,8 @@ class Engine:
                 ws["dvb"] = dict(dcomb=mk(M, Lt), dz=mk(M, Lt), delta=mk(B, P))
                 ws["scratch"] = mk(max(ops.outer_scratch_elems(Lt, C), 128 * C))
                 ws["rscratch"] = mk(32 * (Lt + 64))
+            elif self.kind == "evp":
+                pass                                        # scratch / rscratch sized with the EVP buffers above
             else:
                 if self.kind == "ssf":
                     ws["ssf_scratch"] = torch.zeros(64 * 2 * max(self.mlp, 3 * C), device=device)
@@ -443,8 +490,14 @@ class Engine:
         ops.patchify(ws["img"], ws["cols"], self.patch)
         pos = d(nm.root + "pos_embedding")[0]
         G0 = ws["G"][0]
-        ops.gemm_nt(ws["cols"], w["conv"], B * N, G0, epilogue=ops.EPI_PATCH_F32, out1=ws["Lc"][0] if self.kind == "gaviko" else None,
-                    bias=d(nm.root + "conv_proj.0.bias"), pos=pos[1:], rows_in=N, rows_out=T, row_off=self.row_off)
+        if self.kind == "evp":
+            # the raw patch embedding is needed on its own (embedding_generator reads it, evp.py:347-348): conv -> xc, tokens = xc + pos
+            ops.gemm_nt(ws["cols"], w["conv"], B * N, ws["xc"], epilogue=ops.EPI_STORE_F32, bias=d(nm.conv() + ".bias"))
+            ops.rows_patch(G0, ws["xc"], pos[1:], B, T, N, C, 1, False)
+            self._evp_latents(ws, B)
+        else:
+            ops.gemm_nt(ws["cols"], w["conv"], B * N, G0, epilogue=ops.EPI_PATCH_F32, out1=ws["Lc"][0] if self.kind == "gaviko" else None,
+                        bias=d(nm.conv() + ".bias"), pos=pos[1:], rows_in=N, rows_out=T, row_off=self.row_off)
         if marking:
             nout = 2 if self.kind == "gaviko" else 1
             self._gemm_marks.append(("__patch_embed__", 2.0 * B * N * self.Kp * C, [B * N, C, self.Kp],
@@ -483,6 +536,8 @@ class Engine:
                     if self._fuse_proj:
                         self._gpa_down_local(ws, i, si, ws["Lc"][go], B)
             self._mark(f"f{i}:start")
+            if self.kind == "evp":
+                self._evp_add_prompt(ws, i, si, ws["G"][gi], B)               # x[:, 1:] += prompt_i (evp.py:235-238)
             self._attn_block_fwd(ws, i, si, ws["G"][gi], ws["G1"][si], Mi)
             self._mark(f"f{i}:attn")
             fused = gaviko and self._fuse_proj
@@ -799,6 +854,8 @@ class Engine:
                     self._ev_wait(torch.cuda.current_stream(), prev_scl)
                 prev_scl = scl_done
                 self._wait("gpa", None)                                      # the next layer's GPA backward needs this dG[i]
+            if self.kind == "evp":
+                self._evp_bwd_layer(ws, gv, i, dGout, B)
             self._mark(f"b{i}:end")
             if self.kind == "vpt" and (i == 0 or self.deep):
                 # prompt rows 1..P of this layer's input are this layer's projected prompts (vpt.py:127-131,147-153)
@@ -811,6 +868,8 @@ class Engine:
         if gaviko:
             self._wait(None, "gpa")
             self._wait(None, "loc")
+        if last and self.kind == "evp":
+            self._evp_bwd_finish(ws, gv, B)
         if last and self.kind == "ssf":
             # patch embedding + ssf (ssf.py:229-232): dy = the patch rows of the input gradient, y = G[0] patch rows - pos[1:]
             pos = self.p["pos_embedding"].detach()[0]
@@ -840,6 +899,8 @@ class Engine:
             return "ssf_scale_" in name or "ssf_shift_" in name
         if self.kind == "dvpt":
             return "prompt" in name
+        if self.kind == "evp":
+            return "prompt_generator" in name
         return False
 
     def _needs_backbone_backward(self) -> bool:
@@ -986,6 +1047,85 @@ class Engine:
             if self.lora_s != 1:
                 ops.scale_(gv[na], float(self.lora_s))
                 ops.scale_(gv[nb], float(self.lora_s))
+
+    # ---- EVP (evp.py): prompts from a high-pass copy of the volume + the patch embeddings, added in front of every layer --------
+    def _evp_state(self, device):
+        """Static per-engine buffers: the high-pass operator, zero-padded copies of the trainable prompt-generator weights and of
+        their gradients (the latents have rank r = dim/32 = 6 / 24 / 32; the rank-L kernels run at the padded width Lp)."""
+        st = self.__dict__.get("_evp")
+        if st is not None:
+            return st
+        C, Lp, Kp = self.C, self.Lp, self.Kp
+        mk = lambda *s_: torch.zeros(s_, device=device)
+        D, H, W = (g * p_ for g, p_ in zip(self.grid, self.patch))
+        hp, dm = evp_highpass_operator(D, H, W, self.freq)
+        st = dict(hp=torch.from_numpy(hp).to(device), dmask=torch.from_numpy(dm).to(device),
+                  Wp=mk(64, Kp), bp=mk(64), We=mk(Lp, C), be=mk(Lp), Ws=mk(C, Lp),
+                  Wi=[mk(Lp, Lp) for _ in range(self.depth)], WiT=[mk(Lp, Lp) for _ in range(self.depth)], bi=[mk(Lp) for _ in range(self.depth)],
+                  dWs=mk(C, Lp), dWe=mk(Lp, C), dWp=mk(Lp, Kp), dvec=mk(Lp), dWi=mk(Lp, Lp))
+        self.__dict__["_evp"] = st
+        return st
+
+    def _evp_latents(self, ws, B):
+        """s = proj(highpass(img)) + embedding_generator(conv(img))  (evp.py:76-84, 347-349), at the padded width."""
+        st, ev, d = self._evp_state(ws["img"].device), ws["ev"], self._d
+        r, Lp, C, Kp, BN = self.r, self.Lp, self.C, self.Kp, B * self.N
+        pg = "prompt_generator."
+        ops.pad2d(d(pg + "prompt_generator.proj.weight").reshape(r, Kp), r, Kp, st["Wp"], 64, Kp)
+        ops.pad2d(d(pg + "prompt_generator.proj.bias"), 1, r, st["bp"], 1, 64)
+        ops.pad2d(d(pg + "embedding_generator.weight"), r, C, st["We"], Lp, C)
+        ops.pad2d(d(pg + "embedding_generator.bias"), 1, r, st["be"], 1, Lp)
+        ops.pad2d(d(pg + "shared_mlp.weight"), C, r, st["Ws"], C, Lp)
+        for i in range(self.depth):
+            wi = d(pg + f"lightweight_mlp_{i}.0.weight")
+            ops.pad2d(wi, r, r, st["Wi"][i], Lp, Lp)
+            ops.pad2d(wi, r, r, st["WiT"][i], Lp, Lp, transpose=True)
+            ops.pad2d(d(pg + f"lightweight_mlp_{i}.0.bias"), 1, r, st["bi"][i], 1, Lp)
+        ops.skinny_down(x=ws["xc"], w=st["We"], bias=st["be"], y=ev["e"], M=BN, C=C, L=Lp, act=0, w_layout=0)
+        ops.evp_highpass(ws["img"], st["hp"], st["dmask"], ws["hp"])
+        ops.patchify(ws["hp"], ws["hcols"], self.patch)
+        ops.gemm_nt(ws["hcols"], st["Wp"], BN, ws["hc"], epilogue=ops.EPI_STORE_F32, bias=st["bp"])      # fp32 GEMM in both precisions (1.6 GF)
+        ops.add2d(ws["hc"], 64, ev["e"], Lp, ev["s"], Lp, BN, Lp)
+
+    def _evp_add_prompt(self, ws, i, si, g, B):
+        """prompt_i = shared_mlp(GELU(lightweight_mlp_i(s)))  (evp.py:86-95), added to the patch rows of the layer input."""
+        st, ev, d = self._evp_state(g.device), ws["ev"], self._d
+        Lp, C, BN = self.Lp, self.C, B * self.N
+        ops.small_linear_fwd(ev["s"], st["Wi"][i], st["bi"][i], ev["pre"][si], BN, Lp, Lp)
+        ops.gelu_fwd(ev["pre"][si], ev["u"][si])
+        ops.skinny_up(lat=ev["u"][si], w=st["Ws"], bias=d("prompt_generator.shared_mlp.bias"), out=ev["tmp"], M=BN, C=C, L=Lp, w_layout=0)
+        ops.rows_patch(g, ev["tmp"], None, B, self.T, self.N, C, 1, True)
+
+    def _evp_bwd_layer(self, ws, gv, i, dG, B):
+        """d prompt_i = the patch rows of the gradient of layer i's input; accumulates d shared_mlp over the layers and d s."""
+        st, ev, bw = self._evp_state(dG.device), ws["ev"], ws["evb"]
+        Lp, C, BN, r = self.Lp, self.C, B * self.N, self.r
+        pg = "prompt_generator."
+        top = i == self.depth - 1
+        ops.rows_gather(dG, ev["tmp"], B, self.T, self.N, C, 1)
+        ops.outer_reduce(narrow=ev["u"][i], wide=ev["tmp"], scratch=ws["scratch"], out=st["dWs"], colsum=gv[pg + "shared_mlp.bias"], M=BN, C=C, L=Lp,
+                         transposed=1, accumulate=0 if top else 1)
+        ops.skinny_down(x=ev["tmp"], w=st["Ws"], y=bw["du"], M=BN, C=C, L=Lp, act=0, w_layout=1)
+        ops.gelu_bwd(bw["du"], ev["pre"][i], bw["dpre"])
+        ops.reduce_batch([(bw["dpre"], ev["s"], st["dWi"], 0), (bw["dpre"], None, st["dvec"], 0)], ws["rscratch"])
+        ops.pad2d(st["dWi"], r, r, gv[pg + f"lightweight_mlp_{i}.0.weight"], r, r, ld_src=Lp)
+        ops.pad2d(st["dvec"], 1, r, gv[pg + f"lightweight_mlp_{i}.0.bias"], 1, r, ld_src=Lp)
+        ops.small_linear_fwd(bw["dpre"], st["WiT"][i], None, bw["ds"] if top else bw["ds_tmp"], BN, Lp, Lp)       # d s = dpre . W_i
+        if not top:
+            ops.add2d(bw["ds"], Lp, bw["ds_tmp"], Lp, bw["ds"], Lp, BN, Lp)
+
+    def _evp_bwd_finish(self, ws, gv, B):
+        st, ev, bw = self._evp_state(ws["img"].device), ws["ev"], ws["evb"]
+        Lp, C, BN, r, Kp = self.Lp, self.C, B * self.N, self.r, self.Kp
+        pg = "prompt_generator."
+        ops.pad2d(st["dWs"], C, r, gv[pg + "shared_mlp.weight"], C, r, ld_src=Lp)
+        ops.outer_reduce(narrow=bw["ds"], wide=ws["xc"], scratch=ws["scratch"], out=st["dWe"], M=BN, C=C, L=Lp, transposed=0, accumulate=0)
+        ops.pad2d(st["dWe"], r, C, gv[pg + "embedding_generator.weight"], r, C)
+        ops.reduce_batch([(bw["ds"], None, st["dvec"], 0)], ws["rscratch"])
+        ops.pad2d(st["dvec"], 1, r, gv[pg + "embedding_generator.bias"], 1, r, ld_src=Lp)
+        ops.pad2d(st["dvec"], 1, r, gv[pg + "prompt_generator.proj.bias"], 1, r, ld_src=Lp)
+        ops.outer_reduce(narrow=bw["ds"], wide=ws["hcols"], scratch=ws["scratch"], out=st["dWp"], M=BN, C=Kp, L=Lp, transposed=0, accumulate=0)
+        ops.pad2d(st["dWp"], r, Kp, gv[pg + "prompt_generator.proj.weight"].view(r, Kp), r, Kp)
 
     # ---- DVPT (dvpt.py:24-63): share_MLP beside the MLP block ------------------------------------------------------------------
     def _dvpt_names(self, i):

@@ -109,6 +109,13 @@ SIGNATURES = {
     "gvk_dvpt_fwd": [C.POINTER(DvptDesc), _P],
     "gvk_dvpt_bwd": [C.POINTER(DvptDesc), _P],
     "gvk_scale_dev": [_P, _P, C.c_int64, _P],
+    "gvk_evp_highpass": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "gvk_pad2d_f32": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
+    "gvk_add2d_f32": [_P, _I, _P, _I, _P, _I, _I, _I, _P],
+    "gvk_gelu_fwd_f32": [_P, _P, C.c_int64, _P],
+    "gvk_gelu_bwd_f32": [_P, _P, _P, C.c_int64, _P],
+    "gvk_rows_patch": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gvk_rows_gather": [_P, _P, _I, _I, _I, _I, _I, _P],
     "gvk_sumsq": [_P, C.c_int64, _P, _P, _P],
     "gvk_adam_step": [C.POINTER(AdamDesc), _P],
     "gvk_memset_async": [_P, _I, C.c_size_t, _P],

@@ -521,3 +521,52 @@ def scale_dev_(t: torch.Tensor, alpha: torch.Tensor) -> None:
     _chk(t, torch.float32, "scale_dev_ x")
     _chk(alpha, torch.float32, "scale_dev_ alpha", 1)
     L.check(L.load().gvk_scale_dev(L.ptr(t), L.ptr(alpha), t.numel(), L.stream_ptr()), "gvk_scale_dev")
+
+
+# ---- EVP (model/evp.py) --------------------------------------------------------------------------------------------------
+def evp_highpass(img, hp, depth_mask, out):
+    _chk(img, torch.float32, "evp_highpass img")
+    B, ch, D, H, W = img.shape
+    _chk(hp, torch.float32, "evp_highpass hp", H * H)
+    _chk(depth_mask, torch.int32, "evp_highpass depth_mask", D)
+    _chk(out, torch.float32, "evp_highpass out", img.numel())
+    L.check(L.load().gvk_evp_highpass(L.ptr(img), L.ptr(hp), L.ptr(depth_mask), L.ptr(out), B * ch, D, H, W, L.stream_ptr()), "gvk_evp_highpass")
+
+
+def pad2d(src, rows, cols, dst, drows, dcols, *, ld_src=None, ld_dst=None, transpose=False):
+    """dst[drows x dcols] = src[rows x cols] (optionally transposed) zero-padded."""
+    _chk(src, torch.float32, "pad2d src")
+    _chk(dst, torch.float32, "pad2d dst")
+    L.check(L.load().gvk_pad2d_f32(L.ptr(src), cols if ld_src is None else ld_src, rows, cols, int(transpose), L.ptr(dst),
+                                   dcols if ld_dst is None else ld_dst, drows, dcols, L.stream_ptr()), "gvk_pad2d_f32")
+
+
+def add2d(a, lda, b, ldb, out, ldo, rows, cols):
+    for t, n in ((a, "a"), (b, "b"), (out, "out")):
+        _chk(t, torch.float32, "add2d " + n)
+    L.check(L.load().gvk_add2d_f32(L.ptr(a), lda, L.ptr(b), ldb, L.ptr(out), ldo, rows, cols, L.stream_ptr()), "gvk_add2d_f32")
+
+
+def gelu_fwd(x, y):
+    _chk(x, torch.float32, "gelu_fwd x")
+    _chk(y, torch.float32, "gelu_fwd y", x.numel())
+    L.check(L.load().gvk_gelu_fwd_f32(L.ptr(x), L.ptr(y), x.numel(), L.stream_ptr()), "gvk_gelu_fwd_f32")
+
+
+def gelu_bwd(dy, x, dx):
+    for t, n in ((dy, "dy"), (x, "x"), (dx, "dx")):
+        _chk(t, torch.float32, "gelu_bwd " + n, x.numel())
+    L.check(L.load().gvk_gelu_bwd_f32(L.ptr(dy), L.ptr(x), L.ptr(dx), x.numel(), L.stream_ptr()), "gvk_gelu_bwd_f32")
+
+
+def rows_patch(tok, src, pos, B, T, N, C_, row_off, accumulate):
+    _chk(tok, torch.float32, "rows_patch tok", B * T * C_)
+    _chk(src, torch.float32, "rows_patch src", B * N * C_)
+    _chk(pos, torch.float32, "rows_patch pos", N * C_)
+    L.check(L.load().gvk_rows_patch(L.ptr(tok), L.ptr(src), L.ptr(pos), B, T, N, C_, row_off, int(accumulate), L.stream_ptr()), "gvk_rows_patch")
+
+
+def rows_gather(tok, dst, B, T, N, C_, row_off):
+    _chk(tok, torch.float32, "rows_gather tok", B * T * C_)
+    _chk(dst, torch.float32, "rows_gather dst", B * N * C_)
+    L.check(L.load().gvk_rows_gather(L.ptr(tok), L.ptr(dst), B, T, N, C_, row_off, L.stream_ptr()), "gvk_rows_gather")

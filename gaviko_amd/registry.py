@@ -38,6 +38,6 @@ def build_model(model_cfg):
         from .model.dvpt import DynamicVisualPromptTuning
         return DynamicVisualPromptTuning(**cfg)
     if method == "evp":
-        raise NotImplementedError(f"--method {method} resolves in the reference (train.py:139-146) but its kernels (slice-wise fft2 high-pass) are not built yet "
-                                  "(SURVEY.md 8(f)-2)")
+        from .model.evp import ExplicitVisualPrompting
+        return ExplicitVisualPrompting(**cfg)
     raise ValueError(f"unknown method {method!r}; expected one of {METHODS}")

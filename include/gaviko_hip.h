@@ -342,6 +342,24 @@ int gvk_dvpt_fwd(const gvk_dvpt_desc* d, void* stream);
 int gvk_dvpt_bwd(const gvk_dvpt_desc* d, void* stream);
 int gvk_scale_dev(float* x, const float* alpha, int64_t n, void* stream);   /* x[i] *= alpha[0], alpha on the device */
 
+/* ------------------------------------------------------------------ EVP, `--method evp` (model/evp.py)
+ * gvk_evp_highpass: PromptGenerator.fft (evp.py:126-147) as it executes on [B,1,D,H,W]: out[b,d] = |hp . img[b,d]| on the depth slices
+ *   with depth_mask[d] != 0, |img[b,d]| on the others; hp f32 [H][H] = I - Re(F^-1 diag(band) F) and the slice mask are built by
+ *   the host (gaviko_amd/engine.py::evp_highpass_operator) from the reference's mask indexing.  No FFT library involved.
+ * The remaining entry points are glue for the rank-(dim/32) prompt latents (zero-padded to a width the rank-L kernels support):
+ *   gvk_pad2d_f32   dst (drows x dcols) = src (rows x cols, optionally transposed), zero elsewhere
+ *   gvk_add2d_f32   out = a + b on a rows x cols window with independent leading dimensions
+ *   gvk_gelu_fwd/bwd_f32  exact (erf) GELU of the light-weight MLPs (evp.py:45-49) and dy * GELU'(x)
+ *   gvk_rows_patch  tok[b][row_off+n] (= or +=) src[b*N+n] (+ pos[n])     (tokens = conv + pos; x[:,1:] += prompt_i, evp.py:235-238)
+ *   gvk_rows_gather the inverse read (the prompt gradient is the patch rows of the layer-input gradient) */
+int gvk_evp_highpass(const float* img, const float* hp, const int32_t* depth_mask, float* out, int B, int D, int H, int W, void* stream);
+int gvk_pad2d_f32(const float* src, int ld_src, int rows, int cols, int transpose, float* dst, int ld_dst, int drows, int dcols, void* stream);
+int gvk_add2d_f32(const float* a, int lda, const float* b, int ldb, float* out, int ldo, int rows, int cols, void* stream);
+int gvk_gelu_fwd_f32(const float* x, float* y, int64_t n, void* stream);
+int gvk_gelu_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, void* stream);
+int gvk_rows_patch(float* tok, const float* src, const float* pos, int B, int T, int N, int C, int row_off, int accumulate, void* stream);
+int gvk_rows_gather(const float* tok, float* dst, int B, int T, int N, int C, int row_off, void* stream);
+
 /* ------------------------------------------------------------------ optimisation step
  * Replaces train.py:315-319: torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step() over every
  * trainable tensor, on the engine's flat fp32 gradient buffer (exp_avg / exp_avg_sq share its layout).

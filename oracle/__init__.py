@@ -9,17 +9,18 @@ from .peft_ref import (adaptformer_forward, adaptformer_param_shapes, adaptforme
                        melo_param_shapes, melo_trainable, vpt_forward, vpt_param_shapes, vpt_trainable)
 from .ssf_ref import ssf_forward, ssf_param_shapes, ssf_trainable  # noqa: F401
 from .dvpt_ref import dvpt_forward, dvpt_param_shapes, dvpt_trainable  # noqa: F401
+from .evp_ref import evp_forward, evp_param_shapes, evp_trainable, fft_highpass  # noqa: F401
 from .losses_ref import cross_entropy, focal_loss  # noqa: F401
 
 FORWARD = {
     "gaviko": gaviko_forward, "linear": vit_forward, "fft": vit_forward, "bitfit": vit_forward,
     "deep_vpt": vpt_forward, "shallow_vpt": vpt_forward, "adaptformer": adaptformer_forward, "melo": melo_forward,
-    "ssf": ssf_forward, "dvpt": dvpt_forward,
+    "ssf": ssf_forward, "dvpt": dvpt_forward, "evp": evp_forward,
 }
 SHAPES = {
     "gaviko": gaviko_param_shapes, "linear": vit_param_shapes, "fft": vit_param_shapes, "bitfit": vit_param_shapes,
     "deep_vpt": vpt_param_shapes, "shallow_vpt": vpt_param_shapes, "adaptformer": adaptformer_param_shapes,
-    "melo": melo_param_shapes, "ssf": ssf_param_shapes, "dvpt": dvpt_param_shapes,
+    "melo": melo_param_shapes, "ssf": ssf_param_shapes, "dvpt": dvpt_param_shapes, "evp": evp_param_shapes,
 }
 
 
@@ -42,4 +43,6 @@ def trainable(method: str, name: str) -> bool:
         return ssf_trainable(name)
     if method == "dvpt":
         return dvpt_trainable(name)
+    if method == "evp":
+        return evp_trainable(name)
     raise ValueError(method)

@@ -111,8 +111,31 @@ def test_ssf_schema_and_freeze_rule():
     assert tr == sorted(str(k) for k in golden("ssf_t16_b2")["meta/trainable"])
     assert all(oracle.ssf_trainable(k) == named[k].requires_grad for k in named)
     assert m.train() is None and not m.transformer.training and m.mlp_head.training
-    with pytest.raises(NotImplementedError):
-        build_model(dict(BASE, method="evp"))
+
+
+def test_evp_schema_freeze_rule_and_highpass_operator():
+    """ExplicitVisualPrompting mirror (state_dict keys / order / freeze rule of the reference) and the host-built linear operator that
+    replaces PromptGenerator.fft: it reproduces the oracle's torch.fft restatement -- including the reference's mask-on-(D,H) indexing
+    and its all-axes fftshift -- to fp32 round-off."""
+    from conftest import golden
+    from gaviko_amd.engine import evp_highpass_operator
+    cfg = dict(BASE, method="evp", freeze_vit=True)
+    m = build_model(cfg)
+    assert type(m).__name__ == "ExplicitVisualPrompting"
+    sd = m.state_dict()
+    want = oracle.evp_param_shapes(cfg)
+    assert list(sd) == list(want) and all(tuple(sd[k].shape) == tuple(want[k]) for k in sd)
+    named = dict(m.named_parameters())
+    tr = sorted(k for k, p in named.items() if p.requires_grad)
+    assert tr == sorted(str(k) for k in golden("evp_t16_b2")["meta/trainable"]) and len(tr) == 32
+    assert all(oracle.evp_trainable(k) == named[k].requires_grad for k in named)
+    assert m.train() is None and not m.transformer.training and m.prompt_generator.training
+    for D, H, W in ((24, 32, 32), (12, 16, 16), (120, 160, 160)):
+        x = torch.rand(1, 1, D, H, W, generator=torch.Generator().manual_seed(D))
+        hp, dm = evp_highpass_operator(D, H, W, 0.25)
+        got = torch.where(torch.from_numpy(dm).bool()[None, None, :, None, None], torch.einsum("ik,bcdkj->bcdij", torch.from_numpy(hp), x).abs(), x.abs())
+        assert (got - oracle.fft_highpass(x, 0.25)).abs().max() < 2e-6
+    assert int(evp_highpass_operator(120, 160, 160, 0.25)[1].sum()) == 80       # 80 of the 120 depth slices are filtered (quirk 17)
 
 
 def test_dvpt_schema_and_freeze_rule():

@@ -146,7 +146,9 @@ PEFT_CASES = [("deep_vpt_t16_b2", "deep_vpt", "vit-t16", 2, dict(num_prompts=8, 
               ("ssf_b16_b4", "ssf", "vit-b16", 4, dict(freeze_vit=True)),
               ("dvpt_t16_b2", "dvpt", "vit-t16", 2, dict(num_prompts=50, freeze_vit=True)),
               ("dvpt_t16_b2_mean_p8", "dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=True, pool="mean")),
-              ("dvpt_b16_b4", "dvpt", "vit-b16", 4, dict(num_prompts=50, freeze_vit=True))]
+              ("dvpt_b16_b4", "dvpt", "vit-b16", 4, dict(num_prompts=50, freeze_vit=True)),
+              ("evp_t16_b2", "evp", "vit-t16", 2, dict(freeze_vit=True)),
+              ("evp_b16_b2", "evp", "vit-b16", 2, dict(freeze_vit=True))]
 
 
 def _check_against_golden(m, g, B, first=0, logit_tol=1e-2):
@@ -270,7 +272,9 @@ FP32_CASES = [("cfg1_linear_t16_b1", "linear", "vit-t16", 1, dict()),
               ("ssf_b16_b4", "ssf", "vit-b16", 4, dict(freeze_vit=True)),
               ("dvpt_t16_b2", "dvpt", "vit-t16", 2, dict(num_prompts=50, freeze_vit=True)),
               ("dvpt_t16_b2_mean_p8", "dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=True, pool="mean")),
-              ("dvpt_b16_b4", "dvpt", "vit-b16", 4, dict(num_prompts=50, freeze_vit=True))]
+              ("dvpt_b16_b4", "dvpt", "vit-b16", 4, dict(num_prompts=50, freeze_vit=True)),
+              ("evp_t16_b2", "evp", "vit-t16", 2, dict(freeze_vit=True)),
+              ("evp_b16_b2", "evp", "vit-b16", 2, dict(freeze_vit=True))]
 
 
 @pytest.mark.parametrize("name,method,backbone,B,extra", FP32_CASES)
@@ -349,4 +353,4 @@ def test_wrong_volume_shape_and_unsupported_modes_fail_loudly(dev):
         m.set_precision("fp8")
     from gaviko_amd.registry import build_model
     with pytest.raises(NotImplementedError):
-        build_model(dict(BASE, backbone="vit-t16", method="evp"))
+        build_model(dict(BASE, backbone="vit-t16", method="evp", input_type="laplacian"))

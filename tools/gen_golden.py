@@ -55,6 +55,8 @@ CASES = {
     "dvpt_t16_b2": ("dvpt", "vit-t16", 2, dict(num_prompts=50, freeze_vit=True)),
     "dvpt_t16_b2_mean_p8": ("dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=True, pool="mean")),
     "dvpt_b16_b4": ("dvpt", "vit-b16", 4, dict(num_prompts=50, freeze_vit=True)),
+    "evp_t16_b2": ("evp", "vit-t16", 2, dict(freeze_vit=True)),
+    "evp_b16_b2": ("evp", "vit-b16", 2, dict(freeze_vit=True)),
 }
 
 
@@ -71,10 +73,11 @@ def import_reference():
     import model.melo as melo
     import model.ssf as ssf
     import model.dvpt as dvpt
+    import model.evp as evp
     import losses.focal_loss as fl
-    for m in (vt, gv, af, ssf, dvpt):
+    for m in (vt, gv, af, ssf, dvpt, evp):
         m.load_pretrain = lp.load_pretrain
-    return dict(vt=vt, gv=gv, vpt=vpt, af=af, melo=melo, ssf=ssf, dvpt=dvpt, fl=fl)
+    return dict(vt=vt, gv=gv, vpt=vpt, af=af, melo=melo, ssf=ssf, dvpt=dvpt, evp=evp, fl=fl)
 
 
 def build_reference(mods, method, cfg):
@@ -99,6 +102,8 @@ def build_reference(mods, method, cfg):
         return mods["ssf"].ScalingShiftingFeatures(**cfg)
     if method == "dvpt":
         return mods["dvpt"].DynamicVisualPromptTuning(**cfg)
+    if method == "evp":
+        return mods["evp"].ExplicitVisualPrompting(**cfg)
     raise ValueError(method)
 
 
@@ -165,7 +170,8 @@ def attach_hooks(model, method, taps):
 
 
 FULL_GRAD_PATTERNS = (
-    "mlp_head", "ssf_s", "layers.0.0.prompt_proj", "prompt_embeddings", "prompt_positional_embedding", "prompt_proj.",
+    "mlp_head", "ssf_s", "layers.0.0.prompt_proj", "prompt_generator.shared_mlp", "prompt_generator.embedding_generator",
+    "prompt_generator.lightweight_mlp_0.", "prompt_generator.prompt_generator.proj.bias", "prompt_embeddings", "prompt_positional_embedding", "prompt_proj.",
     "prompt_projs.0.", "local_attns.0.", "layers.0.1.", "layers.0.0.to_qkv.linear_",
 )
 
