@@ -17,14 +17,14 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
 }
 
 // out[c][r] = in[r][c]; 64x64 tile through LDS (+1 pad), coalesced both sides.
-template <typename OUT>
-__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ in, OUT* __restrict__ out, int rows, int cols) {
+template <typename OUT, typename IN = float>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const IN* __restrict__ in, OUT* __restrict__ out, int rows, int cols) {
   __shared__ float tile[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
     const int r = r0 + i, c = c0 + tx;
-    tile[i][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+    tile[i][tx] = (r < rows && c < cols) ? (float)in[(size_t)r * cols + c] : 0.f;
   }
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
@@ -116,6 +116,14 @@ extern "C" int gvk_transpose_f32(const float* in, float* out, int rows, int cols
   GVK_REQUIRE(in && out && rows > 0 && cols > 0, "gvk_transpose_f32: bad arguments");
   GVK_LAUNCH(transpose_cast_kernel<float>, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, in, out, rows, cols);
   return check_launch("transpose_f32");
+}
+
+extern "C" int gvk_transpose_bf16(const void* in, void* out, int rows, int cols, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(in && out && rows > 0 && cols > 0, "gvk_transpose_bf16: bad arguments");
+  GVK_LAUNCH((transpose_cast_kernel<bf16, bf16>), dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, (bf16*)out,
+             rows, cols);
+  return check_launch("transpose_bf16");
 }
 
 extern "C" int gvk_patchify_f32(const float* img, float* out, int B, int D, int H, int W, int pd, int ph, int pw, void* stream) {

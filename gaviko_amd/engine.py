@@ -179,6 +179,7 @@ class Engine:
         self._wss = {}
         self._streams = {}
         self._recording = False
+        self._keep_inputs = False               # unfrozen backbone weights: the forward keeps the GEMM inputs for their wgrads
         self._eff: Dict[str, torch.Tensor] = {}
         # GPA projections of backbone rows ride along in the backbone's LayerNorm kernels (gvk_layernorm_*_proj)
         self._fuse_proj = (kind == "gaviko" and not self.fp32 and ops.rowproj_supported(self.Lat, dim)
@@ -470,7 +471,14 @@ class Engine:
         self.refresh_weights(need_dgrad=train)
         ws = self.workspace(B, img.device, train)
         ws["img"].copy_(img.detach())                       # static input buffer (the only per-step host-visible copy-in)
-        key = (B, train, sv["attn_drop"], sv["proj_drop"])
+        # unfrozen backbone tensors (`fft` / `bitfit`, train.py:123-137): which ones train, and whether GEMM inputs must be kept
+        bb = frozenset(n for n in self.trainable_names() if not n.startswith(self.names.head())) if (train and self.kind == "vit") else frozenset()
+        sv["bb"] = bb
+        sv["wgrad"] = any(self.p[n].dim() >= 2 and n.endswith("weight") for n in bb)
+        if bb:
+            self._bb_buffers(ws, B, img.device, sv["wgrad"])
+        key = (B, train, sv["attn_drop"], sv["proj_drop"], len(bb), sv["wgrad"])
+        self._keep_inputs = bool(sv["wgrad"])
         self._run("fwd", key, lambda: self._forward_impl(ws, sv))
         self._saved = sv if train else None
         self._saved_key = key
@@ -594,6 +602,8 @@ class Engine:
         a = nm.attn(i)
         st = ws["stat"][si]
         ops.layernorm_fwd(gin, d(a + ".norm.weight"), d(a + ".norm.bias"), M, C, y16=ws["xn"], mean=st[0], rstd=st[1])
+        if self._keep_inputs:
+            ops.copy_(ws["sav"]["xn1"][si], ws["xn"])
         self._gemm(ws["xn"], w[f"qkv{i}"], M, ws["qkv"][si], epilogue=ops.EPI_STORE_BF16, bias=self._eff.get(a + ".to_qkv.bias"))
         ops.attention_fwd(ws["qkv"][si], ws["ctx"][si], ws["lse"][si], ws["B"], self.Ts[i], self.heads, 64 ** -0.5)
         self._gemm(ws["ctx"][si], w[f"out{i}"], M, g1, epilogue=ops.EPI_BIAS_RES_F32, bias=d(a + ".to_out.0.bias"), res=gin)
@@ -613,8 +623,12 @@ class Engine:
     def _mlp_block_fwd(self, ws, i, si, g1, gout, M, train):
         nm, w, d, C = self.names, self._w16, self._d, self.C
         m = nm.mlp(i)
+        if self._keep_inputs:
+            ops.copy_(ws["sav"]["xn2"][si], ws["xn"])
         self._gemm(ws["xn"], w[f"fc1{i}"], M, ws["pre"][si] if train else None, epilogue=ops.EPI_BIAS_GELU_BF16, out1=ws["act"],
                     bias=d(m + ".net.1.bias"))           # inference keeps no pre-activation (out0 = NULL)
+        if self._keep_inputs:
+            ops.copy_(ws["sav"]["act"][si], ws["act"])
         self._gemm(ws["act"], w[f"fc2{i}"], M, gout, epilogue=ops.EPI_BIAS_RES_F32, bias=d(m + ".net.4.bias"), res=g1)
 
     # ---- GAViKO side paths --------------------------------------------------------------------------------------
@@ -736,6 +750,13 @@ class Engine:
                      ln_beta=d(nm.root + "transformer.norm.bias"), wh=d(nm.head() + ".weight"), bh=d(nm.head() + ".bias"), pooled=ws["pooled"],
                      dlogits=ws["dlogits"], dg=dG, dwh=gv[nm.head() + ".weight"], dbh=gv[nm.head() + ".bias"], B=B, T=self.Ts[-1], C=C,
                      K=self.K, r0=r0, R=R, accumulate=0)
+        bb = sv.get("bb") or ()
+        if backbone_bwd and ("transformer.norm.weight" in bb or "transformer.norm.bias" in bb):
+            g, bw = self._final_stream(ws, True), ws["bbw"]
+            ops.layernorm_fwd(g, d("transformer.norm.weight"), d("transformer.norm.bias"), B * T, C, y16=ws["xn"], mean=bw["stat"][0], rstd=bw["stat"][1])
+            ops.ssf_head_grad(g, bw["stat"][0], bw["stat"][1], d(nm.head() + ".weight"), ws["dlogits"], bw["ones"][:C], bw["zeros"][:C],
+                              gv["transformer.norm.weight"] if "transformer.norm.weight" in bb else bw["junk"][:C],
+                              gv["transformer.norm.bias"] if "transformer.norm.bias" in bb else bw["junk"][C: 2 * C], B, T, C, self.K, r0, R)
         if self.kind == "ssf" and backbone_bwd:
             # final norm + ssf (ssf.py:138): statistics of the final stream, then the pooled rows' scale / shift gradients
             g = self._final_stream(ws, True)
@@ -787,6 +808,9 @@ class Engine:
                     par_done = self._ev_record(gpa)
             # main stream, MLP block: dG1 = dGout + LN'(fc1^T(GELU'(pre) * fc2^T(dGout)))
             self._mark(f"b{i}:start")
+            bb = sv.get("bb") or ()
+            if bb:                                                           # fc2: db = colsum(dGout), dW = dGout^T . act
+                self._bb_linear_grads(ws, gv, bb, m + ".net.4", dGout, ws["dG16"], ws["sav"]["act"][i] if sv["wgrad"] else None, M, C, self.mlp)
             dvpt = self.kind == "dvpt"
             if dvpt:
                 self._dvpt_bwd_latents(ws, gv, i, dGout, M, B)
@@ -796,7 +820,11 @@ class Engine:
             self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i])
             if ssf:                                                          # fc1 + ssf_1: dy = d(pre-activation), y = saved pre-activation
                 self._ssf_linear_grad(ws, gv, m, 1, ws["dpre"], ws["pre"][i], M, self.mlp)
+            if bb:                                                           # fc1: db = colsum(dpre), dW = dpre^T . LN2(G1)
+                self._bb_linear_grads(ws, gv, bb, m + ".net.1", ws["dpre"], ws["dpre"], ws["sav"]["xn2"][i] if sv["wgrad"] else None, M, self.mlp, C)
             self._gemm(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
+            if bb:
+                self._bb_ln_grads(ws, gv, bb, m + ".net.0", ws["dx32"], ws["G1"][i], st[2], st[3], M)
             if ssf:                                                          # LN2 + ssf_0
                 self._ssf_ln_grad(ws, gv, m, ".net.0", ws["dx32"], ws["G1"][i], st[2], st[3], M)
             adapter = self.kind == "adaptformer"
@@ -819,13 +847,19 @@ class Engine:
             # main stream, attention block: dG0 = dG1 + LN'(qkv^T(attn'(out^T(dG1))))
             if ssf:                                                          # to_out + ssf_2: dy = dG1, y = G1[i] - G[i]
                 self._ssf_linear_grad(ws, gv, a, 2, dGin, ws["G1"][i], M, C, y1=ws["G"][i])
+            if bb:                                                           # to_out: db = colsum(dG1), dW = dG1^T . ctx
+                self._bb_linear_grads(ws, gv, bb, a + ".to_out.0", dGin, ws["dG16"], ws["ctx"][i], M, C, C)
             self._gemm(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
             ops.attention_bwd(ws["qkv"][i], ws["ctx"][i], ws["dctx"], ws["lse"][i], ws["delta"], ws["dqkv"], B, T, self.heads, 64 ** -0.5)
             if self.kind == "melo":
                 self._melo_bwd(ws, gv, i, M)
             if ssf:                                                          # to_qkv + ssf_1: dy = dqkv, y = saved qkv
                 self._ssf_linear_grad(ws, gv, a, 1, ws["dqkv"], ws["qkv"][i], M, 3 * C)
+            if bb:                                                           # to_qkv (bias-free): dW = dqkv^T . LN1(G)
+                self._bb_linear_grads(ws, gv, bb, a + ".to_qkv", None, ws["dqkv"], ws["sav"]["xn1"][i] if sv["wgrad"] else None, M, 3 * C, C)
             self._gemm(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
+            if bb:
+                self._bb_ln_grads(ws, gv, bb, a + ".norm", ws["dx32"], ws["G"][i], st[0], st[1], M)
             if ssf:                                                          # LN1 + ssf_0
                 self._ssf_ln_grad(ws, gv, a, ".norm", ws["dx32"], ws["G"][i], st[0], st[1], M)
             self._mark(f"b{i}:qkvd")
@@ -868,6 +902,8 @@ class Engine:
         if gaviko:
             self._wait(None, "gpa")
             self._wait(None, "loc")
+        if last and sv.get("bb"):
+            self._bb_embed_grads(ws, gv, sv["bb"], dGout, B)
         if last and self.kind == "evp":
             self._evp_bwd_finish(ws, gv, B)
         if last and self.kind == "ssf":
@@ -885,7 +921,7 @@ class Engine:
                                self.P, C)
 
     def _grad_supported(self, name: str) -> bool:
-        if name.startswith(self.names.head()):
+        if name.startswith(self.names.head()) or self.kind == "vit":       # plain ViT: every tensor (`linear` / `bitfit` / `fft`)
             return True
         if self.kind == "gaviko":
             return ("local_attns" in name or "prompt_projs" in name or name in ("prompt_embeddings", "prompt_positional_embedding"))
@@ -1047,6 +1083,63 @@ class Engine:
             if self.lora_s != 1:
                 ops.scale_(gv[na], float(self.lora_s))
                 ops.scale_(gv[nb], float(self.lora_s))
+
+    # ---- unfrozen ViT tensors (`bitfit` / `fft`, train.py:123-137): biases and LayerNorm affines from column sums, weights from
+    #      wgrad GEMMs dW = dY^T . X run as NT GEMMs over the transposed operands (contraction over the padded token count) -------
+    def _bb_buffers(self, ws, B, device, wgrad):
+        if "bbw" not in ws:
+            C, M = self.C, B * self.T
+            n = max(self.mlp, 3 * C, self.Kp)
+            ws["bbw"] = dict(ones=torch.ones(n, device=device), zeros=torch.zeros(n, device=device), junk=torch.zeros(2 * n, device=device),
+                             scratch=torch.zeros(64 * 2 * n, device=device), stat=[torch.zeros(M, device=device), torch.zeros(M, device=device)])
+        if wgrad and "sav" not in ws:
+            C, M, Mp = self.C, B * self.T, ops.pad_rows(B * self.T)
+            z = lambda r, c: ops.act_zeros(r, c, self.adt, device)
+            ws["sav"] = dict(xn1=[z(M, C) for _ in range(self.depth)], xn2=[z(M, C) for _ in range(self.depth)],
+                             act=[z(M, self.mlp) for _ in range(self.depth)])
+            ws["tA"] = z(max(self.mlp, 3 * C), Mp)
+            ws["tB"] = z(max(self.mlp, self.Kp), Mp)
+            ws["pg16"] = z(B * self.N, C)
+            ws["pg32"] = ops.act_zeros(B * self.N, C, torch.float32, device)
+
+    def _bb_wgrad(self, ws, dy_op, x_op, out, M, N, K):
+        """out [N][K] (fp32) = dy_op[0:M, 0:N]^T . x_op[0:M, 0:K]; rows >= M of both operand buffers are zero by construction."""
+        Mp = ops.pad_rows(M)
+        tA, tB = ws["tA"].view(-1)[: ops.pad_rows(N) * Mp].view(-1, Mp), ws["tB"].view(-1)[: ops.pad_rows(K) * Mp].view(-1, Mp)
+        ops.transpose_any(dy_op, tA, Mp, N)
+        ops.transpose_any(x_op, tB, Mp, K)
+        self._gemm(tA, tB[:K], N, out.view(N, K), epilogue=ops.EPI_STORE_F32)
+
+    def _bb_linear_grads(self, ws, gv, bb, prefix, dy32, dy_op, x_op, M, N, K):
+        """db = colsum(dy), dW = dy^T . x for one Linear of the backbone, for whichever of the two trains."""
+        bw = ws["bbw"]
+        if prefix + ".bias" in bb:
+            src = dy32 if dy32 is not None else dy_op
+            ops.colsum_any(src, gv[prefix + ".bias"], bw["ones"][:N], bw["zeros"][:N], bw["junk"][:N], bw["scratch"], M, N)
+        if prefix + ".weight" in bb:
+            self._bb_wgrad(ws, dy_op, x_op, gv[prefix + ".weight"], M, N, K)
+
+    def _bb_ln_grads(self, ws, gv, bb, prefix, dy, x, mean, rstd, M):
+        wn, bn = prefix + ".weight", prefix + ".bias"
+        if wn in bb or bn in bb:
+            C, junk = self.C, ws["bbw"]["junk"]
+            ops.layernorm_bwd_affine(dy, x, mean, rstd, gv[wn] if wn in bb else junk[:C], gv[bn] if bn in bb else junk[C: 2 * C], ws["scratch"], M, C)
+
+    def _bb_embed_grads(self, ws, gv, bb, dG0, B):
+        """pos_embedding / cls_token (batch sums of the input gradient), conv_proj bias and weight (the patch rows)."""
+        C, T, N, bw = self.C, self.T, self.N, ws["bbw"]
+        nm = self.names
+        if "pos_embedding" in bb:
+            ops.rows_batch_sum(dG0, gv["pos_embedding"].view(T, C), None, B, T, 0, T, C)
+        if "cls_token" in bb:
+            ops.rows_batch_sum(dG0, gv["cls_token"].view(1, C), None, B, T, 0, 1, C)
+        cw, cb = nm.conv() + ".weight", nm.conv() + ".bias"
+        if cb in bb:
+            ops.colsum_any(dG0, gv[cb], bw["ones"][:C], bw["zeros"][:C], bw["junk"][:C], bw["scratch"], B * N, C, rows_in=N, rows_out=T, row_off=1)
+        if cw in bb:
+            ops.rows_gather(dG0, ws["pg32"], B, T, N, C, 1)
+            ops.to_operand(ws["pg32"], ws["pg16"], self.adt)
+            self._bb_wgrad(ws, ws["pg16"], ws["cols"], gv[cw].view(C, self.Kp), B * N, C, self.Kp)
 
     # ---- EVP (evp.py): prompts from a high-pass copy of the volume + the patch embeddings, added in front of every layer --------
     def _evp_state(self, device):

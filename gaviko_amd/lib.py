@@ -70,6 +70,7 @@ SIGNATURES = {
     "gvk_attention_bwd_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "gvk_patchify_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gvk_transpose_f32": [_P, _P, _I, _I, _P],
+    "gvk_transpose_bf16": [_P, _P, _I, _I, _P],
     "gvk_copy_async": [_P, _P, C.c_size_t, _P],
     "gvk_copy_f32_strided": [_P, _P, _I, _I, _I, _P],
     "gvk_cast_f32_bf16": [_P, _P, _L, _P],

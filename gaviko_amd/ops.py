@@ -109,6 +109,21 @@ def transpose_operand(x: torch.Tensor, out: torch.Tensor = None, dtype=torch.bfl
     return out
 
 
+def transpose_any(x: torch.Tensor, out: torch.Tensor, rows: int, cols: int) -> None:
+    """out [cols][rows] = x[rows][cols]^T within one dtype (bf16 or fp32): operand transposes of the wgrad GEMMs."""
+    if x.dtype != out.dtype or x.dtype not in (torch.bfloat16, torch.float32):
+        raise L.GavikoHipError("transpose_any: x and out must both be bf16 or both fp32")
+    _chk(x, x.dtype, "transpose_any x", rows * cols)
+    _chk(out, x.dtype, "transpose_any out", rows * cols)
+    fn = L.load().gvk_transpose_f32 if x.dtype == torch.float32 else L.load().gvk_transpose_bf16
+    L.check(fn(L.ptr(x), L.ptr(out), rows, cols, L.stream_ptr()), "gvk_transpose")
+
+
+def colsum_any(x, out, ones, zeros, junk, scratch, M, N, *, ld=None, rows_in=0, rows_out=0, row_off=0):
+    """out[n] = sum_m x[m][n] for a bf16 / fp32 matrix (optionally through the PATCH row mapping): the column-sum half of gvk_ssf_colgrad."""
+    ssf_colgrad(x, x, ones, zeros, junk, out, scratch, M, N, ld_dy=ld, ld_y=ld, rows_in=rows_in, rows_out=rows_out, row_off=row_off)
+
+
 def memset_zero(t: torch.Tensor) -> None:
     """Stream-ordered zero fill (hipMemsetAsync through the library so that it is part of a recorded launch plan)."""
     if not t.is_contiguous():

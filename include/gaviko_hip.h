@@ -98,6 +98,7 @@ int gvk_attention_bwd_f32(const float* qkv, const float* out, const float* dout,
                           int B, int T, int H, int ld_qkv, int ld_out, float scale, void* stream);
 int gvk_patchify_f32(const float* img, float* out, int B, int D, int H, int W, int pd, int ph, int pw, void* stream);
 int gvk_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
+int gvk_transpose_bf16(const void* in, void* out, int rows, int cols, void* stream);   /* operand transposes of the unfrozen-backbone wgrad GEMMs */
 int gvk_copy_f32_strided(const float* in, float* out, int M, int C, int ld_in, void* stream);   /* out[M][C] = in[M][ld_in] cols 0..C */
 /* stream-ordered device-to-device copy (recorded into a launch plan like any launch) */
 int gvk_copy_async(void* dst, const void* src, size_t bytes, void* stream);

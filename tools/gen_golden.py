@@ -55,6 +55,9 @@ CASES = {
     "dvpt_t16_b2": ("dvpt", "vit-t16", 2, dict(num_prompts=50, freeze_vit=True)),
     "dvpt_t16_b2_mean_p8": ("dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=True, pool="mean")),
     "dvpt_b16_b4": ("dvpt", "vit-b16", 4, dict(num_prompts=50, freeze_vit=True)),
+    "bitfit_t16_b2": ("bitfit", "vit-t16", 2, {}),
+    "fft_t16_b2": ("fft", "vit-t16", 2, {}),
+    "fft_b16_b2": ("fft", "vit-b16", 2, {}),
     "evp_t16_b2": ("evp", "vit-t16", 2, dict(freeze_vit=True)),
     "evp_b16_b2": ("evp", "vit-b16", 2, dict(freeze_vit=True)),
 }
@@ -170,7 +173,7 @@ def attach_hooks(model, method, taps):
 
 
 FULL_GRAD_PATTERNS = (
-    "mlp_head", "ssf_s", "layers.0.0.prompt_proj", "prompt_generator.shared_mlp", "prompt_generator.embedding_generator",
+    "mlp_head", "ssf_s", "cls_token", "transformer.norm.", "conv_proj.0.bias", "layers.0.0.norm", "layers.0.0.to_out.0.bias", "layers.0.0.prompt_proj", "prompt_generator.shared_mlp", "prompt_generator.embedding_generator",
     "prompt_generator.lightweight_mlp_0.", "prompt_generator.prompt_generator.proj.bias", "prompt_embeddings", "prompt_positional_embedding", "prompt_proj.",
     "prompt_projs.0.", "local_attns.0.", "layers.0.1.", "layers.0.0.to_qkv.linear_",
 )
