@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="volumes per GPU")
     ap.add_argument("--backbone", default="vit-b16")
-    ap.add_argument("--loss", default="ce", choices=["ce", "focal"])
+    ap.add_argument("--loss", default="ce", choices=["ce", "focal", "ce-torch"])   # ce-torch: torch's own op, for A/B only
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -143,13 +143,10 @@ def main():
     lo = rank * B                                    # shard of the global batch owned by this rank
     x = torch.from_numpy(synth.volumes(lo, B)).to(dev)
     y = torch.from_numpy(synth.labels(lo, B)).to(dev)
-    if args.loss == "focal":
-        def criterion(lg, t):                        # focal_loss.py:84-115 as it executes (double clamp+softmax)
-            p = torch.softmax(torch.clamp(lg, 1e-16, 1 - 1e-16), -1)
-            p = torch.softmax(torch.clamp(p, 1e-16, 1 - 1e-16), -1)
-            pt = p.gather(-1, t.view(-1, 1)).squeeze(-1)
-            return ((1 - pt) ** 1.2 * -torch.log(1e-16 + pt)).mean()
-    else:
+    # the loss seed is part of the step: one fused launch (loss + dlogits + the running loss / accuracy sums of train.py:327-328)
+    from gaviko_amd.losses import CrossEntropyLoss, FocalLoss, StepMeter
+    criterion = (FocalLoss(gamma=1.2) if args.loss == "focal" else CrossEntropyLoss()).attach_meter(StepMeter(dev))
+    if args.loss == "ce-torch":
         criterion = torch.nn.functional.cross_entropy
 
     params = list(model.parameters())                 # what optimizer.zero_grad() walks: a flat list, not the module tree

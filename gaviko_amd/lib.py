@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgaviko_hip.so")
+LIB_PATH = os.environ.get("GAVIKO_HIP_LIB") or os.path.join(_HERE, "libgaviko_hip.so")     # override: A/B runs of two builds
 
 
 class GemmDesc(C.Structure):
@@ -25,10 +25,10 @@ class GemmDesc(C.Structure):
     ]
 
 
-def _struct(name, ptrs, ints, floats=(), u64=()):
-    """C struct with the header's field order: pointers, int32s, floats, uint64s."""
+def _struct(name, ptrs, ints, floats=(), u64=(), i64=()):
+    """C struct with the header's field order: pointers, int32s, floats, uint64s, int64s."""
     fields = [(f, C.c_void_p) for f in ptrs] + [(f, C.c_int32) for f in ints] + [(f, C.c_float) for f in floats] + \
-             [(f, C.c_uint64) for f in u64]
+             [(f, C.c_uint64) for f in u64] + [(f, C.c_int64) for f in i64]
     return type(name, (C.Structure,), {"_fields_": fields})
 
 
@@ -53,6 +53,7 @@ SsfColgradDesc = _struct("SsfColgradDesc", ["dy", "y0", "y1", "pos", "s", "t", "
 DvptDesc = _struct("DvptDesc", ["z", "enh", "lse", "dcomb", "gate", "bu", "colsum_dy", "delta", "dz", "dgate"], ["B", "T", "P", "L", "C"], ["scale"])
 AdamDesc = _struct("AdamDesc", ["ptr_tab", "blk_tab", "grad", "m", "v", "norm_sq"], ["nblocks"],
                    ["lr", "beta1", "beta2", "eps", "bias_c1", "bias_c2", "max_norm"])
+LossDesc = _struct("LossDesc", ["logits", "target", "weights", "loss", "dlogits", "meter"], ["B", "K", "kind", "reduction"], ["gamma", "eps"], i64=["ignore_index"])
 RowProjDesc = _struct("RowProjDesc", ["w", "bias", "y", "z"], ["L", "w_layout", "act"])
 ReduceJob = _struct("ReduceJob", ["a", "b", "out"], ["M", "J", "L", "accumulate"])
 HeadDesc = _struct("HeadDesc", ["g", "ln_gamma", "ln_beta", "wh", "bh", "logits", "pooled", "dlogits", "dg", "dwh", "dbh"],
@@ -119,6 +120,7 @@ SIGNATURES = {
     "gvk_rows_gather": [_P, _P, _I, _I, _I, _I, _I, _P],
     "gvk_sumsq": [_P, C.c_int64, _P, _P, _P],
     "gvk_adam_step": [C.POINTER(AdamDesc), _P],
+    "gvk_loss_fwd_bwd": [C.POINTER(LossDesc), _P],
     "gvk_memset_async": [_P, _I, C.c_size_t, _P],
     "gvk_seed_advance": [_P, C.c_uint64, _P],
     "gvk_scale_f32": [_P, _F, C.c_long, _P],
@@ -133,7 +135,7 @@ NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, [
              "gvk_plan_set_timing": (C.c_int, [C.c_int]),
              "gvk_plan_event_elapsed": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)])}
 STRUCTS = {"gvk_gemm_desc": GemmDesc, "gvk_skinny_down_desc": SkinnyDownDesc, "gvk_skinny_up_desc": SkinnyUpDesc,
-           "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob, "gvk_rowproj_desc": RowProjDesc, "gvk_adam_desc": AdamDesc, "gvk_ssf_colgrad_desc": SsfColgradDesc, "gvk_dvpt_desc": DvptDesc}
+           "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob, "gvk_rowproj_desc": RowProjDesc, "gvk_adam_desc": AdamDesc, "gvk_loss_desc": LossDesc, "gvk_ssf_colgrad_desc": SsfColgradDesc, "gvk_dvpt_desc": DvptDesc}
 
 _lib = None
 

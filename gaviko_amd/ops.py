@@ -585,3 +585,25 @@ def rows_gather(tok, dst, B, T, N, C_, row_off):
     _chk(tok, torch.float32, "rows_gather tok", B * T * C_)
     _chk(dst, torch.float32, "rows_gather dst", B * N * C_)
     L.check(L.load().gvk_rows_gather(L.ptr(tok), L.ptr(dst), B, T, N, C_, row_off, L.stream_ptr()), "gvk_rows_gather")
+
+
+# ---- loss seed (train.py:176-179, 283/306, 327-328) -------------------------------------------------------------------------
+LOSS_CE, LOSS_FOCAL = 0, 1
+
+
+def loss_fwd_bwd(logits, target, loss, dlogits, kind, gamma=0.0, eps=1e-16, ignore_index=-100, weights=None, meter=None, reduction="mean"):
+    """loss[0] = criterion(logits, target), dlogits = its gradient, meter += (loss*B, #correct, B): one launch, no host read."""
+    _chk(logits, torch.float32, "loss logits")
+    B, K = logits.shape
+    if target.dtype != torch.int64 or not target.is_contiguous() or target.numel() != B:
+        raise ValueError("loss target must be a contiguous int64 [B] tensor")
+    _chk(loss, torch.float32, "loss out", 1)
+    _chk(dlogits, torch.float32, "loss dlogits", B * K)
+    if weights is not None:
+        _chk(weights, torch.float32, "loss weights", K)
+    if meter is not None:
+        _chk(meter, torch.float32, "loss meter", 3)
+    d = L.LossDesc(logits=L.ptr(logits), target=L.ptr(target), weights=L.ptr(weights) if weights is not None else None,
+                   loss=L.ptr(loss), dlogits=L.ptr(dlogits), meter=L.ptr(meter) if meter is not None else None,
+                   B=B, K=K, kind=kind, reduction={"mean": 0, "sum": 1}[reduction], gamma=gamma, eps=eps, ignore_index=ignore_index)
+    L.check(L.load().gvk_loss_fwd_bwd(C.byref(d), L.stream_ptr()), "gvk_loss_fwd_bwd")

@@ -380,6 +380,22 @@ typedef struct gvk_adam_desc {
 int gvk_sumsq(const float* x, int64_t n, float* scratch, float* out, void* stream);
 int gvk_adam_step(const gvk_adam_desc* d, void* stream);
 
+/* ---- loss seed (caller side of the path) --------------------------------------------------------------------------
+ * Replaces train.py:176-179 + 283/306 (criterion = FocalLoss(gamma=1.2) | CrossEntropyLoss; loss = criterion(outputs,
+ * labels); loss.backward() seed) and the two per-step host reads of train.py:327-328.  One launch: loss[0] = the reduced
+ * loss, dlogits = d loss / d logits, and (meter != NULL) meter[0] += loss*B, meter[1] += #(argmax == target),
+ * meter[2] += B.  GVK_LOSS_FOCAL follows losses/focal_loss.py:84-115 as it executes (clamp to [eps, 1-eps] + softmax,
+ * TWICE; weights = per-class rescaling or NULL; ignore_index rows contribute nothing).  target is int64 [B]. */
+enum { GVK_LOSS_CE = 0, GVK_LOSS_FOCAL = 1 };
+typedef struct gvk_loss_desc {
+  const float* logits; const void* target; const float* weights;
+  float* loss; float* dlogits; float* meter;
+  int32_t B, K, kind, reduction;           /* reduction 0 = 'mean', 1 = 'sum' */
+  float gamma, eps;
+  int64_t ignore_index;
+} gvk_loss_desc;
+int gvk_loss_fwd_bwd(const gvk_loss_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,15 +43,15 @@ def test_ctypes_structs_match_header_field_order():
             stmt = stmt.strip()
             if not stmt:
                 continue
-            typ = re.match(r"(const\s+)?(void|float|int32_t|uint64_t)\s*(\*?)", stmt)
-            names = re.sub(r"^(const\s+)?(void|float|int32_t|uint64_t)", "", stmt)
+            typ = re.match(r"(const\s+)?(void|float|int32_t|uint64_t|int64_t)\s*(\*?)", stmt)
+            names = re.sub(r"^(const\s+)?(void|float|int32_t|uint64_t|int64_t)", "", stmt)
             for nm in names.split(","):
                 nm = nm.strip()
                 is_ptr = nm.startswith("*") or typ.group(3) == "*" and nm == names.split(",")[0].strip()
                 fields.append((nm.lstrip("* ").strip(), "ptr" if "*" in nm or (typ.group(3) == "*" and nm == names.split(",")[0].strip()) else typ.group(2)))
         want = []
         for name, ct in cls._fields_:
-            kind = {ctypes.c_void_p: "ptr", ctypes.c_int32: "int32_t", ctypes.c_float: "float", ctypes.c_uint64: "uint64_t"}[ct]
+            kind = {ctypes.c_void_p: "ptr", ctypes.c_int32: "int32_t", ctypes.c_float: "float", ctypes.c_uint64: "uint64_t", ctypes.c_int64: "int64_t"}[ct]
             want.append((name, kind))
         assert fields == want, f"{cname}: header {fields} != ctypes {want}"
 

@@ -81,6 +81,17 @@ def test_focal_loss_quirk_matches_reference_fixture():
     assert (g["grad"][outside] == 0).all()
 
 
+@pytest.mark.parametrize("red", ["mean", "sum"])
+def test_focal_loss_weights_and_ignored_rows_match_reference_fixture(red):
+    g = golden("focal_loss_weighted")
+    lg = torch.from_numpy(g["logits"]).requires_grad_(True)
+    loss = oracle.focal_loss(lg, torch.from_numpy(g["target"]), weights=torch.from_numpy(g["weights"]), reduction=red)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss_" + red])) < 1e-5 * max(1.0, float(g["loss_" + red]))
+    assert np.abs(lg.grad.numpy() - g["grad_" + red]).max() < 1e-6
+    assert (lg.grad.numpy()[g["target"] == -100] == 0).all()
+
+
 @pytest.mark.parametrize("lk", [(6, 6, 6), (3, 6, 6), (3, 3, 3)])
 def test_window_mask_matches_reference_mask(lk):
     g = golden(f"mwsa_mask_{lk[0]}{lk[1]}{lk[2]}")

@@ -279,6 +279,19 @@ def focal_case(mods, outdir):
     np.savez_compressed(os.path.join(outdir, "focal_loss.npz"), logits=lg.detach().numpy(), target=y.numpy(),
                         loss=np.float32(loss.item()), grad=lg.grad.numpy())
     print("focal_loss:", loss.item())
+    # class weights + ignored rows + both reductions (focal_loss.py:54-58, 60-68, 103-118)
+    w = torch.tensor([0.5, 1.0, 2.0, 1.5, 0.7])
+    y2 = y.clone()
+    y2[3] = -100
+    y2[11] = -100
+    out = {"logits": lg.detach().numpy(), "target": y2.numpy(), "weights": w.numpy()}
+    for red in ("mean", "sum"):
+        lg2 = lg.detach().clone().requires_grad_(True)
+        loss = mods["fl"].FocalLoss(gamma=1.2, weights=w, reduction=red)(lg2, y2)
+        loss.backward()
+        out["loss_" + red], out["grad_" + red] = np.float32(loss.item()), lg2.grad.numpy()
+        print("focal_loss weighted/ignored", red, loss.item())
+    np.savez_compressed(os.path.join(outdir, "focal_loss_weighted.npz"), **out)
 
 
 def mask_case(mods, outdir):
