@@ -83,6 +83,7 @@ class AdaptFormer(HotPathModule):
         self.__dict__["_kw_precision"] = kwargs.get("precision")      # "bf16" (default) | "fp32": see HotPathModule.set_precision
         self._cfg = dict(image_size=ih, image_patch_size=ph, frames=frames, frame_patch_size=frame_patch_size, num_classes=num_classes,
                          pool=pool, channels=channels, dim_head=dim_head, backbone=backbone, dropout=dropout, emb_dropout=emb_dropout)
+        self._load_backbone()
 
     def train(self, mode=True):
         """adaptformer.py:175-191 (returns None)."""

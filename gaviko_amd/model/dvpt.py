@@ -83,6 +83,7 @@ class DynamicVisualPromptTuning(HotPathModule):
         self._cfg = dict(image_size=ih, image_patch_size=ph, frames=frames, frame_patch_size=frame_patch_size, num_classes=num_classes,
                          pool=pool, channels=channels, dim_head=dim_head, backbone=backbone, dropout=dropout, emb_dropout=emb_dropout,
                          num_prompts=num_prompts)
+        self._load_backbone()
 
     def train(self, mode=True):
         """dvpt.py:170-184 (returns None)."""

@@ -84,6 +84,7 @@ class ExplicitVisualPrompting(HotPathModule):
         self._cfg = dict(image_size=ih, image_patch_size=ph, frames=frames, frame_patch_size=frame_patch_size, num_classes=num_classes,
                          pool=pool, channels=channels, dim_head=dim_head, backbone=backbone, dropout=dropout, emb_dropout=emb_dropout,
                          scale_factor=scale_factor, freq_nums=freq_nums)
+        self._load_backbone()
 
     def train(self, mode=True):
         """evp.py:333-344 (returns None)."""

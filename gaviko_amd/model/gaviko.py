@@ -192,6 +192,7 @@ class Gaviko(HotPathModule):
                          prompt_latent_dim=prompt_latent_dim, local_dim=local_dim, local_k=tuple(local_k),
                          DHW=None if DHW is None else tuple(DHW), share_factor=share_factor, attn_drop=attn_drop, proj_drop=proj_drop,
                          dropout=dropout, emb_dropout=emb_dropout)
+        self._load_backbone()
 
     def init_weights(model, scale_factor=1.0):
         """Initialisation scheme of gaviko.py:445-511 (including its quirk: proj_down.bias zeroed twice, proj_up.bias left

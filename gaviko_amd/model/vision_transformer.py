@@ -8,6 +8,9 @@ include/gaviko_hip.h (see gaviko_amd/engine.py); there is no eager or CPU implem
 """
 from __future__ import annotations
 
+import logging
+import os
+
 import torch
 from torch import nn
 
@@ -130,6 +133,24 @@ class HotPathModule(nn.Module):
     def _drop_config(self) -> dict:
         return {}
 
+    def _load_backbone(self) -> None:
+        """The constructor step of vision_transformer.py:140-145 (and its five copies): converted timm weights loaded with
+        strict=False.  Offline: the raw timm state dict is read from ./pretrained/<timm model name> -- where the reference leaves it
+        (load_pretrained.py:26-28) -- or from $GAVIKO_PRETRAINED_DIR; when the file is absent the random initialisation stays."""
+        from ..utils import load_pretrained as lp
+        backbone = self._cfg.get("backbone")
+        if backbone is None:
+            return
+        save_dir = os.environ.get("GAVIKO_PRETRAINED_DIR", "./pretrained")
+        path = lp.pretrained_path(backbone, save_dir)
+        if path is None or not os.path.exists(path):
+            logging.info(f"no pretrained file for {backbone} under {save_dir}: keeping the random initialisation")
+            return
+        logging.info(f"Loading pretrained {backbone}...")
+        new_dict = lp.load_pretrain(backbone, self.num_patches, self._cfg["frame_patch_size"], save_dir)
+        self.load_state_dict(new_dict, strict=False)
+        logging.info(f"Load pretrained {backbone} sucessfully!")
+
     def set_precision(self, precision):
         """'bf16' (default): MFMA bf16 operands with fp32 accumulation / residual stream / statistics.  'fp32': exact fp32
         arithmetic throughout -- what the reference computes when config['train']['fp16'] is false (train.py:157).
@@ -199,6 +220,7 @@ class VisionTransformer(HotPathModule):
         self.__dict__["_kw_precision"] = kwargs.get("precision")      # "bf16" (default) | "fp32": see HotPathModule.set_precision
         self._cfg = dict(image_size=ih, image_patch_size=ph, frames=frames, frame_patch_size=frame_patch_size, num_classes=num_classes,
                          pool=pool, channels=channels, dim_head=dim_head, backbone=backbone, dropout=dropout, emb_dropout=emb_dropout)
+        self._load_backbone()
 
     def forward(self, img):
         if self.training and (self._cfg["dropout"] > 0 or self._cfg["emb_dropout"] > 0):

@@ -68,6 +68,7 @@ def import_reference():
     sys.modules.setdefault("timm", types.ModuleType("timm"))
     sys.path.insert(0, REF)
     import utils.load_pretrained as lp
+    lp_orig = lp.load_pretrain
     lp.load_pretrain = lambda *a, **k: {}
     import model.vision_transformer as vt
     import model.gaviko as gv
@@ -80,7 +81,7 @@ def import_reference():
     import losses.focal_loss as fl
     for m in (vt, gv, af, ssf, dvpt, evp):
         m.load_pretrain = lp.load_pretrain
-    return dict(vt=vt, gv=gv, vpt=vpt, af=af, melo=melo, ssf=ssf, dvpt=dvpt, evp=evp, fl=fl)
+    return dict(vt=vt, gv=gv, vpt=vpt, af=af, melo=melo, ssf=ssf, dvpt=dvpt, evp=evp, fl=fl, lp=lp, lp_orig=lp_orig)
 
 
 def build_reference(mods, method, cfg):
@@ -294,6 +295,45 @@ def focal_case(mods, outdir):
     np.savez_compressed(os.path.join(outdir, "focal_loss_weighted.npz"), **out)
 
 
+def fake_timm_state_dict(C=16, depth=2, seed=0):
+    """A tiny state dict with the key set and tensor ranks of a timm in21k ViT (vision_transformer.py of timm 0.x: cls_token, pos_embed,
+    patch_embed.proj, blocks.i.{norm1,attn.qkv,attn.proj,norm2,mlp.fc1,mlp.fc2}, norm, pre_logits.fc, head)."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    sd = {"cls_token": r(1, 1, C), "pos_embed": r(1, 197, C), "patch_embed.proj.weight": r(C, 3, 16, 16), "patch_embed.proj.bias": r(C)}
+    for i in range(depth):
+        b = f"blocks.{i}."
+        sd.update({b + "norm1.weight": r(C), b + "norm1.bias": r(C), b + "attn.qkv.weight": r(3 * C, C), b + "attn.qkv.bias": r(3 * C),
+                   b + "attn.proj.weight": r(C, C), b + "attn.proj.bias": r(C), b + "norm2.weight": r(C), b + "norm2.bias": r(C),
+                   b + "mlp.fc1.weight": r(4 * C, C), b + "mlp.fc1.bias": r(4 * C), b + "mlp.fc2.weight": r(C, 4 * C), b + "mlp.fc2.bias": r(C)})
+    sd.update({"norm.weight": r(C), "norm.bias": r(C), "pre_logits.fc.weight": r(C, C), "pre_logits.fc.bias": r(C),
+               "head.weight": r(7, C), "head.bias": r(7)})
+    return sd
+
+
+def pretrain_case(mods, outdir):
+    """The reference's load_pretrain (load_pretrained.py:8-99) run on a synthetic timm-shaped state dict: timm.create_model is
+    pointed at an object that returns it (there is no network); everything after line 24 is the reference's own code."""
+    import tempfile
+    lp = mods["lp"]
+    for tag, num_patches, depth_dim in (("", 1000, 12), ("_n216_d4", 216, 4)):
+        sd = fake_timm_state_dict()
+
+        class Fake:
+            def state_dict(self):
+                return sd
+        lp.timm.create_model = lambda name, pretrained=True: Fake()
+        with tempfile.TemporaryDirectory() as tmp:
+            out = mods["lp_orig"]("vit-t16", num_patches, depth_dim, tmp)
+            saved = sorted(os.listdir(tmp))
+        fx = {"in/" + k: v.numpy() for k, v in sd.items()}
+        fx.update({"out/" + k: v.numpy() for k, v in out.items()})
+        fx["meta/num_patches"], fx["meta/depth_dim"], fx["meta/saved_as"] = np.int64(num_patches), np.int64(depth_dim), np.array(saved)
+        path = os.path.join(outdir, f"pretrain_convert{tag}.npz")
+        np.savez_compressed(path, **fx)
+        print("pretrain_convert" + tag, len(out), "keys,", saved, f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def mask_case(mods, outdir):
     """MWSA window masks of the reference for both shipped local_k (gaviko.py:212-227), as bit-packed allow maps."""
     for lk in ((6, 6, 6), (3, 6, 6), (3, 3, 3)):
@@ -308,12 +348,14 @@ def main():
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
     mods = import_reference()
-    names = sys.argv[1:] or (["focal", "mask"] + list(CASES))
+    names = sys.argv[1:] or (["focal", "mask", "pretrain"] + list(CASES))
     for n in names:
         if n == "focal":
             focal_case(mods, outdir)
         elif n == "mask":
             mask_case(mods, outdir)
+        elif n == "pretrain":
+            pretrain_case(mods, outdir)
         else:
             run_case(mods, n, outdir)
 
