@@ -133,7 +133,12 @@ extern "C" int gvk_plan_event_record(void* stream) {
   GVK_REQUIRE(g_rec != nullptr, "gvk_plan_event_record: only valid while a plan is being recorded");
   static const bool env_timing = getenv("GAVIKO_HIP_PLAN_TIMING") != nullptr;  // diagnostics: tools/plan_marks.py
   hipEvent_t ev;
-  hipError_t e = hipEventCreateWithFlags(&ev, (env_timing || g_plan_timing) ? hipEventDefault : hipEventDisableTiming);
+  // Plan events only order streams of ONE device: kernel boundaries already carry the device-scope release/acquire, so the
+  // system-scope fence (an L2 writeback + invalidate per record, and refetches for whatever runs next) is switched off.
+  // GAVIKO_HIP_EVENT_FENCE=1 restores the default events.
+  static const bool sys_fence = getenv("GAVIKO_HIP_EVENT_FENCE") != nullptr;
+  const unsigned flags = ((env_timing || g_plan_timing) ? hipEventDefault : hipEventDisableTiming) | (sys_fence ? 0u : hipEventDisableSystemFence);
+  hipError_t e = hipEventCreateWithFlags(&ev, flags);
   if (e != hipSuccess) return set_error(-1, "hipEventCreate: %s", hipGetErrorString(e));
   g_rec->events.push_back(ev);
   hipStream_t s = (hipStream_t)stream;

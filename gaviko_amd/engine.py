@@ -37,6 +37,9 @@ STEP_MODE = {"1": "plan", "0": "eager"}.get(_MODE, _MODE)
 USE_GRAPHS = STEP_MODE != "eager"
 GRAPH_WARMUP = 2
 PLAN_TIMING = os.environ.get("GAVIKO_HIP_PLAN_TIMING") is not None
+# Timing ablations (tools/ablate_streams.py) -- the RESULTS ARE WRONG with either switch; they only answer "where does the step go":
+#   nowait: the main stream skips its waits on the side chains;  noside: the MWSA / GPA chains are not launched at all.
+_ABLATE = set(filter(None, os.environ.get("GAVIKO_HIP_ABLATE", "").split(",")))
 
 # bench.py instrumentation: when a dict, every GEMM launch is bracketed by HIP events recorded on the launch stream
 # bench.py instrumentation: when set to a dict, plans recorded from then on bracket every GEMM launch (and the patch-embed
@@ -382,6 +385,8 @@ class Engine:
 
     def _ev_record(self, stream):
         """Record an event on `stream`; while a launch plan is being recorded the event belongs to the plan."""
+        if "noevents" in _ABLATE:
+            return None
         if self._recording:
             rc = L.load().gvk_plan_event_record(stream.cuda_stream)
             if rc < 0:
@@ -397,6 +402,8 @@ class Engine:
             self._marks.append((name, self._ev_record(torch.cuda.current_stream())))
 
     def _ev_wait(self, stream, ev):
+        if "noevents" in _ABLATE or ("nowait" in _ABLATE and stream.cuda_stream == torch.cuda.current_stream().cuda_stream):
+            return
         if self._recording:
             L.check(L.load().gvk_plan_event_wait(stream.cuda_stream, ev), "gvk_plan_event_wait")
         else:
@@ -633,6 +640,8 @@ class Engine:
 
     # ---- GAViKO side paths --------------------------------------------------------------------------------------
     def _mwsa_fwd(self, ws, sv, i, si, lin, lout):
+        if "noside" in _ABLATE:
+            return
         s = i // self.share
         pre = f"transformer.local_attns.{s}"
         d, C, Lt, B = self._d, self.C, self.Lat, ws["B"]
@@ -658,12 +667,16 @@ class Engine:
 
     def _gpa_down_local(self, ws, i, si, lnew, B):
         """ll = QuickGELU(proj_down(L')) (gaviko.py:156): depends on the MWSA chain only, so it runs at its tail."""
+        if "noside" in _ABLATE:
+            return
         pre, _ = self._gpa_names(i)
         d, g = self._d, ws["gp"][si]
         ops.skinny_down(x=lnew, w=d(pre + ".proj_down.0.weight"), bias=d(pre + ".proj_down.0.bias"), z=g["zl"], y=g["ll"], M=B * self.N,
                         C=self.C, L=self.Lat, act=1, w_layout=0)
 
     def _gpa_fwd_latents(self, ws, i, si, g1, lnew, M, B, project):
+        if "noside" in _ABLATE:
+            return
         pre, names = self._gpa_names(i)
         d, C, Lt = self._d, self.C, self.Lat
         g = ws["gp"][si]
@@ -951,6 +964,8 @@ class Engine:
     def _gpa_bwd_core(self, ws, sv, gv, i, dGout, M, B, par, project=True):
         """Critical part of the GPA backward: dcomb = dGout . Wup and the latent-space backward -> dzx / dzl
         (what the main stream's dG1 update and the MWSA chain wait for)."""
+        if "noside" in _ABLATE:
+            return
         pre, names = self._gpa_names(i)
         d, C, Lt, P, T, N = self._d, self.C, self.Lat, self.P, self.T, self.N
         g, bw = ws["gp"][i], ws["bw"]
@@ -964,6 +979,8 @@ class Engine:
 
     def _gpa_bwd_params(self, ws, sv, gv, i, dGout, M, B, par):
         """Off the critical path: every parameter gradient of the GPA module (reads dGout, dzx, dzl, saved activations)."""
+        if "noside" in _ABLATE:
+            return
         pre, names = self._gpa_names(i)
         d, C, Lt, P, T, N = self._d, self.C, self.Lat, self.P, self.T, self.N
         g, bw, sc = ws["gp"][i], ws["bw"], ws["scratch"]
@@ -997,6 +1014,8 @@ class Engine:
 
     def _gpa_bwd_scatter_l(self, ws, i, dLnew, B, par):
         """MWSA chain: dL += dzl . Wd."""
+        if "noside" in _ABLATE:
+            return
         pre, _ = self._gpa_names(i)
         ops.skinny_up(lat=ws["bw"]["dzl"][par], w=self._d(pre + ".proj_down.0.weight"), out=dLnew, M=B * self.N, C=self.C, L=self.Lat, w_layout=1,
                       accumulate=1)
@@ -1314,6 +1333,8 @@ class Engine:
         return (self._flat_grad["views"][name].data_ptr() - self._flat_grad["buf"].data_ptr()) // 4
 
     def _mwsa_bwd(self, ws, sv, gv, i, dLout, dLin, B):
+        if "noside" in _ABLATE:
+            return
         s = i // self.share
         pre = f"transformer.local_attns.{s}"
         d, C, Lt, N = self._d, self.C, self.Lat, self.N
