@@ -121,6 +121,11 @@ SIGNATURES = {
     "gvk_sumsq": [_P, C.c_int64, _P, _P, _P],
     "gvk_adam_step": [C.POINTER(AdamDesc), _P],
     "gvk_loss_fwd_bwd": [C.POINTER(LossDesc), _P],
+    "gvk_volume_minmax": [_P, _P, _I, _L, _P],
+    "gvk_rescale_intensity": [_P, _P, _P, _P, _I, _L, _F, _F, _P],
+    "gvk_spatial_transform": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "gvk_eval_rows": [_P, _P, _P, _P, _P, _I, _I, _P],
+    "gvk_ovr_auc_counts": [_P, _P, _P, _I, _I, _P],
     "gvk_memset_async": [_P, _I, C.c_size_t, _P],
     "gvk_seed_advance": [_P, C.c_uint64, _P],
     "gvk_scale_f32": [_P, _F, C.c_long, _P],
@@ -128,7 +133,7 @@ SIGNATURES = {
     "gvk_head_bwd": [C.POINTER(HeadDesc), _P],
 }
 NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, []), "gvk_abi_version": (C.c_int, []),
-             "gvk_gpa_gate_param_count": (C.c_int, [C.c_int, C.c_int]),
+             "gvk_gpa_gate_param_count": (C.c_int, [C.c_int, C.c_int]), "gvk_minmax_partials": (C.c_int, []),
              "gvk_plan_begin": (C.c_int, []), "gvk_plan_end": (C.c_int, []), "gvk_plan_abort": (C.c_int, []),
              "gvk_plan_size": (C.c_int, [C.c_int]), "gvk_plan_replay": (C.c_int, [C.c_int]), "gvk_plan_free": (C.c_int, [C.c_int]),
              "gvk_plan_event_record": (C.c_int, [_P]), "gvk_plan_event_wait": (C.c_int, [_P, C.c_int]),

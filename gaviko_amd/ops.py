@@ -607,3 +607,53 @@ def loss_fwd_bwd(logits, target, loss, dlogits, kind, gamma=0.0, eps=1e-16, igno
                    loss=L.ptr(loss), dlogits=L.ptr(dlogits), meter=L.ptr(meter) if meter is not None else None,
                    B=B, K=K, kind=kind, reduction={"mean": 0, "sum": 1}[reduction], gamma=gamma, eps=eps, ignore_index=ignore_index)
     L.check(L.load().gvk_loss_fwd_bwd(C.byref(d), L.stream_ptr()), "gvk_loss_fwd_bwd")
+
+
+# ---- data side + evaluation metrics (train.py:38-62, eval.py:103-122) --------------------------------------------------------
+def minmax_partials(B: int, device) -> torch.Tensor:
+    return torch.empty(B * L.load().gvk_minmax_partials(), dtype=torch.float32, device=device)
+
+
+def volume_minmax(x: torch.Tensor, partials: torch.Tensor) -> None:
+    _chk(x, torch.float32, "volume_minmax x")
+    B = x.shape[0]
+    _chk(partials, torch.float32, "volume_minmax partials", B * L.load().gvk_minmax_partials())
+    L.check(L.load().gvk_volume_minmax(L.ptr(x), L.ptr(partials), B, x.numel() // B, L.stream_ptr()), "gvk_volume_minmax")
+
+
+def rescale_intensity(x, partials, y, out_min=0.0, out_max=1.0, minmax=None) -> None:
+    _chk(x, torch.float32, "rescale_intensity x")
+    _chk(y, torch.float32, "rescale_intensity y", x.numel())
+    B = x.shape[0]
+    if minmax is not None:
+        _chk(minmax, torch.float32, "rescale_intensity minmax", 2 * B)
+    L.check(L.load().gvk_rescale_intensity(L.ptr(x), L.ptr(partials), L.ptr(y), L.ptr(minmax) if minmax is not None else None, B, x.numel() // B,
+                                           out_min, out_max, L.stream_ptr()), "gvk_rescale_intensity")
+
+
+def spatial_transform(x, out, mats, flags, partials) -> None:
+    _chk(x, torch.float32, "spatial_transform in")
+    _chk(out, torch.float32, "spatial_transform out", x.numel())
+    B, D, H, W = x.shape[0], x.shape[-3], x.shape[-2], x.shape[-1]
+    _chk(mats, torch.float32, "spatial_transform mats", 12 * B)
+    _chk(flags, torch.int32, "spatial_transform flags", B)
+    L.check(L.load().gvk_spatial_transform(L.ptr(x), L.ptr(out), L.ptr(mats), L.ptr(flags), L.ptr(partials), B, D, H, W, L.stream_ptr()),
+            "gvk_spatial_transform")
+
+
+def eval_rows(logits, target, proba, pred, confusion) -> None:
+    _chk(logits, torch.float32, "eval_rows logits")
+    N, K = logits.shape
+    _chk(proba, torch.float32, "eval_rows proba", N * K)
+    _chk(pred, torch.int32, "eval_rows pred", N)
+    _chk(confusion, torch.int64, "eval_rows confusion", K * K)
+    if target.dtype != torch.int64 or target.numel() != N or not target.is_contiguous():
+        raise ValueError("eval_rows target must be a contiguous int64 [N] tensor")
+    L.check(L.load().gvk_eval_rows(L.ptr(logits), L.ptr(target), L.ptr(proba), L.ptr(pred), L.ptr(confusion), N, K, L.stream_ptr()), "gvk_eval_rows")
+
+
+def ovr_auc_counts(proba, target, counts) -> None:
+    _chk(proba, torch.float32, "ovr_auc proba")
+    N, K = proba.shape
+    _chk(counts, torch.int64, "ovr_auc counts", 3 * K)
+    L.check(L.load().gvk_ovr_auc_counts(L.ptr(proba), L.ptr(target), L.ptr(counts), N, K, L.stream_ptr()), "gvk_ovr_auc_counts")

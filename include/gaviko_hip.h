@@ -396,6 +396,24 @@ typedef struct gvk_loss_desc {
 } gvk_loss_desc;
 int gvk_loss_fwd_bwd(const gvk_loss_desc* d, void* stream);
 
+/* ---- data side and evaluation metrics ------------------------------------------------------------------
+ * Replace the torchio transforms of train.py:38-62 on a batch of raw volumes x [B][V] (V = D*H*W, float32, resident in HBM):
+ * gvk_volume_minmax: partials [B][gvk_minmax_partials()] = per-slab (min, max) pairs of every volume.
+ * gvk_rescale_intensity: tio.RescaleIntensity(out_min_max): y = ((x - min) / (max - min)) * (out_max - out_min) + out_min in
+ *   float32, in that order; a constant volume passes through unchanged; minmax (optional) receives [B][2].  In place allowed.
+ * gvk_spatial_transform: tio.RandomAffine + tio.RandomFlip as ONE resampling pass: out[b] at output voxel q reads in[b] at
+ *   A_b . mirror(q) + t_b (mats [B][12], row-major 3x4 in array-axis order) with trilinear weights; neighbours outside the volume
+ *   read the volume minimum (partials of the INPUT).  flags[b]: bits 0..2 = mirror axis 0..2, bit 3 = affine live (else exact gather).
+ * Replace eval.py:103-122: gvk_eval_rows: proba = softmax(logits), pred = argmax, confusion uint64 [K][K] += (target, pred);
+ * gvk_ovr_auc_counts: counts uint64 [K][3] += {2*#(p_pos > p_neg) + #(p_pos == p_neg), n_pos, n_neg} per class (one-vs-rest). */
+int gvk_volume_minmax(const float* x, float* partials, int B, int64_t V, void* stream);
+int gvk_minmax_partials(void);
+int gvk_rescale_intensity(const float* x, const float* partials, float* y, float* minmax, int B, int64_t V, float out_min, float out_max, void* stream);
+int gvk_spatial_transform(const float* in, float* out, const float* mats, const int32_t* flags, const float* partials, int B, int D, int H, int W,
+                          void* stream);
+int gvk_eval_rows(const float* logits, const void* target, float* proba, int32_t* pred, void* confusion, int N, int K, void* stream);
+int gvk_ovr_auc_counts(const float* proba, const void* target, void* counts, int N, int K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,7 @@ from .ssf_ref import ssf_forward, ssf_param_shapes, ssf_trainable  # noqa: F401
 from .dvpt_ref import dvpt_forward, dvpt_param_shapes, dvpt_trainable  # noqa: F401
 from .evp_ref import evp_forward, evp_param_shapes, evp_trainable, fft_highpass  # noqa: F401
 from .losses_ref import cross_entropy, focal_loss  # noqa: F401
+from . import data_ref  # noqa: F401
 
 FORWARD = {
     "gaviko": gaviko_forward, "linear": vit_forward, "fft": vit_forward, "bitfit": vit_forward,
