@@ -9,6 +9,7 @@
 //              lane, dQ^T += K^T.dS^T with K^T gathered by transposed reads of the row-major K tile.
 // The row constants (-lse/scale) are preloaded into the S accumulators, so P = exp2(c * S') needs no subtraction.
 #include "common.hpp"
+#include "dropout.hpp"
 #include "../../include/gaviko_hip.h"
 
 namespace gvk {
@@ -39,11 +40,16 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 constexpr int kQT = 64;                 // query rows staged per barrier pair (two 32-row MFMA sub-blocks)
 constexpr int kTileQ = kQT * 128;       // bytes of a [kQT][64] bf16 tile
 
+// With attention-probability dropout (mask M, 1/keep folded in): O = (P.M) V, so dV^T += dO^T.(P.M), dS = P.(M.dP - delta) and
+// delta = rowsum(dO.O) is unchanged; the mask is regenerated from (b*H + head, query, key) exactly as the forward drew it.
+struct AttnDrop { unsigned long long seed; const unsigned long long* seed_ptr; unsigned int thresh; float inv_keep; };
+
 // ------------------------------------------------------------------------------------------------ dK, dV
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             bf16* __restrict__ dqkv, int T, int H, int ld_qkv, int ld_o, float scale,
-                                                            float scale_log2e) {
+                                                            float scale_log2e, AttnDrop dr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][Q tile | dO tile | lse' kQT f32 | delta kQT f32]
   constexpr int kBuf = 2 * kTileQ + 2 * kQT * 4;
   const int b = blockIdx.z, head = blockIdx.y, k0 = blockIdx.x * 128;
@@ -65,6 +71,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
     vf[ks] = *(const bf16x8*)(qbase + 2 * inner + (size_t)keyc * ld_qkv + 16 * ks + 8 * hh);
   }
 
+  [[maybe_unused]] unsigned int akey = 0u;
+  if constexpr (DROP) akey = attn_key(dr.seed + *dr.seed_ptr, b * H + head);
   const float inv_scale = 1.0f / scale;
   auto stage = [&](int buf, int qt) {
     char* sQ = smem + buf * kBuf;
@@ -129,8 +137,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float pr = __builtin_amdgcn_exp2f(s[4 * g4 + e] * scale_log2e);
-          s[4 * g4 + e] = pr;
-          dp[4 * g4 + e] = pr * (dp[4 * g4 + e] - d4[e]);
+          if constexpr (DROP) {
+            const unsigned int qq = (unsigned int)(qt * kQT + sub * 32 + 8 * g4 + 4 * hh + e);
+            const float mm = attn_drop_scale(akey, qq * (unsigned int)T + (unsigned int)key, dr.thresh, dr.inv_keep);
+            s[4 * g4 + e] = pr * mm;
+            dp[4 * g4 + e] = pr * (mm * dp[4 * g4 + e] - d4[e]);
+          } else {
+            s[4 * g4 + e] = pr;
+            dp[4 * g4 + e] = pr * (dp[4 * g4 + e] - d4[e]);
+          }
         }
       }
       // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]   (k = q, accumulator row order)
@@ -178,10 +193,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
 constexpr int kKB2 = 64;
 constexpr int kTile64 = 64 * 128;
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           bf16* __restrict__ dqkv, int T, int H, int ld_qkv, int ld_o, float scale,
-                                                          float scale_log2e) {
+                                                          float scale_log2e, AttnDrop dr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][K tile | V tile]
   const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
   const int lane = lane_id(), wave = wave_id();
@@ -197,6 +213,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
   for (int ks = 0; ks < 4; ++ks) {
     qf[ks] = *(const bf16x8*)(base + (size_t)qc * ld_qkv + 16 * ks + 8 * hh);
     dof[ks] = *(const bf16x8*)(d_o + ((size_t)b * T + qc) * ld_o + head * 64 + 16 * ks + 8 * hh);
+  }
+  [[maybe_unused]] unsigned int akey = 0u, qoff = 0u;
+  if constexpr (DROP) {
+    akey = attn_key(dr.seed + *dr.seed_ptr, b * H + head);
+    qoff = (unsigned int)q * (unsigned int)T;
   }
   const float sinit = -lse[((size_t)b * H + head) * T + qc] / scale;
   const float del = delta[((size_t)b * H + head) * T + qc];
@@ -251,7 +272,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
         }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[r] = __builtin_amdgcn_exp2f(st[r] * scale_log2e) * (dpt[r] - del);     // dS^T
+      for (int r = 0; r < 16; ++r) {                                                                        // dS^T
+        if constexpr (DROP) {
+          const int key = kt * kKB2 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          dpt[r] *= attn_drop_scale(akey, qoff + (unsigned int)key, dr.thresh, dr.inv_keep);
+        }
+        st[r] = __builtin_amdgcn_exp2f(st[r] * scale_log2e) * (dpt[r] - del);
+      }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         bf16x8 dsf;
@@ -286,13 +313,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 
 }  // namespace gvk
 
-extern "C" int gvk_attention_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
-                                      int T, int H, int ld_qkv, int ld_out, float scale, void* stream) {
+extern "C" int gvk_attention_bwd_bf16_dropout(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
+                                              int T, int H, int ld_qkv, int ld_out, float scale, float drop_p, uint64_t seed, const void* seed_ptr,
+                                              void* stream) {
   using namespace gvk;
   GVK_REQUIRE(qkv && out && dout && lse && delta && dqkv, "gvk_attention_bwd_bf16: null pointer");
   GVK_REQUIRE(B > 0 && T > 0 && H > 0, "gvk_attention_bwd_bf16: empty shape");
   GVK_REQUIRE(ld_qkv >= 3 * H * 64 && ld_qkv % 8 == 0 && ld_out >= H * 64 && ld_out % 8 == 0,
               "gvk_attention_bwd_bf16: head dim is fixed at 64; ld_qkv=%d ld_out=%d inconsistent with H=%d", ld_qkv, ld_out, H);
+  GVK_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed_ptr != nullptr), "gvk_attention_bwd_bf16: drop_p in [0,1) and a seed word");
+  GVK_REQUIRE(drop_p == 0.f || (int64_t)T * T < (int64_t)1 << 32, "gvk_attention_bwd_bf16: the dropout mask index (query*T + key) is 32-bit");
+  const AttnDrop dr{seed, (const unsigned long long*)seed_ptr, drop_threshold_u32(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f};
   hipStream_t s = (hipStream_t)stream;
   const int64_t n = (int64_t)B * T * H;
   GVK_LAUNCH(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)out, (const bf16*)dout, delta, B, T, H,
@@ -300,11 +331,27 @@ extern "C" int gvk_attention_bwd_bf16(const void* qkv, const void* out, const vo
   int rc = check_launch("attention_bwd/delta");
   if (rc) return rc;
   const float sl2 = scale * 1.44269504088896340736f;
-  GVK_LAUNCH(attn_bwd_dkdv_kernel, dim3((T + 127) / 128, H, B), dim3(256), 2 * (2 * kTileQ + 2 * kQT * 4), s, (const bf16*)qkv,
-                     (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H, ld_qkv, ld_out, scale, sl2);
+  const dim3 grid((T + 127) / 128, H, B);
+  const unsigned lds_kv = 2 * (2 * kTileQ + 2 * kQT * 4), lds_q = 2 * 2 * kTile64;
+  if (drop_p > 0.f) {
+    GVK_LAUNCH(attn_bwd_dkdv_kernel<true>, grid, dim3(256), lds_kv, s, (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H, ld_qkv,
+               ld_out, scale, sl2, dr);
+    rc = check_launch("attention_bwd/dkdv");
+    if (rc) return rc;
+    GVK_LAUNCH(attn_bwd_dq_kernel<true>, grid, dim3(256), lds_q, s, (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H, ld_qkv,
+               ld_out, scale, sl2, dr);
+    return check_launch("attention_bwd/dq");
+  }
+  GVK_LAUNCH(attn_bwd_dkdv_kernel<false>, grid, dim3(256), lds_kv, s, (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H, ld_qkv,
+             ld_out, scale, sl2, dr);
   rc = check_launch("attention_bwd/dkdv");
   if (rc) return rc;
-  GVK_LAUNCH(attn_bwd_dq_kernel, dim3((T + 127) / 128, H, B), dim3(256), 2 * 2 * kTile64, s, (const bf16*)qkv, (const bf16*)dout, lse,
-                     delta, (bf16*)dqkv, T, H, ld_qkv, ld_out, scale, sl2);
+  GVK_LAUNCH(attn_bwd_dq_kernel<false>, grid, dim3(256), lds_q, s, (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H, ld_qkv,
+             ld_out, scale, sl2, dr);
   return check_launch("attention_bwd/dq");
+}
+
+extern "C" int gvk_attention_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
+                                      int T, int H, int ld_qkv, int ld_out, float scale, void* stream) {
+  return gvk_attention_bwd_bf16_dropout(qkv, out, dout, lse, delta, dqkv, B, T, H, ld_qkv, ld_out, scale, 0.f, 0, nullptr, stream);
 }

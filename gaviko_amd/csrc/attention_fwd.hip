@@ -11,6 +11,7 @@
 // LDS tile rows are 64 bf16 = 128 B; 16-B chunk c of row r sits at chunk c ^ swz(r), swz(r) = bit1(r)<<2 | bits3:2(r)
 // -- conflict-free for both the ds_read_b128 row reads and the 4x16 transposed reads.
 #include "common.hpp"
+#include "dropout.hpp"
 #include "../../include/gaviko_hip.h"
 
 namespace gvk {
@@ -21,8 +22,13 @@ constexpr int kQB = 128;   // queries per workgroup
 constexpr int kKB = 128;   // keys per staged tile (4 MFMA key blocks of 32): one barrier pair per 128 keys
 constexpr int kTileBytes = kKB * 128;
 
+// attention-probability dropout (vision_transformer.py:68, live for the unfrozen-backbone methods): the softmax statistics are taken
+// of the undropped scores, the dropped and rescaled P feeds the P.V product; mask element (b*H + head, query, key) -- dropout.hpp
+struct AttnDrop { unsigned long long seed; const unsigned long long* seed_ptr; unsigned int thresh; float inv_keep; };
+
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse,
-                                                       int T, int H, int ld_qkv, int ld_out, float scale_log2e) {
+                                                       int T, int H, int ld_qkv, int ld_out, float scale_log2e, AttnDrop dr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K tile | V tile]
   const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * kQB;
   const int lane = lane_id(), wave = wave_id();
@@ -56,6 +62,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   ot[0] = f32x16{};
   ot[1] = f32x16{};
   float m_run = -INFINITY, l_run = 0.f;
+  [[maybe_unused]] unsigned int akey = 0u, qoff = 0u;
+  if constexpr (DROP) {
+    akey = attn_key(dr.seed + *dr.seed_ptr, b * H + head);
+    qoff = (unsigned int)(q0 + wave * 32 + r31) * (unsigned int)T;
+  }
 
   const int nkt = (T + kKB - 1) / kKB;
   stage(0, 0);
@@ -110,6 +121,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
         psum += p;
       }
     l_run = l_run * alpha + psum;
+    if constexpr (DROP) {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * kKB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          st[kb][r] *= attn_drop_scale(akey, qoff + (unsigned int)key, dr.thresh, dr.inv_keep);
+        }
+    }
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -158,21 +178,37 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 
 }  // namespace gvk
 
-extern "C" int gvk_attention_fwd_bf16(const void* qkv, void* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale,
-                                      void* stream) {
+namespace gvk {
+template <bool DROP>
+static int launch_attn_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale, AttnDrop dr, hipStream_t stream) {
+  const int lds = 2 * 2 * kTileBytes;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(attn_fwd): %s", hipGetErrorString(e));
+    attr = true;
+  }
+  GVK_LAUNCH(attn_fwd_kernel<DROP>, dim3((T + kQB - 1) / kQB, H, B), dim3(256), lds, stream, (const bf16*)qkv,
+                     (bf16*)out, lse, T, H, ld_qkv, ld_out, scale * 1.44269504088896340736f, dr);
+  return check_launch("attention_fwd_bf16");
+}
+}  // namespace gvk
+
+extern "C" int gvk_attention_fwd_bf16_dropout(const void* qkv, void* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale,
+                                              float drop_p, uint64_t seed, const void* seed_ptr, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(qkv && out, "gvk_attention_fwd_bf16: null pointer");
   GVK_REQUIRE(B > 0 && T > 0 && H > 0, "gvk_attention_fwd_bf16: empty shape");
   GVK_REQUIRE(ld_qkv >= 3 * H * 64 && ld_qkv % 8 == 0 && ld_out >= H * 64 && ld_out % 4 == 0,
               "gvk_attention_fwd_bf16: head dim is fixed at 64; ld_qkv=%d ld_out=%d inconsistent with H=%d", ld_qkv, ld_out, H);
-  const int lds = 2 * 2 * kTileBytes;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(attn_fwd): %s", hipGetErrorString(e));
-    attr = true;
-  }
-  GVK_LAUNCH(attn_fwd_kernel, dim3((T + kQB - 1) / kQB, H, B), dim3(256), lds, (hipStream_t)stream, (const bf16*)qkv,
-                     (bf16*)out, lse, T, H, ld_qkv, ld_out, scale * 1.44269504088896340736f);
-  return check_launch("attention_fwd_bf16");
+  GVK_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed_ptr != nullptr), "gvk_attention_fwd_bf16: drop_p in [0,1) and a seed word");
+  GVK_REQUIRE(drop_p == 0.f || (int64_t)T * T < (int64_t)1 << 32, "gvk_attention_fwd_bf16: the dropout mask index (query*T + key) is 32-bit");
+  const AttnDrop dr{seed, (const unsigned long long*)seed_ptr, drop_threshold_u32(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f};
+  if (drop_p > 0.f) return launch_attn_fwd<true>(qkv, out, lse, B, T, H, ld_qkv, ld_out, scale, dr, (hipStream_t)stream);
+  return launch_attn_fwd<false>(qkv, out, lse, B, T, H, ld_qkv, ld_out, scale, dr, (hipStream_t)stream);
+}
+
+extern "C" int gvk_attention_fwd_bf16(const void* qkv, void* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale,
+                                      void* stream) {
+  return gvk_attention_fwd_bf16_dropout(qkv, out, lse, B, T, H, ld_qkv, ld_out, scale, 0.f, 0, nullptr, stream);
 }

@@ -13,6 +13,7 @@
 // with one output: store-instruction bound, not byte bound.)  The weight tile has its own swizzle key so that the
 // interleaved rows stay conflict-free.
 #include "common.hpp"
+#include "dropout.hpp"
 #include "../../include/gaviko_hip.h"
 
 namespace gvk {
@@ -29,6 +30,8 @@ struct GemmArgs {
   int M, N, K, lda, ldw, ldo, ldres, ldaux;
   int rows_in, rows_out, row_off;
   int nbm, nbn;
+  // DROP instantiations only (nn.Dropout behind a Linear of the unfrozen-backbone methods): mask index m * N + n
+  unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;
 };
 
 // LDS swizzles (applied to the 16-byte chunk index of a tile row; conflict-free for the ds_read_b128 lane groups):
@@ -43,7 +46,7 @@ __device__ __forceinline__ int swz_chunk(int row) {
 // so those 16 rows again hit 16 distinct (parity, slot) pairs.
 __device__ __forceinline__ int swz_w(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
 
-template <int BM, int BN, int EPI, int BK = 64>
+template <int BM, int BN, int EPI, int BK = 64, bool DROP = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   static_assert(BK == 64, "the interleaved weight-row mapping is built for 128-byte tile rows");
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -197,9 +200,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
         for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
         *(bf16x8*)dst = o;
       };
+      [[maybe_unused]] auto drop8 = [&]() {               // v *= mask / keep, element (m, n + e)
+        const unsigned long long sd = p.seed + *p.seed_ptr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= drop_scale(sd, (unsigned long long)m * p.N + n + e, p.drop_thresh, p.inv_keep);
+      };
       if constexpr (EPI == GVK_EPI_STORE_BF16) {
         store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
       } else if constexpr (EPI == GVK_EPI_BIAS_RES_F32 || EPI == GVK_EPI_BIAS_RES_F32_BF16) {
+        if constexpr (DROP) drop8();                       // out = res + dropout(acc + bias): vision_transformer.py:34,54
         const float* rp = p.res + (size_t)m * p.ldres + n;
         const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
 #pragma unroll
@@ -210,6 +219,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
         if (p.out0 != nullptr) store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+        if constexpr (DROP) drop8();                       // out1 = dropout(GELU(pre)): vision_transformer.py:32-33
         store_bf16((bf16*)p.out1 + (size_t)m * p.ldo + n);
       } else if constexpr (EPI == GVK_EPI_PATCH_F32) {
         const float* pp = p.pos + (size_t)prow * p.N + n;
@@ -220,6 +230,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
         if (p.out1 != nullptr) store_f32((float*)p.out1 + (size_t)m * p.ldo + n);
       } else if constexpr (EPI == GVK_EPI_GELU_BWD_BF16) {
         const bf16x8 a8 = *(const bf16x8*)(p.aux + (size_t)m * p.ldaux + n);
+        if constexpr (DROP) drop8();                       // gradient through that dropout, same mask
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= gelu_fast_grad((float)a8[e]);
         store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
@@ -239,12 +250,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int EPI, int BK = 64>
+template <int BM, int BN, int EPI, bool DROP = false>
 static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+  constexpr int BK = 64;
   constexpr int lds = 2 * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, EPI, BK>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, EPI, BK, DROP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(gemm %dx%d): %s", BM, BN, hipGetErrorString(e));
     attr_set = true;
@@ -252,7 +264,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   GemmArgs p = a;
   p.nbm = (a.M + BM - 1) / BM;
   p.nbn = a.N / BN;
-  GVK_LAUNCH((gemm_nt_kernel<BM, BN, EPI, BK>), dim3(p.nbm * p.nbn), dim3(256), lds, stream, p);
+  GVK_LAUNCH((gemm_nt_kernel<BM, BN, EPI, BK, DROP>), dim3(p.nbm * p.nbn), dim3(256), lds, stream, p);
   return check_launch("gemm_nt_bf16");
 }
 
@@ -264,6 +276,19 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     const long t128 = (long)((a.M + 127) / 128) * (a.N / bn);
     const int bm = (t128 >= 384) ? 128 : 64;
     tile = bm * 1000 + bn;
+  }
+  if (a.drop_thresh != 0u) {
+    if constexpr (EPI == GVK_EPI_BIAS_RES_F32 || EPI == GVK_EPI_BIAS_GELU_BF16 || EPI == GVK_EPI_GELU_BWD_BF16) {
+      switch (tile) {
+        case 128128: return launch_gemm<128, 128, EPI, true>(a, stream);
+        case 128064: return launch_gemm<128, 64, EPI, true>(a, stream);
+        case 64128: return launch_gemm<64, 128, EPI, true>(a, stream);
+        case 64064: return launch_gemm<64, 64, EPI, true>(a, stream);
+        default: return set_error(-2, "gvk_gemm_nt_bf16: unsupported tile %d", tile);
+      }
+    } else {
+      return set_error(-2, "gvk_gemm_nt_bf16: drop_p > 0 is supported by BIAS_RES_F32, BIAS_GELU_BF16 and GELU_BWD_BF16 only");
+    }
   }
   switch (tile) {
     case 128128: return launch_gemm<128, 128, EPI>(a, stream);
@@ -295,6 +320,9 @@ extern "C" int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream) {
   a.bias = d->bias; a.res = d->res; a.aux = (const bf16*)d->aux; a.pos = d->pos;
   a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldw = d->ldw; a.ldo = d->ldo;
   a.ldres = d->ldres; a.ldaux = d->ldaux; a.rows_in = d->rows_in; a.rows_out = d->rows_out; a.row_off = d->row_off;
+  GVK_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f && (d->drop_p == 0.f || d->seed_ptr != nullptr), "gvk_gemm_nt_bf16: drop_p in [0,1) and a seed word");
+  a.seed = d->seed; a.seed_ptr = (const unsigned long long*)d->seed_ptr; a.drop_thresh = drop_threshold_u32(d->drop_p);
+  a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
   hipStream_t s = (hipStream_t)stream;
   switch (d->epilogue) {
     case GVK_EPI_STORE_BF16:

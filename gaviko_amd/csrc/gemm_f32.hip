@@ -135,6 +135,7 @@ extern "C" int gvk_gemm_nt_f32(const gvk_gemm_desc* d, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(d && d->a && d->w, "gvk_gemm_nt_f32: null operand");
   GVK_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gvk_gemm_nt_f32: empty shape");
+  GVK_REQUIRE(d->drop_p == 0.f, "gvk_gemm_nt_f32: the dropout epilogues exist on the bf16 path only");
   GVK_REQUIRE(d->N % kFT == 0 && d->K % kFK == 0, "gvk_gemm_nt_f32: N=%d must be a multiple of 64 and K=%d of 16", d->N, d->K);
   GVK_REQUIRE(d->lda >= d->K && d->ldw >= d->K && d->lda % 4 == 0 && d->ldw % 4 == 0, "gvk_gemm_nt_f32: lda/ldw must be >= K and multiples of 4");
   GVK_REQUIRE(d->ldo % 4 == 0 && d->ldo >= d->N, "gvk_gemm_nt_f32: ldo=%d must be >= N and a multiple of 4", d->ldo);

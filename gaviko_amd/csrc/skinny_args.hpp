@@ -1,20 +1,9 @@
 // Argument blocks and the dropout hash shared by the rank-L side-path kernels (skinny.hip, rowwise.hip).
 #pragma once
 #include "common.hpp"
+#include "dropout.hpp"
 
 namespace gvk {
-
-// counter-based dropout mask: keep iff hash(seed, idx) >= p * 2^32
-__device__ __forceinline__ unsigned int hash_u32(unsigned long long seed, unsigned long long idx) {
-  unsigned long long x = idx * 0x9E3779B97F4A7C15ull + seed;
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  return (unsigned int)x;
-}
-__device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned long long idx, unsigned int thresh, float inv_keep) {
-  return (hash_u32(seed, idx) >= thresh) ? inv_keep : 0.f;
-}
 
 struct DownArgs {
   const float* x; const float* w; const float* bias;      // x [M][C]; w [L][C] (layout 0) or [C][L] (layout 1)

@@ -40,6 +40,9 @@ PLAN_TIMING = os.environ.get("GAVIKO_HIP_PLAN_TIMING") is not None
 # Timing ablations (tools/ablate_streams.py) -- the RESULTS ARE WRONG with either switch; they only answer "where does the step go":
 #   nowait: the main stream skips its waits on the side chains;  noside: the MWSA / GPA chains are not launched at all.
 _ABLATE = set(filter(None, os.environ.get("GAVIKO_HIP_ABLATE", "").split(",")))
+# Site seeds of the backbone's own nn.Dropout modules (added to the device epoch word): embedding, VPT prompts of layer i, and per layer
+# {+0 attention probabilities, +1 to_out, +2 after GELU, +3 after fc2}.  The MWSA sites use 2*i and 2*i + 1.
+SEED_EMB, SEED_PROMPT, SEED_LAYER = 900, 950, 1000
 
 # bench.py instrumentation: when a dict, every GEMM launch is bracketed by HIP events recorded on the launch stream
 # bench.py instrumentation: when set to a dict, plans recorded from then on bracket every GEMM launch (and the patch-embed
@@ -475,6 +478,12 @@ class Engine:
         B = img.shape[0]
         drop = drop or {}
         sv = {"B": B, "train": train, "attn_drop": float(drop.get("attn_drop", 0.0)), "proj_drop": float(drop.get("proj_drop", 0.0))}
+        # nn.Dropout of the backbone itself (vision_transformer.py:33-34,52-54,157; vpt.py:129,148): live for the classes without a
+        # train() override (linear / bitfit / fft, melo) and for VPT's prompt_dropout.  bf16 path only.
+        sv["bdrop"], sv["edrop"], sv["pdrop"] = (float(drop.get(k, 0.0)) for k in ("dropout", "emb_dropout", "prompt_dropout"))
+        if (sv["bdrop"] > 0 or sv["edrop"] > 0 or sv["pdrop"] > 0) and (self.fp32 or self.kind not in ("vit", "melo", "vpt")):
+            raise L.GavikoHipError(f"backbone dropout > 0 in training mode is built for the bf16 path of the vit / melo / vpt classes, not kind={self.kind!r} "
+                                   f"precision={'fp32' if self.fp32 else 'bf16'}")
         self.refresh_weights(need_dgrad=train)
         ws = self.workspace(B, img.device, train)
         ws["img"].copy_(img.detach())                       # static input buffer (the only per-step host-visible copy-in)
@@ -484,7 +493,7 @@ class Engine:
         sv["wgrad"] = any(self.p[n].dim() >= 2 and n.endswith("weight") for n in bb)
         if bb:
             self._bb_buffers(ws, B, img.device, sv["wgrad"])
-        key = (B, train, sv["attn_drop"], sv["proj_drop"], len(bb), sv["wgrad"])
+        key = (B, train, sv["attn_drop"], sv["proj_drop"], len(bb), sv["wgrad"], sv["bdrop"], sv["edrop"], sv["pdrop"])
         self._keep_inputs = bool(sv["wgrad"])
         self._run("fwd", key, lambda: self._forward_impl(ws, sv))
         self._saved = sv if train else None
@@ -523,10 +532,13 @@ class Engine:
             ops.rows_broadcast(G0, cls, pos[0:1], B, T, self.P, 1, C)
         else:
             ops.rows_broadcast(G0, cls, pos[0:1], B, T, 0, 1, C)
+        if sv["edrop"] > 0:                                   # x = dropout(x + pos) over [cls | patches] (vision_transformer.py:157)
+            ops.dropout_rows(G0, sv["edrop"], SEED_EMB, ws["seed"], out32=G0, M=B * T, N=C)
         if self.kind == "vpt":                                # prompt_proj on every layer's prompts at once (vpt.py:56,127-153)
             emb = d("deep_prompt_embeddings" if self.deep else "prompt_embeddings").reshape(-1, self.pd)
             ops.small_linear_fwd(emb, d("prompt_proj.weight"), d("prompt_proj.bias"), ws["vproj"], emb.shape[0], self.pd, C)
             ops.rows_broadcast(G0, ws["vproj"][: self.P], None, B, T, 1, self.P, C)
+            self._prompt_dropout(ws, sv, 0, G0, self.Ts[0])
         if self.kind == "melo":
             self._melo_merge(ws, train)
         if self.kind == "adaptformer":
@@ -553,7 +565,7 @@ class Engine:
             self._mark(f"f{i}:start")
             if self.kind == "evp":
                 self._evp_add_prompt(ws, i, si, ws["G"][gi], B)               # x[:, 1:] += prompt_i (evp.py:235-238)
-            self._attn_block_fwd(ws, i, si, ws["G"][gi], ws["G1"][si], Mi)
+            self._attn_block_fwd(ws, i, si, ws["G"][gi], ws["G1"][si], Mi, sv["bdrop"])
             self._mark(f"f{i}:attn")
             fused = gaviko and self._fuse_proj
             if gaviko and not fused:
@@ -571,7 +583,7 @@ class Engine:
                 self._wait("gpa", "loc")                             # ll ready (the MWSA chain projects its own L')
                 with torch.cuda.stream(gpa):
                     self._gpa_fwd_latents(ws, i, si, ws["G1"][si], ws["Lc"][go], M, B, False)
-            self._mlp_block_fwd(ws, i, si, ws["G1"][si], gout, Mi, train)
+            self._mlp_block_fwd(ws, i, si, ws["G1"][si], gout, Mi, train, sv["bdrop"])
             if self.kind == "adaptformer":
                 self._adapter_fwd_up(ws, i, si, gout, Mi)
             if self.kind == "dvpt":
@@ -584,6 +596,7 @@ class Engine:
             if repack and i + 1 < self.depth:
                 ops.vpt_repack_fwd(gout, ws["vproj"][(i + 1) * self.P: (i + 2) * self.P], ws["G"][go], B, self.Ts[i], self.Ts[i + 1],
                                    self.P, self.pd, C)
+                self._prompt_dropout(ws, sv, i + 1, ws["G"][go], self.Ts[i + 1])
         if gaviko:
             self._wait(None, "loc")                                  # join the local chain (capture needs every fork joined)
         gfin = self._final_stream(ws, train)
@@ -604,7 +617,13 @@ class Engine:
             return 0, self.P + 1                      # gaviko.py:316 prompts + CLS
         return (0, self.Ts[-1]) if self.pool == "mean" else (0, 1)
 
-    def _attn_block_fwd(self, ws, i, si, gin, g1, M):
+    def _prompt_dropout(self, ws, sv, i, g, T):
+        """prompt_dropout on the projected prompts of layer i, rows 1..P of every sample (vpt.py:129,148,152: applied after .expand(B),
+        so every sample draws its own mask)."""
+        if sv["pdrop"] > 0:
+            ops.dropout_rows(g, sv["pdrop"], SEED_PROMPT + i, ws["seed"], out32=g, M=sv["B"] * self.P, N=self.C, rows_in=self.P, rows_out=T, row_off=1)
+
+    def _attn_block_fwd(self, ws, i, si, gin, g1, M, pdrop=0.0):
         nm, w, d, C = self.names, self._w16, self._d, self.C
         a = nm.attn(i)
         st = ws["stat"][si]
@@ -612,8 +631,10 @@ class Engine:
         if self._keep_inputs:
             ops.copy_(ws["sav"]["xn1"][si], ws["xn"])
         self._gemm(ws["xn"], w[f"qkv{i}"], M, ws["qkv"][si], epilogue=ops.EPI_STORE_BF16, bias=self._eff.get(a + ".to_qkv.bias"))
-        ops.attention_fwd(ws["qkv"][si], ws["ctx"][si], ws["lse"][si], ws["B"], self.Ts[i], self.heads, 64 ** -0.5)
-        self._gemm(ws["ctx"][si], w[f"out{i}"], M, g1, epilogue=ops.EPI_BIAS_RES_F32, bias=d(a + ".to_out.0.bias"), res=gin)
+        ops.attention_fwd(ws["qkv"][si], ws["ctx"][si], ws["lse"][si], ws["B"], self.Ts[i], self.heads, 64 ** -0.5,
+                          drop_p=pdrop, seed=SEED_LAYER + 8 * i, seed_ptr=ws["seed"])
+        self._gemm(ws["ctx"][si], w[f"out{i}"], M, g1, epilogue=ops.EPI_BIAS_RES_F32, bias=d(a + ".to_out.0.bias"), res=gin,
+                   drop_p=pdrop, seed=SEED_LAYER + 8 * i + 1, seed_ptr=ws["seed"])
 
     def _mlp_ln_fwd(self, ws, i, si, g1, M, fused):
         nm, d, C = self.names, self._d, self.C
@@ -627,16 +648,18 @@ class Engine:
         else:
             ops.layernorm_fwd(g1, d(m + ".net.0.weight"), d(m + ".net.0.bias"), M, C, y16=ws["xn"], mean=st[2], rstd=st[3])
 
-    def _mlp_block_fwd(self, ws, i, si, g1, gout, M, train):
+    def _mlp_block_fwd(self, ws, i, si, g1, gout, M, train, pdrop=0.0):
         nm, w, d, C = self.names, self._w16, self._d, self.C
         m = nm.mlp(i)
         if self._keep_inputs:
             ops.copy_(ws["sav"]["xn2"][si], ws["xn"])
         self._gemm(ws["xn"], w[f"fc1{i}"], M, ws["pre"][si] if train else None, epilogue=ops.EPI_BIAS_GELU_BF16, out1=ws["act"],
-                    bias=d(m + ".net.1.bias"))           # inference keeps no pre-activation (out0 = NULL)
+                    bias=d(m + ".net.1.bias"),           # inference keeps no pre-activation (out0 = NULL)
+                    drop_p=pdrop, seed=SEED_LAYER + 8 * i + 2, seed_ptr=ws["seed"])
         if self._keep_inputs:
             ops.copy_(ws["sav"]["act"][si], ws["act"])
-        self._gemm(ws["act"], w[f"fc2{i}"], M, gout, epilogue=ops.EPI_BIAS_RES_F32, bias=d(m + ".net.4.bias"), res=g1)
+        self._gemm(ws["act"], w[f"fc2{i}"], M, gout, epilogue=ops.EPI_BIAS_RES_F32, bias=d(m + ".net.4.bias"), res=g1,
+                   drop_p=pdrop, seed=SEED_LAYER + 8 * i + 3, seed_ptr=ws["seed"])
 
     # ---- GAViKO side paths --------------------------------------------------------------------------------------
     def _mwsa_fwd(self, ws, sv, i, si, lin, lout):
@@ -822,15 +845,21 @@ class Engine:
             # main stream, MLP block: dG1 = dGout + LN'(fc1^T(GELU'(pre) * fc2^T(dGout)))
             self._mark(f"b{i}:start")
             bb = sv.get("bb") or ()
+            pd_ = sv.get("bdrop", 0.0)
+            dy_ff = dGout
+            if pd_ > 0:                                                      # gradient of dropout(fc2(.)): the forward's mask on dGout
+                dy_ff = ws["dyd"] if bb else None
+                ops.dropout_rows(dGout, pd_, SEED_LAYER + 8 * i + 3, ws["seed"], out32=dy_ff, out16=ws["dG16"], M=M, N=C)
             if bb:                                                           # fc2: db = colsum(dGout), dW = dGout^T . act
-                self._bb_linear_grads(ws, gv, bb, m + ".net.4", dGout, ws["dG16"], ws["sav"]["act"][i] if sv["wgrad"] else None, M, C, self.mlp)
+                self._bb_linear_grads(ws, gv, bb, m + ".net.4", dy_ff, ws["dG16"], ws["sav"]["act"][i] if sv["wgrad"] else None, M, C, self.mlp)
             dvpt = self.kind == "dvpt"
             if dvpt:
                 self._dvpt_bwd_latents(ws, gv, i, dGout, M, B)
             ssf = self.kind == "ssf"
             if ssf:                                                          # fc2 + ssf_2: dy = dGout, y = G[i+1] - G1[i]
                 self._ssf_linear_grad(ws, gv, m, 2, dGout, ws["G"][i + 1], M, C, y1=ws["G1"][i])
-            self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i])
+            self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i],
+                       drop_p=pd_, seed=SEED_LAYER + 8 * i + 2, seed_ptr=ws["seed"])
             if ssf:                                                          # fc1 + ssf_1: dy = d(pre-activation), y = saved pre-activation
                 self._ssf_linear_grad(ws, gv, m, 1, ws["dpre"], ws["pre"][i], M, self.mlp)
             if bb:                                                           # fc1: db = colsum(dpre), dW = dpre^T . LN2(G1)
@@ -860,10 +889,15 @@ class Engine:
             # main stream, attention block: dG0 = dG1 + LN'(qkv^T(attn'(out^T(dG1))))
             if ssf:                                                          # to_out + ssf_2: dy = dG1, y = G1[i] - G[i]
                 self._ssf_linear_grad(ws, gv, a, 2, dGin, ws["G1"][i], M, C, y1=ws["G"][i])
+            dy_at = dGin
+            if pd_ > 0:                                                      # gradient of dropout(to_out(.))
+                dy_at = ws["dyd"] if bb else None
+                ops.dropout_rows(dGin, pd_, SEED_LAYER + 8 * i + 1, ws["seed"], out32=dy_at, out16=ws["dG16"], M=M, N=C)
             if bb:                                                           # to_out: db = colsum(dG1), dW = dG1^T . ctx
-                self._bb_linear_grads(ws, gv, bb, a + ".to_out.0", dGin, ws["dG16"], ws["ctx"][i], M, C, C)
+                self._bb_linear_grads(ws, gv, bb, a + ".to_out.0", dy_at, ws["dG16"], ws["ctx"][i], M, C, C)
             self._gemm(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
-            ops.attention_bwd(ws["qkv"][i], ws["ctx"][i], ws["dctx"], ws["lse"][i], ws["delta"], ws["dqkv"], B, T, self.heads, 64 ** -0.5)
+            ops.attention_bwd(ws["qkv"][i], ws["ctx"][i], ws["dctx"], ws["lse"][i], ws["delta"], ws["dqkv"], B, T, self.heads, 64 ** -0.5,
+                              drop_p=pd_, seed=SEED_LAYER + 8 * i, seed_ptr=ws["seed"])
             if self.kind == "melo":
                 self._melo_bwd(ws, gv, i, M)
             if ssf:                                                          # to_qkv + ssf_1: dy = dqkv, y = saved qkv
@@ -906,6 +940,8 @@ class Engine:
             self._mark(f"b{i}:end")
             if self.kind == "vpt" and (i == 0 or self.deep):
                 # prompt rows 1..P of this layer's input are this layer's projected prompts (vpt.py:127-131,147-153)
+                if sv.get("pdrop", 0.0) > 0:                                 # through prompt_dropout: same mask, in place (these rows end here)
+                    ops.dropout_rows(dGout, sv["pdrop"], SEED_PROMPT + i, ws["seed"], out32=dGout, M=B * self.P, N=C, rows_in=self.P, rows_out=T, row_off=1)
                 ops.rows_batch_sum(dGout, ws["dvproj"][i * self.P: (i + 1) * self.P], None, B, T, 1, self.P, C)
             if vpt_deep and i > 0:
                 other = ws["dGv"] if dGout is ws["dG"][0] else ws["dG"][0]
@@ -916,6 +952,8 @@ class Engine:
             self._wait(None, "gpa")
             self._wait(None, "loc")
         if last and sv.get("bb"):
+            if sv.get("edrop", 0.0) > 0:                                     # through emb_dropout
+                ops.dropout_rows(dGout, sv["edrop"], SEED_EMB, ws["seed"], out32=dGout, M=B * self.T, N=C)
             self._bb_embed_grads(ws, gv, sv["bb"], dGout, B)
         if last and self.kind == "evp":
             self._evp_bwd_finish(ws, gv, B)
@@ -1111,6 +1149,7 @@ class Engine:
             n = max(self.mlp, 3 * C, self.Kp)
             ws["bbw"] = dict(ones=torch.ones(n, device=device), zeros=torch.zeros(n, device=device), junk=torch.zeros(2 * n, device=device),
                              scratch=torch.zeros(64 * 2 * n, device=device), stat=[torch.zeros(M, device=device), torch.zeros(M, device=device)])
+            ws["dyd"] = ops.act_zeros(M, C, torch.float32, device)           # dropout-masked copy of a layer gradient (bias / weight-gradient operand)
         if wgrad and "sav" not in ws:
             C, M, Mp = self.C, B * self.T, ops.pad_rows(B * self.T)
             z = lambda r, c: ops.act_zeros(r, c, self.adt, device)

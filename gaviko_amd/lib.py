@@ -17,11 +17,11 @@ LIB_PATH = os.environ.get("GAVIKO_HIP_LIB") or os.path.join(_HERE, "libgaviko_hi
 class GemmDesc(C.Structure):
     _fields_ = [
         ("a", C.c_void_p), ("w", C.c_void_p), ("out0", C.c_void_p), ("out1", C.c_void_p),
-        ("bias", C.c_void_p), ("res", C.c_void_p), ("aux", C.c_void_p), ("pos", C.c_void_p),
+        ("bias", C.c_void_p), ("res", C.c_void_p), ("aux", C.c_void_p), ("pos", C.c_void_p), ("seed_ptr", C.c_void_p),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
         ("lda", C.c_int32), ("ldw", C.c_int32), ("ldo", C.c_int32), ("ldres", C.c_int32), ("ldaux", C.c_int32),
         ("epilogue", C.c_int32), ("rows_in", C.c_int32), ("rows_out", C.c_int32), ("row_off", C.c_int32),
-        ("tile", C.c_int32),
+        ("tile", C.c_int32), ("drop_p", C.c_float), ("seed", C.c_uint64),
     ]
 
 
@@ -54,6 +54,7 @@ DvptDesc = _struct("DvptDesc", ["z", "enh", "lse", "dcomb", "gate", "bu", "colsu
 AdamDesc = _struct("AdamDesc", ["ptr_tab", "blk_tab", "grad", "m", "v", "norm_sq"], ["nblocks"],
                    ["lr", "beta1", "beta2", "eps", "bias_c1", "bias_c2", "max_norm"])
 LossDesc = _struct("LossDesc", ["logits", "target", "weights", "loss", "dlogits", "meter"], ["B", "K", "kind", "reduction"], ["gamma", "eps"], i64=["ignore_index"])
+DropoutDesc = _struct("DropoutDesc", ["x", "out32", "out16", "seed_ptr"], ["M", "N", "ld", "rows_in", "rows_out", "row_off"], ["drop_p"], ["seed"])
 RowProjDesc = _struct("RowProjDesc", ["w", "bias", "y", "z"], ["L", "w_layout", "act"])
 ReduceJob = _struct("ReduceJob", ["a", "b", "out"], ["M", "J", "L", "accumulate"])
 HeadDesc = _struct("HeadDesc", ["g", "ln_gamma", "ln_beta", "wh", "bh", "logits", "pooled", "dlogits", "dg", "dwh", "dbh"],
@@ -82,6 +83,8 @@ SIGNATURES = {
     "gvk_layernorm_bwd_affine": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gvk_attention_fwd_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "gvk_attention_bwd_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "gvk_attention_fwd_bf16_dropout": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P, _P],
+    "gvk_attention_bwd_bf16_dropout": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P, _P],
     "gvk_skinny_down": [C.POINTER(SkinnyDownDesc), _P],
     "gvk_skinny_up": [C.POINTER(SkinnyUpDesc), _P],
     "gvk_outer_reduce": [C.POINTER(OuterDesc), _P],
@@ -121,6 +124,7 @@ SIGNATURES = {
     "gvk_sumsq": [_P, C.c_int64, _P, _P, _P],
     "gvk_adam_step": [C.POINTER(AdamDesc), _P],
     "gvk_loss_fwd_bwd": [C.POINTER(LossDesc), _P],
+    "gvk_dropout_rows": [C.POINTER(DropoutDesc), _P],
     "gvk_volume_minmax": [_P, _P, _I, _L, _P],
     "gvk_rescale_intensity": [_P, _P, _P, _P, _I, _L, _F, _F, _P],
     "gvk_spatial_transform": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -140,7 +144,7 @@ NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, [
              "gvk_plan_set_timing": (C.c_int, [C.c_int]),
              "gvk_plan_event_elapsed": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)])}
 STRUCTS = {"gvk_gemm_desc": GemmDesc, "gvk_skinny_down_desc": SkinnyDownDesc, "gvk_skinny_up_desc": SkinnyUpDesc,
-           "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob, "gvk_rowproj_desc": RowProjDesc, "gvk_adam_desc": AdamDesc, "gvk_loss_desc": LossDesc, "gvk_ssf_colgrad_desc": SsfColgradDesc, "gvk_dvpt_desc": DvptDesc}
+           "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob, "gvk_rowproj_desc": RowProjDesc, "gvk_adam_desc": AdamDesc, "gvk_loss_desc": LossDesc, "gvk_dropout_desc": DropoutDesc, "gvk_ssf_colgrad_desc": SsfColgradDesc, "gvk_dvpt_desc": DvptDesc}
 
 _lib = None
 

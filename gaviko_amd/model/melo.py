@@ -53,8 +53,11 @@ class MeLO(HotPathModule):
         self.__dict__["_kw_precision"] = kwargs.get("precision")      # "bf16" (default) | "fp32": see HotPathModule.set_precision
         self._cfg = dict(vit._cfg, r=r, alpha=alpha)
 
-    def forward(self, x):
+    def _drop_config(self):
+        # no train() override (melo.py:56-110): the wrapped ViT's nn.Dropout modules follow module.training
         vt = self.lora_vit
-        if self.training and (vt._cfg["dropout"] > 0 or vt._cfg["emb_dropout"] > 0):
-            raise NotImplementedError("MeLO has no train() override, so backbone dropout > 0 is live in training mode (not built)")
+        return {"dropout": vt._cfg["dropout"] if vt.transformer.layers[0][0].dropout.training else 0.0,
+                "emb_dropout": vt._cfg["emb_dropout"] if vt.dropout.training else 0.0}
+
+    def forward(self, x):
         return self._run(x)

@@ -222,8 +222,10 @@ class VisionTransformer(HotPathModule):
                          pool=pool, channels=channels, dim_head=dim_head, backbone=backbone, dropout=dropout, emb_dropout=emb_dropout)
         self._load_backbone()
 
+    def _drop_config(self):
+        # no train() override (vision_transformer.py:91-164): every nn.Dropout follows module.training
+        return {"dropout": self._cfg["dropout"] if self.transformer.layers[0][0].dropout.training else 0.0,
+                "emb_dropout": self._cfg["emb_dropout"] if self.dropout.training else 0.0}
+
     def forward(self, img):
-        if self.training and (self._cfg["dropout"] > 0 or self._cfg["emb_dropout"] > 0):
-            raise NotImplementedError("VisionTransformer has no train() override, so dropout/emb_dropout > 0 is live in training mode "
-                                      "(vision_transformer.py:157,68); dropout inside the fused backbone kernels is not built yet")
         return self._run(img)

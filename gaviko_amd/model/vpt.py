@@ -65,10 +65,12 @@ class PromptedVisionTransformer(HotPathModule):
             for module in self.children():
                 module.eval()
 
+    def _drop_config(self):
+        # vpt.py:106-119 leaves prompt_dropout in training mode while the frozen backbone (and its dropouts) go to eval
+        return {"prompt_dropout": self._cfg["prompt_dropout"] if self.prompt_dropout.training else 0.0}
+
     def forward(self, x):
         vt = self.vision_transformer
-        if (self.prompt_dropout.training and self._cfg["prompt_dropout"] > 0) or \
-                (vt.dropout.training and self._cfg["emb_dropout"] > 0) or \
-                (vt.transformer.layers[0][0].dropout.training and self._cfg["dropout"] > 0):
-            raise NotImplementedError("prompt_dropout / backbone dropout > 0 in training mode is not built for the VPT path yet")
+        if (vt.dropout.training and self._cfg["emb_dropout"] > 0) or (vt.transformer.layers[0][0].dropout.training and self._cfg["dropout"] > 0):
+            raise NotImplementedError("backbone dropout is live only with freeze_vit=False; that VPT training mode is not built")
         return self._run(x)

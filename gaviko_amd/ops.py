@@ -40,7 +40,8 @@ def _chk(t, dtype, what, min_elems=0):
 
 
 def gemm_nt(a, w, M, out0, *, epilogue, out1=None, bias=None, res=None, aux=None, pos=None,
-            lda=None, ldo=None, ldres=None, ldaux=None, rows_in=0, rows_out=0, row_off=0, tile=0, N=None, K=None):
+            lda=None, ldo=None, ldres=None, ldaux=None, rows_in=0, rows_out=0, row_off=0, tile=0, N=None, K=None,
+            drop_p=0.0, seed=0, seed_ptr=None):
     """Y[M,N] = A[M,K] . W[N,K]^T with a fused epilogue.  The operand dtype picks the kernel: bf16 -> gvk_gemm_nt_bf16 (MFMA
     bf16, fp32 accumulate), fp32 -> gvk_gemm_nt_f32 (every 16-bit slot of the epilogue table then carries fp32)."""
     adt = a.dtype
@@ -62,8 +63,9 @@ def gemm_nt(a, w, M, out0, *, epilogue, out1=None, bias=None, res=None, aux=None
     _chk(aux, adt, "gemm aux")
     _chk(pos, torch.float32, "gemm pos", rows_in * N)
     d = L.GemmDesc(L.ptr(a), L.ptr(w), L.ptr(out0), L.ptr(out1), L.ptr(bias), L.ptr(res), L.ptr(aux), L.ptr(pos),
+                   L.ptr(seed_ptr) if (seed_ptr is not None and drop_p > 0) else None,
                    M, N, K, lda, ldw, ldo, (N if ldres is None else ldres), (N if ldaux is None else ldaux),
-                   epilogue, rows_in, rows_out, row_off, tile)
+                   epilogue, rows_in, rows_out, row_off, tile, float(drop_p), int(seed))
     if adt == torch.float32:
         L.check(L.load().gvk_gemm_nt_f32(C.byref(d), L.stream_ptr()), "gvk_gemm_nt_f32")
     else:
@@ -251,10 +253,12 @@ def layernorm_bwd_affine(dy, x, mean, rstd, dgamma, dbeta, scratch, M, C_, accum
                                               L.ptr(scratch), M, C_, int(accumulate), L.stream_ptr()), "gvk_layernorm_bwd_affine")
 
 
-def attention_fwd(qkv, out, lse, B, T, H, scale):
-    """qkv bf16 [pad(B*T), 3*H*64] -> out bf16 [pad(B*T), H*64], lse f32 [B,H,T]."""
+def attention_fwd(qkv, out, lse, B, T, H, scale, drop_p=0.0, seed=0, seed_ptr=None):
+    """qkv bf16 [pad(B*T), 3*H*64] -> out bf16 [pad(B*T), H*64], lse f32 [B,H,T].  drop_p > 0: dropout on the probabilities (bf16 path)."""
     inner = H * 64
     if qkv.dtype == torch.float32:
+        if drop_p > 0:
+            raise L.GavikoHipError("attention dropout is built on the bf16 path only")
         _chk(qkv, torch.float32, "attn qkv", B * T * 3 * inner)
         _chk(out, torch.float32, "attn out", B * T * inner)
         _chk(lse, torch.float32, "attn lse", B * H * T)
@@ -264,6 +268,10 @@ def attention_fwd(qkv, out, lse, B, T, H, scale):
     _chk(qkv, torch.bfloat16, "attn qkv", pad_rows(B * T) * 3 * inner)
     _chk(out, torch.bfloat16, "attn out", B * T * inner)
     _chk(lse, torch.float32, "attn lse", B * H * T)
+    if drop_p > 0:
+        L.check(L.load().gvk_attention_fwd_bf16_dropout(L.ptr(qkv), L.ptr(out), L.ptr(lse), B, T, H, 3 * inner, inner, scale, float(drop_p),
+                                                        int(seed), L.ptr(seed_ptr), L.stream_ptr()), "gvk_attention_fwd_bf16_dropout")
+        return
     L.check(L.load().gvk_attention_fwd_bf16(L.ptr(qkv), L.ptr(out), L.ptr(lse), B, T, H, 3 * inner, inner, scale, L.stream_ptr()),
             "gvk_attention_fwd_bf16")
 
@@ -368,9 +376,11 @@ def head_bwd(**kw):
     L.check(L.load().gvk_head_bwd(C.byref(d), L.stream_ptr()), "gvk_head_bwd")
 
 
-def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, scale):
+def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, scale, drop_p=0.0, seed=0, seed_ptr=None):
     inner = H * 64
     if qkv.dtype == torch.float32:
+        if drop_p > 0:
+            raise L.GavikoHipError("attention dropout is built on the bf16 path only")
         for t, n, k in ((qkv, "qkv", 3), (out, "out", 1), (dout, "dout", 1), (dqkv, "dqkv", 3)):
             _chk(t, torch.float32, "attn_bwd " + n, B * T * k * inner)
         _chk(lse, torch.float32, "attn_bwd lse", B * H * T)
@@ -384,6 +394,11 @@ def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, scale):
     _chk(dqkv, torch.bfloat16, "attn_bwd dqkv", B * T * 3 * inner)
     _chk(lse, torch.float32, "attn_bwd lse", B * H * T)
     _chk(delta, torch.float32, "attn_bwd delta", B * H * T)
+    if drop_p > 0:
+        L.check(L.load().gvk_attention_bwd_bf16_dropout(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), B, T, H,
+                                                        3 * inner, inner, scale, float(drop_p), int(seed), L.ptr(seed_ptr), L.stream_ptr()),
+                "gvk_attention_bwd_bf16_dropout")
+        return
     L.check(L.load().gvk_attention_bwd_bf16(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), B, T, H,
                                             3 * inner, inner, scale, L.stream_ptr()), "gvk_attention_bwd_bf16")
 
@@ -657,3 +672,18 @@ def ovr_auc_counts(proba, target, counts) -> None:
     N, K = proba.shape
     _chk(counts, torch.int64, "ovr_auc counts", 3 * K)
     L.check(L.load().gvk_ovr_auc_counts(L.ptr(proba), L.ptr(target), L.ptr(counts), N, K, L.stream_ptr()), "gvk_ovr_auc_counts")
+
+
+def dropout_rows(x, drop_p, seed, seed_ptr, out32=None, out16=None, M=None, N=None, rows_in=0, rows_out=0, row_off=0):
+    """out = x * mask / (1 - p) over logical rows (optionally a row range of every sample); out32 may be x itself."""
+    _chk(x, torch.float32, "dropout_rows x")
+    ld = x.shape[-1]
+    N = ld if N is None else N
+    M = x.numel() // ld if M is None else M
+    if out32 is not None:
+        _chk(out32, torch.float32, "dropout_rows out32")
+    if out16 is not None:
+        _chk(out16, torch.bfloat16, "dropout_rows out16")
+    d = L.DropoutDesc(x=L.ptr(x), out32=L.ptr(out32) if out32 is not None else None, out16=L.ptr(out16) if out16 is not None else None,
+                      seed_ptr=L.ptr(seed_ptr), M=M, N=N, ld=ld, rows_in=rows_in, rows_out=rows_out, row_off=row_off, drop_p=float(drop_p), seed=int(seed))
+    L.check(L.load().gvk_dropout_rows(C.byref(d), L.stream_ptr()), "gvk_dropout_rows")

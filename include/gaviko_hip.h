@@ -77,11 +77,15 @@ typedef struct gvk_gemm_desc {
   const float* res;   /* f32 [M][ldres] or NULL */
   const void* aux;    /* bf16 [M][ldaux] or NULL */
   const float* pos;   /* f32 [rows_in][N] or NULL */
+  const void* seed_ptr; /* device uint64 dropout epoch (drop_p > 0) */
   int32_t M, N, K;
   int32_t lda, ldw, ldo, ldres, ldaux;
   int32_t epilogue;
   int32_t rows_in, rows_out, row_off; /* GVK_EPI_PATCH_F32 only */
   int32_t tile;       /* 0 = auto, else BM*1000+BN (128128, 128064, 64064, 64128) */
+  float drop_p;       /* nn.Dropout behind the Linear (vision_transformer.py:32-34,54), epilogues 1, 2 (on out1), 4: the value at
+                         (m, n) is multiplied by mask(seed + *seed_ptr, m*N + n) / (1 - drop_p); 0 = off */
+  uint64_t seed;
 } gvk_gemm_desc;
 int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream);
 
@@ -151,6 +155,14 @@ int gvk_attention_fwd_bf16(const void* qkv, void* out, float* lse, int B, int T,
  * delta = rowsum(dout*out)), dout and lse.  delta f32 [B][H][T] is scratch.  Deterministic (no atomics). */
 int gvk_attention_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                            int B, int T, int H, int ld_qkv, int ld_out, float scale, void* stream);
+/* the same with nn.Dropout(drop_p) on the attention probabilities (vision_transformer.py:52,68 -- live in training for the methods
+ * that do not freeze the backbone): softmax statistics of the undropped scores, out = (P * mask / (1 - drop_p)) . V; the backward
+ * regenerates mask(seed + *seed_ptr; b*H + head, query, key).  drop_p = 0 is the plain call. */
+int gvk_attention_fwd_bf16_dropout(const void* qkv, void* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale,
+                                   float drop_p, uint64_t seed, const void* seed_ptr, void* stream);
+int gvk_attention_bwd_bf16_dropout(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                                   int B, int T, int H, int ld_qkv, int ld_out, float scale, float drop_p, uint64_t seed, const void* seed_ptr,
+                                   void* stream);
 
 /* ------------------------------------------------------------------ rank-L ("skinny") fp32 projections of the trainable
  * side paths, L in {4, 8, 16, 20, 32}.  GAViKO: gaviko.py:231-232,242 (MWSA norm/proj_down/qkv/proj_up) and
@@ -413,6 +425,19 @@ int gvk_spatial_transform(const float* in, float* out, const float* mats, const 
                           void* stream);
 int gvk_eval_rows(const float* logits, const void* target, float* proba, int32_t* pred, void* confusion, int N, int K, void* stream);
 int gvk_ovr_auc_counts(const float* proba, const void* target, void* counts, int N, int K, void* stream);
+
+/* ---- nn.Dropout as its own pass (sites without a producing kernel to fuse into) ------------------------------------------
+ * Replaces vision_transformer.py:157 (emb_dropout), vpt.py:129,148,152 (prompt_dropout) and carries the masks of the
+ * Linear+Dropout pairs (vision_transformer.py:34,54) onto the gradient side.  out32 / out16 (either may be NULL, out32 may alias x)
+ * = x * mask(seed + *seed_ptr, m*N + n) / (1 - drop_p) over logical rows m < M; with rows_in > 0 logical row m lives in buffer row
+ * (m / rows_in) * rows_out + row_off + m % rows_in (a row range of every sample).  The mask function is the one of gvk_gemm_desc.drop_p. */
+typedef struct gvk_dropout_desc {
+  const float* x; float* out32; void* out16; const void* seed_ptr;
+  int32_t M, N, ld, rows_in, rows_out, row_off;
+  float drop_p;
+  uint64_t seed;
+} gvk_dropout_desc;
+int gvk_dropout_rows(const gvk_dropout_desc* d, void* stream);
 
 #ifdef __cplusplus
 }

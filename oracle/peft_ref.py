@@ -29,15 +29,20 @@ def vpt_forward(sd: SD, img: Tensor, cfg: dict, taps: Optional[dict] = None) -> 
     deep = cfg.get("deep_prompt", True)
     P = cfg.get("num_prompts", 8)
 
-    def proj(e):
-        return F.linear(e, sd["prompt_proj.weight"], sd["prompt_proj.bias"]).expand(b, -1, -1)
+    masks = cfg.get("_masks")                       # explicit prompt_dropout masks (tests): {('prompt', layer): [b, P, dim]}
+
+    def proj(e, i):
+        y = F.linear(e, sd["prompt_proj.weight"], sd["prompt_proj.bias"]).expand(b, -1, -1)
+        if masks is not None and ("prompt", i) in masks:
+            y = y * masks[("prompt", i)]
+        return y
 
     if not deep:
-        x = torch.cat((x[:, :1], proj(sd["prompt_embeddings"]), x[:, 1:]), dim=1)
+        x = torch.cat((x[:, :1], proj(sd["prompt_embeddings"], 0), x[:, 1:]), dim=1)
     for i in range(depth):
         if deep:
             keep = x[:, 1:] if i == 0 else x[:, 1 + sd["deep_prompt_embeddings"].shape[2]:]
-            x = torch.cat((x[:, :1], proj(sd["deep_prompt_embeddings"][i]), keep), dim=1)
+            x = torch.cat((x[:, :1], proj(sd["deep_prompt_embeddings"][i], i), keep), dim=1)
         p = f"{pre}transformer.layers.{i}"
         x = attention(sd, p + ".0", x, heads) + x
         f = feed_forward(sd, p + ".1", x)

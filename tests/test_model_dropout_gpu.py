@@ -1,0 +1,124 @@
+"""Backbone nn.Dropout live in training (the shipped configs set dropout = emb_dropout = prompt_dropout = 0.1, and the classes without a
+train() override keep them live): the HIP path with p = 0.1 against the ORACLE run with exactly the masks the kernels drew
+(tests/dropmask.py rebuilds them from the device seed word)."""
+import numpy as np
+import pytest
+import torch
+
+import dropmask
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+BASE = dict(image_size=160, image_patch_size=16, frames=120, frame_patch_size=12, num_classes=5, channels=1, pool="cls", dim_head=64)
+P = 0.1
+
+
+def build(method, extra, dev):
+    from gaviko_amd.registry import build_model
+    from gaviko_amd.utils import synth
+    cfg = dict(BASE, backbone="vit-t16", method=method, **extra)
+    m = build_model(cfg)
+    filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    m.to(dev)
+    m.train()
+    return m, cfg
+
+
+def masks_for(eng, word, B, backbone_p, emb_p, prompt_p):
+    from gaviko_amd import engine as E
+    t = lambda a: torch.from_numpy(a)  # noqa: E731
+    masks = {}
+    C, H, mlp = eng.C, eng.heads, eng.mlp
+    if emb_p > 0:
+        masks[("emb", 0)] = t(dropmask.rows_mask(E.SEED_EMB + word, B * eng.T, C, emb_p)).view(B, eng.T, C)
+    for i in range(eng.depth):
+        T = eng.Ts[i]
+        if backbone_p > 0:
+            s = E.SEED_LAYER + 8 * i + word
+            masks[("attn", i)] = t(dropmask.attn_mask(s, B, H, T, backbone_p))
+            masks[("proj", i)] = t(dropmask.rows_mask(s + 1, B * T, C, backbone_p)).view(B, T, C)
+            masks[("act", i)] = t(dropmask.rows_mask(s + 2, B * T, mlp, backbone_p)).view(B, T, mlp)
+            masks[("ff", i)] = t(dropmask.rows_mask(s + 3, B * T, C, backbone_p)).view(B, T, C)
+        if prompt_p > 0:
+            masks[("prompt", i)] = t(dropmask.rows_mask(E.SEED_PROMPT + i + word, B * eng.P, C, prompt_p)).view(B, eng.P, C)
+    return masks
+
+
+CASES = [("fft", dict(dropout=P, emb_dropout=P), (P, P, 0.0)),
+         ("bitfit", dict(dropout=P, emb_dropout=P), (P, P, 0.0)),
+         ("linear", dict(dropout=P, emb_dropout=P), (P, P, 0.0)),
+         ("melo", dict(dropout=P, emb_dropout=P, r=4, alpha=4), (P, P, 0.0)),
+         ("deep_vpt", dict(dropout=P, emb_dropout=P, num_prompts=8, prompt_dim=64, prompt_dropout=P, freeze_vit=True, deep_prompt=True), (0.0, 0.0, P)),
+         ("shallow_vpt", dict(dropout=P, emb_dropout=P, num_prompts=8, prompt_dim=64, prompt_dropout=P, freeze_vit=True, deep_prompt=False), (0.0, 0.0, P))]
+
+
+@pytest.mark.parametrize("method,extra,live", CASES)
+def test_training_step_with_live_dropout_matches_oracle_with_the_same_masks(dev, method, extra, live):
+    from gaviko_amd.utils import synth
+    B = 2
+    m, cfg = build(method, extra, dev)
+    x = torch.from_numpy(synth.volumes(0, B))
+    y = torch.from_numpy(synth.labels(0, B))
+    logits = m(x.to(dev))
+    loss = torch.nn.functional.cross_entropy(logits, y.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    eng = m._engine()
+    word = int(eng._ws["seed"].item())
+    # ---- the oracle on the CPU with the masks of THIS step
+    masks = masks_for(eng, word, B, *live)
+    for k, v in masks.items():
+        keep = (v > 0).float().mean().item()
+        assert abs(keep - (1 - P)) < 0.02, (k, keep)
+    osd = {k: v.detach().cpu().clone().requires_grad_(oracle.trainable(method, k)) for k, v in m.state_dict().items()}
+    ologits = oracle.FORWARD[method](osd, x, dict(cfg, _masks=masks), None)
+    oloss = torch.nn.functional.cross_entropy(ologits, y)
+    oloss.backward()
+    lg = logits.detach().cpu()
+    scale = ologits.abs().max().item()
+    assert (lg - ologits.detach()).abs().max().item() < 1.5e-2 * scale, (lg, ologits)
+    assert (lg.argmax(-1) == ologits.argmax(-1)).all()
+    # and the masks matter: without them the oracle lands somewhere else
+    plain = oracle.FORWARD[method]({k: v.detach() for k, v in osd.items()}, x, cfg, None)
+    # (prompt dropout touches 8 of ~1000 tokens: within bf16 noise on the logits -- there the prompt gradients below carry the proof:
+    #  a dropped element contributes exactly nothing to them)
+    if "vpt" not in method:
+        assert (plain - ologits.detach()).abs().max().item() > 5 * (lg - ologits.detach()).abs().max().item()
+    errs = []
+    for k, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, k
+        want = osd[k].grad
+        if want is None or ".global_query." in k:
+            continue
+        wn = want.norm().item()
+        errs.append((abs(p.grad.norm().item() - wn) / max(wn, 1e-12), k))
+        if wn > 1e-6 and want.numel() <= 200000:
+            e = (p.grad.cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
+            assert e < 6e-2, (k, e)
+    e = np.array([v[0] for v in errs])
+    assert len(e) > 0 and np.median(e) < 1.5e-2 and e.max() < 0.15, sorted(errs, reverse=True)[:5]
+
+
+def test_dropout_draws_fresh_masks_every_step_and_eval_is_deterministic(dev):
+    from gaviko_amd.utils import synth
+    m, cfg = build("fft", dict(dropout=P, emb_dropout=P), dev)
+    x = torch.from_numpy(synth.volumes(0, 2)).to(dev)
+    a = m(x).detach().clone()
+    b = m(x).detach().clone()
+    assert not torch.equal(a, b)                                         # the device epoch word moved between the two (replayed) forwards
+    m.eval()
+    with torch.no_grad():
+        c, d = m(x).clone(), m(x).clone()
+    assert torch.equal(c, d)
+
+
+def test_fp32_path_refuses_live_dropout(dev):
+    from gaviko_amd import lib
+    from gaviko_amd.utils import synth
+    m, cfg = build("fft", dict(dropout=P, emb_dropout=P, precision="fp32"), dev)
+    with pytest.raises(lib.GavikoHipError, match="bf16 path"):
+        m(torch.from_numpy(synth.volumes(0, 1)).to(dev))
