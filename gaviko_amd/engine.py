@@ -826,7 +826,7 @@ class Engine:
             loc, gpa = self._stream("loc"), self._stream("gpa")
             self._wait("gpa", None)
             self._wait("loc", None)
-        prev_scl = prev_par = None
+        prev_scl = None
         for i in range(hi, lo - 1, -1):
             M = B * self.Ts[i]
             T = self.Ts[i]
@@ -841,7 +841,6 @@ class Engine:
                     self._gpa_bwd_core(ws, sv, gv, i, dGout, M, B, par, project=not (self._fuse_proj and i < self.depth - 1))
                     dz_ready = self._ev_record(gpa)
                     self._gpa_bwd_params(ws, sv, gv, i, dGout, M, B, par)
-                    par_done = self._ev_record(gpa)
             # main stream, MLP block: dG1 = dGout + LN'(fc1^T(GELU'(pre) * fc2^T(dGout)))
             self._mark(f"b{i}:start")
             bb = sv.get("bb") or ()
@@ -912,10 +911,8 @@ class Engine:
             self._mark(f"b{i}:qkvd")
             if gaviko:
                 # The new boundary gradient goes to the OTHER parity buffer: the GPA parameter kernels of this layer keep reading
-                # dGout off the critical path.  The buffer being overwritten was last read by layer i+1's parameter kernels.
-                if prev_par is not None:
-                    self._ev_wait(torch.cuda.current_stream(), prev_par)
-                prev_par = par_done
+                # dGout off the critical path.  The buffer being overwritten was last read by layer i+1's parameter kernels, which
+                # precede this layer's dz_ready in the GPA stream -- and the main stream has already waited for that above.
                 dGnext = ws["dGb"] if dGout is ws["dG"][0] else ws["dG"][0]
                 if self._fuse_proj and i > 0:
                     pre_lo, _ = self._gpa_names(i - 1)
@@ -930,9 +927,9 @@ class Engine:
             if gaviko:
                 # The MWSA chain never feeds the global stream in the backward, so the main stream does not join it per layer: dzl
                 # is double-buffered by layer parity and the only cross-stream hazard left is layer i-1's GPA rewriting the buffer
-                # layer i+1's scatter read -- ordered by waiting for THAT (long finished) kernel, one layer late.
+                # layer i+1's scatter read -- ordered by making the GPA stream (not the main one) wait for THAT long finished kernel.
                 if prev_scl is not None:
-                    self._ev_wait(torch.cuda.current_stream(), prev_scl)
+                    self._ev_wait(gpa, prev_scl)
                 prev_scl = scl_done
                 self._wait("gpa", None)                                      # the next layer's GPA backward needs this dG[i]
             if self.kind == "evp":
