@@ -187,7 +187,8 @@ class HotPathModule(nn.Module):
         params = [p for _, p in self._named_cache()[0] if p.requires_grad]
         if torch.is_grad_enabled() and params:
             return _HotPathFn.apply(self, img, self._drop_config(), *params)
-        return self._engine().forward(img, train=False)
+        # no autograd: nothing is saved for a backward, but modules left in training mode still drop (nn.Dropout follows .training)
+        return self._engine().forward(img, train=False, drop=self._drop_config())
 
 
 class VisionTransformer(HotPathModule):
