@@ -11,6 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 4                                   # gvk_abi_version() of the library these declarations describe
 LIB_PATH = os.environ.get("GAVIKO_HIP_LIB") or os.path.join(_HERE, "libgaviko_hip.so")     # override: A/B runs of two builds
 
 
@@ -169,6 +170,9 @@ def load() -> C.CDLL:
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = C.c_int, args
+    if lib.gvk_abi_version() != ABI_VERSION:
+        raise GavikoHipError(f"{LIB_PATH} has ABI version {lib.gvk_abi_version()}, these bindings describe {ABI_VERSION}: rebuild with "
+                             "`python -m gaviko_amd.build`")
     _lib = lib
     return lib
 
