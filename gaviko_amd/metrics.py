@@ -69,14 +69,12 @@ class Evaluator:
                 "y_pred": pred.cpu().numpy(), "y_pred_proba": proba.cpu().numpy(), "y_test": labels.cpu().numpy()}
 
 
-def write_eval_outputs(results_dir: str, method: str, backbone: str, mri_paths, y_pred, acc, qwk, auc) -> str:
-    """eval.py:127-153: '<method>_<backbone>_eval_results_v<n>.csv' (first free n) with columns mri_path (basename), outputs; and the
-    '_metrics.txt' next to it."""
+def _versioned_csv(results_dir: str, method: str, backbone: str, kind: str, mri_paths, y_pred):
     os.makedirs(results_dir, exist_ok=True)
     version = 1
     bb = backbone.replace("-", "_")
     while True:
-        name = f"{method}_{bb}_eval_results_v{version}.csv"
+        name = f"{method}_{bb}_{kind}_results_v{version}.csv"
         path = os.path.join(results_dir, name)
         if not os.path.exists(path):
             break
@@ -85,6 +83,30 @@ def write_eval_outputs(results_dir: str, method: str, backbone: str, mri_paths, 
         f.write("mri_path,outputs\n")
         for p, y in zip(mri_paths, y_pred):
             f.write(f"{os.path.basename(str(p))},{int(y)}\n")
+    return path, name
+
+
+def write_inference_outputs(results_dir: str, method: str, backbone: str, mri_paths, y_pred) -> str:
+    """inference.py:117-139: '<method>_<backbone>_inference_results_v<n>.csv' (first free n), columns mri_path (basename), outputs."""
+    return _versioned_csv(results_dir, method, backbone, "inference", mri_paths, y_pred)[0]
+
+
+@torch.no_grad()
+def predict(model, loader, transforms=None, device=None) -> np.ndarray:
+    """The loop of inference.py:100-113: argmax class of every volume a CustomDatasetPrediction loader yields (one host copy at the end)."""
+    device = device or next(model.parameters()).device
+    model.eval()
+    preds = []
+    for inputs in loader:
+        x = inputs.to(device)
+        preds.append(torch.argmax(model(transforms(x) if transforms is not None else x), dim=1))
+    return torch.cat(preds).cpu().numpy()
+
+
+def write_eval_outputs(results_dir: str, method: str, backbone: str, mri_paths, y_pred, acc, qwk, auc) -> str:
+    """eval.py:127-153: '<method>_<backbone>_eval_results_v<n>.csv' (first free n) with columns mri_path (basename), outputs; and the
+    '_metrics.txt' next to it."""
+    path, name = _versioned_csv(results_dir, method, backbone, "eval", mri_paths, y_pred)
     with open(os.path.join(results_dir, name.replace(".csv", "") + "_metrics.txt"), "w") as f:
         f.write(f"Test Accuracy: {acc}\n")
         f.write(f"Test Quadratic Kappa: {qwk}\n")

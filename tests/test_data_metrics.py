@@ -123,6 +123,8 @@ def test_eval_outputs_files(tmp_path):
     assert os.path.basename(a) == "gaviko_vit_b16_eval_results_v1.csv" and os.path.basename(b) == "gaviko_vit_b16_eval_results_v2.csv"   # eval.py:137-144
     assert open(a).read() == "mri_path,outputs\na.npz,3\nb.npz,0\n"
     assert open(str(tmp_path / "gaviko_vit_b16_eval_results_v1_metrics.txt")).read() == "Test Accuracy: 0.5\nTest Quadratic Kappa: 0.25\nTest AUC: 0.75\n"
+    c = metrics.write_inference_outputs(str(tmp_path), "gaviko", "vit-b16", ["/x/a.npz", "b.npz"], [4, 2])          # inference.py:125-139
+    assert os.path.basename(c) == "gaviko_vit_b16_inference_results_v1.csv" and open(c).read() == "mri_path,outputs\na.npz,4\nb.npz,2\n"
 
 
 # ------------------------------------------------------------------------------------------------ GPU: kernels vs the oracle
