@@ -7,6 +7,7 @@
 // As in the bf16 kernel the weight is the MFMA A operand, so a lane owns 4 consecutive output columns of one row.
 // Every "bf16" slot of the epilogue table carries fp32 here (out0 / out1 / aux are all float); GELU uses erff.
 #include "common.hpp"
+#include "dropout.hpp"
 #include "../../include/gaviko_hip.h"
 
 namespace gvk {
@@ -23,6 +24,7 @@ struct GemmF32Args {
   int M, N, K, lda, ldw, ldo, ldres, ldaux;
   int rows_in, rows_out, row_off;
   int nbn;
+  unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;   // nn.Dropout behind the Linear: mask index m*N + n
 };
 
 constexpr int kFT = 64;        // tile rows / cols
@@ -93,15 +95,23 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmF32Args p) {
       const int n = n0 + wn * 32 + j * 16 + lq * 4;
       f32x4 v = acc[i][j];
       if (p.bias != nullptr) v += *(const f32x4*)(p.bias + n);
+      f32x4 dm = {1.f, 1.f, 1.f, 1.f};                   // dropout scale mask of these four elements (this path is for parity, not speed)
+      if (p.drop_thresh != 0u) {
+        const unsigned long long sd = p.seed + *p.seed_ptr;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dm[e] = drop_scale(sd, (unsigned long long)m * p.N + n + e, p.drop_thresh, p.inv_keep);
+      }
       if constexpr (EPI == GVK_EPI_STORE_BF16 || EPI == GVK_EPI_STORE_F32) {
         *(f32x4*)(p.out0 + (size_t)m * p.ldo + n) = v;
       } else if constexpr (EPI == GVK_EPI_BIAS_RES_F32 || EPI == GVK_EPI_BIAS_RES_F32_BF16) {
+        v *= dm;
         v += *(const f32x4*)(p.res + (size_t)m * p.ldres + n);
         *(f32x4*)(p.out0 + (size_t)m * p.ldo + n) = v;
         if constexpr (EPI == GVK_EPI_BIAS_RES_F32_BF16) *(f32x4*)(p.out1 + (size_t)m * p.ldo + n) = v;
       } else if constexpr (EPI == GVK_EPI_BIAS_GELU_BF16) {
         if (p.out0 != nullptr) *(f32x4*)(p.out0 + (size_t)m * p.ldo + n) = v;
-        const f32x4 g = {gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
+        f32x4 g = {gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
+        g *= dm;
         *(f32x4*)(p.out1 + (size_t)m * p.ldo + n) = g;
       } else if constexpr (EPI == GVK_EPI_PATCH_F32) {
         v += *(const f32x4*)(p.pos + (size_t)prow * p.N + n);
@@ -109,6 +119,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(GemmF32Args p) {
         if (p.out1 != nullptr) *(f32x4*)(p.out1 + (size_t)m * p.ldo + n) = v;
       } else if constexpr (EPI == GVK_EPI_GELU_BWD_BF16) {
         const f32x4 a = *(const f32x4*)(p.aux + (size_t)m * p.ldaux + n);
+        v *= dm;
         const f32x4 o = {v[0] * gelu_erf_grad(a[0]), v[1] * gelu_erf_grad(a[1]), v[2] * gelu_erf_grad(a[2]), v[3] * gelu_erf_grad(a[3])};
         *(f32x4*)(p.out0 + (size_t)m * p.ldo + n) = o;
       } else if constexpr (EPI == GVK_EPI_BIAS_RELU_BF16) {
@@ -135,7 +146,9 @@ extern "C" int gvk_gemm_nt_f32(const gvk_gemm_desc* d, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(d && d->a && d->w, "gvk_gemm_nt_f32: null operand");
   GVK_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gvk_gemm_nt_f32: empty shape");
-  GVK_REQUIRE(d->drop_p == 0.f, "gvk_gemm_nt_f32: the dropout epilogues exist on the bf16 path only");
+  GVK_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f && (d->drop_p == 0.f || d->seed_ptr != nullptr), "gvk_gemm_nt_f32: drop_p in [0,1) and a seed word");
+  GVK_REQUIRE(d->drop_p == 0.f || d->epilogue == GVK_EPI_BIAS_RES_F32 || d->epilogue == GVK_EPI_BIAS_GELU_BF16 || d->epilogue == GVK_EPI_GELU_BWD_BF16,
+              "gvk_gemm_nt_f32: drop_p > 0 is supported by BIAS_RES_F32, BIAS_GELU_BF16 and GELU_BWD_BF16 only");
   GVK_REQUIRE(d->N % kFT == 0 && d->K % kFK == 0, "gvk_gemm_nt_f32: N=%d must be a multiple of 64 and K=%d of 16", d->N, d->K);
   GVK_REQUIRE(d->lda >= d->K && d->ldw >= d->K && d->lda % 4 == 0 && d->ldw % 4 == 0, "gvk_gemm_nt_f32: lda/ldw must be >= K and multiples of 4");
   GVK_REQUIRE(d->ldo % 4 == 0 && d->ldo >= d->N, "gvk_gemm_nt_f32: ldo=%d must be >= N and a multiple of 4", d->ldo);
@@ -143,6 +156,8 @@ extern "C" int gvk_gemm_nt_f32(const gvk_gemm_desc* d, void* stream) {
   a.A = (const float*)d->a; a.W = (const float*)d->w; a.out0 = (float*)d->out0; a.out1 = (float*)d->out1; a.bias = d->bias; a.res = d->res;
   a.aux = (const float*)d->aux; a.pos = d->pos; a.M = d->M; a.N = d->N; a.K = d->K; a.lda = d->lda; a.ldw = d->ldw; a.ldo = d->ldo;
   a.ldres = d->ldres; a.ldaux = d->ldaux; a.rows_in = d->rows_in; a.rows_out = d->rows_out; a.row_off = d->row_off; a.nbn = d->N / kFT;
+  a.seed = d->seed; a.seed_ptr = (const unsigned long long*)d->seed_ptr; a.drop_thresh = drop_threshold_u32(d->drop_p);
+  a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
   hipStream_t s = (hipStream_t)stream;
   switch (d->epilogue) {
     case GVK_EPI_STORE_BF16:

@@ -481,9 +481,8 @@ class Engine:
         # nn.Dropout of the backbone itself (vision_transformer.py:33-34,52-54,157; vpt.py:129,148): live for the classes without a
         # train() override (linear / bitfit / fft, melo) and for VPT's prompt_dropout.  bf16 path only.
         sv["bdrop"], sv["edrop"], sv["pdrop"] = (float(drop.get(k, 0.0)) for k in ("dropout", "emb_dropout", "prompt_dropout"))
-        if (sv["bdrop"] > 0 or sv["edrop"] > 0 or sv["pdrop"] > 0) and (self.fp32 or self.kind not in ("vit", "melo", "vpt")):
-            raise L.GavikoHipError(f"backbone dropout > 0 in training mode is built for the bf16 path of the vit / melo / vpt classes, not kind={self.kind!r} "
-                                   f"precision={'fp32' if self.fp32 else 'bf16'}")
+        if (sv["bdrop"] > 0 or sv["edrop"] > 0 or sv["pdrop"] > 0) and self.kind not in ("vit", "melo", "vpt"):
+            raise L.GavikoHipError(f"backbone dropout > 0 in training mode is built for the vit / melo / vpt classes, not kind={self.kind!r}")
         self.refresh_weights(need_dgrad=train)
         ws = self.workspace(B, img.device, train)
         ws["img"].copy_(img.detach())                       # static input buffer (the only per-step host-visible copy-in)
@@ -616,6 +615,15 @@ class Engine:
         if self.kind == "gaviko":
             return 0, self.P + 1                      # gaviko.py:316 prompts + CLS
         return (0, self.Ts[-1]) if self.pool == "mean" else (0, 1)
+
+    def _masked_grad(self, ws, dy, p, seed, need32, M):
+        """ws['dG16'] (the dgrad GEMM operand) = dy * mask; also returns the fp32 masked gradient when bias / weight gradients need it."""
+        if self.fp32:                                        # the operand IS fp32 on this path
+            ops.dropout_rows(dy, p, seed, ws["seed"], out32=ws["dG16"], M=M, N=self.C)
+            return ws["dG16"]
+        out32 = ws["dyd"] if need32 else None
+        ops.dropout_rows(dy, p, seed, ws["seed"], out32=out32, out16=ws["dG16"], M=M, N=self.C)
+        return out32
 
     def _prompt_dropout(self, ws, sv, i, g, T):
         """prompt_dropout on the projected prompts of layer i, rows 1..P of every sample (vpt.py:129,148,152: applied after .expand(B),
@@ -847,8 +855,7 @@ class Engine:
             pd_ = sv.get("bdrop", 0.0)
             dy_ff = dGout
             if pd_ > 0:                                                      # gradient of dropout(fc2(.)): the forward's mask on dGout
-                dy_ff = ws["dyd"] if bb else None
-                ops.dropout_rows(dGout, pd_, SEED_LAYER + 8 * i + 3, ws["seed"], out32=dy_ff, out16=ws["dG16"], M=M, N=C)
+                dy_ff = self._masked_grad(ws, dGout, pd_, SEED_LAYER + 8 * i + 3, bool(bb), M)
             if bb:                                                           # fc2: db = colsum(dGout), dW = dGout^T . act
                 self._bb_linear_grads(ws, gv, bb, m + ".net.4", dy_ff, ws["dG16"], ws["sav"]["act"][i] if sv["wgrad"] else None, M, C, self.mlp)
             dvpt = self.kind == "dvpt"
@@ -890,8 +897,7 @@ class Engine:
                 self._ssf_linear_grad(ws, gv, a, 2, dGin, ws["G1"][i], M, C, y1=ws["G"][i])
             dy_at = dGin
             if pd_ > 0:                                                      # gradient of dropout(to_out(.))
-                dy_at = ws["dyd"] if bb else None
-                ops.dropout_rows(dGin, pd_, SEED_LAYER + 8 * i + 1, ws["seed"], out32=dy_at, out16=ws["dG16"], M=M, N=C)
+                dy_at = self._masked_grad(ws, dGin, pd_, SEED_LAYER + 8 * i + 1, bool(bb), M)
             if bb:                                                           # to_out: db = colsum(dG1), dW = dG1^T . ctx
                 self._bb_linear_grads(ws, gv, bb, a + ".to_out.0", dy_at, ws["dG16"], ws["ctx"][i], M, C, C)
             self._gemm(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)

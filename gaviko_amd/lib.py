@@ -84,6 +84,8 @@ SIGNATURES = {
     "gvk_layernorm_bwd_affine": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gvk_attention_fwd_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "gvk_attention_bwd_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "gvk_attention_fwd_f32_dropout": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P, _P],
+    "gvk_attention_bwd_f32_dropout": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P, _P],
     "gvk_attention_fwd_bf16_dropout": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P, _P],
     "gvk_attention_bwd_bf16_dropout": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P, _P],
     "gvk_skinny_down": [C.POINTER(SkinnyDownDesc), _P],

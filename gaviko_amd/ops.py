@@ -257,13 +257,11 @@ def attention_fwd(qkv, out, lse, B, T, H, scale, drop_p=0.0, seed=0, seed_ptr=No
     """qkv bf16 [pad(B*T), 3*H*64] -> out bf16 [pad(B*T), H*64], lse f32 [B,H,T].  drop_p > 0: dropout on the probabilities (bf16 path)."""
     inner = H * 64
     if qkv.dtype == torch.float32:
-        if drop_p > 0:
-            raise L.GavikoHipError("attention dropout is built on the bf16 path only")
         _chk(qkv, torch.float32, "attn qkv", B * T * 3 * inner)
         _chk(out, torch.float32, "attn out", B * T * inner)
         _chk(lse, torch.float32, "attn lse", B * H * T)
-        L.check(L.load().gvk_attention_fwd_f32(L.ptr(qkv), L.ptr(out), L.ptr(lse), B, T, H, 3 * inner, inner, scale, L.stream_ptr()),
-                "gvk_attention_fwd_f32")
+        L.check(L.load().gvk_attention_fwd_f32_dropout(L.ptr(qkv), L.ptr(out), L.ptr(lse), B, T, H, 3 * inner, inner, scale, float(drop_p), int(seed),
+                                                       L.ptr(seed_ptr) if drop_p > 0 else None, L.stream_ptr()), "gvk_attention_fwd_f32")
         return
     _chk(qkv, torch.bfloat16, "attn qkv", pad_rows(B * T) * 3 * inner)
     _chk(out, torch.bfloat16, "attn out", B * T * inner)
@@ -379,14 +377,13 @@ def head_bwd(**kw):
 def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, scale, drop_p=0.0, seed=0, seed_ptr=None):
     inner = H * 64
     if qkv.dtype == torch.float32:
-        if drop_p > 0:
-            raise L.GavikoHipError("attention dropout is built on the bf16 path only")
         for t, n, k in ((qkv, "qkv", 3), (out, "out", 1), (dout, "dout", 1), (dqkv, "dqkv", 3)):
             _chk(t, torch.float32, "attn_bwd " + n, B * T * k * inner)
         _chk(lse, torch.float32, "attn_bwd lse", B * H * T)
         _chk(delta, torch.float32, "attn_bwd delta", B * H * T)
-        L.check(L.load().gvk_attention_bwd_f32(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), B, T, H,
-                                               3 * inner, inner, scale, L.stream_ptr()), "gvk_attention_bwd_f32")
+        L.check(L.load().gvk_attention_bwd_f32_dropout(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), B, T, H,
+                                                       3 * inner, inner, scale, float(drop_p), int(seed), L.ptr(seed_ptr) if drop_p > 0 else None,
+                                                       L.stream_ptr()), "gvk_attention_bwd_f32")
         return
     _chk(qkv, torch.bfloat16, "attn_bwd qkv", pad_rows(B * T) * 3 * inner)
     _chk(out, torch.bfloat16, "attn_bwd out", pad_rows(B * T) * inner)

@@ -100,6 +100,12 @@ int gvk_attention_fwd_f32(const float* qkv, float* out, float* lse, int B, int T
                           void* stream);
 int gvk_attention_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv,
                           int B, int T, int H, int ld_qkv, int ld_out, float scale, void* stream);
+/* fp32 counterparts of gvk_attention_fwd/bwd_bf16_dropout (same mask function, so the two precisions drop the same elements) */
+int gvk_attention_fwd_f32_dropout(const float* qkv, float* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale,
+                                  float drop_p, uint64_t seed, const void* seed_ptr, void* stream);
+int gvk_attention_bwd_f32_dropout(const float* qkv, const float* out, const float* dout, const float* lse, float* delta, float* dqkv,
+                                  int B, int T, int H, int ld_qkv, int ld_out, float scale, float drop_p, uint64_t seed, const void* seed_ptr,
+                                  void* stream);
 int gvk_patchify_f32(const float* img, float* out, int B, int D, int H, int W, int pd, int ph, int pw, void* stream);
 int gvk_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
 int gvk_transpose_bf16(const void* in, void* out, int rows, int cols, void* stream);   /* operand transposes of the unfrozen-backbone wgrad GEMMs */

@@ -116,9 +116,29 @@ def test_dropout_draws_fresh_masks_every_step_and_eval_is_deterministic(dev):
     assert torch.equal(c, d)
 
 
-def test_fp32_path_refuses_live_dropout(dev):
-    from gaviko_amd import lib
+@pytest.mark.parametrize("method,extra,live", [CASES[0], CASES[3], CASES[4]])
+def test_fp32_path_with_live_dropout_is_exact_against_the_oracle(dev, method, extra, live):
+    """The same masks through exact fp32 arithmetic: logits to 2e-5, every gradient to 2e-4 -- the mask logic itself, free of bf16 noise."""
     from gaviko_amd.utils import synth
-    m, cfg = build("fft", dict(dropout=P, emb_dropout=P, precision="fp32"), dev)
-    with pytest.raises(lib.GavikoHipError, match="bf16 path"):
-        m(torch.from_numpy(synth.volumes(0, 1)).to(dev))
+    B = 2
+    m, cfg = build(method, dict(extra, precision="fp32"), dev)
+    x = torch.from_numpy(synth.volumes(0, B))
+    y = torch.from_numpy(synth.labels(0, B))
+    logits = m(x.to(dev))
+    torch.nn.functional.cross_entropy(logits, y.to(dev)).backward()
+    torch.cuda.synchronize()
+    eng = m._engine()
+    masks = masks_for(eng, int(eng._ws["seed"].item()), B, *live)
+    osd = {k: v.detach().cpu().clone().requires_grad_(oracle.trainable(method, k)) for k, v in m.state_dict().items()}
+    ocfg = {k: v for k, v in cfg.items() if k != "precision"}
+    ologits = oracle.FORWARD[method](osd, x, dict(ocfg, _masks=masks), None)
+    torch.nn.functional.cross_entropy(ologits, y).backward()
+    assert (logits.detach().cpu() - ologits.detach()).abs().max().item() < 2e-5 * max(1.0, ologits.abs().max().item())
+    worst, who = 0.0, None
+    for k, p in m.named_parameters():
+        if p.requires_grad and osd[k].grad is not None and ".global_query." not in k:
+            want = osd[k].grad
+            e = (p.grad.cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
+            if e > worst:
+                worst, who = e, k
+    assert worst < 5e-4, (worst, who)
