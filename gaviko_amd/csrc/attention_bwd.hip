@@ -130,22 +130,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
       }
-      // P = exp2(c * S');  dS = P * (dP - delta[q])
+      // P = exp2(c * S');  dS = P * (dP - delta[q]) -- two scores per packed instruction (these loops, not the MFMAs, fill the SIMD)
+      const f32x2 sc2 = {scale_log2e, scale_log2e};
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const f32x4 d4 = *(const f32x4*)(sL + kQT + 8 * g4 + 4 * hh);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float pr = __builtin_amdgcn_exp2f(s[4 * g4 + e] * scale_log2e);
+        for (int e = 0; e < 4; e += 2) {
+          const f32x2 a = f32x2{s[4 * g4 + e], s[4 * g4 + e + 1]} * sc2;
+          f32x2 pr = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+          f32x2 dpv = {dp[4 * g4 + e], dp[4 * g4 + e + 1]};
+          f32x2 pd = pr;                                      // the P that multiplies dO in dV: dropped and rescaled under DROP
           if constexpr (DROP) {
             const unsigned int qq = (unsigned int)(qt * kQT + sub * 32 + 8 * g4 + 4 * hh + e);
-            const float mm = attn_drop_scale(akey, qq * (unsigned int)T + (unsigned int)key, dr.thresh, dr.inv_keep);
-            s[4 * g4 + e] = pr * mm;
-            dp[4 * g4 + e] = pr * (mm * dp[4 * g4 + e] - d4[e]);
-          } else {
-            s[4 * g4 + e] = pr;
-            dp[4 * g4 + e] = pr * (dp[4 * g4 + e] - d4[e]);
+            const f32x2 mm = {attn_drop_scale(akey, qq * (unsigned int)T + (unsigned int)key, dr.thresh, dr.inv_keep),
+                              attn_drop_scale(akey, (qq + 1u) * (unsigned int)T + (unsigned int)key, dr.thresh, dr.inv_keep)};
+            pd = pr * mm;
+            dpv = dpv * mm;
           }
+          const f32x2 ds = pr * (dpv - f32x2{d4[e], d4[e + 1]});
+          s[4 * g4 + e] = pd[0]; s[4 * g4 + e + 1] = pd[1];
+          dp[4 * g4 + e] = ds[0]; dp[4 * g4 + e + 1] = ds[1];
         }
       }
       // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]   (k = q, accumulator row order)
@@ -271,13 +276,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
           st[r] = (key < T) ? st[r] : -INFINITY;
         }
       }
+      const f32x2 sc2 = {scale_log2e, scale_log2e}, del2 = {del, del};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {                                                                        // dS^T
+      for (int r = 0; r < 16; r += 2) {                                                                     // dS^T, two scores per packed op
+        f32x2 dpv = {dpt[r], dpt[r + 1]};
         if constexpr (DROP) {
-          const int key = kt * kKB2 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          dpt[r] *= attn_drop_scale(akey, qoff + (unsigned int)key, dr.thresh, dr.inv_keep);
+          const int key = kt * kKB2 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;          // r even: r + 1 is the next key
+          dpv = dpv * f32x2{attn_drop_scale(akey, qoff + (unsigned int)key, dr.thresh, dr.inv_keep),
+                            attn_drop_scale(akey, qoff + (unsigned int)key + 1u, dr.thresh, dr.inv_keep)};
         }
-        st[r] = __builtin_amdgcn_exp2f(st[r] * scale_log2e) * (dpt[r] - del);
+        const f32x2 a = f32x2{st[r], st[r + 1]} * sc2;
+        const f32x2 ds = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} * (dpv - del2);
+        st[r] = ds[0];
+        st[r + 1] = ds[1];
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {

@@ -44,17 +44,39 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(base + (size_t)qrow * ld_qkv + 16 * ks + 8 * hh);
 
+  // K / V staging: lane-private source pointers advanced by one tile per call (the straightforward form recomputed a clamped 64-bit
+  // address per 16-byte piece: ~100 VALU instructions per tile in a kernel whose softmax is VALU-bound).  Only the last tile can
+  // reach past the sequence; it clamps its rows to T-1 (finite data that the key mask then ignores).
+  const int rsub = lane >> 3, slot = lane & 7;
+  const bf16* kp[kKB / 32];
+  const bf16* vp[kKB / 32];
+#pragma unroll
+  for (int r = 0; r < kKB / 32; ++r) {
+    const int row = r * 32 + wave * 8 + rsub;
+    kp[r] = kbase + (size_t)row * ld_qkv + ((slot ^ swz(row)) << 3);
+    vp[r] = kp[r] + inner;
+  }
+  const size_t tile_step = (size_t)kKB * ld_qkv;
+  const int nkt = (T + kKB - 1) / kKB;
   auto stage = [&](int buf, int kt) {
     char* sK = smem + buf * 2 * kTileBytes;
     char* sV = sK + kTileBytes;
-    const int rsub = lane >> 3, slot = lane & 7;
+    if (kt == nkt - 1) {
 #pragma unroll
-    for (int r = 0; r < kKB / 32; ++r) {
-      const int row = r * 32 + wave * 8 + rsub;
-      const int key = min(kt * kKB + row, T - 1);
-      const int chunk = slot ^ swz(row);
-      glds16(kbase + (size_t)key * ld_qkv + chunk * 8, sK + (r * 32 + wave * 8) * 128);
-      glds16(vbase + (size_t)key * ld_qkv + chunk * 8, sV + (r * 32 + wave * 8) * 128);
+      for (int r = 0; r < kKB / 32; ++r) {
+        const int row = r * 32 + wave * 8 + rsub;
+        const int over = max(kt * kKB + row - (T - 1), 0);            // rows past the end step back to row T-1
+        glds16(kp[r] - (size_t)over * ld_qkv, sK + (r * 32 + wave * 8) * 128);
+        glds16(vp[r] - (size_t)over * ld_qkv, sV + (r * 32 + wave * 8) * 128);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < kKB / 32; ++r) {
+        glds16(kp[r], sK + (r * 32 + wave * 8) * 128);
+        glds16(vp[r], sV + (r * 32 + wave * 8) * 128);
+        kp[r] += tile_step;
+        vp[r] += tile_step;
+      }
     }
   };
 
@@ -68,7 +90,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     qoff = (unsigned int)(q0 + wave * 32 + r31) * (unsigned int)T;
   }
 
-  const int nkt = (T + kKB - 1) / kKB;
   stage(0, 0);
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
@@ -77,19 +98,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     const char* sK = smem + buf * 2 * kTileBytes;
     const char* sV = sK + kTileBytes;
 
-    // ---- S^T = K . Q^T   (kKB/32 key blocks of 32)
+    // ---- S^T = K . Q^T   (kKB/32 key blocks of 32).  The K fragments of block kb+1 are read from LDS while the four MFMAs of block kb
+    //      run: left to itself the compiler issued every ds_read right before its MFMA and waited lgkmcnt(0) in between (16 exposed
+    //      LDS round trips per tile).
     constexpr int NKB = kKB / 32;
     f32x16 st[NKB];
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      st[kb] = f32x16{};
+    bf16x8 kfr[2][4];
+    auto load_k = [&](int kb, bf16x8 (&dst)[4]) {
       const int row = kb * 32 + r31;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int chunk = 2 * ks + hh;
-        const bf16x8 kf = *(const bf16x8*)(sK + row * 128 + ((chunk ^ swz(row)) << 4));
-        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
-      }
+      for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const bf16x8*)(sK + row * 128 + (((2 * ks + hh) ^ swz(row)) << 4));
+    };
+    load_k(0, kfr[0]);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (kb + 1 < NKB) load_k(kb + 1, kfr[(kb + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      st[kb] = f32x16{};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb & 1][ks], qf[ks], st[kb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // ---- online softmax in the log2 domain.  VALU budget per score: max, fma, exp2, add (the scale is folded into the fma,
     //      the key mask is applied on the last tile only) -- this block, not the MFMAs, was the largest share of the kernel.
@@ -111,15 +139,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     const float m_new = fmaxf(m_run, mx);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
     m_run = m_new;
-    float psum = 0.f;
+    // two scores per v_pk_fma_f32 / v_pk_add_f32: the softmax is VALU-bound (the quarter-rate v_exp_f32 alone costs as many cycles
+    // as the tile's 32 MFMAs), so every full-rate instruction saved shows
+    f32x2 psum2 = {0.f, 0.f};
+    const f32x2 sc2 = {scale_log2e, scale_log2e}, nm2 = {-m_new, -m_new};
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], scale_log2e, -m_new));
-        st[kb][r] = p;
-        psum += p;
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 a = __builtin_elementwise_fma(f32x2{st[kb][r], st[kb][r + 1]}, sc2, nm2);
+        const f32x2 p2 = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        st[kb][r] = p2[0];
+        st[kb][r + 1] = p2[1];
+        psum2 += p2;
       }
+    const float psum = psum2[0] + psum2[1];
     l_run = l_run * alpha + psum;
     if constexpr (DROP) {
 #pragma unroll
@@ -135,26 +169,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) ot[db][r] *= alpha;
 
-    // ---- O^T += V^T . P^T : P^T straight from the accumulator registers as the B operand
+    // ---- O^T += V^T . P^T : P^T straight from the accumulator registers as the B operand; the V^T fragments of step (kb, s) + 1 are
+    //      gathered while the two MFMAs of step (kb, s) run
     const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    bf16x8 vfr[2][2];
+    auto load_v = [&](int step, bf16x8 (&dst)[2]) {
+      const int kb = step >> 1, sb = step & 1;
+      const int key0 = kb * 32 + 16 * sb + 4 * (g >> 1);   // lane half hh == g>>1
+      const int ra = key0 + tq, rb = key0 + 8 + tq;
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 pf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[kb][8 * s + j];
-        const int key0 = kb * 32 + 16 * s + 4 * (g >> 1);   // lane half hh == g>>1
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
-          const int ra = key0 + tq, rb = key0 + 8 + tq;
-          const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((chunk ^ swz(ra)) << 4) + (tp & 1) * 8);
-          const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((chunk ^ swz(rb)) << 4) + (tp & 1) * 8);
-          const bf16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
-          ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[db], 0, 0, 0);
-        }
+      for (int db = 0; db < 2; ++db) {
+        const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
+        const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((chunk ^ swz(ra)) << 4) + (tp & 1) * 8);
+        const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((chunk ^ swz(rb)) << 4) + (tp & 1) * 8);
+        dst[db] = bf16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
       }
+    };
+    load_v(0, vfr[0]);
+#pragma unroll
+    for (int step = 0; step < 2 * NKB; ++step) {
+      if (step + 1 < 2 * NKB) load_v(step + 1, vfr[(step + 1) & 1]);
+      const int kb = step >> 1, sb = step & 1;
+      bf16x8 pf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[kb][8 * sb + j];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[step & 1][db], pf, ot[db], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();
   }
 

@@ -1,26 +1,34 @@
-"""GPU box: isolated timing of the attention kernels at the cfg2 shape (B=4, T=1033, H=12)."""
+"""GPU box: isolated timing of the bf16 attention kernels at the cfg2 shape (B=4, T=1033, H=12), 50 launches replayed from a plan."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from gaviko_amd import ops, lib
+from gaviko_amd import lib, ops
 lib.require_device()
 dev = torch.device("cuda:0")
-B, T, H = 4, 1033, 12
+B, T, H = (int(a) for a in (sys.argv[1:4] + ["4", "1033", "12"][len(sys.argv) - 1:]))
 inner = H * 64
-M = B * T
-qkv = ops.act_zeros(M, 3 * inner, torch.bfloat16, dev); qkv[:M] = torch.randn(M, 3 * inner, device=dev).bfloat16()
-O = ops.act_zeros(M, inner, torch.bfloat16, dev)
-dO = ops.act_zeros(M, inner, torch.bfloat16, dev); dO[:M] = torch.randn(M, inner, device=dev).bfloat16()
-dq = ops.act_zeros(M, 3 * inner, torch.bfloat16, dev)
-lse = torch.zeros(B, H, T, device=dev); delta = torch.zeros(B, H, T, device=dev)
-fl = 4.0 * B * H * T * T * 64
+qkv = ops.act_zeros(B * T, 3 * inner, torch.bfloat16, dev); qkv[:B * T] = (torch.randn(B * T, 3 * inner, device=dev) * 0.7).bfloat16()
+out, dout = ops.act_zeros(B * T, inner, torch.bfloat16, dev), ops.act_zeros(B * T, inner, torch.bfloat16, dev)
+dout[:B * T] = torch.randn(B * T, inner, device=dev).bfloat16()
+lse, delta = torch.empty(B * H * T, device=dev), torch.empty(B * H * T, device=dev)
+dqkv = ops.act_zeros(B * T, 3 * inner, torch.bfloat16, dev)
+
+
 def t(name, fn, flops):
-    for _ in range(5): fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    for _ in range(3): fn()
+    l = lib.load()
+    lib.check(l.gvk_plan_begin(), "begin")
     for _ in range(50): fn()
-    e1.record(); torch.cuda.synchronize()
+    pid = l.gvk_plan_end()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    l.gvk_plan_replay(pid)
+    e0.record(); l.gvk_plan_replay(pid); e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 50
-    print(f"{name:20s} {us:7.1f} us  {flops / us / 1e6:6.0f} TF", flush=True)
-t("attention_fwd", lambda: ops.attention_fwd(qkv, O, lse, B, T, H, 0.125), fl)
-t("attention_bwd", lambda: ops.attention_bwd(qkv, O, dO, lse, delta, dq, B, T, H, 0.125), 2.5 * fl)
+    print(f"{name:28s} {us:7.1f} us  {flops / us / 1e6:6.0f} TFLOP/s")
+    l.gvk_plan_free(pid)
+
+
+f = 4.0 * B * H * T * T * 64
+t("attention_fwd", lambda: ops.attention_fwd(qkv, out, lse, B, T, H, 0.125), f)
+t("attention_bwd (5 products)", lambda: ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, 0.125), 2.5 * f)
