@@ -52,7 +52,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
                                                             float scale_log2e, AttnDrop dr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][Q tile | dO tile | lse' kQT f32 | delta kQT f32]
   constexpr int kBuf = 2 * kTileQ + 2 * kQT * 4;
-  const int b = blockIdx.z, head = blockIdx.y, k0 = blockIdx.x * 128;
+  int bh, kblk;
+  xcd_group_block(blockIdx.x, (T + 127) / 128, gridDim.x / ((T + 127) / 128), bh, kblk);   // all key blocks of a (batch, head) on one XCD
+  const int b = bh / H, head = bh - b * H, k0 = kblk * 128;
   const int lane = lane_id(), wave = wave_id();
   const int r31 = lane & 31, hh = lane >> 5;
   const int inner = H * 64;
@@ -204,7 +206,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
                                                           bf16* __restrict__ dqkv, int T, int H, int ld_qkv, int ld_o, float scale,
                                                           float scale_log2e, AttnDrop dr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][K tile | V tile]
-  const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * 128;
+  int bh, qblk;
+  xcd_group_block(blockIdx.x, (T + 127) / 128, gridDim.x / ((T + 127) / 128), bh, qblk);
+  const int b = bh / H, head = bh - b * H, q0 = qblk * 128;
   const int lane = lane_id(), wave = wave_id();
   const int r31 = lane & 31, hh = lane >> 5;
   const int inner = H * 64;
@@ -342,7 +346,7 @@ extern "C" int gvk_attention_bwd_bf16_dropout(const void* qkv, const void* out, 
   int rc = check_launch("attention_bwd/delta");
   if (rc) return rc;
   const float sl2 = scale * 1.44269504088896340736f;
-  const dim3 grid((T + 127) / 128, H, B);
+  const dim3 grid(((T + 127) / 128) * H * B);
   const unsigned lds_kv = 2 * (2 * kTileQ + 2 * kQT * 4), lds_q = 2 * 2 * kTile64;
   if (drop_p > 0.f) {
     GVK_LAUNCH(attn_bwd_dkdv_kernel<true>, grid, dim3(256), lds_kv, s, (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H, ld_qkv,

@@ -30,7 +30,9 @@ template <bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse,
                                                        int T, int H, int ld_qkv, int ld_out, float scale_log2e, AttnDrop dr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K tile | V tile]
-  const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * kQB;
+  int bh, qb;
+  xcd_group_block(blockIdx.x, (T + kQB - 1) / kQB, gridDim.x / ((T + kQB - 1) / kQB), bh, qb);   // all query blocks of a (batch, head) on one XCD
+  const int b = bh / H, head = bh - b * H, q0 = qb * kQB;
   const int lane = lane_id(), wave = wave_id();
   const int r31 = lane & 31, hh = lane >> 5;
   const int inner = H * 64;
@@ -231,7 +233,7 @@ static int launch_attn_fwd(const void* qkv, void* out, float* lse, int B, int T,
     if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(attn_fwd): %s", hipGetErrorString(e));
     attr = true;
   }
-  GVK_LAUNCH(attn_fwd_kernel<DROP>, dim3((T + kQB - 1) / kQB, H, B), dim3(256), lds, stream, (const bf16*)qkv,
+  GVK_LAUNCH(attn_fwd_kernel<DROP>, dim3(((T + kQB - 1) / kQB) * H * B), dim3(256), lds, stream, (const bf16*)qkv,
                      (bf16*)out, lse, T, H, ld_qkv, ld_out, scale * 1.44269504088896340736f, dr);
   return check_launch("attention_fwd_bf16");
 }
