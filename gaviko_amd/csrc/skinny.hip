@@ -316,8 +316,8 @@ struct OuterArgs {
 };
 
 constexpr int kSlabs = 64;          // row slabs of the small two-stage reductions (colsum, small_wgrad)
-constexpr int kOuterSlabs = 128;    // row slabs of the outer-product reduction
-constexpr int kOuterMaxRows = 80;   // rows of one slab staged in LDS (M <= kOuterSlabs * kOuterMaxRows)
+constexpr int kOuterSlabs = 64;     // row slabs of the outer-product reduction
+constexpr int kOuterMaxRows = 160;  // rows of one slab staged in LDS (M <= kOuterSlabs * kOuterMaxRows)
 
 // Partial outer products on the fp32 matrix cores: D[l][c] += sum over a slab of rows m of narrow'[m][l] * wide'[m][c], where
 // narrow' has an extra column of ones (row L of D is the column sum of wide').  A wave owns 64 columns of one row slab:
