@@ -313,6 +313,9 @@ struct OuterArgs {
   int M, C;
   unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;   // optional dropout mask on `wide`
   int wide_act;                                           // 1: QuickGELU applied to `wide` on the fly (DVPT: dWd = dz^T . QuickGELU(x))
+  // optional second source: rows M1 .. M-1 of the reduction come from (narrow2, wide2) -- one weight fed by two token streams
+  // (GPA proj_down: dW = dzx^T . G1 + dzl^T . L', gaviko.py:155-156) in ONE pass; plain rows only (no LN / dropout / override)
+  const float* narrow2; const float* wide2; int M1;
 };
 
 constexpr int kSlabs = 64;          // row slabs of the small two-stage reductions (colsum, small_wgrad)
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(256) void outer_partial_kernel(OuterArgs p) {
     const int r = i / (NT * 16), l = i - r * (NT * 16), m = r0 + r;
     float v = 0.f;
     if (l < L) {
-      const float* src = p.narrow + (size_t)m * L;
+      const float* src = (p.narrow2 != nullptr && m >= p.M1) ? p.narrow2 + (size_t)(m - p.M1) * L : p.narrow + (size_t)m * L;
       if (p.lat_override != nullptr) {
         const int s = m / p.T, t = m - s * p.T;
         if (t < p.P) src = p.lat_override + ((size_t)s * p.P + t) * L;
@@ -370,7 +373,9 @@ __global__ __launch_bounds__(256) void outer_partial_kernel(OuterArgs p) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {                      // 4 k-steps (16 rows) of loads in flight
       const int r = rb + 4 * u + kq;
-      x[u] = (r < nr && cok) ? *(const f32x4*)(p.wide + (size_t)(r0 + r) * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int gm = r0 + r;
+      const float* wrow = (p.narrow2 != nullptr && gm >= p.M1) ? p.wide2 + (size_t)(gm - p.M1) * C : p.wide + (size_t)gm * C;
+      x[u] = (r < nr && cok) ? *(const f32x4*)(wrow + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -706,6 +711,13 @@ extern "C" int gvk_outer_reduce(const gvk_outer_desc* d, void* stream) {
   a.narrow = d->narrow; a.wide = d->wide; a.lat_override = d->lat_override; a.T = d->T; a.P = d->P;
   a.mean = d->mean; a.rstd = d->rstd; a.ln_g = d->ln_gamma; a.ln_b = d->ln_beta; a.scratch = d->scratch; a.M = d->M; a.C = d->C;
   a.wide_act = d->wide_act;
+  a.narrow2 = d->narrow2; a.wide2 = d->wide2; a.M1 = d->M;
+  if (d->narrow2 != nullptr) {
+    GVK_REQUIRE(d->wide2 != nullptr && d->M2 > 0 && d->mean == nullptr && d->lat_override == nullptr && d->drop_p <= 0.f && d->wide_act == 0,
+                "gvk_outer_reduce: the second source takes plain rows only (no LN, override, dropout, activation)");
+    a.M = d->M + d->M2;
+    GVK_REQUIRE(a.M <= kOuterSlabs * kOuterMaxRows, "gvk_outer_reduce: M + M2 = %d exceeds %d rows", a.M, kOuterSlabs * kOuterMaxRows);
+  }
   a.seed = d->seed; a.seed_ptr = (const unsigned long long*)d->seed_ptr; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
   hipStream_t s = (hipStream_t)stream;
   int rc;

@@ -1042,8 +1042,12 @@ class Engine:
                           (bw["dzx"], None, gbd, acc)], ws["rscratch"])
         ops.reduce_batch([(bw["dzl"][par], None, gbd, 1)], ws["rscratch"])
         # proj_down (shared by both streams): dWd = dzx^T.G1 + dzl^T.Lnew
-        ops.outer_reduce(narrow=bw["dzx"], wide=ws["G1"][i], scratch=sc, out=gwd, M=M, C=C, L=Lt, transposed=0, accumulate=acc)
-        ops.outer_reduce(narrow=bw["dzl"][par], wide=ws["Lc"][i + 1], scratch=sc, out=gwd, M=B * N, C=C, L=Lt, transposed=0, accumulate=1)
+        if M + B * N <= ops.OUTER_MAX_ROWS:                                   # both token streams in one pass
+            ops.outer_reduce(narrow=bw["dzx"], wide=ws["G1"][i], narrow2=bw["dzl"][par], wide2=ws["Lc"][i + 1], scratch=sc, out=gwd, M=M, M2=B * N,
+                             C=C, L=Lt, transposed=0, accumulate=acc)
+        else:
+            ops.outer_reduce(narrow=bw["dzx"], wide=ws["G1"][i], scratch=sc, out=gwd, M=M, C=C, L=Lt, transposed=0, accumulate=acc)
+            ops.outer_reduce(narrow=bw["dzl"][par], wide=ws["Lc"][i + 1], scratch=sc, out=gwd, M=B * N, C=C, L=Lt, transposed=0, accumulate=1)
 
     def _gpa_bwd_scatter_g(self, ws, i, dG1, M):
         """main stream: dG1 += dzx . Wd, with the bf16 copy for the out-proj dgrad."""

@@ -39,8 +39,9 @@ SkinnyDownDesc = _struct("SkinnyDownDesc",
 SkinnyUpDesc = _struct("SkinnyUpDesc", ["lat", "w", "bias", "res", "out", "lat_override", "seed_ptr", "ln_x", "ln_mean", "ln_rstd", "ln_gamma", "out_bf16",
                                         "alpha_ptr", "gg_x"],
                        ["M", "C", "L", "T", "P", "w_layout", "accumulate"], ["drop_p"], ["seed"])
-OuterDesc = _struct("OuterDesc", ["narrow", "wide", "lat_override", "mean", "rstd", "ln_gamma", "ln_beta", "scratch", "out", "colsum", "seed_ptr"],
-                    ["M", "C", "L", "T", "P", "transposed", "accumulate", "wide_act"], ["drop_p"], ["seed"])
+OuterDesc = _struct("OuterDesc", ["narrow", "wide", "lat_override", "mean", "rstd", "ln_gamma", "ln_beta", "scratch", "out", "colsum", "seed_ptr",
+                                  "narrow2", "wide2"],
+                    ["M", "C", "L", "T", "P", "transposed", "accumulate", "wide_act", "M2"], ["drop_p"], ["seed"])
 WindowAttnDesc = _struct("WindowAttnDesc", ["qkv", "ctx", "lse", "dctx", "delta", "dqkv", "seed_ptr"],
                          ["B", "D", "H", "W", "kd", "kh", "kw", "L"], ["scale", "drop_p"], ["seed"])
 GpaDesc = _struct("GpaDesc",

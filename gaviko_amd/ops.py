@@ -305,6 +305,9 @@ def outer_reduce(**kw):
     L.check(L.load().gvk_outer_reduce(C.byref(d), L.stream_ptr()), "gvk_outer_reduce")
 
 
+OUTER_MAX_ROWS = 10240        # rows one gvk_outer_reduce launch covers (64 slabs x 160 rows), second source included
+
+
 def outer_scratch_elems(Lat, C_):
     return 128 * (Lat + 1) * C_
 

@@ -210,14 +210,17 @@ int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream);
 
 /* outer: out[l][c] (transposed=0) or out[c][l] (transposed=1) (+)= sum_m narrow[m][l] * wide'[m][c];
  *        colsum[c] (+)= sum_m wide'[m][c] (optional).  wide' = LN(wide) when mean/rstd(/gamma/beta) are given, times the
- *        dropout mask when drop_p > 0.  scratch: f32 [128*(L+1)*C]; M <= 10240.  Deterministic (two-stage, no atomics). */
+ *        dropout mask when drop_p > 0.  scratch: f32 [128*(L+1)*C]; M (+ M2) <= 10240.  Deterministic (two-stage, no atomics). */
 typedef struct gvk_outer_desc {
   const float* narrow; const float* wide; const float* lat_override;
   const float* mean; const float* rstd; const float* ln_gamma; const float* ln_beta;
   float* scratch; float* out; float* colsum;
   const uint64_t* seed_ptr;
+  const float* narrow2; const float* wide2; /* optional second source [M2][L] / [M2][C] summed into the same result in the same pass
+                                               (one weight fed by two token streams: GPA proj_down, gaviko.py:155-156); plain rows only */
   int32_t M, C, L, T, P, transposed, accumulate;
   int32_t wide_act;                  /* 1: QuickGELU applied to `wide` on the fly (DVPT: dW_d = dz^T . QuickGELU(x)) */
+  int32_t M2;
   float drop_p;
   uint64_t seed;
 } gvk_outer_desc;

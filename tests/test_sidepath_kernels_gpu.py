@@ -383,3 +383,23 @@ def test_fused_projection_rejects_other_latent_widths(dev):
     with pytest.raises(ops.L.GavikoHipError, match="gvk_skinny_down"):
         ops.layernorm_fwd_proj(x, x[0], x[0], 64, 768, y16=torch.empty(64, 768, dtype=torch.bfloat16, device=dev),
                                w=rnd(32, 768, device=dev), y=torch.empty(64, 32, device=dev), L_=32)
+
+
+def test_outer_reduce_two_sources(dev):
+    """One weight gradient fed by two token streams in one pass: out = n1^T . w1 + n2^T . w2."""
+    from gaviko_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=gen).to(dev)  # noqa: E731
+    M1, M2, C, L = 4132, 4000, 768, 20
+    n1, w1, n2, w2 = r(M1, L), r(M1, C), r(M2, L), r(M2, C)
+    sc = torch.zeros(ops.outer_scratch_elems(L, C), device=dev)
+    out = torch.zeros(L, C, device=dev)
+    ops.outer_reduce(narrow=n1, wide=w1, narrow2=n2, wide2=w2, scratch=sc, out=out, M=M1, M2=M2, C=C, L=L, transposed=0, accumulate=0)
+    want = n1.double().t() @ w1.double() + n2.double().t() @ w2.double()
+    assert (out.double() - want).abs().max().item() < 2e-3
+    two = torch.zeros(L, C, device=dev)
+    ops.outer_reduce(narrow=n1, wide=w1, scratch=sc, out=two, M=M1, C=C, L=L, transposed=0, accumulate=0)
+    ops.outer_reduce(narrow=n2, wide=w2, scratch=sc, out=two, M=M2, C=C, L=L, transposed=0, accumulate=1)
+    assert (out - two).abs().max().item() < 2e-3
+    with pytest.raises(Exception, match="exceeds"):
+        ops.outer_reduce(narrow=n1, wide=w1, narrow2=r(8000, L), wide2=r(8000, C), scratch=sc, out=out, M=M1, M2=8000, C=C, L=L, transposed=0, accumulate=0)
