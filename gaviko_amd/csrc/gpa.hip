@@ -181,41 +181,46 @@ __global__ __launch_bounds__(128) void gpa_cross_bwd_p_kernel(GpaArgs p) {
 template <int L>
 __global__ __launch_bounds__(64) void gpa_gates_bwd_kernel(GpaArgs p) {
   __shared__ float a1_s[64], da1_s[64], dpre3_s[64], dhn_s[64][L + 1];
+  __shared__ float w3_s[64][65];                           // ca3_w rows (q < P), +1 pad
   const int b = blockIdx.x, lane = threadIdx.x, P = p.P;
   const int n_gate = 4 * L + 64 * L + 64 + 64 * P + P + L + 1;
   float* out = p.gate_partials + (size_t)b * n_gate;
   float* o_ca0g = out; float* o_ca0b = out + L; float* o_ca1w = out + 2 * L; float* o_ca1b = o_ca1w + 64 * L;
   float* o_ca3w = o_ca1b + 64; float* o_ca3b = o_ca3w + 64 * P; float* o_gl0g = o_ca3b + P; float* o_gl0b = o_gl0g + L;
   float* o_gl1w = o_gl0b + L; float* o_gl1b = o_gl1w + L;
-  float cls[L], hn[L], gn[L], dcls[L];
+  // One wave per sample on a busy chip: every dependent round trip to memory costs microseconds, so EVERYTHING this kernel reads is
+  // requested here, before the first use (the loop form interleaved loads with stores to `out` and paid ~8 round trips: 24 us).
+  float w1[L], cls[L], hn[L], gn[L], dcls[L];
 #pragma unroll
-  for (int l = 0; l < L; ++l) { cls[l] = p.xl[((size_t)b * p.T + P) * L + l]; dcls[l] = 0.f; }
+  for (int l = 0; l < L; ++l) { w1[l] = p.ca1_w[lane * L + l]; cls[l] = p.xl[((size_t)b * p.T + P) * L + l]; dcls[l] = 0.f; }
+  for (int q = 0; q < P && q < 64; ++q) w3_s[q][lane] = p.ca3_w[q * 64 + lane];
+  const float b1 = p.ca1_b[lane];
+  float d3 = 0.f;
+  if (lane < P) {
+    const float im = p.imp[b * P + lane];
+    d3 = p.dimp[b * P + lane] * im * (1.f - im);
+  }
+  float dgw = (lane < P) ? p.dgw_part[b * P + lane] : 0.f;
+  for (int q = lane + 64; q < P; q += 64) dgw += p.dgw_part[b * P + q];
+  const float gwv = p.gw[b];
   float mean_a, rstd_a, mean_g, rstd_g;
   ln_small<L>(cls, p.ca0_g, p.ca0_b, hn, mean_a, rstd_a);
-  float pre1 = p.ca1_b[lane];
+  float pre1 = b1;
 #pragma unroll
-  for (int l = 0; l < L; ++l) pre1 += p.ca1_w[lane * L + l] * hn[l];
+  for (int l = 0; l < L; ++l) pre1 += w1[l] * hn[l];
   a1_s[lane] = gelu_erf(pre1);
-  da1_s[lane] = 0.f;
-  __syncthreads();
   // layer 3 (P outputs): dpre3[q] = dimp * imp * (1 - imp)
-  for (int q = lane; q < 64; q += 64) {
-    float d3 = 0.f;
-    if (q < P) {
-      const float im = p.imp[b * P + q];
-      d3 = p.dimp[b * P + q] * im * (1.f - im);
-      o_ca3b[q] = d3;
-    }
-    dpre3_s[q] = d3;
-  }
+  if (lane < P) o_ca3b[lane] = d3;
+  dpre3_s[lane] = d3;
   __syncthreads();
   // d ca3_w[q][u] = dpre3[q] * a1[u];  da1[u] = sum_q dpre3[q] * ca3_w[q][u]   (lane = u)
   {
     float da = 0.f;
+    const float a1 = a1_s[lane];
     for (int q = 0; q < P && q < 64; ++q) {
-      const float d3 = dpre3_s[q];
-      o_ca3w[q * 64 + lane] = d3 * a1_s[lane];
-      da += d3 * p.ca3_w[q * 64 + lane];
+      const float dq3 = dpre3_s[q];
+      o_ca3w[q * 64 + lane] = dq3 * a1;
+      da += dq3 * w3_s[q][lane];
     }
     da1_s[lane] = da;
   }
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(64) void gpa_gates_bwd_kernel(GpaArgs p) {
 #pragma unroll
   for (int l = 0; l < L; ++l) {
     o_ca1w[lane * L + l] = dpre1 * hn[l];
-    dhn_s[lane][l] = dpre1 * p.ca1_w[lane * L + l];
+    dhn_s[lane][l] = dpre1 * w1[l];
   }
   __syncthreads();
   float dhn[L];
@@ -242,9 +247,7 @@ __global__ __launch_bounds__(64) void gpa_gates_bwd_kernel(GpaArgs p) {
   ln_small_bwd<L>(cls, mean_a, rstd_a, p.ca0_g, dhn, dcls);
   // PCF balance gate
   ln_small<L>(cls, p.gl0_g, p.gl0_b, gn, mean_g, rstd_g);
-  float dgw = 0.f;
-  for (int q = 0; q < P; ++q) dgw += p.dgw_part[b * P + q];
-  const float gwv = p.gw[b];
+  dgw = wave_sum(dgw);
   const float dpre = dgw * gwv * (1.f - gwv);
   float dgn[L];
 #pragma unroll
