@@ -46,9 +46,12 @@ __device__ __forceinline__ int swz_chunk(int row) {
 // so those 16 rows again hit 16 distinct (parity, slot) pairs.
 __device__ __forceinline__ int swz_w(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
 
-template <int BM, int BN, int EPI, int BK = 64, bool DROP = false>
+// NS = LDS stages.  2: the tuned default (two workgroups per CU hide each other's stalls).  3: for the shapes that run ONE workgroup
+// per CU (128 x 128 tiles of the N = 768 GEMMs: 198 tiles) -- there a third tile in flight is what hides the L2 round trip.
+template <int BM, int BN, int EPI, int BK = 64, bool DROP = false, int NS = 2>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   static_assert(BK == 64, "the interleaved weight-row mapping is built for 128-byte tile rows");
+  static_assert(NS == 2 || NS == 3, "2 or 3 LDS stages");
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NT = WN / 16;
   constexpr int ROWB = BK * 2;                       // bytes per LDS tile row
@@ -131,10 +134,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB[j], XA[i], acc[i][j], 0, 0, 0);
     bf16x8 xa0[MT], wb0[NT], xa1[MT], wb1[NT];
+    constexpr int PER_TILE = BM / (4 * RPI) + BN / (4 * RPI);
+    if constexpr (NS == 2) {
     stage(0, 0);
     if (nt > 1) stage(1, 1);
     // tile 0 must have landed; tile 1 may still be in flight (PER_TILE LDS-DMA instructions per wave and tile)
-    constexpr int PER_TILE = BM / (4 * RPI) + BN / (4 * RPI);
     if (nt > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (PER_TILE & 0xF) | ((PER_TILE >> 4) << 14));   // vmcnt(PER_TILE)
     else __builtin_amdgcn_s_waitcnt(0x0F70);                                                        // vmcnt(0)
     __builtin_amdgcn_s_barrier();
@@ -162,6 +166,54 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     for (; t < nt - 2; ++t) GVK_TILE(t, true)
     for (; t < nt; ++t) GVK_TILE(t, false)
 #undef GVK_TILE
+    } else {
+    // Three stages: tiles 0..2 are requested up front, tile t+3 as soon as tile t's buffer is free.  A wave's LDS-DMA instructions
+    // complete in order, so "tile t+1 has landed" is vmcnt(PER_TILE * #tiles requested after t+1): 1 in the steady state.
+    static_assert(2 * PER_TILE <= 63, "vmcnt is a 6-bit counter");
+#pragma unroll
+    for (int sgi = 0; sgi < 3; ++sgi)
+      if (sgi < nt) stage(sgi, sgi);
+    if (nt >= 3) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * PER_TILE) & 0xF) | (((2 * PER_TILE) >> 4) << 14));
+    else if (nt == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (PER_TILE & 0xF) | ((PER_TILE >> 4) << 14));
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_barrier();
+    GVK_LOAD_FRAGS(smem, smem + A_BYTES, 0, xa0, wb0)
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    // AHEAD = tiles requested after tile T+1 when tile T reaches its barrier (a literal: s_waitcnt takes an immediate); LAST: no tile T+1
+#define GVK_TILE3(T, BUF, PREFETCH, AHEAD, LAST)                                                            \
+    {                                                                                                       \
+      const int buf = (BUF);                                                                                \
+      const int nxt = buf == 2 ? 0 : buf + 1;                                                               \
+      const char* sA = smem + buf * STAGE;                                                                  \
+      const char* sW = sA + A_BYTES;                                                                        \
+      GVK_LOAD_FRAGS(sA, sW, 1, xa1, wb1)                                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      GVK_MMA(xa0, wb0)                                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      /* this wave's share of tile T+1 landed, its reads of tile T done; the barrier extends both to all waves */ \
+      __builtin_amdgcn_s_waitcnt(0x0070 | (((AHEAD) * PER_TILE) & 0xF) | ((((AHEAD) * PER_TILE) >> 4) << 14)); \
+      __builtin_amdgcn_s_barrier();                                                                         \
+      if (PREFETCH) stage(buf, (T) + 3);                                                                    \
+      if (!(LAST)) GVK_LOAD_FRAGS(smem + nxt * STAGE, smem + nxt * STAGE + A_BYTES, 0, xa0, wb0)            \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      GVK_MMA(xa1, wb1)                                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                    \
+      __builtin_amdgcn_s_waitcnt(0xC07F);                                                                   \
+    }
+    int t = 0, b = 0;
+    for (; t < nt - 3; ++t) {
+      GVK_TILE3(t, b, true, 1, false)
+      b = b == 2 ? 0 : b + 1;
+    }
+    for (; t < nt; ++t) {                                  // the last (up to) three tiles request nothing
+      const int r = nt - 1 - t;                            // tiles left after this one; r - 1 of them may still be in flight
+      if (r == 2) GVK_TILE3(t, b, false, 1, false)
+      else if (r == 1) GVK_TILE3(t, b, false, 0, false)
+      else GVK_TILE3(t, b, false, 0, true)
+      b = b == 2 ? 0 : b + 1;
+    }
+#undef GVK_TILE3
+    }
 #undef GVK_LOAD_FRAGS
 #undef GVK_MMA
   }
@@ -250,13 +302,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int EPI, bool DROP = false>
+template <int BM, int BN, int EPI, bool DROP = false, int NS = 2>
 static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   constexpr int BK = 64;
-  constexpr int lds = 2 * (BM + BN) * BK * 2;
+  constexpr int lds = NS * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, EPI, BK, DROP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, EPI, BK, DROP, NS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(gemm %dx%d): %s", BM, BN, hipGetErrorString(e));
     attr_set = true;
@@ -264,7 +316,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   GemmArgs p = a;
   p.nbm = (a.M + BM - 1) / BM;
   p.nbn = a.N / BN;
-  GVK_LAUNCH((gemm_nt_kernel<BM, BN, EPI, BK, DROP>), dim3(p.nbm * p.nbn), dim3(256), lds, stream, p);
+  GVK_LAUNCH((gemm_nt_kernel<BM, BN, EPI, BK, DROP, NS>), dim3(p.nbm * p.nbn), dim3(256), lds, stream, p);
   return check_launch("gemm_nt_bf16");
 }
 
@@ -274,8 +326,16 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     const int bn = (a.N % 128 == 0) ? 128 : 64;
     // fill the 256 CUs: fall back to 64-row tiles when 128-row tiles give < ~1.5 workgroups per CU
     const long t128 = (long)((a.M + 127) / 128) * (a.N / bn);
+    // A/B switch GAVIKO_HIP_GEMM_N768: 64 = 64x128 tiles (two workgroups on most CUs), 128 = 128x128 two-stage, default = 128x128
+    // with three stages at one workgroup per CU
+    static const int n768 = getenv("GAVIKO_HIP_GEMM_N768") ? atoi(getenv("GAVIKO_HIP_GEMM_N768")) : 3128;
     const int bm = (t128 >= 384) ? 128 : 64;
     tile = bm * 1000 + bn;
+    static const long t128_lo = getenv("GAVIKO_HIP_GEMM_T128LO") ? atol(getenv("GAVIKO_HIP_GEMM_T128LO")) : 96;
+    if (bm == 64 && bn == 128 && t128 >= t128_lo && t128 <= 256 && a.K >= 512 && a.drop_thresh == 0u) {
+      if (n768 == 3128) tile = 3128128;
+      else if (n768 == 128) tile = 128128;
+    }
   }
   if (a.drop_thresh != 0u) {
     if constexpr (EPI == GVK_EPI_BIAS_RES_F32 || EPI == GVK_EPI_BIAS_GELU_BF16 || EPI == GVK_EPI_GELU_BWD_BF16) {
@@ -291,6 +351,7 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     }
   }
   switch (tile) {
+    case 3128128: return launch_gemm<128, 128, EPI, false, 3>(a, stream);
     case 128128: return launch_gemm<128, 128, EPI>(a, stream);
     case 128064: return launch_gemm<128, 64, EPI>(a, stream);
     case 64128: return launch_gemm<64, 128, EPI>(a, stream);
