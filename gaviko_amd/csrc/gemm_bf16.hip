@@ -51,7 +51,7 @@ __device__ __forceinline__ int swz_w(int row) { return ((row >> 1) & 1) | (((row
 template <int BM, int BN, int EPI, int BK = 64, bool DROP = false, int NS = 2>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   static_assert(BK == 64, "the interleaved weight-row mapping is built for 128-byte tile rows");
-  static_assert(NS == 2 || NS == 3, "2 or 3 LDS stages");
+  static_assert(NS >= 2 && NS <= 4, "2..4 LDS stages");
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NT = WN / 16;
   constexpr int ROWB = BK * 2;                       // bytes per LDS tile row
@@ -167,15 +167,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     for (; t < nt; ++t) GVK_TILE(t, false)
 #undef GVK_TILE
     } else {
-    // Three stages: tiles 0..2 are requested up front, tile t+3 as soon as tile t's buffer is free.  A wave's LDS-DMA instructions
-    // complete in order, so "tile t+1 has landed" is vmcnt(PER_TILE * #tiles requested after t+1): 1 in the steady state.
-    static_assert(2 * PER_TILE <= 63, "vmcnt is a 6-bit counter");
+    // NS stages: tiles 0..NS-1 are requested up front, tile t+NS as soon as tile t's buffer is free.  A wave's LDS-DMA instructions
+    // complete in order, so "tile t+1 has landed" is vmcnt(PER_TILE * #tiles requested after t+1): NS-2 in the steady state.
+    static_assert((NS - 1) * PER_TILE <= 63, "vmcnt is a 6-bit counter");
 #pragma unroll
-    for (int sgi = 0; sgi < 3; ++sgi)
+    for (int sgi = 0; sgi < NS; ++sgi)
       if (sgi < nt) stage(sgi, sgi);
-    if (nt >= 3) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * PER_TILE) & 0xF) | (((2 * PER_TILE) >> 4) << 14));
-    else if (nt == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (PER_TILE & 0xF) | ((PER_TILE >> 4) << 14));
-    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    {
+      const int ahead = min(nt, NS) - 1;                   // tiles that may still be in flight once tile 0 is in
+      if (ahead >= 3) __builtin_amdgcn_s_waitcnt(0x0F70 | ((3 * PER_TILE) & 0xF) | (((3 * PER_TILE) >> 4) << 14));
+      else if (ahead == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * PER_TILE) & 0xF) | (((2 * PER_TILE) >> 4) << 14));
+      else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (PER_TILE & 0xF) | ((PER_TILE >> 4) << 14));
+      else __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
     __builtin_amdgcn_s_barrier();
     GVK_LOAD_FRAGS(smem, smem + A_BYTES, 0, xa0, wb0)
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 #define GVK_TILE3(T, BUF, PREFETCH, AHEAD, LAST)                                                            \
     {                                                                                                       \
       const int buf = (BUF);                                                                                \
-      const int nxt = buf == 2 ? 0 : buf + 1;                                                               \
+      const int nxt = buf == NS - 1 ? 0 : buf + 1;                                                          \
       const char* sA = smem + buf * STAGE;                                                                  \
       const char* sW = sA + A_BYTES;                                                                        \
       GVK_LOAD_FRAGS(sA, sW, 1, xa1, wb1)                                                                   \
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
       /* this wave's share of tile T+1 landed, its reads of tile T done; the barrier extends both to all waves */ \
       __builtin_amdgcn_s_waitcnt(0x0070 | (((AHEAD) * PER_TILE) & 0xF) | ((((AHEAD) * PER_TILE) >> 4) << 14)); \
       __builtin_amdgcn_s_barrier();                                                                         \
-      if (PREFETCH) stage(buf, (T) + 3);                                                                    \
+      if (PREFETCH) stage(buf, (T) + NS);                                                                   \
       if (!(LAST)) GVK_LOAD_FRAGS(smem + nxt * STAGE, smem + nxt * STAGE + A_BYTES, 0, xa0, wb0)            \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
       GVK_MMA(xa1, wb1)                                                                                     \
@@ -201,16 +205,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
       __builtin_amdgcn_s_waitcnt(0xC07F);                                                                   \
     }
     int t = 0, b = 0;
-    for (; t < nt - 3; ++t) {
-      GVK_TILE3(t, b, true, 1, false)
-      b = b == 2 ? 0 : b + 1;
+    for (; t < nt - NS; ++t) {
+      GVK_TILE3(t, b, true, NS - 2, false)
+      b = b == NS - 1 ? 0 : b + 1;
     }
-    for (; t < nt; ++t) {                                  // the last (up to) three tiles request nothing
+    for (; t < nt; ++t) {                                  // the last (up to) NS tiles request nothing
       const int r = nt - 1 - t;                            // tiles left after this one; r - 1 of them may still be in flight
-      if (r == 2) GVK_TILE3(t, b, false, 1, false)
+      if (NS > 3 && r == 3) GVK_TILE3(t, b, false, 2, false)
+      else if (r == 2) GVK_TILE3(t, b, false, 1, false)
       else if (r == 1) GVK_TILE3(t, b, false, 0, false)
       else GVK_TILE3(t, b, false, 0, true)
-      b = b == 2 ? 0 : b + 1;
+      b = b == NS - 1 ? 0 : b + 1;
     }
 #undef GVK_TILE3
     }
