@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64) void gpa_gates_bwd_kernel(GpaArgs p) {
   }
 }
 
-// ---- backward, token side: one thread per latent row (global rows first, then local rows).
+// ---- backward, token side: four lanes per latent row (global rows first, then local rows).
 // Gathers over the P prompts (staged in LDS), adds the proj_up / gate / query-path gradients, applies QuickGELU'.
 template <int L>
 __global__ __launch_bounds__(256) void gpa_bwd_tok_kernel(GpaArgs p) {
@@ -283,8 +283,11 @@ __global__ __launch_bounds__(256) void gpa_bwd_tok_kernel(GpaArgs p) {
     de_s[i] = p.delta_g[b * P + i]; de_s[P + i] = p.delta_l[b * P + i];
   }
   __syncthreads();
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= p.T + p.N) return;
+  // four lanes per latent row, each taking every fourth prompt: one thread per row left this kernel at one wave per SIMD on 32 CUs,
+  // 35 us of exposed LDS latency at the head of the GPA backward chain that the main stream waits for
+  const int part = threadIdx.x & 3;
+  const int r = blockIdx.x * 64 + (threadIdx.x >> 2);
+  if (r >= p.T + p.N) return;                              // (whole quads leave together)
   const bool is_local = r >= p.T;
   const int t = is_local ? r - p.T : r;
   const size_t row = is_local ? (size_t)b * p.N + t : (size_t)b * p.T + t;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(256) void gpa_bwd_tok_kernel(GpaArgs p) {
     const int side = is_local ? 1 : 0;
     const float* qs = q_s + side * P * L;
     const float* dcs = dc_s + side * P * L;
-    for (int q = 0; q < P; ++q) {
+    for (int q = part; q < P; q += 4) {
       float d = 0.f, da = 0.f;
 #pragma unroll
       for (int l = 0; l < L; ++l) { d += qs[q * L + l] * tok[l]; da += dcs[q * L + l] * tok[l]; }
@@ -307,6 +310,12 @@ __global__ __launch_bounds__(256) void gpa_bwd_tok_kernel(GpaArgs p) {
       for (int l = 0; l < L; ++l) g[l] += a * dcs[q * L + l] + ds * qs[q * L + l];
     }
   }
+#pragma unroll
+  for (int l = 0; l < L; ++l) {                            // sum of the quad's four partial gathers
+    g[l] += __shfl_xor(g[l], 1, 64);
+    g[l] += __shfl_xor(g[l], 2, 64);
+  }
+  if (part != 0) return;
   if (!is_local) {
     if (t < P) {
 #pragma unroll
@@ -390,7 +399,7 @@ extern "C" int gvk_gpa_bwd(const gvk_gpa_desc* d, void* stream) {
   rc = check_launch("gpa_gates_bwd");
   if (rc) return rc;
   const int lds = (4 * d->P * d->L + 4 * d->P) * 4;
-  GVK_GPA_LAUNCH(gpa_bwd_tok_kernel, dim3((d->T + d->N + 255) / 256, d->B), dim3(256), lds);
+  GVK_GPA_LAUNCH(gpa_bwd_tok_kernel, dim3((d->T + d->N + 63) / 64, d->B), dim3(256), lds);
   return check_launch("gpa_bwd_tok");
 }
 
