@@ -1,6 +1,6 @@
 // Flash-style attention backward for gfx950, head dim 64, bf16 operands / fp32 accumulate.
 // Autograd of vision_transformer.py:63-71.  P is recomputed from Q, K and the forward's log-sum-exp; nothing N x N is
-// stored.  Two passes, no atomics, bitwise reproducible:
+// stored.  Two passes, no atomics, bitwise reproducible (dq pass first: it also leaves delta = rowsum(dO * O) for the other):
 //   dkdv pass: workgroup = 128 keys (4 waves x 32) of one (batch, head), sweeping 32-query slices.  S[q][key] and
 //              dP[q][key] are computed with the KEY on the MFMA lane, so their accumulators are directly the B operands
 //              of dV^T += dO^T.P and dK^T += Q^T.dS (Q / dO tiles are read row-wise for S, dP and 4x16-transposed
@@ -15,27 +15,6 @@
 namespace gvk {
 
 __device__ __forceinline__ int swz_b(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
-
-// delta[b][h][t] = sum_d dO * O
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ d_o, float* __restrict__ delta,
-                                                         int B, int T, int H, int ld) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)B * T * H) return;
-  const int h = idx % H;
-  const int64_t row = idx / H;
-  const int b = row / T, t = row - (int64_t)b * T;
-  const bf16* po = o + row * ld + h * 64;
-  const bf16* pd = d_o + row * ld + h * 64;
-  float s = 0.f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const bf16x8 a = *(const bf16x8*)(po + 8 * k);
-    const bf16x8 c = *(const bf16x8*)(pd + 8 * k);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)c[e];
-  }
-  delta[((size_t)b * H + h) * T + t] = s;
-}
 
 constexpr int kQT = 64;                 // query rows staged per barrier pair (two 32-row MFMA sub-blocks)
 constexpr int kTileQ = kQT * 128;       // bytes of a [kQT][64] bf16 tile
@@ -200,9 +179,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
 constexpr int kKB2 = 64;
 constexpr int kTile64 = 64 * 128;
 
+// Runs FIRST: it also produces delta[b][h][q] = sum_d dO * O for its own queries (the rows are in its registers anyway) and leaves
+// it in memory for the dK/dV pass, so no separate row-sum kernel sits on the critical path.
 template <bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
-                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd, const bf16* __restrict__ d_o,
+                                                          const float* __restrict__ lse, float* __restrict__ delta,
                                                           bf16* __restrict__ dqkv, int T, int H, int ld_qkv, int ld_o, float scale,
                                                           float scale_log2e, AttnDrop dr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][K tile | V tile]
@@ -218,18 +199,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
   const int q = q0 + wave * 32 + r31;
   const int qc = min(q, T - 1);
   bf16x8 qf[4], dof[4];
+  float del = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     qf[ks] = *(const bf16x8*)(base + (size_t)qc * ld_qkv + 16 * ks + 8 * hh);
     dof[ks] = *(const bf16x8*)(d_o + ((size_t)b * T + qc) * ld_o + head * 64 + 16 * ks + 8 * hh);
+    const bf16x8 of = *(const bf16x8*)(o_fwd + ((size_t)b * T + qc) * ld_o + head * 64 + 16 * ks + 8 * hh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) del += (float)of[j] * (float)dof[ks][j];
   }
+  del += __shfl_xor(del, 32, 64);                         // the two half-waves hold the two halves of the 64-wide row
+  if (hh == 0 && q < T) delta[((size_t)b * H + head) * T + q] = del;
   [[maybe_unused]] unsigned int akey = 0u, qoff = 0u;
   if constexpr (DROP) {
     akey = attn_key(dr.seed + *dr.seed_ptr, b * H + head);
     qoff = (unsigned int)q * (unsigned int)T;
   }
   const float sinit = -lse[((size_t)b * H + head) * T + qc] / scale;
-  const float del = delta[((size_t)b * H + head) * T + qc];
 
   auto stage = [&](int buf, int kt) {
     char* sK = smem + buf * 2 * kTile64;
@@ -340,30 +326,26 @@ extern "C" int gvk_attention_bwd_bf16_dropout(const void* qkv, const void* out, 
   GVK_REQUIRE(drop_p == 0.f || (int64_t)T * T < (int64_t)1 << 32, "gvk_attention_bwd_bf16: the dropout mask index (query*T + key) is 32-bit");
   const AttnDrop dr{seed, (const unsigned long long*)seed_ptr, drop_threshold_u32(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f};
   hipStream_t s = (hipStream_t)stream;
-  const int64_t n = (int64_t)B * T * H;
-  GVK_LAUNCH(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)out, (const bf16*)dout, delta, B, T, H,
-                     ld_out);
-  int rc = check_launch("attention_bwd/delta");
-  if (rc) return rc;
   const float sl2 = scale * 1.44269504088896340736f;
   const dim3 grid(((T + 127) / 128) * H * B);
   const unsigned lds_kv = 2 * (2 * kTileQ + 2 * kQT * 4), lds_q = 2 * 2 * kTile64;
+  int rc;
   if (drop_p > 0.f) {
+    GVK_LAUNCH(attn_bwd_dq_kernel<true>, grid, dim3(256), lds_q, s, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H,
+               ld_qkv, ld_out, scale, sl2, dr);
+    rc = check_launch("attention_bwd/dq");
+    if (rc) return rc;
     GVK_LAUNCH(attn_bwd_dkdv_kernel<true>, grid, dim3(256), lds_kv, s, (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H, ld_qkv,
                ld_out, scale, sl2, dr);
-    rc = check_launch("attention_bwd/dkdv");
-    if (rc) return rc;
-    GVK_LAUNCH(attn_bwd_dq_kernel<true>, grid, dim3(256), lds_q, s, (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H, ld_qkv,
-               ld_out, scale, sl2, dr);
-    return check_launch("attention_bwd/dq");
+    return check_launch("attention_bwd/dkdv");
   }
+  GVK_LAUNCH(attn_bwd_dq_kernel<false>, grid, dim3(256), lds_q, s, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H,
+             ld_qkv, ld_out, scale, sl2, dr);
+  rc = check_launch("attention_bwd/dq");
+  if (rc) return rc;
   GVK_LAUNCH(attn_bwd_dkdv_kernel<false>, grid, dim3(256), lds_kv, s, (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H, ld_qkv,
              ld_out, scale, sl2, dr);
-  rc = check_launch("attention_bwd/dkdv");
-  if (rc) return rc;
-  GVK_LAUNCH(attn_bwd_dq_kernel<false>, grid, dim3(256), lds_q, s, (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H, ld_qkv,
-             ld_out, scale, sl2, dr);
-  return check_launch("attention_bwd/dq");
+  return check_launch("attention_bwd/dkdv");
 }
 
 extern "C" int gvk_attention_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
