@@ -30,6 +30,7 @@ struct GemmArgs {
   int M, N, K, lda, ldw, ldo, ldres, ldaux;
   int rows_in, rows_out, row_off;
   int nbm, nbn;
+  int a_rows;                                            // rows the A buffer really has (M padded to 128): the 256-row tile clamps to it
   // DROP instantiations only (nn.Dropout behind a Linear of the unfrozen-backbone methods): mask index m * N + n
   unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;
 };
@@ -48,11 +49,13 @@ __device__ __forceinline__ int swz_w(int row) { return ((row >> 1) & 1) | (((row
 
 // NS = LDS stages.  2: the tuned default (two workgroups per CU hide each other's stalls).  3: for the shapes that run ONE workgroup
 // per CU (128 x 128 tiles of the N = 768 GEMMs: 198 tiles) -- there a third tile in flight is what hides the L2 round trip.
-template <int BM, int BN, int EPI, int BK = 64, bool DROP = false, int NS = 2>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
+// NW = waves per workgroup: 4 (2 x 2 over the tile) or 8 (4 x 2: the 256 x 256 tile of the wide shapes, 64 x 128 per wave).
+template <int BM, int BN, int EPI, int BK = 64, bool DROP = false, int NS = 2, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs p) {
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   static_assert(BK == 64, "the interleaved weight-row mapping is built for 128-byte tile rows");
   static_assert(NS >= 2 && NS <= 4, "2..4 LDS stages");
-  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int WM = BM / (NW / 2), WN = BN / 2;
   constexpr int MT = WM / 16, NT = WN / 16;
   constexpr int ROWB = BK * 2;                       // bytes per LDS tile row
   constexpr int RPI = 1024 / ROWB;                   // rows covered by one 1-KiB wave LDS-DMA instruction
@@ -92,16 +95,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
     const int k0 = kt * BK;
     const int rsub = lane / CPR, slot = lane % CPR;
 #pragma unroll
-    for (int r = 0; r < BM / (4 * RPI); ++r) {
-      const int row = (r * 4 + wave) * RPI + rsub;
+    for (int r = 0; r < BM / (NW * RPI); ++r) {
+      const int row = (r * NW + wave) * RPI + rsub;
       const int chunk = slot ^ swz_chunk<BK>(row);
-      glds16(Ag + (size_t)row * p.lda + k0 + chunk * 8, sA + (r * 4 + wave) * 1024);
+      int srow = row;
+      if constexpr (BM > 128) srow = min(row, p.a_rows - 1 - m0);     // activations are padded to 128 rows, not to the tile: re-read the last one
+      glds16(Ag + (size_t)srow * p.lda + k0 + chunk * 8, sA + (r * NW + wave) * 1024);
     }
 #pragma unroll
-    for (int r = 0; r < BN / (4 * RPI); ++r) {
-      const int row = (r * 4 + wave) * RPI + rsub;
+    for (int r = 0; r < BN / (NW * RPI); ++r) {
+      const int row = (r * NW + wave) * RPI + rsub;
       const int chunk = slot ^ swz_w(row);
-      glds16(Wg + (size_t)row * p.ldw + k0 + chunk * 8, sW + (r * 4 + wave) * 1024);
+      glds16(Wg + (size_t)row * p.ldw + k0 + chunk * 8, sW + (r * NW + wave) * 1024);
     }
   };
 
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                            \
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WB[j], XA[i], acc[i][j], 0, 0, 0);
     bf16x8 xa0[MT], wb0[NT], xa1[MT], wb1[NT];
-    constexpr int PER_TILE = BM / (4 * RPI) + BN / (4 * RPI);
+    constexpr int PER_TILE = BM / (NW * RPI) + BN / (NW * RPI);
     if constexpr (NS == 2) {
     stage(0, 0);
     if (nt > 1) stage(1, 1);
@@ -307,13 +312,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int EPI, bool DROP = false, int NS = 2>
+template <int BM, int BN, int EPI, bool DROP = false, int NS = 2, int NW = 4>
 static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   constexpr int BK = 64;
   constexpr int lds = NS * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, EPI, BK, DROP, NS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, EPI, BK, DROP, NS, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(gemm %dx%d): %s", BM, BN, hipGetErrorString(e));
     attr_set = true;
@@ -321,8 +326,14 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   GemmArgs p = a;
   p.nbm = (a.M + BM - 1) / BM;
   p.nbn = a.N / BN;
-  GVK_LAUNCH((gemm_nt_kernel<BM, BN, EPI, BK, DROP, NS>), dim3(p.nbm * p.nbn), dim3(256), lds, stream, p);
+  p.a_rows = (a.M + 127) / 128 * 128;
+  GVK_LAUNCH((gemm_nt_kernel<BM, BN, EPI, BK, DROP, NS, NW>), dim3(p.nbm * p.nbn), dim3(64 * NW), lds, stream, p);
   return check_launch("gemm_nt_bf16");
+}
+
+static long wide_lo() {
+  static const long v = getenv("GAVIKO_HIP_GEMM_WIDE_LO") ? atol(getenv("GAVIKO_HIP_GEMM_WIDE_LO")) : 180;
+  return v;
 }
 
 template <int EPI>
@@ -336,6 +347,12 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     static const int n768 = getenv("GAVIKO_HIP_GEMM_N768") ? atoi(getenv("GAVIKO_HIP_GEMM_N768")) : 3128;
     const int bm = (t128 >= 384) ? 128 : 64;
     tile = bm * 1000 + bn;
+    if constexpr (EPI == GVK_EPI_STORE_BF16 || EPI == GVK_EPI_BIAS_GELU_BF16 || EPI == GVK_EPI_GELU_BWD_BF16) {
+      // wide shapes whose 256 x 256 tiles give (just under) one workgroup per CU: eight waves share one staging of twice the rows
+      static const int wide = getenv("GAVIKO_HIP_GEMM_WIDE") ? atoi(getenv("GAVIKO_HIP_GEMM_WIDE")) : 256;   // A/B switch: 0 = off
+      const long t256 = (long)((a.M + 255) / 256) * (a.N / 256);
+      if (wide == 256 && a.N % 256 == 0 && a.drop_thresh == 0u && t256 >= wide_lo() && t256 <= 256) tile = 256256;
+    }
     static const long t128_lo = getenv("GAVIKO_HIP_GEMM_T128LO") ? atol(getenv("GAVIKO_HIP_GEMM_T128LO")) : 96;
     if (bm == 64 && bn == 128 && t128 >= t128_lo && t128 <= 256 && a.K >= 512 && a.drop_thresh == 0u) {
       if (n768 == 3128) tile = 3128128;
@@ -357,6 +374,9 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
   }
   switch (tile) {
     case 3128128: return launch_gemm<128, 128, EPI, false, 3>(a, stream);
+    case 256256:
+      if constexpr (EPI == GVK_EPI_STORE_BF16 || EPI == GVK_EPI_BIAS_GELU_BF16 || EPI == GVK_EPI_GELU_BWD_BF16) return launch_gemm<256, 256, EPI, false, 2, 8>(a, stream);
+      else return set_error(-2, "gvk_gemm_nt_bf16: the 256x256 tile is built for STORE_BF16, BIAS_GELU_BF16 and GELU_BWD_BF16");
     case 128128: return launch_gemm<128, 128, EPI>(a, stream);
     case 128064: return launch_gemm<128, 64, EPI>(a, stream);
     case 64128: return launch_gemm<64, 128, EPI>(a, stream);

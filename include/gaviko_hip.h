@@ -82,7 +82,8 @@ typedef struct gvk_gemm_desc {
   int32_t lda, ldw, ldo, ldres, ldaux;
   int32_t epilogue;
   int32_t rows_in, rows_out, row_off; /* GVK_EPI_PATCH_F32 only */
-  int32_t tile;       /* 0 = auto, else BM*1000+BN (128128, 128064, 64064, 64128); 3128128 = 128x128 with three LDS stages (one workgroup per CU) */
+  int32_t tile;       /* 0 = auto, else BM*1000+BN (128128, 128064, 64064, 64128); 3128128 = 128x128 with three LDS stages (one workgroup per CU);
+                         256256 = eight waves on a 256x256 tile (STORE_BF16, BIAS_GELU_BF16, GELU_BWD_BF16 only) */
   float drop_p;       /* nn.Dropout behind the Linear (vision_transformer.py:32-34,54), epilogues 1, 2 (on out1), 4: the value at
                          (m, n) is multiplied by mask(seed + *seed_ptr, m*N + n) / (1 - drop_p); 0 = off */
   uint64_t seed;

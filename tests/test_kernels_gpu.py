@@ -246,3 +246,28 @@ def test_attention_f32_fwd_bwd(dev, B, T, H):
     ops.attention_bwd(Q, O, dO.reshape(B * T, -1).float().to(dev).contiguous(), lse, delta, dQ, B, T, H, 0.125)
     want = qkv.grad.reshape(B * T, -1)
     assert (dQ.cpu().double() - want).abs().max() <= 1e-5 * want.abs().max()
+
+
+@pytest.mark.parametrize("M,N,K", [(4132, 3072, 768), (1033, 768, 192), (300, 256, 64), (2066, 2304, 768)])
+def test_gemm_256x256_eight_wave_tile(dev, M, N, K):
+    """tile 256256 (8 waves, 64 x 128 per wave): the three epilogues of the wide GEMMs, against the 128 x 128 kernel and torch."""
+    from gaviko_amd import ops
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = ops.act_zeros(M, K, torch.bfloat16, dev); A[:M] = torch.randn(M, K, generator=gen).bfloat16().to(dev)
+    W = (torch.randn(N, K, generator=gen) / K ** 0.5).bfloat16().to(dev)
+    bias = torch.randn(N, generator=gen).to(dev)
+    aux = ops.act_zeros(M, N, torch.bfloat16, dev); aux[:M] = torch.randn(M, N, generator=gen).bfloat16().to(dev)
+    ref = A[:M].float() @ W.float().t()
+    for epi, kw in ((ops.EPI_STORE_BF16, dict(bias=bias)), (ops.EPI_BIAS_GELU_BF16, dict(bias=bias)), (ops.EPI_GELU_BWD_BF16, dict(aux=aux))):
+        outs = []
+        for tile in (256256, 128128):
+            o0, o1 = ops.act_zeros(M, N, torch.bfloat16, dev), ops.act_zeros(M, N, torch.bfloat16, dev)
+            k2 = dict(kw, out1=o1) if epi == ops.EPI_BIAS_GELU_BF16 else kw
+            ops.gemm_nt(A, W, M, o0, epilogue=epi, tile=tile, **k2)
+            outs.append((o0[:M].float(), o1[:M].float()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])      # same k order per element: bit-identical
+    o = ops.act_zeros(M, N, torch.bfloat16, dev)
+    ops.gemm_nt(A, W, M, o, epilogue=ops.EPI_STORE_BF16, tile=256256)
+    assert (o[:M].float() - ref).abs().max().item() < 3e-2 * max(1.0, ref.abs().max().item())
+    with pytest.raises(Exception, match="256x256"):
+        ops.gemm_nt(A, W, M, torch.zeros(M, N, device=dev), epilogue=ops.EPI_STORE_F32, tile=256256)
