@@ -82,7 +82,7 @@ def pmc_traffic(name, stats):
     epi = {v: k for k, v in eng_mod._EPI_NAMES.items()}[m.group(1)]
     with open(path) as f:
         ker = json.load(f)["kernels"]
-    hits = [v for k, v in ker.items() if re.match(rf"gemm_nt_kernel<\d+, \d+, {epi}, \d+(, false)?(, \d+)?>", k)]
+    hits = [v for k, v in ker.items() if re.match(rf"gemm_nt_kernel<\d+, \d+, {epi}, \d+(, false)?(, \d+)*>", k)]
     if len(hits) != 1:
         return {}
 

@@ -351,7 +351,9 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
       // wide shapes whose 256 x 256 tiles give (just under) one workgroup per CU: eight waves share one staging of twice the rows
       static const int wide = getenv("GAVIKO_HIP_GEMM_WIDE") ? atoi(getenv("GAVIKO_HIP_GEMM_WIDE")) : 256;   // A/B switch: 0 = off
       const long t256 = (long)((a.M + 255) / 256) * (a.N / 256);
-      if (wide == 256 && a.N % 256 == 0 && a.drop_thresh == 0u && t256 >= wide_lo() && t256 <= 256) tile = 256256;
+      static const bool wide_bwd = getenv("GAVIKO_HIP_GEMM_WIDE_BWD") == nullptr || getenv("GAVIKO_HIP_GEMM_WIDE_BWD")[0] != '0';
+      if (wide == 256 && a.N % 256 == 0 && a.drop_thresh == 0u && t256 >= wide_lo() && t256 <= 256 && (EPI != GVK_EPI_GELU_BWD_BF16 || wide_bwd))
+        tile = 256256;
     }
     static const long t128_lo = getenv("GAVIKO_HIP_GEMM_T128LO") ? atol(getenv("GAVIKO_HIP_GEMM_T128LO")) : 96;
     if (bm == 64 && bn == 128 && t128 >= t128_lo && t128 <= 256 && a.K >= 512 && a.drop_thresh == 0u) {
