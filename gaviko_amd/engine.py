@@ -1397,14 +1397,14 @@ class Engine:
                             D=self.grid[0], H=self.grid[1], W=self.grid[2], kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt,
                             scale=C ** -0.5, drop_p=sv["attn_drop"], seed=seed_a, seed_ptr=sp)
         wqkv = d(pre + ".qkv.weight")
-        ops.reduce_batch([(bw["dqkv"], m["lat"], gv[pre + ".qkv.weight"], acc)], ws["rscratch_l"])
         ops.skinny_down(x=bw["dqkv"], w=wqkv, y=bw["dlat"], M=BN, C=3 * Lt, L=Lt, act=0, w_layout=1)
         wd = d(pre + ".proj_down.weight")
         g_, b_ = d(pre + ".norm.weight"), d(pre + ".norm.bias")
         # Q[l][c] = sum_m dlat[m][l] xhat[m][c], S[l] = sum_m dlat[m][l]  ->  dWd, dbd, dgamma, dbeta in one tiny kernel
         ops.outer_reduce(narrow=bw["dlat"], wide=lin, mean=m["mean"], rstd=m["rstd"], scratch=sc, out=bw["Q"], M=BN, C=C, L=Lt, transposed=0,
                          accumulate=0)
-        ops.reduce_batch([(bw["dlat"], None, bw["S"], 0)], ws["rscratch_l"])
+        # qkv weight gradient (dqkv^T . lat) and S[l] = sum_m dlat[m][l] in one two-stage reduction
+        ops.reduce_batch([(bw["dqkv"], m["lat"], gv[pre + ".qkv.weight"], acc), (bw["dlat"], None, bw["S"], 0)], ws["rscratch_l"])
         ops.ln_lowrank_affine(bw["Q"], bw["S"], wd, g_, b_, gv[pre + ".proj_down.weight"], gv[pre + ".norm.weight"], gv[pre + ".norm.bias"],
                               gv[pre + ".proj_down.bias"], Lt, C, accumulate=bool(acc))
         # dL_in = dL_out + LN'(dlat . Wd): the rank-L product never touches HBM
