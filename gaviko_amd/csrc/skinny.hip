@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 // combined through LDS in a fixed order; stage 2 sums the kRedSlabs partials of every output of every job.
 constexpr int kMaxJobs = 8;
 constexpr int kRedSlabs = 32;
-struct ReduceJob { const float* a; const float* b; float* out; int M, J, L, accumulate, wg0, o_base; };
+struct ReduceJob { const float* a; const float* b; float* out; int M, J, L, accumulate, wg0, o_base; const float* a2; int M1; };   // a2: rows M1.. of a column sum
 struct ReduceBatch { ReduceJob job[kMaxJobs]; int njobs; float* scratch; int total_out; };
 
 __global__ __launch_bounds__(1024) void reduce_batch_partial_kernel(ReduceBatch bt) {
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(1024) void reduce_batch_partial_kernel(ReduceBatch 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int mm = m + u * 16;
-          av[u] = mm < r1 ? jb.a[(size_t)mm * jb.J + o] : 0.f;
+          av[u] = mm < r1 ? (mm < jb.M1 ? jb.a[(size_t)mm * jb.J + o] : jb.a2[(size_t)(mm - jb.M1) * jb.J + o]) : 0.f;
         }
         acc += (av[0] + av[1]) + (av[2] + av[3]);
       }
@@ -769,8 +769,9 @@ extern "C" int gvk_reduce_batch(const gvk_reduce_job* jobs, int njobs, float* sc
   for (int k = 0; k < njobs; ++k) {
     const gvk_reduce_job& j = jobs[k];
     GVK_REQUIRE(j.a && j.out && j.M > 0 && j.J > 0 && (j.b == nullptr || j.L > 0), "gvk_reduce_batch: job %d malformed", k);
+    GVK_REQUIRE(j.a2 == nullptr || (j.b == nullptr && j.M2 > 0), "gvk_reduce_batch: job %d: a second source (a2, M2) goes with a column sum only", k);
     const int nout = j.b ? j.J * j.L : j.J;
-    bt.job[k] = ReduceJob{j.a, j.b, j.out, j.M, j.J, j.L, j.accumulate, wg, ob};
+    bt.job[k] = ReduceJob{j.a, j.b, j.out, j.M + (j.a2 ? j.M2 : 0), j.J, j.L, j.accumulate, wg, ob, j.a2, j.a2 ? j.M : 0x7fffffff};
     wg += (nout + 63) / 64;
     ob += nout;
   }

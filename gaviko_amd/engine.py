@@ -1039,8 +1039,7 @@ class Engine:
         ops.reduce_batch([(bw["gate_partials"], None, gate_flat, acc),
                           (dqg, prm, gv[names["wgq"]], acc), (dqg, None, gv[names["bgq"]], acc),
                           (dql, prm, gv[names["wlq"]], acc), (dql, None, gv[names["blq"]], acc),
-                          (bw["dzx"], None, gbd, acc)], ws["rscratch"])
-        ops.reduce_batch([(bw["dzl"][par], None, gbd, 1)], ws["rscratch"])
+                          (bw["dzx"], None, gbd, acc, bw["dzl"][par])], ws["rscratch"])      # proj_down bias: both token streams
         # proj_down (shared by both streams): dWd = dzx^T.G1 + dzl^T.Lnew
         if M + B * N <= ops.OUTER_MAX_ROWS:                                   # both token streams in one pass
             ops.outer_reduce(narrow=bw["dzx"], wide=ws["G1"][i], narrow2=bw["dzl"][par], wide2=ws["Lc"][i + 1], scratch=sc, out=gwd, M=M, M2=B * N,

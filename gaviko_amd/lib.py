@@ -58,7 +58,7 @@ AdamDesc = _struct("AdamDesc", ["ptr_tab", "blk_tab", "grad", "m", "v", "norm_sq
 LossDesc = _struct("LossDesc", ["logits", "target", "weights", "loss", "dlogits", "meter"], ["B", "K", "kind", "reduction"], ["gamma", "eps"], i64=["ignore_index"])
 DropoutDesc = _struct("DropoutDesc", ["x", "out32", "out16", "seed_ptr"], ["M", "N", "ld", "rows_in", "rows_out", "row_off"], ["drop_p"], ["seed"])
 RowProjDesc = _struct("RowProjDesc", ["w", "bias", "y", "z"], ["L", "w_layout", "act"])
-ReduceJob = _struct("ReduceJob", ["a", "b", "out"], ["M", "J", "L", "accumulate"])
+ReduceJob = _struct("ReduceJob", ["a", "b", "out", "a2"], ["M", "J", "L", "accumulate", "M2"])
 HeadDesc = _struct("HeadDesc", ["g", "ln_gamma", "ln_beta", "wh", "bh", "logits", "pooled", "dlogits", "dg", "dwh", "dbh"],
                    ["B", "T", "C", "K", "r0", "R", "accumulate"])
 

@@ -453,11 +453,14 @@ def lora_merge(w, a_q, b_q, a_v, b_v, out, C_, r, s):
 
 
 def reduce_batch(jobs, scratch):
-    """jobs: list of (a [M,J], b [M,L] or None, out, accumulate).  One launch pair for up to 8 small column-sum / J x L wgrad
-    reductions; scratch f32 >= 32 * total outputs."""
+    """jobs: list of (a [M,J], b [M,L] or None, out, accumulate[, a2 [M2,J]]).  One launch pair for up to 8 small column-sum / J x L
+    wgrad reductions; a2 (column sums only) appends more rows to the same sum.  scratch f32 >= 32 * total outputs."""
     arr = (L.ReduceJob * len(jobs))()
     total = 0
-    for k, (a, b, out, acc) in enumerate(jobs):
+    for k, job in enumerate(jobs):
+        a, b, out, acc = job[:4]
+        a2 = job[4] if len(job) > 4 else None
+        _chk(a2, torch.float32, "reduce_batch a2")
         _chk(a, torch.float32, "reduce_batch a")
         _chk(b, torch.float32, "reduce_batch b")
         _chk(out, torch.float32, "reduce_batch out")
@@ -468,7 +471,9 @@ def reduce_batch(jobs, scratch):
         if out.numel() < (J * Lb if b is not None else J):
             raise L.GavikoHipError("reduce_batch: out too small")
         total += J * Lb if b is not None else J
-        arr[k] = L.ReduceJob(L.ptr(a), L.ptr(b), L.ptr(out), M, J, Lb, int(bool(acc)))
+        if a2 is not None and (b is not None or a2.numel() // a2.shape[0] != J):
+            raise L.GavikoHipError("reduce_batch: a2 goes with column sums of the same width only")
+        arr[k] = L.ReduceJob(L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(a2), M, J, Lb, int(bool(acc)), 0 if a2 is None else a2.shape[0])
     _chk(scratch, torch.float32, "reduce_batch scratch", 32 * total)
     L.check(L.load().gvk_reduce_batch(arr, len(jobs), L.ptr(scratch), L.stream_ptr()), "gvk_reduce_batch")
 

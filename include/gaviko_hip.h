@@ -237,7 +237,8 @@ int gvk_small_wgrad(const float* a, const float* b, float* out, float* scratch, 
  * scratch: f32 [32 * total number of outputs]. */
 typedef struct gvk_reduce_job {
   const float* a; const float* b; float* out;
-  int32_t M, J, L, accumulate;
+  const float* a2;                   /* column sums only (b == NULL): M2 more rows [M2][J] summed into the same outputs */
+  int32_t M, J, L, accumulate, M2;
 } gvk_reduce_job;
 int gvk_reduce_batch(const gvk_reduce_job* jobs, int njobs, float* scratch, void* stream);
 /* out[c] (+)= sum_m x[m][c]; scratch f32 [64*C] */

@@ -403,3 +403,15 @@ def test_outer_reduce_two_sources(dev):
     assert (out - two).abs().max().item() < 2e-3
     with pytest.raises(Exception, match="exceeds"):
         ops.outer_reduce(narrow=n1, wide=w1, narrow2=r(8000, L), wide2=r(8000, C), scratch=sc, out=out, M=M1, M2=8000, C=C, L=L, transposed=0, accumulate=0)
+
+
+def test_reduce_batch_column_sum_over_two_sources(dev):
+    from gaviko_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    a, a2, b = torch.randn(4132, 20, generator=gen).to(dev), torch.randn(4000, 20, generator=gen).to(dev), torch.randn(4132, 20, generator=gen).to(dev)
+    out, w = torch.ones(20, device=dev), torch.zeros(20, 20, device=dev)
+    sc = torch.zeros(32 * (20 + 400), device=dev)
+    ops.reduce_batch([(a, None, out, 1, a2), (a, b, w, 0)], sc)
+    want = 1.0 + a.double().sum(0) + a2.double().sum(0)
+    assert (out.double() - want).abs().max().item() < 1e-3
+    assert (w.double() - a.double().t() @ b.double()).abs().max().item() < 1e-2
