@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs p) {
   }
 }
 
-// grid (B): dpooled = dlogits . Wh; every pooled row gets dy = dpooled / R through the LN backward
+// grid (B, ceil(R / 4)), one pooled row per wave: dpooled = dlogits . Wh (recomputed per workgroup: K * C products); every pooled row gets
+// dy = dpooled / R through the LN backward.  (One workgroup per sample walked its 33 rows nine deep at the very start of the backward.)
 __global__ __launch_bounds__(256) void head_bwd_rows_kernel(HeadArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* dp_s = (float*)smem;   // [C]
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void head_bwd_rows_kernel(HeadArgs p) {
     dp_s[c] = a * invR;
   }
   __syncthreads();
-  for (int r = wave; r < p.R; r += 4) {
+  for (int r = blockIdx.y * 4 + wave; r < p.R; r += 4 * gridDim.y) {
     const size_t off = ((size_t)b * p.T + p.r0 + r) * C;
     f32x4 xh[4], dh[4];
     float s = 0.f;
@@ -244,7 +245,7 @@ extern "C" int gvk_head_bwd(const gvk_head_desc* d, void* stream) {
   GVK_REQUIRE(d->dlogits && d->pooled && d->dwh && d->dbh, "gvk_head_bwd: null pointer");
   hipStream_t s = (hipStream_t)stream;
   if (d->dg != nullptr) {
-    GVK_LAUNCH(head_bwd_rows_kernel, dim3(d->B), dim3(256), d->C * 4, s, a);
+    GVK_LAUNCH(head_bwd_rows_kernel, dim3(d->B, (d->R + 3) / 4), dim3(256), d->C * 4, s, a);
     rc = check_launch("head_bwd_rows");
     if (rc) return rc;
   }
