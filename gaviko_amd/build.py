@@ -23,7 +23,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
 # attention_*: the score accumulator is re-used in place as the next MFMA's B operand, which the AGPR form can only do through
 # v_accvgpr_read copies (352 / 688 of them in the forward / backward kernels).
 _VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
-FILE_FLAGS = {"gemm_bf16.hip": _VGPR_FORM, "attention_fwd.hip": _VGPR_FORM, "attention_bwd.hip": _VGPR_FORM, "skinny.hip": _VGPR_FORM}
+FILE_FLAGS = {"gemm_bf16.hip": _VGPR_FORM, "gemm8p_bf16.hip": _VGPR_FORM, "attention_fwd.hip": _VGPR_FORM, "attention_bwd.hip": _VGPR_FORM, "skinny.hip": _VGPR_FORM}
 
 
 def hipcc() -> str:

@@ -12,28 +12,9 @@
 // the row-major output.  (With 4-wide pieces the two-output GELU epilogue took 44 us against 31 us for the same GEMM
 // with one output: store-instruction bound, not byte bound.)  The weight tile has its own swizzle key so that the
 // interleaved rows stay conflict-free.
-#include "common.hpp"
-#include "dropout.hpp"
-#include "../../include/gaviko_hip.h"
+#include "gemm_epilogue.hpp"
 
 namespace gvk {
-
-struct GemmArgs {
-  const bf16* A;
-  const bf16* W;
-  void* out0;
-  void* out1;
-  const float* bias;
-  const float* res;
-  const bf16* aux;
-  const float* pos;
-  int M, N, K, lda, ldw, ldo, ldres, ldaux;
-  int rows_in, rows_out, row_off;
-  int nbm, nbn;
-  int a_rows;                                            // rows the A buffer really has (M padded to 128): the 256-row tile clamps to it
-  // DROP instantiations only (nn.Dropout behind a Linear of the unfrozen-backbone methods): mask index m * N + n
-  unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;
-};
 
 // LDS swizzles (applied to the 16-byte chunk index of a tile row; conflict-free for the ds_read_b128 lane groups):
 //   BK = 64: 128-byte rows, chunk ^ ((row >> 1) & 7);   BK = 32: 64-byte rows, chunk ^ {0,2,3,1}[(row >> 2) & 3]
@@ -42,10 +23,6 @@ __device__ __forceinline__ int swz_chunk(int row) {
   if constexpr (BK == 64) return (row >> 1) & 7;
   else return (0x78 >> (((row >> 2) & 3) * 2)) & 3;      // 0b01'11'10'00 -> 0,2,3,1
 }
-
-// Weight tile (BK = 64): a fragment read touches rows base + 8q + 4b + r (q, r = 0..3, b fixed); the key takes row bits 1, 3, 4
-// so those 16 rows again hit 16 distinct (parity, slot) pairs.
-__device__ __forceinline__ int swz_w(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
 
 // NS = LDS stages.  2: the tuned default (two workgroups per CU hide each other's stalls).  3: for the shapes that run ONE workgroup
 // per CU (128 x 128 tiles of the N = 768 GEMMs: 198 tiles) -- there a third tile in flight is what hides the L2 round trip.
@@ -228,88 +205,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs p) {
 #undef GVK_MMA
   }
 
-  // ---- epilogue: lane owns rows m (one per i) x 8 consecutive columns n (per tile pair jp)
-  static_assert(NT % 2 == 0, "tile pairs");
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = m0 + wm * WM + i * 16 + l15;
-    if (m >= p.M) continue;
-    size_t orow = (size_t)m;
-    int prow = 0;
-    if constexpr (EPI == GVK_EPI_PATCH_F32) {
-      const int s = m / p.rows_in;
-      prow = m - s * p.rows_in;
-      orow = (size_t)s * p.rows_out + p.row_off + prow;
-    }
-#pragma unroll
-    for (int jp = 0; jp < NT / 2; ++jp) {
-      const int n = n0 + wn * WN + 32 * jp + 8 * lq;
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jp][e]; v[4 + e] = acc[i][2 * jp + 1][e]; }
-      if (p.bias != nullptr) {
-        const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-      }
-      auto store_f32 = [&](float* dst) {
-        *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
-        *(f32x4*)(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
-      };
-      auto store_bf16 = [&](bf16* dst) {
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-        *(bf16x8*)dst = o;
-      };
-      [[maybe_unused]] auto drop8 = [&]() {               // v *= mask / keep, element (m, n + e)
-        const unsigned long long sd = p.seed + *p.seed_ptr;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= drop_scale(sd, (unsigned long long)m * p.N + n + e, p.drop_thresh, p.inv_keep);
-      };
-      if constexpr (EPI == GVK_EPI_STORE_BF16) {
-        store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
-      } else if constexpr (EPI == GVK_EPI_BIAS_RES_F32 || EPI == GVK_EPI_BIAS_RES_F32_BF16) {
-        if constexpr (DROP) drop8();                       // out = res + dropout(acc + bias): vision_transformer.py:34,54
-        const float* rp = p.res + (size_t)m * p.ldres + n;
-        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-        store_f32((float*)p.out0 + (size_t)m * p.ldo + n);
-        if constexpr (EPI == GVK_EPI_BIAS_RES_F32_BF16) store_bf16((bf16*)p.out1 + (size_t)m * p.ldo + n);
-      } else if constexpr (EPI == GVK_EPI_BIAS_GELU_BF16) {
-        if (p.out0 != nullptr) store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
-        if constexpr (DROP) drop8();                       // out1 = dropout(GELU(pre)): vision_transformer.py:32-33
-        store_bf16((bf16*)p.out1 + (size_t)m * p.ldo + n);
-      } else if constexpr (EPI == GVK_EPI_PATCH_F32) {
-        const float* pp = p.pos + (size_t)prow * p.N + n;
-        const f32x4 q0 = *(const f32x4*)pp, q1 = *(const f32x4*)(pp + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] += q0[e]; v[4 + e] += q1[e]; }
-        store_f32((float*)p.out0 + orow * p.ldo + n);
-        if (p.out1 != nullptr) store_f32((float*)p.out1 + (size_t)m * p.ldo + n);
-      } else if constexpr (EPI == GVK_EPI_GELU_BWD_BF16) {
-        const bf16x8 a8 = *(const bf16x8*)(p.aux + (size_t)m * p.ldaux + n);
-        if constexpr (DROP) drop8();                       // gradient through that dropout, same mask
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= gelu_fast_grad((float)a8[e]);
-        store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
-      } else if constexpr (EPI == GVK_EPI_STORE_F32) {
-        store_f32((float*)p.out0 + (size_t)m * p.ldo + n);
-      } else if constexpr (EPI == GVK_EPI_BIAS_RELU_BF16) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
-      } else if constexpr (EPI == GVK_EPI_RELU_BWD_BF16) {
-        const bf16x8 a8 = *(const bf16x8*)(p.aux + (size_t)m * p.ldaux + n);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (float)a8[e] > 0.f ? v[e] : 0.f;
-        store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
-      }
-    }
-  }
+  gemm_epilogue<EPI, DROP, MT, NT>(p, acc, m0 + wm * WM, n0 + wn * WN, l15, lq);
 }
 
 template <int BM, int BN, int EPI, bool DROP = false, int NS = 2, int NW = 4>
@@ -349,11 +245,11 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     tile = bm * 1000 + bn;
     if constexpr (EPI == GVK_EPI_STORE_BF16 || EPI == GVK_EPI_BIAS_GELU_BF16 || EPI == GVK_EPI_GELU_BWD_BF16) {
       // wide shapes whose 256 x 256 tiles give (just under) one workgroup per CU: eight waves share one staging of twice the rows
-      static const int wide = getenv("GAVIKO_HIP_GEMM_WIDE") ? atoi(getenv("GAVIKO_HIP_GEMM_WIDE")) : 256;   // A/B switch: 0 = off
+      static const int wide = getenv("GAVIKO_HIP_GEMM_WIDE") ? atoi(getenv("GAVIKO_HIP_GEMM_WIDE")) : 8;   // A/B switch: 0 = off, 256 = the one-barrier 256x256 kernel, 8 = gemm8p
       const long t256 = (long)((a.M + 255) / 256) * (a.N / 256);
       static const bool wide_bwd = getenv("GAVIKO_HIP_GEMM_WIDE_BWD") == nullptr || getenv("GAVIKO_HIP_GEMM_WIDE_BWD")[0] != '0';
-      if (wide == 256 && a.N % 256 == 0 && a.drop_thresh == 0u && t256 >= wide_lo() && t256 <= 256 && (EPI != GVK_EPI_GELU_BWD_BF16 || wide_bwd))
-        tile = 256256;
+      if (wide != 0 && a.N % 256 == 0 && a.drop_thresh == 0u && t256 >= wide_lo() && t256 <= 256 && (EPI != GVK_EPI_GELU_BWD_BF16 || wide_bwd))
+        tile = (wide == 256 || a.K < 128) ? 256256 : 8256256;
     }
     static const long t128_lo = getenv("GAVIKO_HIP_GEMM_T128LO") ? atol(getenv("GAVIKO_HIP_GEMM_T128LO")) : 96;
     if (bm == 64 && bn == 128 && t128 >= t128_lo && t128 <= 256 && a.K >= 512 && a.drop_thresh == 0u) {
@@ -375,6 +271,8 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     }
   }
   switch (tile) {
+    case 8256256: return launch_gemm8p(a, EPI, 0, stream);      // eight-phase kernel, LDS-DMA issued in the load sections (default)
+    case 7256256: return launch_gemm8p(a, EPI, 1, stream);      // ... issued inside the MFMA clusters (2546 vs 2426 cycles per k-tile)
     case 3128128: return launch_gemm<128, 128, EPI, false, 3>(a, stream);
     case 256256:
       if constexpr (EPI == GVK_EPI_STORE_BF16 || EPI == GVK_EPI_BIAS_GELU_BF16 || EPI == GVK_EPI_GELU_BWD_BF16) return launch_gemm<256, 256, EPI, false, 2, 8>(a, stream);

@@ -368,15 +368,24 @@ __global__ __launch_bounds__(256) void outer_partial_kernel(OuterArgs p) {
   const bool cok = c < C;
   f32x4 g4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
   if (p.ln_g != nullptr && cok) { g4 = *(const f32x4*)(p.ln_g + c); b4 = *(const f32x4*)(p.ln_b + c); }
-  for (int rb = 0; rb < nr; rb += 16) {
-    f32x4 x[4];
+  // 16 rows (4 k-steps) per iteration; the next iteration's rows are requested before this iteration's MFMAs (one wave per SIMD has
+  // nothing else to hide the HBM round trip behind)
+  auto fetch = [&](int rb, f32x4 (&x)[4]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {                      // 4 k-steps (16 rows) of loads in flight
+    for (int u = 0; u < 4; ++u) {
       const int r = rb + 4 * u + kq;
       const int gm = r0 + r;
       const float* wrow = (p.narrow2 != nullptr && gm >= p.M1) ? p.wide2 + (size_t)(gm - p.M1) * C : p.wide + (size_t)gm * C;
       x[u] = (r < nr && cok) ? *(const f32x4*)(wrow + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  };
+  f32x4 xn[4];
+  fetch(0, xn);
+  for (int rb = 0; rb < nr; rb += 16) {
+    f32x4 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = xn[u];
+    if (rb + 16 < nr) fetch(rb + 16, xn);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int r = rb + 4 * u + kq;
@@ -648,12 +657,15 @@ extern "C" int gvk_skinny_down(const gvk_skinny_down_desc* d, void* stream) {
   if (d->act_in != 0) {
     GVK_REQUIRE(d->act_in == 1 && d->ln_gamma == nullptr && d->drop_p <= 0.f, "gvk_skinny_down: act_in=1 (QuickGELU on the input) takes no LN / dropout");
     a.mode = 3;
-    const int rc = launch_row_down(a, d->L, s);
+    int rc = launch_side_down(a, d->L, s);
+    if (rc == 1) rc = launch_row_down(a, d->L, s);
     if (rc == 1) return set_error(-2, "gvk_skinny_down: act_in needs the row-per-wave kernel (L in {4,8,16,20}, C >= 128)");
     return rc;
   }
   if (!mfma_only) {
-    const int rc = launch_row_down(a, d->L, s);                                   // row-per-wave form for the wide shapes
+    int rc = launch_side_down(a, d->L, s);                                        // 16-row tiles on the fp32 matrix cores
+    if (rc != 1) return rc;
+    rc = launch_row_down(a, d->L, s);                                             // row-per-wave form for the wide shapes
     if (rc != 1) return rc;
   }
   switch (d->L) {
@@ -681,6 +693,12 @@ extern "C" int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   static const bool mfma_only = getenv("GAVIKO_HIP_SKINNY_MFMA") != nullptr;
   a.alpha_ptr = d->alpha_ptr; a.gg_x = d->gg_x;
+  GVK_REQUIRE(d->w2 == nullptr || ((d->z2 || d->y2) && d->L2 > 0), "gvk_skinny_up: the second projection needs z2 or y2 and L2");
+  if (!mfma_only) {
+    const int rc = launch_side_up(a, d->L, d->w2, d->bias2, d->z2, d->y2, d->L2, d->act2, s);
+    if (rc != 1) return rc;
+  }
+  GVK_REQUIRE(d->w2 == nullptr, "gvk_skinny_up: the fused second projection needs the 16-row-tile kernel (C %% 32 == 0, L %% 4 == 0, L <= 32)");
   if (a.alpha_ptr != nullptr || a.gg_x != nullptr) {
     GVK_REQUIRE(d->ln_x == nullptr, "gvk_skinny_up: alpha_ptr / gg_x do not combine with the LayerNorm-backward epilogue");
     const int rc = launch_row_up(a, d->L, s);

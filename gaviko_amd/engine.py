@@ -179,6 +179,8 @@ class Engine:
                 raise L.GavikoHipError("deep VPT: the shrinking sequence runs out of tokens for this depth / prompt_dim")
         self._w16: Dict[str, torch.Tensor] = {}
         self._w16_version = None
+        self._shadowed = frozenset(self._backbone_weight_names())
+        self._fwd_gen = 0                       # counts training-mode forwards: the autograd node checks it owns the saved state
         self._have_dgrad = False
         self._graphs = {}
         self._calls = {}
@@ -190,6 +192,7 @@ class Engine:
         # GPA projections of backbone rows ride along in the backbone's LayerNorm kernels (gvk_layernorm_*_proj)
         self._fuse_proj = (kind == "gaviko" and not self.fp32 and ops.rowproj_supported(self.Lat, dim)
                            and os.environ.get("GAVIKO_HIP_FUSE_PROJ", "1") != "0")
+        self._fuse_local = kind == "gaviko" and ops.side_tile_supported(self.Lat, dim)
         self._marks = []
         self.plan_marks = {}                # plan id -> [(name, event id)]
         self._gemm_marks = []
@@ -266,6 +269,28 @@ class Engine:
         self._w16_version = version
 
     # ------------------------------------------------------------------ workspace
+    def _seed_base(self, train: bool) -> int:
+        """Initial value of the device-side dropout epoch word.  Mixes torch's base seed (torch.manual_seed = the user's knob), the
+        data-parallel rank and the mode, so that ranks -- and the train / eval workspaces of one rank -- draw independent masks, as
+        the reference's per-process torch RNG streams do (train.py has no seeding; every process draws its own)."""
+        rank = 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                rank = dist.get_rank()
+        except Exception:
+            rank = 0
+        x = (torch.initial_seed() & 0xFFFFFFFFFFFF) * 0x9E3779B97F4A7C15 + (rank + 1) * 0xBF58476D1CE4E5B9 + (0x94D049BB133111EB if train else 0)
+        x &= (1 << 64) - 1
+        x ^= x >> 31
+        return 0x5EED0000 ^ (x & 0x3FFFFFFFFFFF0000)          # stays positive in int64; the low 16 bits are left to the per-site offsets
+
+    def invalidate_weights(self, names=None) -> None:
+        """Tell the engine that parameters were written behind torch's back (a raw-pointer optimizer step: `p._version` does not move).
+        With `names`, only if one of them is a backbone weight the engine keeps operand shadows of."""
+        if names is None or any(n in self._shadowed for n in names):
+            self._w16_version = None
+
     def workspace(self, B: int, device, train: bool):
         key = (B, train, str(device))
         if key in self._wss:
@@ -279,7 +304,7 @@ class Engine:
         ws["img"] = torch.zeros((B, 1) + tuple(g * p for g, p in zip(self.grid, self.patch)), device=device)
         ws["logits"] = torch.zeros((B, self.K), device=device)
         ws["dlogits"] = torch.zeros((B, self.K), device=device)
-        ws["seed"] = torch.full((1,), 0x5EED0000, dtype=torch.int64, device=device)
+        ws["seed"] = torch.full((1,), self._seed_base(train), dtype=torch.int64, device=device)
         ws["cols"] = z(B * N, self.Kp, bf16)
         ws["G"] = [z(M, C, f32) for _ in range(self.depth + 1)] if train else [z(M, C, f32), z(M, C, f32)]
         ws["G1"] = [z(M, C, f32) for _ in range(nsave)]
@@ -497,6 +522,8 @@ class Engine:
         self._run("fwd", key, lambda: self._forward_impl(ws, sv))
         self._saved = sv if train else None
         self._saved_key = key
+        if train:
+            self._fwd_gen += 1
         return ws["logits"].clone()
 
     def _forward_impl(self, ws, sv):
@@ -558,8 +585,10 @@ class Engine:
                 if not train and i > 0:
                     self._wait("loc", "gpa")                         # eval ping-pongs Lc: the GPA of layer i-1 must be done with it
                 with torch.cuda.stream(loc):
-                    self._mwsa_fwd(ws, sv, i, si, ws["Lc"][gi], ws["Lc"][go])
-                    if self._fuse_proj:
+                    # with the 16-row-tile kernels the MWSA up-projection also emits GPA's proj_down of the rows it writes
+                    fuse_local = self._fuse_proj and self._fuse_local
+                    self._mwsa_fwd(ws, sv, i, si, ws["Lc"][gi], ws["Lc"][go], gpa_local=fuse_local)
+                    if self._fuse_proj and not fuse_local:
                         self._gpa_down_local(ws, i, si, ws["Lc"][go], B)
             self._mark(f"f{i}:start")
             if self.kind == "evp":
@@ -670,7 +699,7 @@ class Engine:
                    drop_p=pdrop, seed=SEED_LAYER + 8 * i + 3, seed_ptr=ws["seed"])
 
     # ---- GAViKO side paths --------------------------------------------------------------------------------------
-    def _mwsa_fwd(self, ws, sv, i, si, lin, lout):
+    def _mwsa_fwd(self, ws, sv, i, si, lin, lout, gpa_local=False):
         if "noside" in _ABLATE:
             return
         s = i // self.share
@@ -684,8 +713,13 @@ class Engine:
         ops.window_attn_fwd(qkv=m["qkv"], ctx=m["ctx"], lse=m["lse"], B=B, D=self.grid[0], H=self.grid[1], W=self.grid[2],
                             kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt, scale=C ** -0.5, drop_p=sv["attn_drop"],
                             seed=2 * i, seed_ptr=ws["seed"])
+        second = {}
+        if gpa_local:                                       # ll = QuickGELU(proj_down(L')) (gaviko.py:156) of the rows this launch produces
+            gpre, _ = self._gpa_names(i)
+            g = ws["gp"][si]
+            second = dict(w2=d(gpre + ".proj_down.0.weight"), bias2=d(gpre + ".proj_down.0.bias"), z2=g["zl"], y2=g["ll"], L2=Lt, act2=1)
         ops.skinny_up(lat=m["ctx"], w=d(pre + ".proj_up.weight"), bias=d(pre + ".proj_up.bias"), res=lin, out=lout, M=BN, C=C, L=Lt,
-                      w_layout=0, drop_p=sv["proj_drop"], seed=2 * i + 1, seed_ptr=ws["seed"])
+                      w_layout=0, drop_p=sv["proj_drop"], seed=2 * i + 1, seed_ptr=ws["seed"], **second)
 
     def _gpa_names(self, i):
         s = i // self.share

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 4                                   # gvk_abi_version() of the library these declarations describe
+ABI_VERSION = 5                                   # gvk_abi_version() of the library these declarations describe
 LIB_PATH = os.environ.get("GAVIKO_HIP_LIB") or os.path.join(_HERE, "libgaviko_hip.so")     # override: A/B runs of two builds
 
 
@@ -37,8 +37,8 @@ SkinnyDownDesc = _struct("SkinnyDownDesc",
                          ["x", "w", "bias", "ln_gamma", "ln_beta", "mean", "rstd", "z", "y", "w2", "y2", "seed_ptr"],
                          ["M", "C", "L", "L2", "act", "w_layout", "act_in"], ["eps", "drop_p"], ["seed"])
 SkinnyUpDesc = _struct("SkinnyUpDesc", ["lat", "w", "bias", "res", "out", "lat_override", "seed_ptr", "ln_x", "ln_mean", "ln_rstd", "ln_gamma", "out_bf16",
-                                        "alpha_ptr", "gg_x"],
-                       ["M", "C", "L", "T", "P", "w_layout", "accumulate"], ["drop_p"], ["seed"])
+                                        "alpha_ptr", "gg_x", "w2", "bias2", "z2", "y2"],
+                       ["M", "C", "L", "T", "P", "w_layout", "accumulate", "L2", "act2"], ["drop_p"], ["seed"])
 OuterDesc = _struct("OuterDesc", ["narrow", "wide", "lat_override", "mean", "rstd", "ln_gamma", "ln_beta", "scratch", "out", "colsum", "seed_ptr",
                                   "narrow2", "wide2"],
                     ["M", "C", "L", "T", "P", "transposed", "accumulate", "wide_act", "M2"], ["drop_p"], ["seed"])

@@ -76,12 +76,19 @@ class _HotPathFn(torch.autograd.Function):
     def forward(ctx, owner, img, drop, *params):
         ctx.owner = owner
         ctx.nparams = len(params)
-        return owner._engine().forward(img, train=True, drop=drop)
+        eng = owner._engine()
+        out = eng.forward(img, train=True, drop=drop)
+        ctx.gen = eng._fwd_gen                  # the engine keeps ONE set of saved activations: this node owns it until the next forward
+        return out
 
     @staticmethod
     def backward(ctx, dlogits):
         owner = ctx.owner
         eng = owner._engine()
+        if eng._fwd_gen != ctx.gen:
+            raise L.GavikoHipError("backward() of a forward whose saved activations were overwritten by a later training-mode forward of the "
+                                   "same model (e.g. loss = f(model(x1), model(x2))): the engine keeps one forward's state -- concatenate "
+                                   "the inputs into one batch, or call backward() before the next forward")
         named = owner._named_cache()[1]
         had_grads = [n for n in eng.trainable_names() if named[n].grad is not None]
         if not had_grads:

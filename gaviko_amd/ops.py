@@ -187,6 +187,13 @@ def layernorm_fwd(x, gamma, beta, M, C_, *, y16=None, y32=None, mean=None, rstd=
 ROWPROJ_L = 20      # default latent width (configs/gaviko.yaml prompt_latent_dim)
 
 
+def side_tile_supported(L_: int, C_: int) -> bool:
+    """Shapes the 16-row-tile fp32-MFMA projections (csrc/sidepass.hip) cover -- and with them the second projection fused into
+    gvk_skinny_up (w2 / z2 / y2)."""
+    import os
+    return os.environ.get("GAVIKO_HIP_SIDE", "1")[:1] != "0" and C_ % 32 == 0 and 64 <= C_ <= 1024 and L_ % 4 == 0 and 4 <= L_ <= 32
+
+
 def rowproj_supported(L_: int, C_: int) -> bool:
     """Shapes the fused LayerNorm+projection kernels (row-per-wave form) cover."""
     return L_ in (4, 8, 16, 20) and C_ % 4 == 0 and 128 <= C_ <= 1024

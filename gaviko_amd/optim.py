@@ -73,7 +73,8 @@ class OneCycle:
 
 class FusedAdamOneCycle:
     """clip_grad_norm_(max_norm) + Adam + OneCycleLR for the trainable tensors of a gaviko_amd model, or for an explicit
-    (params, flat_grad) pair whose gradient layout is the concatenation of the params in order."""
+    (params, flat_grad) pair whose gradient layout is the concatenation of the params in order.  In the (params, flat_grad) form the
+    caller must call `engine.invalidate_weights()` after step() if any of the params is a backbone weight of a gaviko_amd model."""
 
     def __init__(self, model_or_params, *, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm: Optional[float] = 1.0,
                  max_lr=None, total_steps=None, pct_start=0.3, div_factor=25.0, final_div_factor=1e4, anneal_strategy="cos",
@@ -154,6 +155,11 @@ class FusedAdamOneCycle:
                        bias_c1=1.0 - b1 ** self.t, bias_c2=1.0 - self.beta2 ** self.t,
                        max_norm=float(self.max_norm if self.max_norm is not None else 0.0))
         L.check(lib.gvk_adam_step(C.byref(d), st), "gvk_adam_step")
+        if self.model is not None:
+            # the kernel writes parameters through raw pointers, so torch's version counters do not move: tell the engine, which keeps
+            # bf16 / transposed operand shadows of the backbone weights (`--method fft` trains them)
+            eng = self.model._engine()
+            eng.invalidate_weights(eng.trainable_names())
 
     def grad_norm(self) -> torch.Tensor:
         """Device scalar: the pre-clip total gradient norm of the last step (what clip_grad_norm_ returns)."""

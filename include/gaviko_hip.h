@@ -83,7 +83,9 @@ typedef struct gvk_gemm_desc {
   int32_t epilogue;
   int32_t rows_in, rows_out, row_off; /* GVK_EPI_PATCH_F32 only */
   int32_t tile;       /* 0 = auto, else BM*1000+BN (128128, 128064, 64064, 64128); 3128128 = 128x128 with three LDS stages (one workgroup per CU);
-                         256256 = eight waves on a 256x256 tile (STORE_BF16, BIAS_GELU_BF16, GELU_BWD_BF16 only) */
+                         256256 = eight waves on a 256x256 tile (STORE_BF16, BIAS_GELU_BF16, GELU_BWD_BF16 only);
+                         8256256 / 7256256 = the eight-phase 256x256 kernel (gemm8p_bf16.hip: two wave groups one barrier apart, counted
+                         vmcnt), LDS-DMA issued in the load sections / inside the MFMA clusters; epilogues 0, 1, 2, 4, 5, N % 256 == 0, K >= 128 */
   float drop_p;       /* nn.Dropout behind the Linear (vision_transformer.py:32-34,54), epilogues 1, 2 (on out1), 4: the value at
                          (m, n) is multiplied by mask(seed + *seed_ptr, m*N + n) / (1 - drop_p); 0 = off */
   uint64_t seed;
@@ -203,7 +205,11 @@ typedef struct gvk_skinny_up_desc {
   void* out_bf16;                   /* optional bf16 copy of out (plain epilogue only) */
   const float* alpha_ptr;           /* optional device scalar: v = alpha * (lat . W^T + bias)          (DVPT prompt_gate, dvpt.py:46) */
   const float* gg_x;                /* optional f32 [M][C]: v *= QuickGELU'(gg_x[m][c])                 (dgrad through DVPT's input GELU) */
+  /* optional second projection of the rows just written (plain epilogue only): z2 = out[m] . W2^T + bias2, y2 = act2(z2); W2 [L2][C]
+     (GPA's proj_down of the new local tokens, gaviko.py:156, rides on the MWSA up-projection that produces them, gaviko.py:242) */
+  const float* w2; const float* bias2; float* z2; float* y2;
   int32_t M, C, L, T, P, w_layout, accumulate;
+  int32_t L2, act2;
   float drop_p;
   uint64_t seed;
 } gvk_skinny_up_desc;

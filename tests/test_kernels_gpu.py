@@ -271,3 +271,34 @@ def test_gemm_256x256_eight_wave_tile(dev, M, N, K):
     assert (o[:M].float() - ref).abs().max().item() < 3e-2 * max(1.0, ref.abs().max().item())
     with pytest.raises(Exception, match="256x256"):
         ops.gemm_nt(A, W, M, torch.zeros(M, N, device=dev), epilogue=ops.EPI_STORE_F32, tile=256256)
+
+
+@pytest.mark.parametrize("tile8", [8256256, 7256256])
+@pytest.mark.parametrize("M,N,K", [(4132, 3072, 768), (4132, 768, 3072), (1033, 768, 192), (300, 256, 128), (2066, 2304, 768), (130, 512, 2304)])
+def test_gemm_eight_phase_kernel(dev, M, N, K, tile8):
+    """tile 8256256 (gemm8p_bf16.hip: 256 x 256, two wave groups one barrier apart, counted vmcnt): every epilogue it is built for,
+    bit for bit against the four-wave 128 x 128 kernel (same k order per element) and against torch in float32."""
+    from gaviko_amd import ops
+    gen = torch.Generator().manual_seed(7 * M + N + K)
+    A = ops.act_zeros(M, K, torch.bfloat16, dev); A[:M] = torch.randn(M, K, generator=gen).bfloat16().to(dev)
+    W = (torch.randn(N, K, generator=gen) / K ** 0.5).bfloat16().to(dev)
+    bias = torch.randn(N, generator=gen).to(dev)
+    aux = ops.act_zeros(M, N, torch.bfloat16, dev); aux[:M] = torch.randn(M, N, generator=gen).bfloat16().to(dev)
+    res = ops.act_zeros(M, N, torch.float32, dev); res[:M] = torch.randn(M, N, generator=gen).to(dev)
+    ref = A[:M].float() @ W.float().t()
+    cases = ((ops.EPI_STORE_BF16, dict(bias=bias), torch.bfloat16), (ops.EPI_BIAS_GELU_BF16, dict(bias=bias), torch.bfloat16),
+             (ops.EPI_GELU_BWD_BF16, dict(aux=aux), torch.bfloat16), (ops.EPI_STORE_F32, dict(), torch.float32),
+             (ops.EPI_BIAS_RES_F32, dict(bias=bias, res=res), torch.float32))
+    for rep in range(3):                                    # the LDS-DMA ordering is a race if it is wrong: repeat
+        for epi, kw, dt in cases:
+            outs = []
+            for tile in (tile8, 128128):
+                o0, o1 = ops.act_zeros(M, N, dt, dev), ops.act_zeros(M, N, torch.bfloat16, dev)
+                k2 = dict(kw, out1=o1) if epi == ops.EPI_BIAS_GELU_BF16 else kw
+                ops.gemm_nt(A, W, M, o0, epilogue=epi, tile=tile, **k2)
+                outs.append((o0.float(), o1.float()))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), f"epilogue {epi} differs from the 128x128 kernel"
+            assert not outs[0][0][M:].any(), "rows >= M must not be written"
+    o = ops.act_zeros(M, N, torch.float32, dev)
+    ops.gemm_nt(A, W, M, o, epilogue=ops.EPI_STORE_F32, tile=tile8)
+    assert (o[:M] - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
