@@ -10,7 +10,9 @@
 //     under 20 KiB of LDS and co-reside with the backbone's GEMM workgroups),
 //   * the reduction over C happens inside the MFMA accumulators + ONE cross-wave pass through LDS per tile (the row-per-wave kernels in
 //     rowwise.hip spend 20 wave reductions per row and re-stage the weight chunk by chunk behind barriers),
-//   * all of a tile's loads (48 KiB of x per workgroup) are in flight together.
+//   * all of a tile's loads (48 KiB of x per workgroup, the weight fragments, the side operands) are in flight together: the kernels are
+//     templated on everything that shapes a loop (latent width L = 20, 32-column groups per wave, weight layout), loads are clamped rather
+//     than branched around, so the compiler emits one block of loads followed by one block of MFMAs.
 // k-order inside an MFMA is free (the sum runs over all of it), so an operand register is whatever 16-byte piece loads best:
 //   down: lane (i = lane & 15, kq = lane >> 4) holds x[row i][c .. c+3], c = 32 g + 16 h + 4 kq -- A operand, element e feeds MFMA e;
 //         the B operand is W[n = lane & 15 (+16)][same c .. c+3].
@@ -24,9 +26,11 @@ namespace gvk {
 
 namespace {
 constexpr int kSW = 8;                 // waves per workgroup
-constexpr int kMaxG = 4;               // 32-column groups per wave: C <= 1024
+constexpr int kSL = 20;                // latent width these kernels are built for (configs/gaviko.yaml prompt_latent_dim / local_dim)
+constexpr int kK4 = kSL / 4;           // MFMA k-steps of the up projection
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
 // sum over the four kq lanes that share lane & 15
 __device__ __forceinline__ float kq_sum(float v) {
@@ -35,17 +39,20 @@ __device__ __forceinline__ float kq_sum(float v) {
   return v;
 }
 
-// W fragment of the down projection: W[n][c .. c+3] for n < L, zero above.  layout 0: w [L][C]; 1: w [C][L]
-__device__ __forceinline__ f32x4 load_w_down(const float* __restrict__ w, int layout, int L, int C, int n, int c) {
-  if (n >= L) return f32x4{0.f, 0.f, 0.f, 0.f};
-  if (layout == 0) return *(const f32x4*)(w + (size_t)n * C + c);
-  return f32x4{w[(size_t)c * L + n], w[(size_t)(c + 1) * L + n], w[(size_t)(c + 2) * L + n], w[(size_t)(c + 3) * L + n]};
+// W fragment of a down projection: W[n][c .. c+3], zero for n >= kSL (the load itself is clamped, never skipped).  WL 0: w [L][C]; 1: w [C][L]
+template <int WL>
+__device__ __forceinline__ f32x4 load_w_down(const float* __restrict__ w, int C, int n, int c) {
+  const int nn = n < kSL ? n : 0;
+  f32x4 v;
+  if constexpr (WL == 0) v = *(const f32x4*)(w + (size_t)nn * C + c);
+  else v = f32x4{w[(size_t)c * kSL + nn], w[(size_t)(c + 1) * kSL + nn], w[(size_t)(c + 2) * kSL + nn], w[(size_t)(c + 3) * kSL + nn]};
+  return n < kSL ? v : zero4();
 }
 }  // namespace
 
-// MODE 0: plain rows (optional LayerNorm of the row first, optional dropout mask on the row);  3: QuickGELU of the row first
-template <int MODE>
-__global__ __launch_bounds__(64 * kSW) void side_down_kernel(DownArgs p, int L) {
+// NGW = 32-column groups per wave (C = 256 NGW, or fewer: waves past the end work on zeros), WL = weight layout
+template <int NGW, int WL>
+__global__ __launch_bounds__(64 * kSW, NGW <= 3 ? 4 : 2) void side_down_kernel(DownArgs p) {     // <= 128 VGPRs: two workgroups per CU (259 tiles on 256 CUs)
   __shared__ float red[kSW][16];
   __shared__ f32x4 part[kSW][2][64];
   __shared__ float yrow[16][33];
@@ -55,51 +62,51 @@ __global__ __launch_bounds__(64 * kSW) void side_down_kernel(DownArgs p, int L) 
   const int C = p.C, NG = C >> 5;                       // groups of 32 columns; wave w owns groups w, w + 8, ...
   const int row0 = blockIdx.x * 16;
   const int row = min(row0 + i, p.M - 1);
-  const bool ln = MODE == 0 && p.ln_g != nullptr;
-  // every load of the tile goes out first
-  f32x4 x[kMaxG][2];
+  const bool ln = p.ln_g != nullptr;
+  // ---- every load of the tile goes out first: the rows, the weight fragments, the LayerNorm affine
+  f32x4 x[NGW][2], wf[NGW][2][2];
+  int col[NGW][2];
+  bool ok[NGW];
 #pragma unroll
-  for (int gi = 0; gi < kMaxG; ++gi) {
+  for (int gi = 0; gi < NGW; ++gi) {
     const int g = wave + kSW * gi;
+    ok[gi] = g < NG;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-      x[gi][h] = g < NG ? *(const f32x4*)(p.x + (size_t)row * C + 32 * g + 16 * h + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < 2; ++h) {
+      col[gi][h] = 32 * (ok[gi] ? g : 0) + 16 * h + 4 * kq;
+      x[gi][h] = *(const f32x4*)(p.x + (size_t)row * C + col[gi][h]);
+    }
   }
+#pragma unroll
+  for (int gi = 0; gi < NGW; ++gi)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      wf[gi][h][0] = load_w_down<WL>(p.w, C, i, col[gi][h]);
+      wf[gi][h][1] = load_w_down<WL>(p.w, C, 16 + i, col[gi][h]);
+    }
   if (p.w2 != nullptr) {                                 // second-stage weight [L2][L] -> LDS, rows padded to 33 floats
-    for (int t = threadIdx.x; t < p.L2 * L; t += 64 * kSW) {
-      const int j = t / L, l = t - j * L;
+    for (int t = threadIdx.x; t < p.L2 * kSL; t += 64 * kSW) {
+      const int j = t / kSL, l = t - j * kSL;
       w2s[j * 33 + l] = p.w2[t];
     }
   }
-  if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
-  if constexpr (MODE == 3) {
+  if (p.drop_thresh != 0u) {
+    if (p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
 #pragma unroll
-    for (int gi = 0; gi < kMaxG; ++gi)
+    for (int gi = 0; gi < NGW; ++gi)
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x[gi][h][e] = quick_gelu(x[gi][h][e]);
-  }
-  if (MODE == 0 && p.drop_thresh != 0u) {
-#pragma unroll
-    for (int gi = 0; gi < kMaxG; ++gi) {
-      const int g = wave + kSW * gi;
-      if (g < NG) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            x[gi][h][e] *= drop_scale(p.seed, (unsigned long long)row * C + 32 * g + 16 * h + 4 * kq + e, p.drop_thresh, p.inv_keep);
-      }
-    }
+        for (int e = 0; e < 4; ++e)
+          x[gi][h][e] *= drop_scale(p.seed, (unsigned long long)row * C + col[gi][h] + e, p.drop_thresh, p.inv_keep);
   }
   if (ln) {
     // two-pass statistics like torch's LayerNorm: mean, then the centred sum of squares (eps inside the square root)
     float s = 0.f;
 #pragma unroll
-    for (int gi = 0; gi < kMaxG; ++gi)
+    for (int gi = 0; gi < NGW; ++gi)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) s += (x[gi][h][0] + x[gi][h][1]) + (x[gi][h][2] + x[gi][h][3]);     // groups beyond NG hold zeros
+      for (int h = 0; h < 2; ++h) s += ok[gi] ? (x[gi][h][0] + x[gi][h][1]) + (x[gi][h][2] + x[gi][h][3]) : 0.f;
     s = kq_sum(s);
     if (kq == 0) red[wave][i] = s;
     __syncthreads();
@@ -109,14 +116,11 @@ __global__ __launch_bounds__(64 * kSW) void side_down_kernel(DownArgs p, int L) 
     mean /= (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int gi = 0; gi < kMaxG; ++gi) {
-      if (wave + kSW * gi < NG) {
+    for (int gi = 0; gi < NGW; ++gi)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { const float d = x[gi][h][e] - mean; q += d * d; }
-      }
-    }
+        for (int e = 0; e < 4; ++e) { const float d = x[gi][h][e] - mean; q += ok[gi] ? d * d : 0.f; }
     q = kq_sum(q);
     __syncthreads();                                     // everyone has read the first-pass sums
     if (kq == 0) red[wave][i] = q;
@@ -130,50 +134,36 @@ __global__ __launch_bounds__(64 * kSW) void side_down_kernel(DownArgs p, int L) 
       if (p.rstd) p.rstd[row] = rstd;
     }
 #pragma unroll
-    for (int gi = 0; gi < kMaxG; ++gi) {
-      const int g = wave + kSW * gi;
-      if (g < NG) {
+    for (int gi = 0; gi < NGW; ++gi)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int c = 32 * g + 16 * h + 4 * kq;
-          const f32x4 g4 = *(const f32x4*)(p.ln_g + c), b4 = *(const f32x4*)(p.ln_b + c);
+      for (int h = 0; h < 2; ++h) {                       // the affine vectors are cache-resident: fetched here, not held across the statistics
+        const f32x4 g4 = *(const f32x4*)(p.ln_g + col[gi][h]), b4 = *(const f32x4*)(p.ln_b + col[gi][h]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) x[gi][h][e] = (x[gi][h][e] - mean) * rstd * g4[e] + b4[e];
-        }
+        for (int e = 0; e < 4; ++e) x[gi][h][e] = (x[gi][h][e] - mean) * rstd * g4[e] + b4[e];
       }
-    }
   }
-  // ---- projection: this wave's share of the sum over C
-  const int ntl = (L + 15) >> 4;                         // latent tiles of 16
-  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  // ---- projection: this wave's share of the sum over C (groups past the end contribute zeros)
+  f32x4 acc[2] = {zero4(), zero4()};
 #pragma unroll
-  for (int gi = 0; gi < kMaxG; ++gi) {
-    const int g = wave + kSW * gi;
-    if (g < NG) {                                        // wave-uniform
+  for (int gi = 0; gi < NGW; ++gi)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int c = 32 * g + 16 * h + 4 * kq;
-        const f32x4 w0 = load_w_down(p.w, p.w_layout, L, C, i, c);
-        const f32x4 w1 = ntl > 1 ? load_w_down(p.w, p.w_layout, L, C, 16 + i, c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 xv = ok[gi] ? x[gi][h] : zero4();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[0] = mfma4(x[gi][h][e], w0[e], acc[0]);
-        if (ntl > 1) {
+      for (int e = 0; e < 4; ++e) acc[0] = mfma4(xv[e], wf[gi][h][0][e], acc[0]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[1] = mfma4(x[gi][h][e], w1[e], acc[1]);
-        }
-      }
+      for (int e = 0; e < 4; ++e) acc[1] = mfma4(xv[e], wf[gi][h][1][e], acc[1]);
     }
-  }
   part[wave][0][lane] = acc[0];
   part[wave][1][lane] = acc[1];
   __syncthreads();
-  // waves 0 (and 1 when L > 16) finish one latent tile each: D lane (n = lane & 15, token rows 4 kq + e)
-  if (wave < ntl) {
+  // waves 0 and 1 finish one latent tile each: D lane (n = lane & 15, token rows 4 kq + e)
+  if (wave < 2) {
     f32x4 t = part[0][wave][lane];
 #pragma unroll
     for (int w = 1; w < kSW; ++w) t += part[w][wave][lane];
     const int n = 16 * wave + i;
-    if (n < L) {
+    if (n < kSL) {
       const float b = p.bias != nullptr ? p.bias[n] : 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -182,8 +172,8 @@ __global__ __launch_bounds__(64 * kSW) void side_down_kernel(DownArgs p, int L) 
         const float yy = p.act == 1 ? quick_gelu(zz) : zz;
         yrow[r][n] = yy;
         if (m < p.M) {
-          if (p.z) p.z[(size_t)m * L + n] = zz;
-          if (p.y) p.y[(size_t)m * L + n] = yy;
+          if (p.z) p.z[(size_t)m * kSL + n] = zz;
+          if (p.y) p.y[(size_t)m * kSL + n] = yy;
         }
       }
     }
@@ -193,7 +183,8 @@ __global__ __launch_bounds__(64 * kSW) void side_down_kernel(DownArgs p, int L) 
     for (int t = threadIdx.x; t < 16 * p.L2; t += 64 * kSW) {
       const int r = t / p.L2, j = t - r * p.L2, m = row0 + r;
       float a = 0.f;
-      for (int l = 0; l < L; ++l) a = __builtin_fmaf(yrow[r][l], w2s[j * 33 + l], a);
+#pragma unroll
+      for (int l = 0; l < kSL; ++l) a = __builtin_fmaf(yrow[r][l], w2s[j * 33 + l], a);
       if (m < p.M) p.y2[(size_t)m * p.L2 + j] = a;
     }
   }
@@ -201,111 +192,103 @@ __global__ __launch_bounds__(64 * kSW) void side_down_kernel(DownArgs p, int L) 
 
 // ---- up projection ------------------------------------------------------------------------------------------------------------------
 struct Up2Args {                                        // optional down-projection of the rows side_up has just written
-  const float* w; const float* bias; float* z; float* y; int L, act;          // w [L][C]; z / y [M][L]
+  const float* w; const float* bias; float* z; float* y; int act;            // w [kSL][C]; z / y [M][kSL]
 };
 
-// LNB: LayerNorm-backward epilogue (out = base + LN'(v; ln_x, mean, rstd, gamma));  EXT: DVPT's scalar gate / input-GELU derivative
-template <bool LNB, bool EXT>
-__global__ __launch_bounds__(64 * kSW) void side_up_kernel(UpArgs p, int L, Up2Args q) {
+// NPW = 32-column pairs per wave, WL = weight layout (0: w [C][L], 1: w [L][C]), LNB = LayerNorm-backward epilogue
+// (out = base + LN'(v; ln_x, mean, rstd, gamma))
+template <int NPW, int WL, bool LNB>
+__global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpArgs p, Up2Args q) {
   __shared__ float red[kSW][16][2];
   __shared__ f32x4 part[kSW][2][64];
-  constexpr int kMaxP = 4;                              // 32-column pairs per wave: C <= 1024
   const int lane = lane_id(), wave = wave_id();
   const int a = lane & 15, kq = lane >> 4;              // A operand: weight row a of a column tile; B operand / D: token row a
-  const int C = p.C, NP = C >> 5, K4 = L >> 2;          // K4 k-steps of 4 latents
+  const int C = p.C, NP = C >> 5;
   const int row0 = blockIdx.x * 16;
   const int row = min(row0 + a, p.M - 1);
   const bool rvalid = row0 + a < p.M;
   const float* __restrict__ base = p.accumulate ? p.out : p.res;
-  if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
-  // the wide stream first: base (and the LayerNorm input for LNB) of this lane's 8-column pieces
-  f32x4 bs[kMaxP][2], xs[LNB ? kMaxP : 1][2];
+  // ---- loads: base (+ LayerNorm input) pieces of 8 columns, the latent row, the weight fragments, bias / gamma
+  f32x4 bs[NPW][2], xs[LNB ? NPW : 1][2], vec[LNB ? 1 : NPW][2];
+  float wa[NPW][2][kK4], lb[kK4];
+  int cc[NPW];
+  bool ok[NPW];
 #pragma unroll
-  for (int pi = 0; pi < kMaxP; ++pi) {
+  for (int pi = 0; pi < NPW; ++pi) {
     const int pp = wave + kSW * pi;
-    const int c = 32 * pp + 8 * kq;
+    ok[pi] = pp < NP;
+    cc[pi] = 32 * (ok[pi] ? pp : 0) + 8 * kq;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      bs[pi][j] = (pp < NP && base != nullptr) ? *(const f32x4*)(base + (size_t)row * C + c + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (LNB) xs[pi][j] = pp < NP ? *(const f32x4*)(p.ln_x + (size_t)row * C + c + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+      bs[pi][j] = base != nullptr ? *(const f32x4*)(base + (size_t)row * C + cc[pi] + 4 * j) : zero4();
+      if constexpr (LNB) xs[pi][j] = *(const f32x4*)(p.ln_x + (size_t)row * C + cc[pi] + 4 * j);
     }
   }
-  // B operand: lat[row][kq K4 + s]
-  float lb[8];
   {
-    const float* src = p.lat + (size_t)row * L;
+    const float* src = p.lat + (size_t)row * kSL;
     if (p.lat_override != nullptr) {
       const int sidx = row / p.T, t = row - sidx * p.T;
-      if (t < p.P) src = p.lat_override + ((size_t)sidx * p.P + t) * L;
+      if (t < p.P) src = p.lat_override + ((size_t)sidx * p.P + t) * kSL;
     }
 #pragma unroll
-    for (int s = 0; s < 8; ++s) lb[s] = s < K4 ? src[kq * K4 + s] : 0.f;
+    for (int s = 0; s < kK4; ++s) lb[s] = src[kq * kK4 + s];
   }
-  f32x4 acc[kMaxP][2];
 #pragma unroll
-  for (int pi = 0; pi < kMaxP; ++pi) {
-    const int pp = wave + kSW * pi;
-    acc[pi][0] = acc[pi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (pp < NP) {                                       // wave-uniform
+  for (int pi = 0; pi < NPW; ++pi)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int c = 32 * pp + 8 * (a >> 2) + 4 * j + (a & 3);           // weight row fed to A-operand row a of column tile j
-        float wa[8];
+    for (int j = 0; j < 2; ++j) {
+      const int c = cc[pi] - 8 * kq + 8 * (a >> 2) + 4 * j + (a & 3);      // weight row fed to A-operand row a of column tile j
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
-          wa[s] = s < K4 ? (p.w_layout == 0 ? p.w[(size_t)c * L + kq * K4 + s] : p.w[(size_t)(kq * K4 + s) * C + c]) : 0.f;
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-          if (s < K4) acc[pi][j] = mfma4(wa[s], lb[s], acc[pi][j]);
-      }
+      for (int s = 0; s < kK4; ++s)
+        wa[pi][j][s] = WL == 0 ? p.w[(size_t)c * kSL + kq * kK4 + s] : p.w[(size_t)(kq * kK4 + s) * C + c];
+      if constexpr (!LNB) vec[pi][j] = p.bias != nullptr ? *(const f32x4*)(p.bias + cc[pi] + 4 * j) : zero4();
     }
-  }
-  // ---- epilogue: lane = token row a, columns 32 pp + 8 kq + (4 j + e)
-  [[maybe_unused]] float s1 = 0.f, s2 = 0.f, mu = 0.f, rs = 0.f;
+  if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
+  [[maybe_unused]] float mu = 0.f, rs = 0.f;
   if constexpr (LNB) { mu = p.ln_mean[row]; rs = p.ln_rstd[row]; }
+  // ---- D[column a of tile j][token row] = sum over the latent index
+  f32x4 acc[NPW][2];
 #pragma unroll
-  for (int pi = 0; pi < kMaxP; ++pi) {
-    const int pp = wave + kSW * pi;
-    if (pp < NP) {
-      const int c = 32 * pp + 8 * kq;
+  for (int pi = 0; pi < NPW; ++pi)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f32x4 v = acc[pi][j];
-        if constexpr (LNB) {
-          const f32x4 g4 = *(const f32x4*)(p.ln_g + c + 4 * j);
+    for (int j = 0; j < 2; ++j) {
+      acc[pi][j] = zero4();
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float dh = v[e] * g4[e], xh = (xs[pi][j][e] - mu) * rs;
-            v[e] = dh;
-            xs[pi][j][e] = xh;
-            s1 += dh;
-            s2 += dh * xh;
-          }
-        } else {
-          if (p.bias != nullptr) v += *(const f32x4*)(p.bias + c + 4 * j);
-          if constexpr (EXT) {
-            if (p.alpha_ptr != nullptr) v *= p.alpha_ptr[0];
-            if (p.gg_x != nullptr) {
-              const f32x4 xg = *(const f32x4*)(p.gg_x + (size_t)row * C + c + 4 * j);
+      for (int s = 0; s < kK4; ++s) acc[pi][j] = mfma4(wa[pi][j][s], lb[s], acc[pi][j]);
+    }
+  // ---- epilogue: lane = token row a, columns cc + (4 j + e)
+  [[maybe_unused]] float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] *= quick_gelu_grad(xg[e]);
-            }
-          }
-          if (p.drop_thresh != 0u) {
+  for (int pi = 0; pi < NPW; ++pi) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= drop_scale(p.seed, (unsigned long long)row * C + c + 4 * j + e, p.drop_thresh, p.inv_keep);
-          }
-          v += bs[pi][j];
-          if (rvalid) *(f32x4*)(p.out + (size_t)row * C + c + 4 * j) = v;
+    for (int j = 0; j < 2; ++j) {
+      f32x4 v = acc[pi][j];
+      if constexpr (LNB) {
+        const f32x4 gam = *(const f32x4*)(p.ln_g + cc[pi] + 4 * j);       // cache-resident: fetched at its use
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dh = v[e] * gam[e], xh = (xs[pi][j][e] - mu) * rs;
+          v[e] = dh;
+          xs[pi][j][e] = xh;
+          s1 += ok[pi] ? dh : 0.f;
+          s2 += ok[pi] ? dh * xh : 0.f;
         }
-        acc[pi][j] = v;
-      }
-      if (!LNB && p.out16 != nullptr && rvalid) {
-        bf16x8 h8;
+      } else {
+        v += vec[pi][j];
+        if (p.drop_thresh != 0u) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { h8[e] = (bf16)acc[pi][0][e]; h8[4 + e] = (bf16)acc[pi][1][e]; }
-        *(bf16x8*)(p.out16 + (size_t)row * C + c) = h8;
+          for (int e = 0; e < 4; ++e) v[e] *= drop_scale(p.seed, (unsigned long long)row * C + cc[pi] + 4 * j + e, p.drop_thresh, p.inv_keep);
+        }
+        v += bs[pi][j];
+        if (rvalid && ok[pi]) *(f32x4*)(p.out + (size_t)row * C + cc[pi] + 4 * j) = v;
       }
+      acc[pi][j] = v;
+    }
+    if (!LNB && p.out16 != nullptr && rvalid && ok[pi]) {
+      bf16x8 h8;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { h8[e] = (bf16)acc[pi][0][e]; h8[4 + e] = (bf16)acc[pi][1][e]; }
+      *(bf16x8*)(p.out16 + (size_t)row * C + cc[pi]) = h8;
     }
   }
   if constexpr (LNB) {
@@ -320,71 +303,62 @@ __global__ __launch_bounds__(64 * kSW) void side_up_kernel(UpArgs p, int L, Up2A
     s1 /= (float)C;
     s2 /= (float)C;
 #pragma unroll
-    for (int pi = 0; pi < kMaxP; ++pi) {
-      const int pp = wave + kSW * pi;
-      if (pp < NP && rvalid) {
-        const int c = 32 * pp + 8 * kq;
+    for (int pi = 0; pi < NPW; ++pi) {
+      if (rvalid && ok[pi]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = rs * (acc[pi][j][e] - s1 - xs[pi][j][e] * s2) + bs[pi][j][e];
-          *(f32x4*)(p.out + (size_t)row * C + c + 4 * j) = o;
+          *(f32x4*)(p.out + (size_t)row * C + cc[pi] + 4 * j) = o;
         }
       }
     }
-  }
-  if constexpr (!LNB && !EXT) {
+  } else {
     if (q.w != nullptr) {
-      // second projection of the rows just written: A operand = the output piece itself (token row a, k <-> column c + 4 j + e), B operand
-      // W2[n][c + 4 j + e] with c = 32 pp + 8 kq
-      const int ntl = (q.L + 15) >> 4;
-      f32x4 d2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      // second projection of the rows just written: A operand = the output piece itself (token row a, k <-> column cc + 4 j + e), B operand
+      // W2[n][cc + 4 j + e]
+      f32x4 d2[2] = {zero4(), zero4()}, w2f[NPW][2][2];
 #pragma unroll
-      for (int pi = 0; pi < kMaxP; ++pi) {
-        const int pp = wave + kSW * pi;
-        if (pp < NP) {
-          const int c = 32 * pp + 8 * kq;
+      for (int pi = 0; pi < NPW; ++pi)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const f32x4 w0 = load_w_down(q.w, 0, q.L, C, a, c + 4 * j);
-            const f32x4 w1 = ntl > 1 ? load_w_down(q.w, 0, q.L, C, 16 + a, c + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) d2[0] = mfma4(acc[pi][j][e], w0[e], d2[0]);
-            if (ntl > 1) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) d2[1] = mfma4(acc[pi][j][e], w1[e], d2[1]);
-            }
-          }
+        for (int j = 0; j < 2; ++j) {
+          w2f[pi][j][0] = load_w_down<0>(q.w, C, a, cc[pi] + 4 * j);
+          w2f[pi][j][1] = load_w_down<0>(q.w, C, 16 + a, cc[pi] + 4 * j);
         }
-      }
+#pragma unroll
+      for (int pi = 0; pi < NPW; ++pi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x4 ov = ok[pi] ? acc[pi][j] : zero4();
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d2[0] = mfma4(ov[e], w2f[pi][j][0][e], d2[0]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d2[1] = mfma4(ov[e], w2f[pi][j][1][e], d2[1]);
+        }
       part[wave][0][lane] = d2[0];
       part[wave][1][lane] = d2[1];
       __syncthreads();
-      if (wave < ntl) {
+      if (wave < 2) {
         f32x4 t = part[0][wave][lane];
 #pragma unroll
         for (int w = 1; w < kSW; ++w) t += part[w][wave][lane];
         const int n = 16 * wave + a;
-        if (n < q.L) {
+        if (n < kSL) {
           const float b = q.bias != nullptr ? q.bias[n] : 0.f;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int m = row0 + 4 * kq + e;
             const float zz = t[e] + b;
             if (m < p.M) {
-              if (q.z) q.z[(size_t)m * q.L + n] = zz;
-              if (q.y) q.y[(size_t)m * q.L + n] = q.act == 1 ? quick_gelu(zz) : zz;
+              if (q.z) q.z[(size_t)m * kSL + n] = zz;
+              if (q.y) q.y[(size_t)m * kSL + n] = q.act == 1 ? quick_gelu(zz) : zz;
             }
           }
         }
       }
     }
   }
-}
-
-static bool side_shape_ok(int L, int C, int L2) {
-  return C % 32 == 0 && C >= 64 && C <= 32 * kSW * kMaxG && L % 4 == 0 && L >= 4 && L <= 32 && L2 <= 64;
 }
 
 static bool side_enabled() {
@@ -392,24 +366,36 @@ static bool side_enabled() {
   return on;
 }
 
+// 32-column groups per wave for the widths of the three backbones (vit-t16 192, vit-b16 768, vit-l16 1024); 0 = not covered
+static int groups_per_wave(int C) { return C == 192 ? 1 : C == 768 ? 3 : C == 1024 ? 4 : 0; }
+
 // returns 1 when the call is not covered (the caller falls back to the row-per-wave / MFMA-tile kernels)
 int launch_side_down(const DownArgs& a, int L, hipStream_t s) {
-  if (!side_enabled() || !side_shape_ok(L, a.C, a.w2 ? a.L2 : 0) || (a.mode != 0 && a.mode != 3)) return 1;
+  // mode 3 (DVPT's QuickGELU input) stays on the row-per-wave kernel: its scalar prompt_gate gradient is one signed sum over every latent
+  // of the batch and is pinned at 1e-4 on the fp32 path with that kernel's summation order
+  const int ngw = groups_per_wave(a.C);
+  if (!side_enabled() || L != kSL || ngw == 0 || a.mode != 0 || (a.w2 != nullptr && a.L2 > 64)) return 1;
   const dim3 grid((a.M + 15) / 16), block(64 * kSW);
-  if (a.mode == 3) GVK_LAUNCH(side_down_kernel<3>, grid, block, 0, s, a, L);
-  else GVK_LAUNCH(side_down_kernel<0>, grid, block, 0, s, a, L);
+#define GVK_SD(N_, W_) GVK_LAUNCH((side_down_kernel<N_, W_>), grid, block, 0, s, a)
+  if (a.w_layout == 0) { if (ngw == 1) GVK_SD(1, 0); else if (ngw == 3) GVK_SD(3, 0); else GVK_SD(4, 0); }
+  else { if (ngw == 1) GVK_SD(1, 1); else if (ngw == 3) GVK_SD(3, 1); else GVK_SD(4, 1); }
+#undef GVK_SD
   return check_launch("side_down");
 }
 
 int launch_side_up(const UpArgs& a, int L, const float* w2, const float* bias2, float* z2, float* y2, int L2, int act2, hipStream_t s) {
-  if (!side_enabled() || !side_shape_ok(L, a.C, 0)) return 1;
+  const int npw = groups_per_wave(a.C);
   const bool lnb = a.ln_x != nullptr, ext = a.alpha_ptr != nullptr || a.gg_x != nullptr;
-  if (w2 != nullptr && (lnb || ext || L2 % 4 != 0 || L2 > 32)) return set_error(-2, "side_up: the fused second projection takes the plain epilogue and L2 in 4..32");
-  Up2Args q{w2, bias2, z2, y2, L2, act2};
+  if (!side_enabled() || L != kSL || npw == 0 || ext) return 1;       // DVPT's gate / GELU' epilogue: row-per-wave kernel (see launch_side_down)
+  if (w2 != nullptr && (lnb || L2 != kSL)) return set_error(-2, "side_up: the fused second projection takes the plain epilogue and L2 = %d", kSL);
+  Up2Args q{w2, bias2, z2, y2, act2};
   const dim3 grid((a.M + 15) / 16), block(64 * kSW);
-  if (lnb) GVK_LAUNCH((side_up_kernel<true, false>), grid, block, 0, s, a, L, q);
-  else if (ext) GVK_LAUNCH((side_up_kernel<false, true>), grid, block, 0, s, a, L, q);
-  else GVK_LAUNCH((side_up_kernel<false, false>), grid, block, 0, s, a, L, q);
+#define GVK_SU(N_, W_, B_) GVK_LAUNCH((side_up_kernel<N_, W_, B_>), grid, block, 0, s, a, q)
+#define GVK_SU_N(W_, B_) { if (npw == 1) GVK_SU(1, W_, B_); else if (npw == 3) GVK_SU(3, W_, B_); else GVK_SU(4, W_, B_); }
+  if (a.w_layout == 0) { if (lnb) GVK_SU_N(0, true) else GVK_SU_N(0, false) }
+  else { if (lnb) GVK_SU_N(1, true) else GVK_SU_N(1, false) }
+#undef GVK_SU_N
+#undef GVK_SU
   return check_launch("side_up");
 }
 

@@ -79,7 +79,11 @@ def test_training_step_with_live_dropout_matches_oracle_with_the_same_masks(dev,
     lg = logits.detach().cpu()
     scale = ologits.abs().max().item()
     assert (lg - ologits.detach()).abs().max().item() < 1.5e-2 * scale, (lg, ologits)
-    assert (lg.argmax(-1) == ologits.argmax(-1)).all()
+    # argmax must agree wherever the oracle's own decision is not a tie at the stated tolerance (a draw of the dropout masks can leave
+    # two classes closer than bf16 rounding; the mask-free parity tests in test_model_gpu.py keep the unconditional check)
+    top2 = ologits.detach().topk(2, dim=-1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 1.5e-2 * scale
+    assert (lg.argmax(-1) == ologits.argmax(-1))[decided].all()
     # and the masks matter: without them the oracle lands somewhere else
     plain = oracle.FORWARD[method]({k: v.detach() for k, v in osd.items()}, x, cfg, None)
     # (prompt dropout touches 8 of ~1000 tokens: within bf16 noise on the logits -- there the prompt gradients below carry the proof:
