@@ -48,25 +48,71 @@ def build(backbone, device):
     return m
 
 
+def host_cores():
+    """Cores this process may actually use: the scheduler affinity mask, cut down to the cgroup CPU quota when there is one (a GPU box
+    hands a one-GPU job a share of the host; more threads than that quota only oversubscribe it)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    how = f"affinity {n}"
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: None if int(t) <= 0 else int(t) / 100000.0)):
+        try:
+            with open(path) as f:
+                q = parse(f.read())
+            if q is not None and q >= 1 and q < n:
+                n = int(q + 0.5)
+                how += f", cgroup quota {q:.1f}"
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if os.environ.get("GAVIKO_BENCH_CPU_THREADS"):
+        n = int(os.environ["GAVIKO_BENCH_CPU_THREADS"])
+        how += ", GAVIKO_BENCH_CPU_THREADS"
+    return max(1, n), how
+
+
 def cpu_baseline(backbone, batch):
-    """Oracle on the host cores: one fwd + CE + bwd step of the same batch (dropouts off: the oracle has none)."""
+    """Oracle on the host cores: fwd + CE + bwd steps of the same batch, every core this process may use, one
+    warm-up step, best of three timed ones (dropouts off: the oracle has none)."""
     import oracle
     from gaviko_amd.utils import synth
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(avail, 16)))          # the GPU box gives one GPU a 16-core host share
+    avail, how = host_cores()
+    torch.set_num_threads(avail)
     cfg = dict(MODEL, backbone=backbone)
     sd = {k: torch.from_numpy(v).requires_grad_(oracle.gaviko_trainable(k)) for k, v in synth.fill_state_dict(oracle.gaviko_param_shapes(cfg)).items()}
     x = torch.from_numpy(synth.volumes(0, batch))
     y = torch.from_numpy(synth.labels(0, batch))
-    t0 = time.perf_counter()
-    loss = torch.nn.functional.cross_entropy(oracle.gaviko_forward(sd, x, cfg), y)
-    loss.backward()
-    dt = time.perf_counter() - t0
-    return {"value": batch / dt, "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 step (fwd + CE + bwd) of the same {batch}-volume batch, fp32 torch oracle, {dt:.1f}s"}
+    times = []
+    for it in range(4):                                      # 0 = warm-up (allocator, thread pool), then best of 3
+        for v in sd.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        loss = torch.nn.functional.cross_entropy(oracle.gaviko_forward(sd, x, cfg), y)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+        print(f"[cpu_baseline] step {it}: {times[-1]:.1f} s on {avail} threads", file=sys.stderr, flush=True)
+        if sum(times) > 90.0:                                # keep the default run within minutes whatever the host is
+            break
+    timed = times[1:] or times
+    dt = min(timed)
+    return {"value": batch / dt, "unit": "volumes/s", "cores": avail, "kind": "port",
+            "sample": f"fwd + CE + bwd of the same {batch}-volume batch, fp32 torch oracle on {avail} threads ({how}): warm-up step "
+                      f"{times[0]:.1f} s, best of {len(times) - 1} timed step(s) ({', '.join(f'{t:.1f}' for t in times[1:])} s)"}
+
+
+GEMM_SOURCES = ("gemm_bf16.hip", "gemm8p_bf16.hip", "gemm_epilogue.hpp", "common.hpp")
+
+
+def gemm_source_hash():
+    """sha256 over the GEMM kernel sources: the PMC traffic figures are only valid for the code they were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in GEMM_SOURCES:
+        with open(os.path.join(ROOT, "gaviko_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(name, stats):
@@ -74,15 +120,18 @@ def pmc_traffic(name, stats):
     by tools/pmc_traffic.py from two `rocprofv3 --pmc` runs of this same command: FETCH_SIZE and WRITE_SIZE, KiB units, reads
     x2 on gfx950).  PMC counters cannot be read from inside the process, so the figure is the last profiled one; it is only
     attached when the kernel instantiation (epilogue id) is used by exactly one GEMM shape of this run, else traffic stays null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
     m = re.match(r"gemm_nt_bf16\[(\w+)\]", name)
     if not (m and os.path.exists(path)):
         return {}
     from gaviko_amd import engine as eng_mod
     epi = {v: k for k, v in eng_mod._EPI_NAMES.items()}[m.group(1)]
     with open(path) as f:
-        ker = json.load(f)["kernels"]
-    hits = [v for k, v in ker.items() if re.match(rf"gemm_nt_kernel<\d+, \d+, {epi}, \d+(, false)?(, \d+)*>", k)]
+        doc = json.load(f)
+    if doc.get("gemm_source_sha") != gemm_source_hash():     # measured on other code: no figure rather than a stale one
+        return {"traffic_note": f"{os.path.basename(path)} was measured on GEMM sources {doc.get('gemm_source_sha')}, this build is {gemm_source_hash()}: traffic withheld"}
+    ker = doc["kernels"]
+    hits = [v for k, v in ker.items() if re.match(rf"gemm_nt_kernel<\d+, \d+, {epi}, \d+(, false)?(, \d+)*>", k) or re.match(rf"gemm8p_kernel<{epi}, \d+>", k)]
     if len(hits) != 1:
         return {}
 
@@ -97,7 +146,7 @@ def pmc_traffic(name, stats):
     cl = hits[0].get("clusters") or [hits[0]]
     if len(cl) != len(same):
         return {}
-    return {"traffic": cl[same.index(name)]["total_bytes"], "traffic_source": "profiles/r01_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB)",
+    return {"traffic": cl[same.index(name)]["total_bytes"], "traffic_source": f"profiles/r02_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB; GEMM sources {doc.get('gemm_source_sha')})",
             "algorithmic_bytes": alg_bytes(stats[name]["shape"])}
 
 
@@ -111,7 +160,11 @@ def main():
     ap.add_argument("--loss", default="ce", choices=["ce", "focal", "ce-torch"])   # ce-torch: torch's own op, for A/B only
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--allow-ablate", action="store_true", help="diagnostics only: run with GAVIKO_HIP_ABLATE set; the output line is marked INVALID")
     args = ap.parse_args()
+    if os.environ.get("GAVIKO_HIP_ABLATE") and not args.allow_ablate:
+        raise SystemExit("bench.py: GAVIKO_HIP_ABLATE is set -- the timing ablations compute WRONG results, so this is not a benchmark; unset it "
+                         "(or pass --allow-ablate: the line is then marked INVALID)")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -141,8 +194,11 @@ def main():
         model.make_reducer()
     B = args.batch
     lo = rank * B                                    # shard of the global batch owned by this rank
-    x = torch.from_numpy(synth.volumes(lo, B)).to(dev)
+    eng = model._engine()
+    x = eng.input_buffer(B, dev, train=True)          # inputs resident in HBM, in the engine's own input slot: no per-step copy-in launch
+    x.copy_(torch.from_numpy(synth.volumes(lo, B)))
     y = torch.from_numpy(synth.labels(lo, B)).to(dev)
+    eng.static_io = True                              # the loss kernel reads the logits in place (no clone launch inside the step)
     # the loss seed is part of the step: one fused launch (loss + dlogits + the running loss / accuracy sums of train.py:327-328)
     from gaviko_amd.losses import CrossEntropyLoss, FocalLoss, StepMeter
     criterion = (FocalLoss(gamma=1.2) if args.loss == "focal" else CrossEntropyLoss()).attach_meter(StepMeter(dev))
@@ -187,6 +243,8 @@ def main():
                                   f"{'CrossEntropy' if args.loss == 'ce' else 'Focal(1.2)'} + bwd (frozen ViT; prompts+MWSA+GPA+head train), "
                                   f"attn_drop=proj_drop=0.2 live, grads all-reduced over {world} rank(s)",
                       "global_batch": world * B, "tokens": 1033, "parallelism": f"dp{world}"}}
+    if os.environ.get("GAVIKO_HIP_ABLATE"):
+        out["INVALID_timing_ablation"] = os.environ["GAVIKO_HIP_ABLATE"]
     gf = GF_PER_VOLUME.get(args.backbone)
     if gf:
         out["mfma_roofline_frac_whole_step"] = round(vps / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)
@@ -197,7 +255,6 @@ def main():
         # stage) is bracketed by timestamped HIP events on its launch stream, then replayed like the timed region -- same
         # three-stream schedule, same neighbours on the other queues.  An empty event pair per plan calibrates the bracket's
         # own cost, which is subtracted.
-        eng = model._engine()
         L.load().gvk_plan_set_timing(1)
         eng_mod.GEMM_MARKS = {}
         eng._graphs.clear()

@@ -181,6 +181,8 @@ class Engine:
         self._w16_version = None
         self._shadowed = frozenset(self._backbone_weight_names())
         self._fwd_gen = 0                       # counts training-mode forwards: the autograd node checks it owns the saved state
+        # static_io = True: forward() returns the workspace's logits buffer itself (valid until the next forward) instead of a copy
+        self.static_io = False
         self._have_dgrad = False
         self._graphs = {}
         self._calls = {}
@@ -510,7 +512,8 @@ class Engine:
             raise L.GavikoHipError(f"backbone dropout > 0 in training mode is built for the vit / melo / vpt classes, not kind={self.kind!r}")
         self.refresh_weights(need_dgrad=train)
         ws = self.workspace(B, img.device, train)
-        ws["img"].copy_(img.detach())                       # static input buffer (the only per-step host-visible copy-in)
+        if img.data_ptr() != ws["img"].data_ptr():           # a caller that fills input_buffer() itself skips the copy-in launch
+            ws["img"].copy_(img.detach())                   # static input buffer (the only per-step host-visible copy-in)
         # unfrozen backbone tensors (`fft` / `bitfit`, train.py:123-137): which ones train, and whether GEMM inputs must be kept
         bb = frozenset(n for n in self.trainable_names() if not n.startswith(self.names.head())) if (train and self.kind == "vit") else frozenset()
         sv["bb"] = bb
@@ -524,7 +527,12 @@ class Engine:
         self._saved_key = key
         if train:
             self._fwd_gen += 1
-        return ws["logits"].clone()
+        return ws["logits"] if self.static_io else ws["logits"].clone()
+
+    def input_buffer(self, B: int, device, train: bool = True) -> torch.Tensor:
+        """The static [B,1,D,H,W] input slot of the (B, train) workspace: a data pipeline that writes its batch here (and passes this very
+        tensor to the model) saves the per-step device copy."""
+        return self.workspace(B, device, train)["img"]
 
     def _forward_impl(self, ws, sv):
         B, C, T, N, train = sv["B"], self.C, self.T, self.N, sv["train"]
@@ -794,7 +802,8 @@ class Engine:
         unsupported = [n for n in gv if not self._grad_supported(n)]
         if unsupported:
             raise NotImplementedError(f"gradients for backbone tensors are not built yet (frozen-backbone PEFT only): {unsupported[:3]}...")
-        ws["dlogits"].copy_(dlogits.detach())
+        if dlogits.data_ptr() != ws["dlogits"].data_ptr():
+            ws["dlogits"].copy_(dlogits.detach())
         flat = self._flat_grad["buf"]
         if reducer is not None:
             reducer.begin()

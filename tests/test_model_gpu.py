@@ -1,6 +1,8 @@
 """-m gpu: whole-model parity of the HIP path against the golden fixtures generated from the reference, and against
 the oracle run on the same inputs.  bf16 MFMA operands / fp32 accumulate+residual: activations within 1e-2 of the
 reference (relative to the tensor's max), argmax bit-exact, gradients within a few percent (bf16 operand rounding)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -46,6 +48,39 @@ def rel(a, b):
     return np.abs(a - b).max() / max(1e-12, np.abs(b).max())
 
 
+def err2(a, b):
+    """(max absolute error, that error relative to the largest reference element, the largest reference element)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    d, sc = np.abs(a - b).max(), np.abs(b).max()
+    return d, d / max(1e-12, sc), sc
+
+
+PARITY_LOG = []
+# The reference's OWN error under the operand rounding of the bf16 path (tools/noise_floor.py: fp32 oracle vs the oracle with every bf16-MFMA
+# operand rounded to bf16, fp32 accumulation): what a bf16 tolerance has to absorb.  Gradient figures there are lower bounds (the backward's
+# own operand rounding is not emulated).
+import json as _json
+FLOOR = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_noise_floor.json")))["cases"]
+
+
+def note(case, what, a, b):
+    """Record (and print: run with -s, or read gpurun_out/parity_report.txt) both error measures of one comparison."""
+    d, r, sc = err2(a, b)
+    PARITY_LOG.append((case, what, d, r, sc))
+    print(f"PARITY {case:28s} {what:52s} max|d|={d:.3e}  rel={r:.3e}  (|ref|max={sc:.3e})")
+    return d, r
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _parity_report():
+    yield
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if PARITY_LOG and os.path.isdir(out):
+        with open(os.path.join(out, "parity_report.txt"), "w") as f:
+            for case, what, d, r, sc in PARITY_LOG:
+                f.write(f"{case}\t{what}\t{d:.4e}\t{r:.4e}\t{sc:.4e}\n")
+
+
 GAVIKO_CASES = [("gaviko_t16_b2", "vit-t16", 2, dict(GAVIKO)),
                 ("gaviko_t16_b2_k366_p8", "vit-t16", 2, dict(GAVIKO, local_k=(3, 6, 6), num_prompts=8)),
                 ("gaviko_t16_b1_share2", "vit-t16", 1, dict(GAVIKO, share_factor=2)),
@@ -73,10 +108,14 @@ def test_gaviko_forward_backward_vs_golden(dev, name, backbone, B, extra):
     for i in range(eng.depth):
         for key, buf, rows in ((f"tap/layer{i}.post_attn", ws["G1"][i], T), (f"tap/layer{i}.post_mlp", ws["G"][i + 1], T),
                                (f"tap/layer{i}.local", ws["Lc"][i + 1], N)):
-            e = rel(tap(buf, B, rows), g[key])
+            d_, e = note(name, key, tap(buf, B, rows), g[key])
             worst = max(worst, e)
-            assert e < 1e-2, f"{key}: rel err {e:.3e}"
-    assert rel(lg, g["logits"]) < 1e-2, (lg, g["logits"])
+            sc = np.abs(g[key]).max()
+            # bf16 tolerance of BASELINE (1e-2) relative to the tensor's scale, and in absolute terms: one bf16 rounding of the largest
+            # residual-stream element (|x| up to 17 at ViT-L) is already 2^-9 |x|, so the absolute bound scales with it
+            assert e < 1e-2 and d_ < 1e-2 + 5e-3 * sc, f"{key}: rel err {e:.3e}, max abs {d_:.3e} (|ref| max {sc:.2f})"
+    d_, e = note(name, "logits", lg, g["logits"])
+    assert e < 1e-2 and d_ < 1e-2 * eng.depth / 12, (lg, g["logits"])
     assert (lg.argmax(-1) == g["argmax"]).all()
     assert abs(loss.item() - float(g["loss_ce"])) < 1e-2
     # ---- gradients
@@ -91,13 +130,17 @@ def test_gaviko_forward_backward_vs_golden(dev, name, backbone, B, extra):
             want = float(g[k])
             errs.append((abs(named[n].grad.norm().item() - want) / max(want, 1e-12), n))
     e = np.array([x[0] for x in errs])
-    assert np.median(e) < 1e-2 and np.percentile(e, 90) < 3e-2 and e.max() < 0.15, sorted(errs, reverse=True)[:5]
+    print(f"PARITY {name:28s} gradnorm rel err: median {np.median(e):.3e} p90 {np.percentile(e, 90):.3e} max {e.max():.3e} ({sorted(errs, reverse=True)[0][1]})")
+    PARITY_LOG.append((name, "gradnorm median/p90/max", float(np.median(e)), float(np.percentile(e, 90)), float(e.max())))
+    # measured: median <= 3.2e-3, p90 <= 1.2e-2, max 7.5e-2; the reference's own floor (FLOOR, a lower bound): median 1.2-2.1e-3, p90
+    # 7.2-8.6e-3, max 3.5e-2 (ViT-B) / 1.1e-1 (ViT-T) -- the max is always one of the gl_balancer scalars (norms 1e-4, 100x below the rest)
+    assert np.median(e) < 1e-2 and np.percentile(e, 90) < 2e-2 and e.max() < 0.12, sorted(errs, reverse=True)[:5]
     for k in g.files:
         if k.startswith("grad/"):
             n = k[len("grad/"):]
-            e = rel(named[n].grad.cpu().numpy(), g[k])
+            d_, e = note(name, "grad/" + n, named[n].grad.cpu().numpy(), g[k])
             # bf16 noise grows with depth (24-layer ViT-L: last-layer GXA query grad sits at 5 %, softmax' cancellation)
-            assert e < 4e-2 * eng.depth / 12, f"grad {n}: rel err {e:.3e}"
+            assert e < 3e-2 * eng.depth / 12, f"grad {n}: rel err {e:.3e}"    # measured <= 2.1e-2 (12 layers), 4.0e-2 (24 layers)
     print(f"{name}: worst activation rel err {worst:.2e}, logits err {rel(lg, g['logits']):.2e}")
 
 
@@ -154,7 +197,7 @@ PEFT_CASES = [("deep_vpt_t16_b2", "deep_vpt", "vit-t16", 2, dict(num_prompts=8, 
               ("fft_b16_b2", "fft", "vit-b16", 2, dict())]
 
 
-def _check_against_golden(m, g, B, first=0, logit_tol=1e-2):
+def _check_against_golden(m, g, B, first=0, logit_tol=1e-2, case="?"):
     from gaviko_amd.utils import synth
     dev = next(m.parameters()).device
     x = torch.from_numpy(synth.volumes(first, B)).to(dev)
@@ -165,8 +208,9 @@ def _check_against_golden(m, g, B, first=0, logit_tol=1e-2):
     torch.cuda.synchronize()
     lg = logits.detach().cpu().numpy()
     want = g["logits"][first:first + B]
-    # 1e-2 of the largest logit; the ViT-B PEFT cases sit right at that line (0.9-1.1e-2, logits |max| < 1): allow 1.5e-2 there
-    assert rel(lg, want) < logit_tol, (lg, want)
+    # 1e-2 of the largest logit (BASELINE's bf16 tolerance)
+    d_, e = note(case, f"logits[{first}:{first + B}]", lg, want)
+    assert e < logit_tol, (lg, want)
     assert (lg.argmax(-1) == want.argmax(-1)).all()
     return lg, loss
 
@@ -175,7 +219,7 @@ def _check_against_golden(m, g, B, first=0, logit_tol=1e-2):
 def test_peft_forward_backward_vs_golden(dev, name, method, backbone, B, extra):
     g = golden(name)
     m, cfg = build(method, backbone, extra, dev)
-    lg, loss = _check_against_golden(m, g, B, logit_tol=1.5e-2 if backbone == "vit-b16" else 1e-2)
+    lg, loss = _check_against_golden(m, g, B, logit_tol=1e-2, case=name)      # measured <= 7.6e-3 (cfg4), floor 6.1-7.1e-3
     assert abs(loss.item() - float(g["loss_ce"])) < 1e-2
     named = dict(m.named_parameters())
     errs = []
@@ -188,19 +232,24 @@ def test_peft_forward_backward_vs_golden(dev, name, method, backbone, B, extra):
             denom = gate_scale if k.endswith("prompt_gate") else max(want, 1e-12)
             errs.append((abs(named[k[9:]].grad.norm().item() - want) / denom, k[9:]))
     e = np.array([x[0] for x in errs])     # same criterion as the gaviko test: the smallest-norm tensors are noise-dominated
-    # (AdaptFormer's whole trainable path runs on bf16 operands incl. the ReLU mask: p90 3.1 % at ViT-B, B=8 -- BASELINE cfg4
-    #  asks for fp32 there; the f32-MFMA family is not built yet)
-    p90 = 5e-2 if method == "adaptformer" else 3e-2
-    assert np.median(e) < 1e-2 and np.percentile(e, 90) < p90 and e.max() < 0.15, sorted(errs, reverse=True)[:5]
+    # AdaptFormer's whole trainable path runs on bf16 operands incl. the ReLU mask (units within bf16 noise of zero flip): p90 2.9e-2, max
+    # 6.6e-2 at ViT-B, B=8, where the reference's own floor is p90 1.5e-2, max 6.4e-2 (FLOOR['cfg4_adaptformer_b16_b8']); BASELINE cfg4 runs
+    # it in fp32 -- test_fp32_path_vs_golden pins that path at 1e-5 / 1e-4.  LoRA (melo): one tensor at 1.0e-1 at ViT-T.
+    p90 = 4e-2 if method == "adaptformer" else 2e-2
+    emax = {"adaptformer": 0.1, "melo": 0.15}.get(method, 5e-2)
+    print(f"PARITY {name:28s} gradnorm rel err: median {np.median(e):.3e} p90 {np.percentile(e, 90):.3e} max {e.max():.3e} ({sorted(errs, reverse=True)[0][1]})")
+    PARITY_LOG.append((name, "gradnorm median/p90/max", float(np.median(e)), float(np.percentile(e, 90)), float(e.max())))
+    assert np.median(e) < 1e-2 and np.percentile(e, 90) < p90 and e.max() < emax, sorted(errs, reverse=True)[:5]
     for k in g.files:
         if k.startswith("grad/") and not k.endswith("prompt_gate"):      # the scalar gates are judged above, against the largest one
-            e = rel(named[k[5:]].grad.cpu().numpy(), g[k])
+            d_, e = note(name, k, named[k[5:]].grad.cpu().numpy(), g[k])
             # elementwise, relative to the tensor's max.  AdaptFormer's ReLU mask is taken from the bf16 hidden state, so units
             # whose pre-activation sits within bf16 noise of zero flip: isolated elements move, norms stay within 5 %.
             # At ViT-B, B=8 the layer-0 adapter gradients are sums of 8008 sign-random token terms: their norms agree to ~1 %
             # but single elements carry bf16 noise of up to 15 % of the largest element (why BASELINE cfg4 asks for fp32).
             # (same for LoRA's A_q, whose gradient passes through the softmax Jacobian: 8.5 % on one element at cfg4)
-            tol = 0.2 if backbone == "vit-b16" else 8e-2
+            # measured: <= 2.4e-2 everywhere except cfg4 (ViT-B, B=8): adaptformer 1.3e-1 (floor 3.3e-1), melo 8.2e-2
+            tol = {"cfg4_adaptformer_b16_b8": 0.2, "cfg4_melo_b16_b8": 0.1}.get(name, 5e-2)
             assert e < tol, f"grad {k[5:]}: rel err {e:.3e}"
 
 
@@ -220,8 +269,12 @@ def test_cfg3_deep_vpt_data_parallel_equivalence(dev):
         logits = m(x)
         torch.nn.functional.cross_entropy(logits, y).backward()
         lg = logits.detach().cpu().numpy()
-        # logits here are small (|max| ~ 1) with the top-2 classes 0.03 apart; bf16 noise sits at 0.7-1.1e-2 of the max logit
-        assert rel(lg, g["logits"][4 * s: 4 * s + 4]) < 1.5e-2
+        # logits here are small (|max| ~ 1.04-1.30).  Measured per shard: 5.7e-3 .. 1.05e-2 of the max logit; the REFERENCE's own error under the
+        # same operand rounding is 6.4e-3 / 6.5e-3 / 9.5e-3 on shards 0 / 2 / 4 (FLOOR): shard 4 sits at 1e-2 by construction, so the bound
+        # is 1e-2 or 1.25x that shard's floor, whichever is larger
+        d_, e = note("cfg3_deep_vpt_b16_8x4", f"logits shard {s}", lg, g["logits"][4 * s: 4 * s + 4])
+        fl = FLOOR.get(f"cfg3_deep_vpt_b16_shard{s}", {}).get("logits_rel", 0.0)
+        assert e < max(1e-2, 1.25 * fl), (s, e, fl)
         assert (lg.argmax(-1) == g["argmax"][4 * s: 4 * s + 4]).all()
         flat = m._engine().flat_grad.clone()
         acc = flat if acc is None else acc + flat
@@ -233,7 +286,8 @@ def test_cfg3_deep_vpt_data_parallel_equivalence(dev):
             n = k[5:]
             off = (views[n].data_ptr() - base) // 4
             got = acc[off: off + views[n].numel()].view(views[n].shape).cpu().numpy()
-            assert rel(got, g[k]) < 5e-2, n
+            d_, e = note("cfg3_deep_vpt_b16_8x4", "mean " + k, got, g[k])
+            assert e < 5e-2, n
 
 
 def test_bucketed_backward_segments_match_single_graph(dev):

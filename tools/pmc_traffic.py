@@ -49,7 +49,9 @@ def clusters(reads, writes):
 def main():
     fetch = load(sys.argv[1], "FETCH_SIZE")
     write = load(sys.argv[2], "WRITE_SIZE")
-    out = {"note": "bytes per launch; read = 2*FETCH_SIZE*1024 (gfx950 half-count correction), write = WRITE_SIZE*1024; 'clusters' splits "
+    sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    import bench
+    out = {"gemm_source_sha": bench.gemm_source_hash(), "note": "bytes per launch; read = 2*FETCH_SIZE*1024 (gfx950 half-count correction), write = WRITE_SIZE*1024; 'clusters' splits "
                    "an instantiation that serves several shapes (ascending traffic)", "kernels": {}}
     for k in sorted(fetch, key=lambda k: -sum(fetch[k])):
         short = k.replace("gvk::", "").replace("void ", "")
