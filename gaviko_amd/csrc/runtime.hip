@@ -128,7 +128,13 @@ extern "C" int gvk_plan_event_elapsed(int plan, int e0, int e1, float* ms) {
   return 0;
 }
 
-extern "C" int gvk_plan_event_record(void* stream) {
+static int plan_event_record_impl(void* stream, bool force_sys_fence);
+extern "C" int gvk_plan_event_record(void* stream) { return plan_event_record_impl(stream, false); }
+// The same with the system-scope fence kept: for events that another DEVICE's reads are ordered behind (the gradient buckets an
+// all-reduce sends to peer GPUs over xGMI).
+extern "C" int gvk_plan_event_record_fenced(void* stream) { return plan_event_record_impl(stream, true); }
+
+static int plan_event_record_impl(void* stream, bool force_sys_fence) {
   using namespace gvk;
   GVK_REQUIRE(g_rec != nullptr, "gvk_plan_event_record: only valid while a plan is being recorded");
   static const bool env_timing = getenv("GAVIKO_HIP_PLAN_TIMING") != nullptr;  // diagnostics: tools/plan_marks.py
@@ -137,7 +143,7 @@ extern "C" int gvk_plan_event_record(void* stream) {
   // system-scope fence (an L2 writeback + invalidate per record, and refetches for whatever runs next) is switched off.
   // GAVIKO_HIP_EVENT_FENCE=1 restores the default events.
   static const bool sys_fence = getenv("GAVIKO_HIP_EVENT_FENCE") != nullptr;
-  const unsigned flags = ((env_timing || g_plan_timing) ? hipEventDefault : hipEventDisableTiming) | (sys_fence ? 0u : hipEventDisableSystemFence);
+  const unsigned flags = ((env_timing || g_plan_timing) ? hipEventDefault : hipEventDisableTiming) | ((sys_fence || force_sys_fence) ? 0u : hipEventDisableSystemFence);
   hipError_t e = hipEventCreateWithFlags(&ev, flags);
   if (e != hipSuccess) return set_error(-1, "hipEventCreate: %s", hipGetErrorString(e));
   g_rec->events.push_back(ev);
@@ -146,6 +152,23 @@ extern "C" int gvk_plan_event_record(void* stream) {
   e = hipEventRecord(ev, s);
   if (e != hipSuccess) return set_error(-1, "hipEventRecord: %s", hipGetErrorString(e));
   return (int)g_rec->events.size() - 1;
+}
+
+// Make `stream` (any stream, e.g. the collective's) wait for event `event` of a recorded plan's most recent replay -- issued now, not
+// recorded.  This is how a gradient bucket's all-reduce is ordered behind the kernels that finalise it without cutting the plan.
+extern "C" int gvk_plan_event_stream_wait(int plan, int event, void* stream) {
+  using namespace gvk;
+  hipEvent_t ev;
+  {
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    GVK_REQUIRE(plan >= 0 && plan < (int)g_plans.size() && g_plans[plan], "gvk_plan_event_stream_wait: no such plan %d", plan);
+    Plan* p = g_plans[plan].get();
+    GVK_REQUIRE(event >= 0 && event < (int)p->events.size(), "gvk_plan_event_stream_wait: no such event %d", event);
+    ev = p->events[event];
+  }
+  hipError_t e = hipStreamWaitEvent((hipStream_t)stream, ev, 0);
+  if (e != hipSuccess) return set_error(-1, "hipStreamWaitEvent: %s", hipGetErrorString(e));
+  return 0;
 }
 
 extern "C" int gvk_plan_event_wait(void* stream, int event) {

@@ -3,11 +3,17 @@ per step -- a mean all-reduce of the flat fp32 buffer of trainable gradients (3.
 RCCL/xGMI.  The reference has no data parallelism of its own; equivalence is pinned by the cfg3
 fixture (8 shards x 4 == 1 x 32, mean-reduced).
 
-The buffer is cut into a few layer-aligned buckets.  A bucket is reduced on a side stream as soon as the backward
-sweep has written its last gradient (the sweep runs from the last layer to the first, so buckets complete in reverse
-order), overlapping the collectives with the remaining backward kernels; the job is latency-bound, not
-bandwidth-bound, hence few buckets.  The bucket planner and the reduction are device-agnostic so the
-N>1 path is covered by world_size-2 `gloo` tests on CPU.
+The buffer is cut into a few layer-aligned buckets.  A bucket is reduced on the collective's own stream as soon as the
+backward sweep has written its last gradient (the sweep runs from the last layer to the first, so buckets complete in
+reverse order), overlapping the collectives with the remaining backward kernels; the job is latency-bound, not
+bandwidth-bound, hence few buckets.
+
+Ordering (default, `mode="events"`): the backward stays ONE recorded launch plan.  The engine records an event on the
+stream that finalises a bucket -- the MWSA chain for `local_attns.*`, the GPA chain for `prompt_projs.*`, the main
+stream for everything else -- and the collective stream waits for exactly that event (gvk_plan_event_stream_wait), so
+no bucket boundary joins the three streams.  `mode="segments"` is the older form (the backward cut into one plan per
+bucket, every cut a three-stream join: +0.7 ms per step at ViT-B), kept for A/B.  The bucket planner and the reduction
+are device-agnostic so the N>1 path is covered by world_size-2 `gloo` tests on CPU.
 """
 from __future__ import annotations
 
@@ -18,7 +24,16 @@ import torch
 import torch.distributed as dist
 
 
-def plan_buckets(names: Sequence[str], numels: Sequence[int], depth: int, share_factor: int = 1, layers_per_bucket: int = 4):
+def stream_kind(name: str) -> str:
+    """Which of the engine's three streams writes the gradient of `name` last (engine.py: MWSA chain / GPA chain / main)."""
+    if ".local_attns." in "." + name:
+        return "loc"
+    if ".prompt_projs." in "." + name:
+        return "gpa"
+    return "main"
+
+
+def plan_buckets(names: Sequence[str], numels: Sequence[int], depth: int, share_factor: int = 1, layers_per_bucket: int = 4, kinds: bool = False):
     """-> list of (ready_layer, start, end) element ranges of the flat buffer, sorted by the order they become ready.
 
     A tensor of module index s (…local_attns.s… / …prompt_projs.s… / …layers.i…) is final once the backward sweep has
@@ -31,6 +46,7 @@ def plan_buckets(names: Sequence[str], numels: Sequence[int], depth: int, share_
         o += n
     pat = re.compile(r"\.(?:local_attns|prompt_projs|layers)\.(\d+)\.")
     ranges: List[Tuple[int, int, int]] = []
+    rkinds: List[str] = []
     for name, off, n in zip(names, offs, numels):
         m = pat.search("." + name)
         if m is None:
@@ -38,23 +54,29 @@ def plan_buckets(names: Sequence[str], numels: Sequence[int], depth: int, share_
         else:
             first_layer = int(m.group(1)) * (share_factor if ("local_attns" in name or "prompt_projs" in name) else 1)
             ready = (first_layer // layers_per_bucket) * layers_per_bucket      # bucket completes at its lowest layer
-        if ranges and ranges[-1][0] == ready and ranges[-1][2] == off:
+        kind = stream_kind(name) if ready >= 0 else "main"
+        if ranges and ranges[-1][0] == ready and ranges[-1][2] == off and rkinds[-1] == kind:
             ranges[-1] = (ready, ranges[-1][1], off + n)
         else:
             ranges.append((ready, off, off + n))
-    ranges.sort(key=lambda r: (-r[0] if r[0] >= 0 else 1, r[1]))                # high layers first, unindexed last
+            rkinds.append(kind)
+    order = sorted(range(len(ranges)), key=lambda i: (-ranges[i][0] if ranges[i][0] >= 0 else 1, ranges[i][1]))   # high layers first, unindexed last
+    ranges, rkinds = [ranges[i] for i in order], [rkinds[i] for i in order]
     assert sum(e - s for _, s, e in ranges) == o
-    return ranges
+    return (ranges, rkinds) if kinds else ranges
 
 
 class GradReducer:
     """Bucketed mean all-reduce of a flat gradient buffer."""
 
     def __init__(self, names: Sequence[str], numels: Sequence[int], depth: int, share_factor: int = 1, layers_per_bucket: int = 4,
-                 group=None):
+                 group=None, mode: str = "events"):
+        if mode not in ("events", "segments"):
+            raise ValueError("GradReducer: mode must be 'events' or 'segments'")
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.group = group
-        self.ranges = plan_buckets(names, numels, depth, share_factor, layers_per_bucket)
+        self.mode = mode
+        self.ranges, self.kinds = plan_buckets(names, numels, depth, share_factor, layers_per_bucket, kinds=True)
         self._pending: List = []
         self._stream: Optional[torch.cuda.Stream] = None
         self._done_upto = None
@@ -75,6 +97,28 @@ class GradReducer:
         else:
             dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group)
             piece.mul_(1.0 / self.world)
+
+    def reduce_marked(self, flat: torch.Tensor, marks: dict, waiter) -> None:
+        """mode 'events': every bucket is all-reduced on the collective stream behind the event the engine recorded for it.
+        marks: {(kind, ready_layer): event handle}; waiter(stream, handle) makes `stream` wait for that event.  Called once per step,
+        after the whole backward has been ENQUEUED -- the GPU still runs it, and each collective starts when its bucket is final."""
+        if self.world > 1 and flat.is_cuda and self._stream is None:
+            self._stream = torch.cuda.Stream(device=flat.device)
+        for (ready, s, e), kind in zip(self.ranges, self.kinds):
+            if self.world == 1:
+                continue
+            piece = flat[s:e]
+            if not flat.is_cuda:
+                dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group)
+                piece.mul_(1.0 / self.world)
+                continue
+            key = (kind, ready) if (kind, ready) in marks else ("main", -1)        # fall back to the end-of-backward event
+            with torch.cuda.stream(self._stream):
+                waiter(self._stream, marks[key])
+                dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group)
+                piece.mul_(1.0 / self.world)
+        if flat.is_cuda and self._stream is not None:
+            torch.cuda.current_stream(flat.device).wait_stream(self._stream)
 
     def begin(self):
         self._next = 0

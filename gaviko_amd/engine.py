@@ -197,6 +197,9 @@ class Engine:
         self._fuse_local = kind == "gaviko" and ops.side_tile_supported(self.Lat, dim)
         self._marks = []
         self.plan_marks = {}                # plan id -> [(name, event id)]
+        self._bucket_marks = {}             # (stream kind, layer) -> event of the pass being issued / recorded: gradients of that layer final
+        self.plan_bucket_marks = {}         # plan id -> that dict, for replays
+        self._want_bucket_marks = False
         self._gemm_marks = []
         self.plan_gemm_marks = {}           # plan id -> [(class, flops, shape, bytes, e0, e1)]
         self._ws = None
@@ -426,6 +429,22 @@ class Engine:
         ev.record(stream)
         return ev
 
+    def _bucket_mark(self, kind, layer):
+        """Data parallelism (distributed.GradReducer, mode 'events'): an event on the CURRENT stream after the last kernel that writes
+        a gradient of (`kind`, `layer`); the collective stream waits for it.  Recorded with the system-scope fence: peers read the data."""
+        if not self._want_bucket_marks:
+            return
+        cur = torch.cuda.current_stream()
+        if self._recording:
+            rc = L.load().gvk_plan_event_record_fenced(cur.cuda_stream)
+            if rc < 0:
+                L.check(rc, "gvk_plan_event_record_fenced")
+            self._bucket_marks[(kind, layer)] = rc
+        else:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._bucket_marks[(kind, layer)] = ev
+
     def _mark(self, name):
         """Diagnostics (GAVIKO_HIP_PLAN_TIMING=1): a timestamped plan event on the current stream, read by tools/plan_marks.py."""
         if self._recording and PLAN_TIMING:
@@ -452,11 +471,14 @@ class Engine:
         Everything `fn` launches reads/writes workspace buffers only, so a replay is exactly one more step."""
         k = (tag,) + key + (torch.cuda.current_stream().cuda_stream,)
         g = self._graphs.get(k)
+        self._last_run = ("eager", None)
         if g is not None:
             if isinstance(g, int):
                 L.check(L.load().gvk_plan_replay(g), "gvk_plan_replay")
+                self._last_run = ("replayed", g)
             else:
                 g.replay()
+                self._last_run = ("graph", None)
             return
         n = self._calls.get(k, 0)
         self._calls[k] = n + 1
@@ -469,6 +491,7 @@ class Engine:
             L.check(lib.gvk_plan_begin(), "gvk_plan_begin")
             self._recording = True
             self._marks, self._gemm_marks = [], []
+            self._bucket_marks = {}
             try:
                 if GEMM_MARKS is not None:               # calibration: an empty event pair on the launch stream
                     cur = torch.cuda.current_stream()
@@ -484,6 +507,8 @@ class Engine:
                 L.check(pid, "gvk_plan_end")
             self._graphs[k] = pid
             self.plan_marks[pid] = (tag, self._marks)
+            self.plan_bucket_marks[pid] = dict(self._bucket_marks)
+            self._last_run = ("recorded", pid)
             if self._gemm_marks:
                 self.plan_gemm_marks[pid] = self._gemm_marks
             return
@@ -812,6 +837,24 @@ class Engine:
             if reducer is not None:
                 reducer.finish(flat)
             return gv
+        if reducer is not None and getattr(reducer, "mode", "segments") == "events" and STEP_MODE != "graph":
+            # ONE plan; every bucket is reduced behind the event recorded on the stream that finalises it (no cut, no join)
+            self._want_bucket_marks = True
+            self._bucket_marks = {}
+            try:
+                self._run("bwd0", self._saved_key + ("events",),
+                          lambda: self._backward_segment(ws, sv, gv, self.depth - 1, 0, True, True))
+            finally:
+                self._want_bucket_marks = False
+            how, pid = self._last_run
+            if how in ("replayed", "recorded"):
+                marks, lib = self.plan_bucket_marks[pid], L.load()
+                waiter = lambda stream, ev: L.check(lib.gvk_plan_event_stream_wait(pid, ev, stream.cuda_stream), "gvk_plan_event_stream_wait")
+            else:
+                marks = self._bucket_marks
+                waiter = lambda stream, ev: stream.wait_event(ev)
+            reducer.reduce_marked(flat, marks, waiter)
+            return gv
         cuts = sorted({r for r, _, _ in reducer.ranges if r >= 0}, reverse=True) if reducer is not None else []
         cuts = [c for c in cuts if 0 < c < self.depth]          # segment k ends (inclusive) at layer cuts[k]
         hi = self.depth - 1
@@ -892,6 +935,7 @@ class Engine:
                     self._gpa_bwd_core(ws, sv, gv, i, dGout, M, B, par, project=not (self._fuse_proj and i < self.depth - 1))
                     dz_ready = self._ev_record(gpa)
                     self._gpa_bwd_params(ws, sv, gv, i, dGout, M, B, par)
+                    self._bucket_mark("gpa", i)                              # prompt_projs.{i // share} gradients final once the lowest layer using it is done
             # main stream, MLP block: dG1 = dGout + LN'(fc1^T(GELU'(pre) * fc2^T(dGout)))
             self._mark(f"b{i}:start")
             bb = sv.get("bb") or ()
@@ -935,6 +979,7 @@ class Engine:
                     self._gpa_bwd_scatter_l(ws, i, ws["dL"][par], B, par)    # dL += dzl.Wd (dL[par] was written on this stream)
                     scl_done = self._ev_record(loc)
                     self._mwsa_bwd(ws, sv, gv, i, ws["dL"][par], ws["dL"][par ^ 1], B)
+                    self._bucket_mark("loc", i)
             # main stream, attention block: dG0 = dG1 + LN'(qkv^T(attn'(out^T(dG1))))
             if ssf:                                                          # to_out + ssf_2: dy = dG1, y = G1[i] - G[i]
                 self._ssf_linear_grad(ws, gv, a, 2, dGin, ws["G1"][i], M, C, y1=ws["G"][i])
@@ -984,6 +1029,8 @@ class Engine:
             if self.kind == "evp":
                 self._evp_bwd_layer(ws, gv, i, dGout, B)
             self._mark(f"b{i}:end")
+            if not gaviko:
+                self._bucket_mark("main", i)                                 # transformer.layers.{i}.* gradients (adapters, LoRA, ...) are final
             if self.kind == "vpt" and (i == 0 or self.deep):
                 # prompt rows 1..P of this layer's input are this layer's projected prompts (vpt.py:127-131,147-153)
                 if sv.get("pdrop", 0.0) > 0:                                 # through prompt_dropout: same mask, in place (these rows end here)
@@ -1016,6 +1063,8 @@ class Engine:
         if last and (gaviko or self.kind == "dvpt"):
             ops.rows_batch_sum(dGout, gv["prompt_embeddings"].view(self.P, C), gv["prompt_positional_embedding"].view(self.P, C), B, T, 0,
                                self.P, C)
+        if last:
+            self._bucket_mark("main", -1)                                    # everything else (prompts, head, unindexed tensors): end of the sweep
 
     def _grad_supported(self, name: str) -> bool:
         if name.startswith(self.names.head()) or self.kind == "vit":       # plain ViT: every tensor (`linear` / `bitfit` / `fft`)

@@ -11,6 +11,11 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The step runs on three streams (+ the collective's and RCCL's own
+# in data-parallel runs); two of them landing on one queue serialises them: 5.9 -> 6.9-7.7 ms per step when a second model instance's
+# side streams wrapped around onto the main stream's queue (tools/bench_reducer.py).  Must be set before the first HIP call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ABI_VERSION = 5                                   # gvk_abi_version() of the library these declarations describe
 LIB_PATH = os.environ.get("GAVIKO_HIP_LIB") or os.path.join(_HERE, "libgaviko_hip.so")     # override: A/B runs of two builds
 
@@ -145,6 +150,7 @@ NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, [
              "gvk_plan_begin": (C.c_int, []), "gvk_plan_end": (C.c_int, []), "gvk_plan_abort": (C.c_int, []),
              "gvk_plan_size": (C.c_int, [C.c_int]), "gvk_plan_replay": (C.c_int, [C.c_int]), "gvk_plan_free": (C.c_int, [C.c_int]),
              "gvk_plan_event_record": (C.c_int, [_P]), "gvk_plan_event_wait": (C.c_int, [_P, C.c_int]),
+             "gvk_plan_event_record_fenced": (C.c_int, [_P]), "gvk_plan_event_stream_wait": (C.c_int, [C.c_int, C.c_int, _P]),
              "gvk_plan_set_timing": (C.c_int, [C.c_int]),
              "gvk_plan_event_elapsed": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)])}
 STRUCTS = {"gvk_gemm_desc": GemmDesc, "gvk_skinny_down_desc": SkinnyDownDesc, "gvk_skinny_up_desc": SkinnyUpDesc,

@@ -172,18 +172,18 @@ class HotPathModule(nn.Module):
         """Data parallelism: `reducer` (gaviko_amd.distributed.GradReducer) all-reduces the flat gradient buffer during backward."""
         self.__dict__["_reducer"] = reducer
 
-    def make_reducer(self, layers_per_bucket: int = None, group=None):
-        """Attach the data-parallel gradient reducer.  Default: the whole backward is one segment and the flat buffer is reduced
-        right after it (layer buckets = depth).  Cutting the backward at bucket boundaries (e.g. layers_per_bucket=4) overlaps the
-        collectives with the remaining backward, but every cut joins the three streams: measured 0.7 ms per step at ViT-B gaviko
-        (tools/bench_reducer.py) against a 3.6 MB exchange that takes tens of microseconds over xGMI."""
+    def make_reducer(self, layers_per_bucket: int = None, group=None, mode: str = "events"):
+        """Attach the data-parallel gradient reducer.  mode 'events' (default): the backward stays one launch plan; every bucket of
+        `layers_per_bucket` layers (default 4) is all-reduced behind the event recorded on the stream that finalises it (MWSA chain,
+        GPA chain or main stream) -- overlapped with the rest of the backward, no stream joins.  mode 'segments': the backward is cut
+        into one plan per bucket (every cut joins the three streams: +0.7 ms per step at ViT-B gaviko, tools/bench_reducer.py)."""
         from ..distributed import GradReducer
         named = dict(self.named_parameters())
         names = [n for n, p in named.items() if p.requires_grad]
         depth = mapping_vit(self._cfg["backbone"])[0]
         if layers_per_bucket is None:
-            layers_per_bucket = depth
-        r = GradReducer(names, [named[n].numel() for n in names], depth, self._cfg.get("share_factor", 1), layers_per_bucket, group)
+            layers_per_bucket = 4 if mode == "events" else depth
+        r = GradReducer(names, [named[n].numel() for n in names], depth, self._cfg.get("share_factor", 1), layers_per_bucket, group, mode)
         self.attach_reducer(r)
         return r
 

@@ -40,6 +40,10 @@ int gvk_plan_replay(int plan);
 int gvk_plan_free(int plan);
 int gvk_plan_event_record(void* stream);           /* -> event id within the plan being recorded */
 int gvk_plan_event_wait(void* stream, int event);
+/* gvk_plan_event_record with the system-scope fence kept (events that peer devices' reads are ordered behind: all-reduce buckets) */
+int gvk_plan_event_record_fenced(void* stream);
+/* issued immediately (not recorded): `stream` waits for event `event` of plan `plan` as recorded by its most recent replay */
+int gvk_plan_event_stream_wait(int plan, int event, void* stream);
 /* measurement: milliseconds between two events of a replayed plan.  Events carry timestamps only in plans recorded after
  * gvk_plan_set_timing(1) (or with GAVIKO_HIP_PLAN_TIMING set in the environment); bench.py brackets the GEMM launches
  * of an instrumented copy of the step this way, so the kernels are timed inside the real three-stream schedule. */

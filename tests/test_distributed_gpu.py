@@ -1,0 +1,82 @@
+"""GPU: the N > 1 path as far as one GPU allows.  Two FRESH processes (gloo, both on cuda:0) each run one data-parallel step of a small
+GAViKO model on their shard with the event-ordered bucket reducer (distributed.GradReducer mode 'events': one backward plan, every bucket
+all-reduced behind the event of the stream that finalises it).  The reduced flat gradient must equal the mean of the two shards'
+single-process gradients BIT FOR BIT -- eagerly (torch events) and from the replayed launch plan (plan events)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+CHILD = textwrap.dedent('''
+    import os, sys
+    import torch, torch.distributed as dist
+    sys.path.insert(0, os.environ["GVK_ROOT"])
+    from gaviko_amd.registry import build_model
+    from gaviko_amd.utils import synth
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = dict(image_size=160, image_patch_size=16, frames=120, frame_patch_size=12, num_classes=5, channels=1, pool="cls", dim_head=64,
+               dropout=0.0, emb_dropout=0.0, backbone="vit-t16", method="gaviko", num_prompts=8, prompt_latent_dim=20, local_dim=20,
+               local_k=(3, 6, 6), DHW=(10, 10, 10), attn_drop=0.0, proj_drop=0.0, freeze_vit=True, share_factor=int(os.environ["GVK_SHARE"]), fp16=False)
+    m = build_model(cfg)
+    filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    m.to(dev).train()
+    B = 2
+
+    def grads(first):
+        for p in m.parameters():
+            p.grad = None
+        x = torch.from_numpy(synth.volumes(first, B)).to(dev); y = torch.from_numpy(synth.labels(first, B)).to(dev)
+        torch.nn.functional.cross_entropy(m(x), y).backward()
+        torch.cuda.synchronize()
+        return m._engine().flat_grad.clone()
+
+    # single-process gradients of BOTH shards (no reducer attached), several times: eager, eager, recorded, replayed
+    single = [[grads(B * r) for _ in range(4)][-1] for r in range(world)]
+    want = (single[0] + single[1]) * 0.5
+    red = m.make_reducer(layers_per_bucket=4)                       # mode 'events'
+    assert red.mode == "events" and red.world == 2
+    kinds = {k for k in red.kinds}
+    assert kinds == {"loc", "gpa", "main"}, kinds
+    for it in range(5):                                              # eager x2, record, replay x2
+        got = grads(B * rank)
+        how = m._engine()._last_run[0]
+        assert torch.equal(got, want), (it, how, (got - want).abs().max().item())
+    assert how == "replayed", how
+    dist.barrier()
+    print("DP-OK", rank, how, flush=True)
+    dist.destroy_process_group()
+''')
+
+
+@pytest.mark.parametrize("share", [1, 2])
+def test_two_process_event_ordered_reduction_bitwise(dev, tmp_path, share):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GVK_ROOT=ROOT, GVK_SHARE=str(share),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", CHILD], env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"DP-OK {rank} replayed" in out, out[-3000:]

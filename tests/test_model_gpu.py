@@ -306,7 +306,7 @@ def test_bucketed_backward_segments_match_single_graph(dev):
         return m._engine().flat_grad.clone()
 
     ref = [step() for _ in range(4)][-1]                # steps 3.. run from the captured single-segment graph
-    red = m.make_reducer(layers_per_bucket=4)
+    red = m.make_reducer(layers_per_bucket=4, mode="segments")
     assert sorted({r for r, _, _ in red.ranges}) == [-1, 0, 4, 8]
     outs = [step() for _ in range(4)]                   # eager, eager, capture, replay -- now 3 segments
     for o in outs:
