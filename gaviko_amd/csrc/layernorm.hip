@@ -181,7 +181,8 @@ static int check_proj(const gvk_rowproj_desc* pj, int C, const char* who) {
 }
 static int launch_proj(DownArgs& a, const gvk_rowproj_desc* pj, hipStream_t s, const char* who) {
   a.w = pj->w; a.bias = pj->bias; a.y = pj->y; a.z = pj->z; a.act = pj->act; a.w_layout = pj->w_layout;
-  const int rc = launch_row_down(a, pj->L, s);
+  int rc = launch_side_down(a, pj->L, s);                 // 16-row tiles on the fp32 matrix cores (sidepass.hip) where they apply
+  if (rc == 1) rc = launch_row_down(a, pj->L, s);
   if (rc == 1) return set_error(-2, "%s: the fused projection covers L in {4, 8, 16, 20} and C >= 128 (got L=%d, C=%d): use gvk_skinny_down", who, pj->L, a.C);
   return rc;
 }
@@ -210,6 +211,20 @@ extern "C" int gvk_layernorm_bwd_proj(const float* dy, const float* x, const flo
   a.mode = 2; a.x = x; a.dy = dy; a.mean_in = mean; a.rstd_in = rstd; a.ln_g = gamma; a.dres = dres; a.dx = dx; a.dx16 = (bf16*)dx_bf16;
   a.M = M; a.C = C; a.eps = 1e-5f; a.inv_keep = 1.f;
   return launch_proj(a, proj, (hipStream_t)stream, "gvk_layernorm_bwd_proj");
+}
+
+// LayerNorm backward of the MLP block fused with GPA's rank-L scatter (gaviko.py:155: dG1 += dzx . W_d): one pass over the row
+extern "C" int gvk_layernorm_bwd_up(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
+                                    float* dx, void* dx_bf16, const float* lat, const float* w, int w_layout, int M, int C, int L, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(dy && x && mean && rstd && gamma && dx && lat && w, "gvk_layernorm_bwd_up: null pointer");
+  GVK_REQUIRE(M > 0 && C > 0 && (w_layout == 0 || w_layout == 1), "gvk_layernorm_bwd_up: bad shape / layout");
+  UpArgs a{};
+  a.lat = lat; a.w = w; a.res = dres; a.out = dx; a.out16 = (bf16*)dx_bf16; a.ln_x = x; a.ln_mean = mean; a.ln_rstd = rstd; a.ln_g = gamma;
+  a.M = M; a.C = C; a.w_layout = w_layout; a.accumulate = 0; a.inv_keep = 1.f;
+  const int rc = launch_side_up(a, L, nullptr, nullptr, nullptr, nullptr, 0, 0, (hipStream_t)stream, dy);
+  if (rc == 1) return set_error(-2, "gvk_layernorm_bwd_up: covers L = 20 and C in {192, 768, 1024} (got L=%d, C=%d): use gvk_layernorm_bwd + gvk_skinny_up", L, C);
+  return rc;
 }
 
 extern "C" int gvk_layernorm_bwd_affine(const float* dy, const float* x, const float* mean, const float* rstd, float* dgamma,

@@ -50,10 +50,14 @@ __device__ __forceinline__ f32x4 load_w_down(const float* __restrict__ w, int C,
 }
 }  // namespace
 
-// NGW = 32-column groups per wave (C = 256 NGW, or fewer: waves past the end work on zeros), WL = weight layout
-template <int NGW, int WL>
+// NGW = 32-column groups per wave (C = 256 NGW, or fewer: waves past the end work on zeros), WL = weight layout.
+// MODE 0: y = act(f(x) . W^T + b), f = identity | LayerNorm(ln_g, ln_b) | dropout mask                                  (gvk_skinny_down)
+// MODE 1: y16 = bf16 LayerNorm(x) with mean / rstd saved, and the projection of the RAW row                            (gvk_layernorm_fwd_proj)
+// MODE 2: dx = dres + LayerNorm'(dy; x, mean_in, rstd_in, ln_g) (+ bf16 copy dx16), and the projection of dx             (gvk_layernorm_bwd_proj)
+template <int NGW, int WL, int MODE>
 __global__ __launch_bounds__(64 * kSW, NGW <= 3 ? 4 : 2) void side_down_kernel(DownArgs p) {     // <= 128 VGPRs: two workgroups per CU (259 tiles on 256 CUs)
   __shared__ float red[kSW][16];
+  __shared__ float red2[kSW][16];
   __shared__ f32x4 part[kSW][2][64];
   __shared__ float yrow[16][33];
   __shared__ float w2s[64 * 33];
@@ -62,9 +66,10 @@ __global__ __launch_bounds__(64 * kSW, NGW <= 3 ? 4 : 2) void side_down_kernel(D
   const int C = p.C, NG = C >> 5;                       // groups of 32 columns; wave w owns groups w, w + 8, ...
   const int row0 = blockIdx.x * 16;
   const int row = min(row0 + i, p.M - 1);
-  const bool ln = p.ln_g != nullptr;
+  const bool ln = MODE == 0 && p.ln_g != nullptr;
   // ---- every load of the tile goes out first: the rows, the weight fragments, the LayerNorm affine
   f32x4 x[NGW][2], wf[NGW][2][2];
+  [[maybe_unused]] f32x4 dyv[MODE == 2 ? NGW : 1][2], drs[MODE == 2 ? NGW : 1][2];
   int col[NGW][2];
   bool ok[NGW];
 #pragma unroll
@@ -75,15 +80,21 @@ __global__ __launch_bounds__(64 * kSW, NGW <= 3 ? 4 : 2) void side_down_kernel(D
     for (int h = 0; h < 2; ++h) {
       col[gi][h] = 32 * (ok[gi] ? g : 0) + 16 * h + 4 * kq;
       x[gi][h] = *(const f32x4*)(p.x + (size_t)row * C + col[gi][h]);
+      if constexpr (MODE == 2) {
+        dyv[gi][h] = *(const f32x4*)(p.dy + (size_t)row * C + col[gi][h]);
+        drs[gi][h] = p.dres != nullptr ? *(const f32x4*)(p.dres + (size_t)row * C + col[gi][h]) : zero4();
+      }
     }
   }
+  if constexpr (MODE != 2) {                             // MODE 2 holds three wide streams: its weight fragments are fetched after the row math
 #pragma unroll
-  for (int gi = 0; gi < NGW; ++gi)
+    for (int gi = 0; gi < NGW; ++gi)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      wf[gi][h][0] = load_w_down<WL>(p.w, C, i, col[gi][h]);
-      wf[gi][h][1] = load_w_down<WL>(p.w, C, 16 + i, col[gi][h]);
-    }
+      for (int h = 0; h < 2; ++h) {
+        wf[gi][h][0] = load_w_down<WL>(p.w, C, i, col[gi][h]);
+        wf[gi][h][1] = load_w_down<WL>(p.w, C, 16 + i, col[gi][h]);
+      }
+  }
   if (p.w2 != nullptr) {                                 // second-stage weight [L2][L] -> LDS, rows padded to 33 floats
     for (int t = threadIdx.x; t < p.L2 * kSL; t += 64 * kSW) {
       const int j = t / kSL, l = t - j * kSL;
@@ -142,6 +153,103 @@ __global__ __launch_bounds__(64 * kSW, NGW <= 3 ? 4 : 2) void side_down_kernel(D
         for (int e = 0; e < 4; ++e) x[gi][h][e] = (x[gi][h][e] - mean) * rstd * g4[e] + b4[e];
       }
   }
+  if constexpr (MODE == 1) {
+    // LayerNorm forward of the rows (two-pass statistics), bf16 output; x stays raw for the projection
+    float s = 0.f;
+#pragma unroll
+    for (int gi = 0; gi < NGW; ++gi)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) s += ok[gi] ? (x[gi][h][0] + x[gi][h][1]) + (x[gi][h][2] + x[gi][h][3]) : 0.f;
+    s = kq_sum(s);
+    if (kq == 0) red[wave][i] = s;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int w = 0; w < kSW; ++w) mean += red[w][i];
+    mean /= (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int gi = 0; gi < NGW; ++gi)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = x[gi][h][e] - mean; q += ok[gi] ? d * d : 0.f; }
+    q = kq_sum(q);
+    __syncthreads();
+    if (kq == 0) red[wave][i] = q;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int w = 0; w < kSW; ++w) var += red[w][i];
+    const float rstd = rsqrtf(var / (float)C + p.eps);
+    const bool rv = row0 + i < p.M;
+    if (wave == 0 && kq == 0 && rv) {
+      if (p.mean) p.mean[row] = mean;
+      if (p.rstd) p.rstd[row] = rstd;
+    }
+#pragma unroll
+    for (int gi = 0; gi < NGW; ++gi)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 g4 = *(const f32x4*)(p.ln_g + col[gi][h]), b4 = *(const f32x4*)(p.ln_b + col[gi][h]);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)((x[gi][h][e] - mean) * rstd * g4[e] + b4[e]);
+        if (rv && ok[gi]) *(bf16x4*)(p.y16 + (size_t)row * C + col[gi][h]) = o;
+      }
+  }
+  if constexpr (MODE == 2) {
+    // LayerNorm backward of the rows (as ln_bwd_kernel); dx replaces x and feeds the projection
+    const float mean = p.mean_in[row], rstd = p.rstd_in[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int gi = 0; gi < NGW; ++gi)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 g4 = *(const f32x4*)(p.ln_g + col[gi][h]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (x[gi][h][e] - mean) * rstd, dh = dyv[gi][h][e] * g4[e];
+          x[gi][h][e] = xh;
+          dyv[gi][h][e] = dh;
+          s1 += ok[gi] ? dh : 0.f;
+          s2 += ok[gi] ? dh * xh : 0.f;
+        }
+      }
+    s1 = kq_sum(s1);
+    s2 = kq_sum(s2);
+    if (kq == 0) { red[wave][i] = s1; red2[wave][i] = s2; }
+    __syncthreads();
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < kSW; ++w) { m1 += red[w][i]; m2 += red2[w][i]; }
+    m1 /= (float)C;
+    m2 /= (float)C;
+    const bool rv = row0 + i < p.M;
+#pragma unroll
+    for (int gi = 0; gi < NGW; ++gi)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd * (dyv[gi][h][e] - m1 - x[gi][h][e] * m2) + drs[gi][h][e];
+        x[gi][h] = o;
+        if (rv && ok[gi]) {
+          *(f32x4*)(p.dx + (size_t)row * C + col[gi][h]) = o;
+          if (p.dx16 != nullptr) {
+            const bf16x4 hh = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+            *(bf16x4*)(p.dx16 + (size_t)row * C + col[gi][h]) = hh;
+          }
+        }
+      }
+#pragma unroll
+    for (int gi = 0; gi < NGW; ++gi)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        wf[gi][h][0] = load_w_down<WL>(p.w, C, i, col[gi][h]);
+        wf[gi][h][1] = load_w_down<WL>(p.w, C, 16 + i, col[gi][h]);
+      }
+  }
   // ---- projection: this wave's share of the sum over C (groups past the end contribute zeros)
   f32x4 acc[2] = {zero4(), zero4()};
 #pragma unroll
@@ -193,12 +301,16 @@ __global__ __launch_bounds__(64 * kSW, NGW <= 3 ? 4 : 2) void side_down_kernel(D
 // ---- up projection ------------------------------------------------------------------------------------------------------------------
 struct Up2Args {                                        // optional down-projection of the rows side_up has just written
   const float* w; const float* bias; float* z; float* y; int act;            // w [kSL][C]; z / y [M][kSL]
+  const float* dy;                                                           // LNM 2: the LayerNorm output gradient [M][C]
 };
 
-// NPW = 32-column pairs per wave, WL = weight layout (0: w [C][L], 1: w [L][C]), LNB = LayerNorm-backward epilogue
-// (out = base + LN'(v; ln_x, mean, rstd, gamma))
-template <int NPW, int WL, bool LNB>
+// NPW = 32-column pairs per wave, WL = weight layout (0: w [C][L], 1: w [L][C]).  LNM selects the epilogue on v = lat . W^T:
+//   0: out = base + dropout(v + bias)            1: out = base + LN'(v; ln_x, mean, rstd, gamma)            (gvk_skinny_up)
+//   2: out = base + LN'(dy; ln_x, mean, rstd, gamma) + v, + bf16 copy     (gvk_layernorm_bwd_up: the MLP block's LayerNorm backward and GPA's
+//      dG1 += dzx . W_d in one pass over the row, engine._backward_segment)
+template <int NPW, int WL, int LNM>
 __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpArgs p, Up2Args q) {
+  constexpr bool LNB = LNM != 0;
   __shared__ float red[kSW][16][2];
   __shared__ f32x4 part[kSW][2][64];
   const int lane = lane_id(), wave = wave_id();
@@ -210,6 +322,7 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
   const float* __restrict__ base = p.accumulate ? p.out : p.res;
   // ---- loads: base (+ LayerNorm input) pieces of 8 columns, the latent row, the weight fragments, bias / gamma
   f32x4 bs[NPW][2], xs[LNB ? NPW : 1][2], vec[LNB ? 1 : NPW][2];
+  [[maybe_unused]] f32x4 ys[LNM == 2 ? NPW : 1][2];
   float wa[NPW][2][kK4], lb[kK4];
   int cc[NPW];
   bool ok[NPW];
@@ -222,6 +335,7 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
     for (int j = 0; j < 2; ++j) {
       bs[pi][j] = base != nullptr ? *(const f32x4*)(base + (size_t)row * C + cc[pi] + 4 * j) : zero4();
       if constexpr (LNB) xs[pi][j] = *(const f32x4*)(p.ln_x + (size_t)row * C + cc[pi] + 4 * j);
+      if constexpr (LNM == 2) ys[pi][j] = *(const f32x4*)(q.dy + (size_t)row * C + cc[pi] + 4 * j);
     }
   }
   {
@@ -267,7 +381,8 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
         const f32x4 gam = *(const f32x4*)(p.ln_g + cc[pi] + 4 * j);       // cache-resident: fetched at its use
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float dh = v[e] * gam[e], xh = (xs[pi][j][e] - mu) * rs;
+          const float dh = (LNM == 2 ? ys[pi][j][e] : v[e]) * gam[e], xh = (xs[pi][j][e] - mu) * rs;
+          if constexpr (LNM == 2) ys[pi][j][e] = v[e];                 // the rank-L term, added after the LayerNorm backward
           v[e] = dh;
           xs[pi][j][e] = xh;
           s1 += ok[pi] ? dh : 0.f;
@@ -310,7 +425,15 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = rs * (acc[pi][j][e] - s1 - xs[pi][j][e] * s2) + bs[pi][j][e];
+          if constexpr (LNM == 2) o += ys[pi][j];
           *(f32x4*)(p.out + (size_t)row * C + cc[pi] + 4 * j) = o;
+          acc[pi][j] = o;
+        }
+        if (LNM == 2 && p.out16 != nullptr) {
+          bf16x8 h8;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { h8[e] = (bf16)acc[pi][0][e]; h8[4 + e] = (bf16)acc[pi][1][e]; }
+          *(bf16x8*)(p.out16 + (size_t)row * C + cc[pi]) = h8;
         }
       }
     }
@@ -374,26 +497,34 @@ int launch_side_down(const DownArgs& a, int L, hipStream_t s) {
   // mode 3 (DVPT's QuickGELU input) stays on the row-per-wave kernel: its scalar prompt_gate gradient is one signed sum over every latent
   // of the batch and is pinned at 1e-4 on the fp32 path with that kernel's summation order
   const int ngw = groups_per_wave(a.C);
-  if (!side_enabled() || L != kSL || ngw == 0 || a.mode != 0 || (a.w2 != nullptr && a.L2 > 64)) return 1;
+  if (!side_enabled() || L != kSL || ngw == 0 || a.mode < 0 || a.mode > 2 || (a.w2 != nullptr && a.L2 > 64)) return 1;
+  if (a.mode != 0 && (a.w2 != nullptr || a.drop_thresh != 0u)) return 1;
+  static const bool ln_modes = getenv("GAVIKO_HIP_SIDE_LN") != nullptr && getenv("GAVIKO_HIP_SIDE_LN")[0] == '1';   // A/B switch, see DESIGN.md section 7
+  if (a.mode != 0 && !ln_modes) return 1;
   const dim3 grid((a.M + 15) / 16), block(64 * kSW);
-#define GVK_SD(N_, W_) GVK_LAUNCH((side_down_kernel<N_, W_>), grid, block, 0, s, a)
-  if (a.w_layout == 0) { if (ngw == 1) GVK_SD(1, 0); else if (ngw == 3) GVK_SD(3, 0); else GVK_SD(4, 0); }
-  else { if (ngw == 1) GVK_SD(1, 1); else if (ngw == 3) GVK_SD(3, 1); else GVK_SD(4, 1); }
+#define GVK_SD(N_, W_, M_) GVK_LAUNCH((side_down_kernel<N_, W_, M_>), grid, block, 0, s, a)
+#define GVK_SD_N(W_, M_) { if (ngw == 1) GVK_SD(1, W_, M_); else if (ngw == 3) GVK_SD(3, W_, M_); else GVK_SD(4, W_, M_); }
+  if (a.mode == 0) { if (a.w_layout == 0) GVK_SD_N(0, 0) else GVK_SD_N(1, 0) }
+  else if (a.mode == 1) { if (a.w_layout == 0) GVK_SD_N(0, 1) else GVK_SD_N(1, 1) }
+  else { if (a.w_layout == 0) GVK_SD_N(0, 2) else GVK_SD_N(1, 2) }
+#undef GVK_SD_N
 #undef GVK_SD
   return check_launch("side_down");
 }
 
-int launch_side_up(const UpArgs& a, int L, const float* w2, const float* bias2, float* z2, float* y2, int L2, int act2, hipStream_t s) {
+int launch_side_up(const UpArgs& a, int L, const float* w2, const float* bias2, float* z2, float* y2, int L2, int act2, hipStream_t s, const float* ln_dy) {
   const int npw = groups_per_wave(a.C);
   const bool lnb = a.ln_x != nullptr, ext = a.alpha_ptr != nullptr || a.gg_x != nullptr;
   if (!side_enabled() || L != kSL || npw == 0 || ext) return 1;       // DVPT's gate / GELU' epilogue: row-per-wave kernel (see launch_side_down)
   if (w2 != nullptr && (lnb || L2 != kSL)) return set_error(-2, "side_up: the fused second projection takes the plain epilogue and L2 = %d", kSL);
-  Up2Args q{w2, bias2, z2, y2, act2};
+  if (ln_dy != nullptr && !lnb) return set_error(-2, "side_up: ln_dy needs the LayerNorm operands (ln_x, mean, rstd, gamma)");
+  Up2Args q{w2, bias2, z2, y2, act2, ln_dy};
+  const int lnm = ln_dy != nullptr ? 2 : (lnb ? 1 : 0);
   const dim3 grid((a.M + 15) / 16), block(64 * kSW);
 #define GVK_SU(N_, W_, B_) GVK_LAUNCH((side_up_kernel<N_, W_, B_>), grid, block, 0, s, a, q)
 #define GVK_SU_N(W_, B_) { if (npw == 1) GVK_SU(1, W_, B_); else if (npw == 3) GVK_SU(3, W_, B_); else GVK_SU(4, W_, B_); }
-  if (a.w_layout == 0) { if (lnb) GVK_SU_N(0, true) else GVK_SU_N(0, false) }
-  else { if (lnb) GVK_SU_N(1, true) else GVK_SU_N(1, false) }
+  if (a.w_layout == 0) { if (lnm == 2) GVK_SU_N(0, 2) else if (lnm == 1) GVK_SU_N(0, 1) else GVK_SU_N(0, 0) }
+  else { if (lnm == 2) GVK_SU_N(1, 2) else if (lnm == 1) GVK_SU_N(1, 1) else GVK_SU_N(1, 0) }
 #undef GVK_SU_N
 #undef GVK_SU
   return check_launch("side_up");

@@ -41,6 +41,8 @@ int launch_row_up(const UpArgs& a, int L, hipStream_t s);
 // sidepass.hip: 16-row tiles on the fp32 matrix cores; return 1 when the call is not covered.  side_up optionally projects the rows it
 // has just written with a second weight w2 [L2][C] (+ bias2, activation act2) into z2 / y2 [M][L2].
 int launch_side_down(const DownArgs& a, int L, hipStream_t s);
-int launch_side_up(const UpArgs& a, int L, const float* w2, const float* bias2, float* z2, float* y2, int L2, int act2, hipStream_t s);
+// ln_dy (with a's LayerNorm operands): out = base + LN'(ln_dy) + lat . W^T instead of base + LN'(lat . W^T)
+int launch_side_up(const UpArgs& a, int L, const float* w2, const float* bias2, float* z2, float* y2, int L2, int act2, hipStream_t s,
+                   const float* ln_dy = nullptr);
 
 }  // namespace gvk

@@ -963,16 +963,27 @@ class Engine:
             if ssf:                                                          # LN2 + ssf_0
                 self._ssf_ln_grad(ws, gv, m, ".net.0", ws["dx32"], ws["G1"][i], st[2], st[3], M)
             adapter = self.kind == "adaptformer"
-            ops.layernorm_bwd(ws["dx32"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), M, C, dx=dGin, dres=dGout,
-                              dx16=None if (gaviko or adapter or dvpt) else ws["dG16"])
+            fuse_scatter = (gaviko and self._fuse_local and not self.fp32 and "noside" not in _ABLATE
+                            and os.environ.get("GAVIKO_HIP_FUSE_SCATTER", "0") == "1")     # measured: 651 vs 676 volumes/s -- off
+            if fuse_scatter:
+                # dG1 = dGout + LN'(dx32) + dzx . W_d (+ the bf16 operand of the out-proj dgrad) in ONE pass: the GPA core of this layer
+                # (started at the top of the layer on its own stream) has long finished when the two MLP dgrad GEMMs are through
+                self._ev_wait(torch.cuda.current_stream(), dz_ready)
+                gpre, _ = self._gpa_names(i)
+                ops.layernorm_bwd_up(ws["dx32"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), M, C, dx=dGin, dres=dGout, dx16=ws["dG16"],
+                                     lat=ws["bw"]["dzx"], w=d(gpre + ".proj_down.0.weight"), L_=self.Lat, w_layout=1)
+            else:
+                ops.layernorm_bwd(ws["dx32"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), M, C, dx=dGin, dres=dGout,
+                                  dx16=None if (gaviko or adapter or dvpt) else ws["dG16"])
             if dvpt:
                 self._dvpt_bwd_scatter(ws, i, dGin, M)                       # dG1 += (dz . Wd) * QuickGELU'(G1)  (+ operand copy)
             if adapter:
                 self._adapter_bwd(ws, gv, i, dGout, dGin, M)                 # adds LN_a'(...) into dG1 and refreshes dG16
             self._mark(f"b{i}:ln2")
             if gaviko:
-                self._ev_wait(torch.cuda.current_stream(), dz_ready)
-                self._gpa_bwd_scatter_g(ws, i, dGin, M)                      # dG1 += dzx.Wd (+ bf16 copy)
+                if not fuse_scatter:
+                    self._ev_wait(torch.cuda.current_stream(), dz_ready)
+                    self._gpa_bwd_scatter_g(ws, i, dGin, M)                  # dG1 += dzx.Wd (+ bf16 copy)
                 self._mark(f"b{i}:scatter")
                 self._ev_wait(loc, dz_ready)
                 with torch.cuda.stream(loc):

@@ -115,6 +115,7 @@ SIGNATURES = {
     "gvk_lora_merge_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "gvk_layernorm_fwd_proj": [_P, _P, _P, _P, _P, _P, _I, _I, _F, C.POINTER(RowProjDesc), _P],
     "gvk_layernorm_bwd_proj": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, C.POINTER(RowProjDesc), _P],
+    "gvk_layernorm_bwd_up": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gvk_ssf_fold_weight": [_P, _P, _P, _P, _I, _I, _I, _P],
     "gvk_ssf_fold_vec": [_P, _P, _P, _P, _I, _P],
     "gvk_ssf_colgrad": [C.POINTER(SsfColgradDesc), _P],

@@ -234,6 +234,20 @@ def layernorm_bwd_proj(dy, x, mean, rstd, gamma, M, C_, *, dx, dres=None, dx16=N
                                             L.ptr(dx16), M, C_, C.byref(d), L.stream_ptr()), "gvk_layernorm_bwd_proj")
 
 
+def layernorm_bwd_up(dy, x, mean, rstd, gamma, M, C_, *, dx, dres, dx16, lat, w, L_, w_layout):
+    """dx = dres + LN'(dy) + lat . W^T (+ bf16 copy): the MLP block's LayerNorm backward and GPA's dG1 += dzx . W_d in one pass."""
+    for t, n in ((dy, "dy"), (x, "x"), (dx, "dx"), (dres, "dres")):
+        _chk(t, torch.float32, "ln_bwd_up " + n, M * C_)
+    _chk(dx16, torch.bfloat16, "ln_bwd_up dx16", M * C_)
+    _chk(mean, torch.float32, "ln_bwd_up mean", M)
+    _chk(rstd, torch.float32, "ln_bwd_up rstd", M)
+    _chk(gamma, torch.float32, "ln_bwd_up gamma", C_)
+    _chk(lat, torch.float32, "ln_bwd_up lat", M * L_)
+    _chk(w, torch.float32, "ln_bwd_up w", L_ * C_)
+    L.check(L.load().gvk_layernorm_bwd_up(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dres), L.ptr(dx), L.ptr(dx16),
+                                          L.ptr(lat), L.ptr(w), w_layout, M, C_, L_, L.stream_ptr()), "gvk_layernorm_bwd_up")
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, M, C_, *, dx, dres=None, dx16=None):
     if dx16 is not None and dx16.dtype == torch.float32:     # fp32 compute path: the operand copy is a plain copy of dx
         layernorm_bwd(dy, x, mean, rstd, gamma, M, C_, dx=dx, dres=dres)

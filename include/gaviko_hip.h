@@ -156,6 +156,12 @@ int gvk_layernorm_fwd_proj(const float* x, const float* gamma, const float* beta
                            int M, int C, float eps, const gvk_rowproj_desc* proj, void* stream);
 int gvk_layernorm_bwd_proj(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                            const float* dres, float* dx, void* dx_bf16, int M, int C, const gvk_rowproj_desc* proj, void* stream);
+/* LayerNorm backward fused with a rank-L update of the same rows:  dx = dres + LN'(dy; x, mean, rstd, gamma) + lat . W^T  (+ bf16 copy).
+ * Replaces gvk_layernorm_bwd followed by gvk_skinny_up(accumulate) on the backbone stream: the autograd of gaviko.py:304 (the MLP block's
+ * LayerNorm) and of gaviko.py:155 (GPA's proj_down of the global tokens: dG1 += dzx . W_d) in one pass.  lat f32 [M][L]; w_layout 0: W [C][L],
+ * 1: W [L][C].  Covers L = 20, C in {192, 768, 1024}. */
+int gvk_layernorm_bwd_up(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
+                         float* dx, void* dx_bf16, const float* lat, const float* w, int w_layout, int M, int C, int L, void* stream);
 
 /* ------------------------------------------------------------------ multi-head self-attention, head dim 64
  * qkv bf16 [B*T (padded)][ld_qkv]: columns [q | k | v], each (head, 64) -- the to_qkv output as is
