@@ -14,6 +14,14 @@
 
 namespace gvk {
 
+// A/B switch (compile-time, tools/gpu experiments): raise the wave's priority around its MFMA clusters so that, of the two waves a SIMD
+// hosts (two workgroups per CU), the one in a matrix phase issues first and the other fills the gaps with its softmax VALU work
+#ifdef GVK_ATTN_PRIO
+#define GVK_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define GVK_PRIO(x)
+#endif
+
 __device__ __forceinline__ int swz_b(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
 constexpr int kQT = 64;                 // query rows staged per barrier pair (two 32-row MFMA sub-blocks)
@@ -67,10 +75,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
       glds16(qbase + (size_t)q * ld_qkv + chunk * 8, sQ + (r * 32 + wave * 8) * 128);
       glds16(dobase + (size_t)q * ld_o + chunk * 8, sD + (r * 32 + wave * 8) * 128);
     }
-    if (wave < kQT / 32) {                                 // wave w stages the row constants of sub-block w
-      const int qq = qt * kQT + wave * 32 + r31;
-      if (hh == 0) sL[wave * 32 + r31] = (qq < T) ? -lse_b[qq] * inv_scale : -INFINITY;   // rows >= T: P = exp2(-inf) = 0
-      else sL[kQT + wave * 32 + r31] = (qq < T) ? del_b[qq] : 0.f;
+    // The row constants ride on the LDS-DMA too (4-byte form, 64 rows per instruction; every wave writes the same 256 bytes: benign, and it
+    // keeps the per-wave vmcnt identical).  As ORDINARY loads they made hipcc wait vmcnt(0) at their first use -- right here, draining the
+    // Q / dO requests issued two lines above: one exposed L2 round trip per 64-row tile (SQ_WAIT_ANY 0.41 of the wave cycles).
+    {
+      const int qq = min(qt * kQT + lane, T - 1);
+      __builtin_amdgcn_global_load_lds((const GVK_GLOBAL void*)(lse_b + qq), (GVK_LDS void*)sL, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((const GVK_GLOBAL void*)(del_b + qq), (GVK_LDS void*)(sL + kQT), 4, 0, 0);
     }
   };
 
@@ -96,13 +107,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
       const float* sL = sL0 + sub * 32;
       // S'[q][key] = Q.K^T - lse/scale ;  dP[q][key] = dO.V^T
       f32x16 s, dp;
+      const int rows_left = T - (qt * kQT + sub * 32);       // query rows of this sub-block inside the sequence (wave-uniform)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const f32x4 l4 = *(const f32x4*)(sL + 8 * g4 + 4 * hh);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[4 * g4 + e] = l4[e];
+        for (int e = 0; e < 4; ++e) s[4 * g4 + e] = -l4[e] * inv_scale;
+      }
+      if (rows_left < 32) {                                  // rows >= T: P = exp2(-inf) = 0
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (8 * g4 + 4 * hh + e >= rows_left) s[4 * g4 + e] = -INFINITY;
       }
       dp = f32x16{};
+      GVK_PRIO(1);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int chunk = 2 * ks + hh;
@@ -111,6 +131,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
       }
+      GVK_PRIO(0);
       // P = exp2(c * S');  dS = P * (dP - delta[q]) -- two scores per packed instruction (these loops, not the MFMAs, fill the SIMD)
       const f32x2 sc2 = {scale_log2e, scale_log2e};
 #pragma unroll
@@ -135,6 +156,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
         }
       }
       // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]   (k = q, accumulator row order)
+      GVK_PRIO(1);
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk) {
         bf16x8 pf, dsf;
@@ -155,6 +177,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
           dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, dsf, dkt[db], 0, 0, 0);
         }
       }
+      GVK_PRIO(0);
     }
     __syncthreads();
   }
@@ -250,6 +273,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
       for (int r = 0; r < 16; ++r) st[r] = sinit;
       dpt = f32x16{};
       const int row = kb * 32 + r31;
+      GVK_PRIO(1);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int chunk = 2 * ks + hh;
@@ -259,6 +283,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], st, 0, 0, 0);
         dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dpt, 0, 0, 0);
       }
+      GVK_PRIO(0);
       if (kt == nkt - 1) {                                 // wave-uniform: only the last tile holds keys >= T
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -280,6 +305,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
         st[r] = ds[0];
         st[r + 1] = ds[1];
       }
+      GVK_PRIO(1);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         bf16x8 dsf;
@@ -296,6 +322,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
           dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt8, dsf, dqt[db], 0, 0, 0);
         }
       }
+      GVK_PRIO(0);
     }
     __syncthreads();
   }

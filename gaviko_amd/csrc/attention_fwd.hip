@@ -16,6 +16,14 @@
 
 namespace gvk {
 
+// A/B switch (compile-time, tools/gpu experiments): raise the wave's priority around its MFMA clusters so that, of the two waves a SIMD
+// hosts (two workgroups per CU), the one in a matrix phase issues first and the other fills the gaps with its softmax VALU work
+#ifdef GVK_ATTN_PRIO
+#define GVK_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define GVK_PRIO(x)
+#endif
+
 __device__ __forceinline__ int swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
 constexpr int kQB = 128;   // queries per workgroup
@@ -117,8 +125,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
       if (kb + 1 < NKB) load_k(kb + 1, kfr[(kb + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
       st[kb] = f32x16{};
+      GVK_PRIO(1);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb & 1][ks], qf[ks], st[kb], 0, 0, 0);
+      GVK_PRIO(0);
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- online softmax in the log2 domain.  VALU budget per score: max, fma, exp2, add (the scale is folded into the fma,
@@ -196,8 +206,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 #pragma unroll
       for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[kb][8 * sb + j];
       __builtin_amdgcn_sched_barrier(0);
+      GVK_PRIO(1);
 #pragma unroll
       for (int db = 0; db < 2; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[step & 1][db], pf, ot[db], 0, 0, 0);
+      GVK_PRIO(0);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -221,11 +233,214 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   }
 }
 
+
+// ---- eight-wave form: two groups of four waves share every staged K / V tile (256 queries per workgroup, one workgroup per CU) and run the
+// same program ONE BARRIER APART.  A tile is two phases,
+//     P1 = S^T = K.Q^T (16 MFMAs) | running max, rescale factor, O *= alpha        P2 = exp2, row sums, bf16 P | O^T += V^T.P^T (16 MFMAs)
+// so while one group is in the MFMA half of a phase the other is in a VALU half (the 4-wave kernel leaves that overlap to two unrelated
+// workgroups that happen to share a CU and mostly move in lockstep: 30 us = 0.17 of the bf16 peak).  Waves w and w+4 share a SIMD.
+// LDS: THREE K|V buffers; tile t+2 is requested at the start of P2(t) -- its buffer (tile t-1) was last read in the other group's P2(t-1),
+// which ended at the barrier this phase began with -- and every wave waits vmcnt(0) at the end of P1(t+1), one barrier (group 0) or two
+// (group 1) before any wave reads the tile.
+constexpr int kQB8 = 256;
+
+template <bool DROP>
+__global__ __launch_bounds__(512) void attn_fwd8_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse,
+                                                        int T, int H, int ld_qkv, int ld_out, float scale_log2e, AttnDrop dr) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [3 buffers][K tile | V tile]
+  int bh, qb;
+  xcd_group_block(blockIdx.x, (T + kQB8 - 1) / kQB8, gridDim.x / ((T + kQB8 - 1) / kQB8), bh, qb);
+  const int b = bh / H, head = bh - b * H, q0 = qb * kQB8;
+  const int lane = lane_id(), wave = wave_id();
+  const int grp = wave >> 2, sw = wave & 3;              // group (phase offset) and the wave's 32-query slice inside the group's 128
+  const int r31 = lane & 31, hh = lane >> 5;
+  const int inner = H * 64;
+  const bf16* base = qkv + (size_t)b * T * ld_qkv + head * 64;
+  const bf16* kbase = base + inner;
+
+  const int qme = q0 + grp * 128 + sw * 32 + r31;
+  const int qrow = min(qme, T - 1);
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(base + (size_t)qrow * ld_qkv + 16 * ks + 8 * hh);
+
+  // staging: 8 waves x 8 rows = 64 rows per pass, two passes per 128-key tile and operand
+  const int rsub = lane >> 3, slot = lane & 7;
+  const int nkt = (T + kKB - 1) / kKB;
+  auto stage = [&](int kt) {
+    char* sK = smem + (kt % 3) * 2 * kTileBytes;
+    char* sV = sK + kTileBytes;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int row = r * 64 + wave * 8 + rsub;
+      const int key = min(kt * kKB + row, T - 1);                       // rows past the end re-read row T-1 (masked below)
+      const bf16* kp = kbase + (size_t)key * ld_qkv + ((slot ^ swz(row)) << 3);
+      glds16(kp, sK + (r * 64 + wave * 8) * 128);
+      glds16(kp + inner, sV + (r * 64 + wave * 8) * 128);
+    }
+  };
+
+  f32x16 ot[2];
+  ot[0] = f32x16{};
+  ot[1] = f32x16{};
+  float m_run = -INFINITY, l_run = 0.f;
+  [[maybe_unused]] unsigned int akey = 0u, qoff = 0u;
+  if constexpr (DROP) {
+    akey = attn_key(dr.seed + *dr.seed_ptr, b * H + head);
+    qoff = (unsigned int)qme * (unsigned int)T;
+  }
+  constexpr int NKB = kKB / 32;
+
+  stage(0);
+  if (nkt > 1) stage(1);
+  __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();            // the stagger
+  for (int kt = 0; kt < nkt; ++kt) {
+    const char* sK = smem + (kt % 3) * 2 * kTileBytes;
+    const char* sV = sK + kTileBytes;
+    // ================= P1: S^T = K . Q^T, then the running max and the rescale of O
+    f32x16 st[NKB];
+    bf16x8 kfr[2][4];
+    auto load_k = [&](int kb, bf16x8 (&dst)[4]) {
+      const int row = kb * 32 + r31;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const bf16x8*)(sK + row * 128 + (((2 * ks + hh) ^ swz(row)) << 4));
+    };
+    load_k(0, kfr[0]);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (kb + 1 < NKB) load_k(kb + 1, kfr[(kb + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      st[kb] = f32x16{};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb & 1][ks], qf[ks], st[kb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (kt == nkt - 1) {                                  // wave-uniform: only the last tile can contain keys >= T
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * kKB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          st[kb][r] = (key < T) ? st[kb][r] : -INFINITY;
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[db][r] *= alpha;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's share of tile kt+1 (requested one phase ago) has landed
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ================= P2: probabilities, row sums, O^T += V^T . P^T
+    if (kt + 2 < nkt) stage(kt + 2);
+    f32x2 psum2 = {0.f, 0.f};
+    const f32x2 sc2 = {scale_log2e, scale_log2e}, nm2 = {-m_new, -m_new};
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 a = __builtin_elementwise_fma(f32x2{st[kb][r], st[kb][r + 1]}, sc2, nm2);
+        const f32x2 p2 = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        st[kb][r] = p2[0];
+        st[kb][r + 1] = p2[1];
+        psum2 += p2;
+      }
+    l_run = l_run * alpha + (psum2[0] + psum2[1]);
+    if constexpr (DROP) {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * kKB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          st[kb][r] *= attn_drop_scale(akey, qoff + (unsigned int)key, dr.thresh, dr.inv_keep);
+        }
+    }
+    const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    bf16x8 vfr[2][2];
+    auto load_v = [&](int step, bf16x8 (&dst)[2]) {
+      const int kb = step >> 1, sb = step & 1;
+      const int key0 = kb * 32 + 16 * sb + 4 * (g >> 1);
+      const int ra = key0 + tq, rb = key0 + 8 + tq;
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
+        const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((chunk ^ swz(ra)) << 4) + (tp & 1) * 8);
+        const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((chunk ^ swz(rb)) << 4) + (tp & 1) * 8);
+        dst[db] = bf16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+      }
+    };
+    load_v(0, vfr[0]);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int step = 0; step < 2 * NKB; ++step) {
+      if (step + 1 < 2 * NKB) load_v(step + 1, vfr[(step + 1) & 1]);
+      const int kb = step >> 1, sb = step & 1;
+      bf16x8 pf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[kb][8 * sb + j];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[step & 1][db], pf, ot[db], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();            // balance the barrier count
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qme < T) {
+    bf16* orow = out + ((size_t)b * T + qme) * ld_out + head * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 o = {(bf16)(ot[db][4 * g4 + 0] * inv), (bf16)(ot[db][4 * g4 + 1] * inv), (bf16)(ot[db][4 * g4 + 2] * inv),
+                    (bf16)(ot[db][4 * g4 + 3] * inv)};
+        *(bf16x4*)(orow + db * 32 + 8 * g4 + 4 * hh) = o;
+      }
+    if (hh == 0 && lse != nullptr) lse[((size_t)b * H + head) * T + qme] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
+  }
+}
+
 }  // namespace gvk
 
 namespace gvk {
 template <bool DROP>
 static int launch_attn_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale, AttnDrop dr, hipStream_t stream) {
+  // opt-in (GAVIKO_HIP_ATTN8=1): parity-green but no faster -- 32.8 vs 30.5 us isolated, 679 vs 684 volumes/s in the step (profiles/r02_pmc_attention.json:
+  // both forms spend ~0.3 of their wave cycles issuing VALU, ~0.2 in MFMA and the rest waiting; forcing the MFMA / VALU halves of the two waves
+  // of a SIMD apart by a barrier did not change that)
+  static const bool use8 = getenv("GAVIKO_HIP_ATTN8") != nullptr && getenv("GAVIKO_HIP_ATTN8")[0] == '1';
+  if (use8 && T > 128) {
+    const int lds8 = 3 * 2 * kTileBytes;
+    static bool attr8 = false;
+    if (!attr8) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd8_kernel<DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds8);
+      if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(attn_fwd8): %s", hipGetErrorString(e));
+      attr8 = true;
+    }
+    GVK_LAUNCH(attn_fwd8_kernel<DROP>, dim3(((T + kQB8 - 1) / kQB8) * H * B), dim3(512), lds8, stream, (const bf16*)qkv,
+                       (bf16*)out, lse, T, H, ld_qkv, ld_out, scale * 1.44269504088896340736f, dr);
+    return check_launch("attention_fwd8_bf16");
+  }
   const int lds = 2 * 2 * kTileBytes;
   static bool attr = false;
   if (!attr) {

@@ -1,9 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r2l; mkdir -p $O
-run() { echo "$1"; env $2 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-roofline 2>$O/err.log | cut -c80-150; tail -2 $O/err.log | grep -i error; }
-run "default" "X=1"
-run "main prio -1" "GAVIKO_BENCH_MAIN_PRIORITY=-1"
-run "main prio 0 (own stream)" "GAVIKO_BENCH_MAIN_PRIORITY=0"
-run "main prio -1, side prio 0 explicit" "GAVIKO_BENCH_MAIN_PRIORITY=-1 GAVIKO_HIP_SIDE_PRIORITY=0"
-run "default again" "X=1"
+python -m pytest tests/test_kernels_gpu.py tests/test_dropout_gpu.py -x -q -k "attention or attn" > $O/t.log 2>&1; tail -3 $O/t.log
+echo "== 4-wave fwd"; GAVIKO_HIP_ATTN8=0 python3 tools/bench_attn.py 2>/dev/null
+echo "== bench (4-wave fwd)"; GAVIKO_HIP_ATTN8=0 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c80-150
