@@ -18,6 +18,13 @@ namespace gvk {
 
 // A/B switch (compile-time, tools/gpu experiments): raise the wave's priority around its MFMA clusters so that, of the two waves a SIMD
 // hosts (two workgroups per CU), the one in a matrix phase issues first and the other fills the gaps with its softmax VALU work
+// tools/probe/probe_attn.hip compiles this file with GVK_STAMPS: shader-clock stamps of ONE steady-state key tile (kt == 4) of the four-wave kernel,
+// written through dr.seed_ptr (unused without dropout) as uint64 [workgroup][wave][8].  Compiled out of the library.
+#ifdef GVK_STAMPS
+#define GVK_ASTAMP(k) if (kt == 4) st_[k] = __builtin_amdgcn_s_memtime();
+#else
+#define GVK_ASTAMP(k)
+#endif
 #ifdef GVK_ATTN_PRIO
 #define GVK_PRIO(x) __builtin_amdgcn_s_setprio(x)
 #else
@@ -100,11 +107,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     qoff = (unsigned int)(q0 + wave * 32 + r31) * (unsigned int)T;
   }
 
+#ifdef GVK_STAMPS
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   stage(0, 0);
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
+    GVK_ASTAMP(0)
     if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
+    GVK_ASTAMP(1)
     const char* sK = smem + buf * 2 * kTileBytes;
     const char* sV = sK + kTileBytes;
 
@@ -131,6 +143,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
       GVK_PRIO(0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    GVK_ASTAMP(2)
     // ---- online softmax in the log2 domain.  VALU budget per score: max, fma, exp2, add (the scale is folded into the fma,
     //      the key mask is applied on the last tile only) -- this block, not the MFMAs, was the largest share of the kernel.
     if (kt == nkt - 1) {                                  // wave-uniform: only the last tile can contain keys >= T
@@ -151,69 +164,89 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     const float m_new = fmaxf(m_run, mx);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
     m_run = m_new;
-    // two scores per v_pk_fma_f32 / v_pk_add_f32: the softmax is VALU-bound (the quarter-rate v_exp_f32 alone costs as many cycles
-    // as the tile's 32 MFMAs), so every full-rate instruction saved shows
+    // Software pipeline over the four 32-key blocks: the exp2 / row-sum / bf16 conversion of block kb+1 is issued right BEHIND the four
+    // PV MFMAs of block kb, so the VALU work runs while the matrix pipe executes them (written as "all exps, then all MFMAs" hipcc
+    // sank every exp in front of the one MFMA that consumes it: 1936 cycles for this section against 512 of MFMA + ~1200 of VALU;
+    // tools/probe/probe_attn.py).  Two scores per v_pk_fma_f32 / v_pk_add_f32.
     f32x2 psum2 = {0.f, 0.f};
     const f32x2 sc2 = {scale_log2e, scale_log2e}, nm2 = {-m_new, -m_new};
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
+    auto exp_block = [&](int kb) {
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const f32x2 a = __builtin_elementwise_fma(f32x2{st[kb][r], st[kb][r + 1]}, sc2, nm2);
-        const f32x2 p2 = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        f32x2 p2 = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        psum2 += p2;                                        // statistics of the undropped probabilities
+        if constexpr (DROP) {
+          const int key = kt * kKB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;        // r even: r + 1 is the next key
+          p2 = p2 * f32x2{attn_drop_scale(akey, qoff + (unsigned int)key, dr.thresh, dr.inv_keep),
+                          attn_drop_scale(akey, qoff + (unsigned int)key + 1u, dr.thresh, dr.inv_keep)};
+        }
         st[kb][r] = p2[0];
         st[kb][r + 1] = p2[1];
-        psum2 += p2;
       }
-    const float psum = psum2[0] + psum2[1];
-    l_run = l_run * alpha + psum;
-    if constexpr (DROP) {
+    };
+    auto cvt_block = [&](int kb, bf16x8 (&pf)[2]) {
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
+      for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt * kKB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          st[kb][r] *= attn_drop_scale(akey, qoff + (unsigned int)key, dr.thresh, dr.inv_keep);
-        }
-    }
+        for (int j = 0; j < 8; ++j) pf[sb][j] = (bf16)st[kb][8 * sb + j];
+    };
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ot[db][r] *= alpha;
 
-    // ---- O^T += V^T . P^T : P^T straight from the accumulator registers as the B operand; the V^T fragments of step (kb, s) + 1 are
-    //      gathered while the two MFMAs of step (kb, s) run
+    GVK_ASTAMP(3)
+    // ---- O^T += V^T . P^T : P^T straight from the accumulator registers as the B operand; V^T fragments of block kb+1 are gathered
+    //      (ds_read_b64_tr_b16) before the MFMAs of block kb are issued
     const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-    bf16x8 vfr[2][2];
-    auto load_v = [&](int step, bf16x8 (&dst)[2]) {
-      const int kb = step >> 1, sb = step & 1;
-      const int key0 = kb * 32 + 16 * sb + 4 * (g >> 1);   // lane half hh == g>>1
-      const int ra = key0 + tq, rb = key0 + 8 + tq;
+    bf16x8 vfr[2][2][2], pfr[2][2];                         // [block parity][16-key step][d half], [block parity][16-key step]
+    auto load_v = [&](int kb, bf16x8 (&dst)[2][2]) {
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
-        const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((chunk ^ swz(ra)) << 4) + (tp & 1) * 8);
-        const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((chunk ^ swz(rb)) << 4) + (tp & 1) * 8);
-        dst[db] = bf16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+      for (int sb = 0; sb < 2; ++sb) {
+        const int key0 = kb * 32 + 16 * sb + 4 * (g >> 1);   // lane half hh == g>>1
+        const int ra = key0 + tq, rb = key0 + 8 + tq;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
+          const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((chunk ^ swz(ra)) << 4) + (tp & 1) * 8);
+          const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((chunk ^ swz(rb)) << 4) + (tp & 1) * 8);
+          dst[sb][db] = bf16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+        }
       }
     };
     load_v(0, vfr[0]);
+    exp_block(0);
+    cvt_block(0, pfr[0]);
 #pragma unroll
-    for (int step = 0; step < 2 * NKB; ++step) {
-      if (step + 1 < 2 * NKB) load_v(step + 1, vfr[(step + 1) & 1]);
-      const int kb = step >> 1, sb = step & 1;
-      bf16x8 pf;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[kb][8 * sb + j];
+    for (int kb = 0; kb < NKB; ++kb) {
+      if (kb + 1 < NKB) load_v(kb + 1, vfr[(kb + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
       GVK_PRIO(1);
 #pragma unroll
-      for (int db = 0; db < 2; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[step & 1][db], pf, ot[db], 0, 0, 0);
+      for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kb & 1][sb][db], pfr[kb & 1][sb], ot[db], 0, 0, 0);
       GVK_PRIO(0);
       __builtin_amdgcn_sched_barrier(0);
+      if (kb + 1 < NKB) {                                   // VALU of the next block, behind the four MFMAs just issued
+        exp_block(kb + 1);
+        cvt_block(kb + 1, pfr[(kb + 1) & 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    l_run = l_run * alpha + (psum2[0] + psum2[1]);
+    GVK_ASTAMP(4)
     __syncthreads();
+    GVK_ASTAMP(5)
   }
+#ifdef GVK_STAMPS
+  if (dr.seed_ptr != nullptr && lane == 0) {
+    unsigned long long* o = (unsigned long long*)dr.seed_ptr + ((size_t)blockIdx.x * 4 + wave) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = st_[k];
+  }
+#endif
 
   // ---- epilogue: O[q][d] = O^T / l ; lse = ln(sum exp(s*scale))
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
