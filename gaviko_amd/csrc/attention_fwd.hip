@@ -41,7 +41,10 @@ constexpr int kTileBytes = kKB * 128;
 // of the undropped scores, the dropped and rescaled P feeds the P.V product; mask element (b*H + head, query, key) -- dropout.hpp
 struct AttnDrop { unsigned long long seed; const unsigned long long* seed_ptr; unsigned int thresh; float inv_keep; };
 
-template <bool DROP>
+// RS: K / V tiles staged through registers (global_load_dwordx4 at the top of a tile, ds_write_b128 in front of its closing barrier) instead
+// of by LDS-DMA: issuing the eight 1-KiB LDS-DMA instructions of a tile holds the wave's instruction stream for ~650 cycles of a ~3900-cycle
+// tile (tools/probe/probe_attn.py), and this kernel is bound by the SIMD's vector issue, not by latency.
+template <bool DROP, bool RS>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse,
                                                        int T, int H, int ld_qkv, int ld_out, float scale_log2e, AttnDrop dr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K tile | V tile]
@@ -96,6 +99,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
       }
     }
   };
+  // register staging (RS): the same source addresses and the same LDS image, in two halves
+  [[maybe_unused]] u32x4 kreg[kKB / 32], vreg[kKB / 32];
+  [[maybe_unused]] auto fetch = [&](int kt) {
+#pragma unroll
+    for (int r = 0; r < kKB / 32; ++r) {
+      const int row = r * 32 + wave * 8 + rsub;
+      const int over = (kt == nkt - 1) ? max(kt * kKB + row - (T - 1), 0) : 0;
+      kreg[r] = *(const u32x4*)(kp[r] - (size_t)over * ld_qkv);
+      vreg[r] = *(const u32x4*)(vp[r] - (size_t)over * ld_qkv);
+      kp[r] += tile_step;
+      vp[r] += tile_step;
+    }
+  };
+  [[maybe_unused]] auto commit = [&](int buf) {
+    char* sK = smem + buf * 2 * kTileBytes;
+    char* sV = sK + kTileBytes;
+#pragma unroll
+    for (int r = 0; r < kKB / 32; ++r) {
+      *(u32x4*)(sK + (r * 32 + wave * 8) * 128 + lane * 16) = kreg[r];
+      *(u32x4*)(sV + (r * 32 + wave * 8) * 128 + lane * 16) = vreg[r];
+    }
+  };
 
   f32x16 ot[2];
   ot[0] = f32x16{};
@@ -110,12 +135,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 #ifdef GVK_STAMPS
   unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-  stage(0, 0);
+  if constexpr (RS) { fetch(0); commit(0); } else { stage(0, 0); }
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     GVK_ASTAMP(0)
-    if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
+    if (kt + 1 < nkt) {
+      if constexpr (RS) fetch(kt + 1); else stage(buf ^ 1, kt + 1);
+    }
     GVK_ASTAMP(1)
     const char* sK = smem + buf * 2 * kTileBytes;
     const char* sV = sK + kTileBytes;
@@ -237,6 +264,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     }
     l_run = l_run * alpha + (psum2[0] + psum2[1]);
     GVK_ASTAMP(4)
+    if constexpr (RS) { if (kt + 1 < nkt) commit(buf ^ 1); }   // the other buffer was last read one barrier ago
     __syncthreads();
     GVK_ASTAMP(5)
   }
@@ -475,14 +503,17 @@ static int launch_attn_fwd(const void* qkv, void* out, float* lse, int B, int T,
     return check_launch("attention_fwd8_bf16");
   }
   const int lds = 2 * 2 * kTileBytes;
+  static const bool rs = getenv("GAVIKO_HIP_ATTN_RS") != nullptr && getenv("GAVIKO_HIP_ATTN_RS")[0] == '1';   // opt-in: measured 32.3 vs 31.0 us (no gain)
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<DROP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<DROP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(attn_fwd): %s", hipGetErrorString(e));
     attr = true;
   }
-  GVK_LAUNCH(attn_fwd_kernel<DROP>, dim3(((T + kQB - 1) / kQB) * H * B), dim3(256), lds, stream, (const bf16*)qkv,
-                     (bf16*)out, lse, T, H, ld_qkv, ld_out, scale * 1.44269504088896340736f, dr);
+  const dim3 grid(((T + kQB - 1) / kQB) * H * B);
+  if (rs) GVK_LAUNCH((attn_fwd_kernel<DROP, true>), grid, dim3(256), lds, stream, (const bf16*)qkv, (bf16*)out, lse, T, H, ld_qkv, ld_out, scale * 1.44269504088896340736f, dr);
+  else GVK_LAUNCH((attn_fwd_kernel<DROP, false>), grid, dim3(256), lds, stream, (const bf16*)qkv, (bf16*)out, lse, T, H, ld_qkv, ld_out, scale * 1.44269504088896340736f, dr);
   return check_launch("attention_fwd_bf16");
 }
 }  // namespace gvk

@@ -6,7 +6,7 @@ import torch
 from gaviko_amd import lib, ops
 lib.require_device(); lib.load()
 dev = torch.device("cuda:0")
-l = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libprobe_attn.so"))
+l = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("PROBE_LIB", "libprobe_attn_false.so")))
 l.probe_attn_fwd.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2
 B, T, H = 4, 1033, 12
 inner = H * 64
