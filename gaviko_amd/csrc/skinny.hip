@@ -368,8 +368,9 @@ __global__ __launch_bounds__(256) void outer_partial_kernel(OuterArgs p) {
   const bool cok = c < C;
   f32x4 g4 = {1.f, 1.f, 1.f, 1.f}, b4 = {0.f, 0.f, 0.f, 0.f};
   if (p.ln_g != nullptr && cok) { g4 = *(const f32x4*)(p.ln_g + c); b4 = *(const f32x4*)(p.ln_b + c); }
-  // 16 rows (4 k-steps) per iteration; the next iteration's rows are requested before this iteration's MFMAs (one wave per SIMD has
-  // nothing else to hide the HBM round trip behind)
+  // 16 rows (4 k-steps) per chunk, kPF chunks (64 rows) requested ahead of the MFMAs that consume them: one wave per SIMD has nothing
+  // else to hide the HBM round trip behind, and a 65-row slab is then ONE round trip instead of five
+  constexpr int kPF = 4;
   auto fetch = [&](int rb, f32x4 (&x)[4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -379,13 +380,18 @@ __global__ __launch_bounds__(256) void outer_partial_kernel(OuterArgs p) {
       x[u] = (r < nr && cok) ? *(const f32x4*)(wrow + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  f32x4 xn[4];
-  fetch(0, xn);
-  for (int rb = 0; rb < nr; rb += 16) {
+  f32x4 xr[kPF][4];
+#pragma unroll
+  for (int i = 0; i < kPF; ++i) fetch(16 * i, xr[i]);
+  for (int rb0 = 0; rb0 < nr; rb0 += 16 * kPF) {
+#pragma unroll
+   for (int pi = 0; pi < kPF; ++pi) {
+    const int rb = rb0 + 16 * pi;
+    if (rb >= nr) break;                                 // wave-uniform
     f32x4 x[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) x[u] = xn[u];
-    if (rb + 16 < nr) fetch(rb + 16, xn);
+    for (int u = 0; u < 4; ++u) x[u] = xr[pi][u];
+    fetch(rb + 16 * kPF, xr[pi]);                        // refill this slot with the chunk kPF ahead (zeros past the slab)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int r = rb + 4 * u + kq;
@@ -415,6 +421,7 @@ __global__ __launch_bounds__(256) void outer_partial_kernel(OuterArgs p) {
         }
       }
     }
+   }
   }
   if (!cok) return;
 #pragma unroll
@@ -429,18 +436,27 @@ __global__ __launch_bounds__(256) void outer_partial_kernel(OuterArgs p) {
     }
 }
 
-// out[l][c] (transposed=0) or out[c][l] (transposed=1); colsum[c] optional
+// out[l][c] (transposed=0) or out[c][l] (transposed=1); colsum[c] optional.  Block = 64 columns x 4 groups of 16 slabs (all 16 loads of a
+// thread in flight; the serial 64-deep sum was a 6 us latency chain behind every outer product), LDS reduce in a fixed order: deterministic
 __global__ __launch_bounds__(256) void outer_final_kernel(const float* __restrict__ scratch, float* __restrict__ out, float* __restrict__ colsum,
                                                           int L, int C, int transposed, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;
-  if (c >= C) return;
-  float a4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-  for (int s = 0; s < kOuterSlabs; s += 4) {
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, l = blockIdx.y;
+  float a = 0.f;
+  if (c < C) {
+    float v[kOuterSlabs / 4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) a4[u] += scratch[((size_t)(s + u) * (L + 1) + l) * C + c];
+    for (int u = 0; u < kOuterSlabs / 4; ++u) v[u] = scratch[((size_t)(sg * (kOuterSlabs / 4) + u) * (L + 1) + l) * C + c];
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < kOuterSlabs / 4; ++u) a4[u & 3] += v[u];
+    a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   }
-  const float a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  part[sg][cl] = a;
+  __syncthreads();
+  if (sg != 0 || c >= C) return;
+  a = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
   if (l < L) {
     if (out == nullptr) return;
     float* o = transposed ? out + (size_t)c * L + l : out + (size_t)l * C + c;
@@ -750,7 +766,7 @@ extern "C" int gvk_outer_reduce(const gvk_outer_desc* d, void* stream) {
     default: return set_error(-2, "gvk_outer_reduce: L=%d unsupported (4, 8, 16, 20, 32, 64)", d->L);
   }
   if (rc) return rc;
-  GVK_LAUNCH(outer_final_kernel, dim3((d->C + 255) / 256, d->L + 1), dim3(256), 0, s, d->scratch, d->out, d->colsum, d->L, d->C,
+  GVK_LAUNCH(outer_final_kernel, dim3((d->C + 63) / 64, d->L + 1), dim3(256), 0, s, d->scratch, d->out, d->colsum, d->L, d->C,
                      d->transposed, d->accumulate);
   return check_launch("outer_final");
 }

@@ -743,9 +743,10 @@ class Engine:
         ops.skinny_down(x=lin, w=d(pre + ".proj_down.weight"), bias=d(pre + ".proj_down.bias"), ln_gamma=d(pre + ".norm.weight"),
                         ln_beta=d(pre + ".norm.bias"), mean=m["mean"], rstd=m["rstd"], y=m["lat"], w2=d(pre + ".qkv.weight"), y2=m["qkv"],
                         M=BN, C=C, L=Lt, L2=3 * Lt, act=0, w_layout=0, eps=1e-5)
-        ops.window_attn_fwd(qkv=m["qkv"], ctx=m["ctx"], lse=m["lse"], B=B, D=self.grid[0], H=self.grid[1], W=self.grid[2],
-                            kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt, scale=C ** -0.5, drop_p=sv["attn_drop"],
-                            seed=2 * i, seed_ptr=ws["seed"])
+        if "nowin" not in _ABLATE:
+          ops.window_attn_fwd(qkv=m["qkv"], ctx=m["ctx"], lse=m["lse"], B=B, D=self.grid[0], H=self.grid[1], W=self.grid[2],
+                              kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt, scale=C ** -0.5, drop_p=sv["attn_drop"],
+                              seed=2 * i, seed_ptr=ws["seed"])
         second = {}
         if gpa_local:                                       # ll = QuickGELU(proj_down(L')) (gaviko.py:156) of the rows this launch produces
             gpre, _ = self._gpa_names(i)
@@ -1123,7 +1124,7 @@ class Engine:
 
     def _gpa_bwd_params(self, ws, sv, gv, i, dGout, M, B, par):
         """Off the critical path: every parameter gradient of the GPA module (reads dGout, dzx, dzl, saved activations)."""
-        if "noside" in _ABLATE:
+        if "noside" in _ABLATE or "noparams" in _ABLATE:
             return
         pre, names = self._gpa_names(i)
         d, C, Lt, P, T, N = self._d, self.C, self.Lat, self.P, self.T, self.N
@@ -1495,9 +1496,10 @@ class Engine:
         ops.skinny_down(x=dLout, w=wup, y=bw["dctx"], M=BN, C=C, L=Lt, act=0, w_layout=1, drop_p=pd, seed=seed_p, seed_ptr=sp)
         ops.outer_reduce(narrow=m["ctx"], wide=dLout, scratch=sc, out=gv[pre + ".proj_up.weight"], colsum=gv[pre + ".proj_up.bias"],
                          M=BN, C=C, L=Lt, transposed=1, accumulate=acc, drop_p=pd, seed=seed_p, seed_ptr=sp)
-        ops.window_attn_bwd(qkv=m["qkv"], ctx=m["ctx"], lse=m["lse"], dctx=bw["dctx"], delta=bw["wdelta"], dqkv=bw["dqkv"], B=B,
-                            D=self.grid[0], H=self.grid[1], W=self.grid[2], kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt,
-                            scale=C ** -0.5, drop_p=sv["attn_drop"], seed=seed_a, seed_ptr=sp)
+        if "nowin" not in _ABLATE:
+            ops.window_attn_bwd(qkv=m["qkv"], ctx=m["ctx"], lse=m["lse"], dctx=bw["dctx"], delta=bw["wdelta"], dqkv=bw["dqkv"], B=B,
+                                D=self.grid[0], H=self.grid[1], W=self.grid[2], kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt,
+                                scale=C ** -0.5, drop_p=sv["attn_drop"], seed=seed_a, seed_ptr=sp)
         wqkv = d(pre + ".qkv.weight")
         ops.skinny_down(x=bw["dqkv"], w=wqkv, y=bw["dlat"], M=BN, C=3 * Lt, L=Lt, act=0, w_layout=1)
         wd = d(pre + ".proj_down.weight")
