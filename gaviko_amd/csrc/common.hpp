@@ -121,11 +121,12 @@ int set_error(int code, const char* fmt, ...);
 // serialises three forked branches on this runtime (tools/probe/probe_streams.hip) -- exact stream/event semantics.
 bool plan_recording();
 void plan_push(std::function<void()>&& node);
+void plan_push_launch(hipStream_t stream, std::function<void()>&& node);   // same; GAVIKO_HIP_ABLATE=sidenop swaps side-stream kernels for empty ones
 
 template <typename... KArgs, typename... Args>
 inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned lds, hipStream_t stream, Args... args) {
   if (plan_recording())
-    plan_push([=]() { hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...); });
+    plan_push_launch(stream, [=]() { hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...); });
   hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...);
 }
 #define GVK_LAUNCH(kernel, grid, block, lds, stream, ...) ::gvk::launch(kernel, grid, block, lds, stream, __VA_ARGS__)

@@ -29,6 +29,8 @@ int check_launch(const char* what) {
 // ---- launch plans ---------------------------------------------------------------------------------------------------------
 struct Plan {
   std::vector<std::function<void()>> nodes;
+  hipStream_t first = nullptr;            // stream of the first recorded launch: the main stream of the step
+  bool has_first = false;
   std::vector<hipEvent_t> events;
   ~Plan() {
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
@@ -41,6 +43,20 @@ static std::vector<std::unique_ptr<Plan>> g_plans;
 static bool g_plan_timing = false;      // gvk_plan_set_timing: events of plans recorded from now on carry timestamps
 bool plan_recording() { return g_rec != nullptr; }
 void plan_push(std::function<void()>&& node) { g_rec->nodes.push_back(std::move(node)); }
+
+__global__ void nop_kernel() {}
+// Diagnostics (GAVIKO_HIP_ABLATE=sidenop, refused by bench.py without --allow-ablate): every launch on a stream other than the plan's
+// first keeps its place, stream and events but runs an empty kernel -- separates what the side streams cost the main one in dispatch
+// and synchronisation from what they cost in CUs and bandwidth.  Results are garbage.
+void plan_push_launch(hipStream_t stream, std::function<void()>&& node) {
+  static const bool sidenop = [] { const char* e = getenv("GAVIKO_HIP_ABLATE"); return e && strstr(e, "sidenop"); }();
+  if (!g_rec->has_first) { g_rec->first = stream; g_rec->has_first = true; }
+  if (sidenop && stream != g_rec->first) {
+    g_rec->nodes.push_back([=]() { hipLaunchKernelGGL(nop_kernel, dim3(1), dim3(64), 0, stream); });
+    return;
+  }
+  g_rec->nodes.push_back(std::move(node));
+}
 
 __global__ void seed_advance_kernel(unsigned long long* seed, unsigned long long inc) { seed[0] += inc; }
 // zero / copy as ordinary kernels: hipMemsetAsync issued inside a torch stream capture was executed immediately instead of

@@ -413,6 +413,8 @@ class Engine:
     def _stream(self, name):
         st = self._streams.get(name)
         if st is None:
+            # (confining the side streams to a CU subset with hipExtStreamCreateWithCUMask was measured: 676 -> 170-260 volumes/s for
+            #  every mask shape tried -- masked queues are far slower to dispatch on this runtime)
             st = self._streams[name] = torch.cuda.Stream(priority=SIDE_STREAM_PRIORITY)
         return st
 

@@ -13,7 +13,11 @@ f = max(glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"), key=os.path.getmtime)
 rows = [r for r in csv.DictReader(open(f))]
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    r["n"] = re.sub(r"\(.*", "", r["Kernel_Name"].replace("gvk::", "").replace("void ", ""))[:44]
+    name = r["Kernel_Name"]
+    mm = re.match(r"_ZN3gvk(\d+)", name)
+    if mm:                                                               # un-demangled template instance: keep the function name
+        name = name[mm.end():mm.end() + int(mm.group(1))]
+    r["n"] = re.sub(r"\(.*", "", name.replace("gvk::", "").replace("void ", ""))[:44]
 rows.sort(key=lambda r: r["s"])
 # last step = from the last patchify launch to the end
 starts = [i for i, r in enumerate(rows) if r["n"].startswith("patchify")]
@@ -27,7 +31,7 @@ for q, rs in byq.items():
     busy = sum(r["e"] - r["s"] for r in rs)
     print(f"queue {q}: {len(rs)} kernels, busy {busy / 1e3:.1f} us, first {(rs[0]['s'] - t0) / 1e3:.1f} last {(rs[-1]['e'] - t0) / 1e3:.1f}")
 # the backbone chain by kernel name (graph replays map capture streams to hardware queues freely, so queue ids do not identify it)
-main = [r for r in step if r["n"].startswith(("gemm_nt", "attn_", "_ZN3gvk13ln_fwd", "ln_fwd"))]
+main = [r for r in step if r["n"].startswith(("gemm_nt", "gemm8p", "attn_", "ln_fwd"))]
 gaps = []
 for a, b in zip(main, main[1:]):
     gaps.append((b["s"] - a["e"], a, b))
@@ -51,7 +55,7 @@ for (q, n), (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
 
 if len(sys.argv) > 3:   # dump a window: every dispatch between the k-th and (k+1)-th fc2-dgrad GEMM of the step
     k = int(sys.argv[3])
-    marks = [r for r in step if r["n"].startswith("gemm_nt_kernel<128, 128, 4")]
+    marks = [r for r in step if r["n"].startswith("gemm8p_kernel<4")]
     a, b = marks[k]["s"], marks[k + 1]["e"]
     print(f"window between fc2-dgrad #{k} and #{k + 1}: {(b - a) / 1e3:.1f} us")
     for r in step:
