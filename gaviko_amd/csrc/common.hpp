@@ -123,8 +123,13 @@ bool plan_recording();
 void plan_push(std::function<void()>&& node);
 void plan_push_launch(hipStream_t stream, std::function<void()>&& node);   // same; GAVIKO_HIP_ABLATE=sidenop swaps side-stream kernels for empty ones
 
+// LDS exclusion (runtime.hip): extra dynamic LDS for launches on a registered stream, so that its workgroups cannot share a CU with
+// the backbone kernels' (0 for every other stream)
+unsigned stream_lds_pad(hipStream_t stream, const void* kernel, unsigned lds);
+
 template <typename... KArgs, typename... Args>
 inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned lds, hipStream_t stream, Args... args) {
+  lds += stream_lds_pad(stream, (const void*)kernel, lds);
   if (plan_recording())
     plan_push_launch(stream, [=]() { hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...); });
   hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...);

@@ -16,6 +16,31 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
     for (int64_t j = i; j < n; ++j) out[j] = (bf16)in[j];
 }
 
+// Split-bf16 packing of a narrow fp32 operand into spare K columns of a bf16 GEMM operand, so that a rank-L fp32 product rides a bf16
+// MFMA GEMM at (nearly) fp32 accuracy: x = hi + lo with hi = bf16(x), lo = bf16(x - hi), and a.w ~ a_hi.w_hi + a_lo.w_hi + a_hi.w_lo
+// (the dropped lo.lo term is 2^-16 relative).  Activation side (weight_side = 0): columns [a_hi | a_lo | a_hi]; weight side:
+// [w_hi | w_hi | w_lo | b_hi | b_lo], the bias riding two constant-1 columns of the activation operand.  3 ca + 2 columns in all.
+__global__ __launch_bounds__(256) void pack_split_bf16_kernel(const float* __restrict__ a, int ca, const float* __restrict__ b,
+                                                              bf16* __restrict__ dst, int ldd, int col0, int rows, int weight_side) {
+  const int w = ca + (weight_side ? 1 : 0);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * w) return;
+  const int r = i / w, c = i - r * w;
+  bf16* d = dst + (size_t)r * ldd + col0;
+  if (c < ca) {
+    const float v = a[(size_t)r * ca + c];
+    const bf16 hi = (bf16)v, lo = (bf16)(v - (float)hi);
+    d[c] = hi;
+    d[ca + c] = weight_side ? hi : lo;
+    d[2 * ca + c] = weight_side ? lo : hi;
+  } else {
+    const float v = b != nullptr ? b[r] : 0.f;
+    const bf16 hi = (bf16)v;
+    d[3 * ca] = hi;
+    d[3 * ca + 1] = (bf16)(v - (float)hi);
+  }
+}
+
 // out[c][r] = in[r][c]; 64x64 tile through LDS (+1 pad), coalesced both sides.
 template <typename OUT, typename IN = float>
 __global__ __launch_bounds__(256) void transpose_cast_kernel(const IN* __restrict__ in, OUT* __restrict__ out, int rows, int cols) {
@@ -100,6 +125,16 @@ extern "C" int gvk_cast_f32_bf16(const float* in, void* out, int64_t n, void* st
   if (blocks > 2048) blocks = 2048;
   GVK_LAUNCH(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, (bf16*)out, n);
   return check_launch("cast_f32_bf16");
+}
+
+extern "C" int gvk_pack_split_bf16(const float* a, int ca, const float* b, void* dst, int ld_dst, int col0, int rows, int weight_side,
+                                   void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(a && dst && ca > 0 && rows > 0 && col0 >= 0 && col0 + 3 * ca + 2 <= ld_dst, "gvk_pack_split_bf16: bad arguments");
+  const long n = (long)rows * (ca + (weight_side ? 1 : 0));
+  GVK_LAUNCH(pack_split_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, ca, b, (bf16*)dst, ld_dst, col0, rows,
+             weight_side);
+  return check_launch("pack_split_bf16");
 }
 
 extern "C" int gvk_transpose_cast_f32_bf16(const float* in, void* out, int rows, int cols, void* stream) {

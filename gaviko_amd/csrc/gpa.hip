@@ -24,6 +24,7 @@ struct GpaArgs {
   // forward outputs / saved
   float* imp; float* gw;                     // [B][P], [B]
   float* enh;                                // [B][P][L]
+  bf16* enh16; int ld16, col16;              // optional split-bf16 copy of enh into row (b*T + p), columns col16.. of a GEMM operand (stride ld16)
   float* prm; float* qg; float* ql; float* cg; float* cl; float* lse_g; float* lse_l;   // [B][P][L] x5, [B][P] x2
   // backward
   const float* dcomb;                        // [B*T][L]  gradient wrt the combined latent (proj_up input)
@@ -61,75 +62,102 @@ __device__ __forceinline__ void ln_small_bwd(const float* x, float mean, float r
   for (int l = 0; l < L; ++l) { const float xh = (x[l] - mean) * rstd; dx_acc[l] += rstd * (dy[l] * g[l] - m1 - xh * m2); }
 }
 
-// ---- gates forward: one wave per sample
+// ---- forward: ONE launch, workgroup = one prompt of one sample, nine waves.
+// Waves 0-3 each take a quarter of the sample's global image tokens (gaviko.py:172-176, the reference's double slice: tokens 2P+2..),
+// waves 4-7 a quarter of its local tokens (:177-181): one round of four 80-byte rows per lane each, read straight from global memory
+// (the per-sample sets are 80 KB and L2-resident), merged through LDS in a fixed order.  Wave 8 evaluates the two gates of the sample
+// (cls_analyzer -> importance of THIS prompt, gl_balancer -> global/local weight; :160-170) meanwhile; wave 0 then fuses (:183-185).
+// The GPA result gates the MLP's second GEMM of the layer (the up-projection rides it as extra K columns), so the chain
+// LayerNorm -> gates -> cross-attention -> fuse is one dependent launch instead of two and a quarter as long.
+// No LDS staging of the tokens: 32 fat workgroups would have to wait for the backbone's GEMM workgroups to retire; these fit beside them.
 template <int L>
-__global__ __launch_bounds__(64) void gpa_gates_fwd_kernel(GpaArgs p) {
-  __shared__ float a1_s[64];
-  const int b = blockIdx.x, lane = threadIdx.x;
-  float cls[L], hn[L], gn[L];
-#pragma unroll
-  for (int l = 0; l < L; ++l) cls[l] = p.xl[((size_t)b * p.T + p.P) * L + l];
-  float mean, rstd;
-  ln_small<L>(cls, p.ca0_g, p.ca0_b, hn, mean, rstd);
-  float a = p.ca1_b[lane];
-#pragma unroll
-  for (int l = 0; l < L; ++l) a += p.ca1_w[lane * L + l] * hn[l];
-  a1_s[lane] = gelu_erf(a);
-  __syncthreads();
-  for (int q = lane; q < p.P; q += 64) {
-    float t = p.ca3_b[q];
-    for (int u = 0; u < 64; ++u) t += p.ca3_w[q * 64 + u] * a1_s[u];
-    p.imp[b * p.P + q] = sigmoidf_(t);
-  }
-  ln_small<L>(cls, p.gl0_g, p.gl0_b, gn, mean, rstd);
-  float t = p.gl1_b[0];
-#pragma unroll
-  for (int l = 0; l < L; ++l) t += p.gl1_w[l] * gn[l];
-  if (lane == 0) p.gw[b] = sigmoidf_(t);
-}
-
-// ---- cross attention of one prompt against one token set (global image tokens or local tokens of its sample) -----------
-// One wave per (prompt, token set): lanes over tokens, four tokens per lane in flight (their 80-byte latent rows are read
-// straight from global memory -- the per-sample sets are 80 KB and L2-resident -- as five 16-byte loads each), online
-// softmax per lane, merged across lanes at the end.  No LDS staging: the earlier form (8 prompts per 512-thread workgroup
-// around an 84 KB LDS copy of the tokens) put 16 fat workgroups on 16 CUs, where they had to wait for the backbone's
-// GEMM workgroups to retire; these 128-thread workgroups fit beside them anywhere.
-// ---- cross-attention forward: workgroup = one prompt of one sample; wave 0 = global image tokens (gaviko.py:172-176, the
-// reference's double slice: tokens 2P+2..), wave 1 = local tokens (:177-181); wave 0 then fuses (:183-185).
-template <int L>
-__global__ __launch_bounds__(128) void gpa_cross_fwd_kernel(GpaArgs p) {
-  __shared__ float cl_s[L];
+__global__ __launch_bounds__(576) void gpa_fwd_kernel(GpaArgs p) {
+  __shared__ float part_c[8][L], part_lse[8], gate_s[2];
   const int b = blockIdx.y, pi = blockIdx.x, wave = wave_id(), lane = lane_id();
   const size_t o = ((size_t)b * p.P + pi) * L;
-  // lane l owns element l of the per-prompt vectors while they are formed; they are then spread with lane shuffles
   const int ll_ = lane < L ? lane : 0;
+  if (wave == 8) {                                       // gates
+    __shared__ float dummy;
+    (void)dummy;
+    float cls[L], hn[L], gn[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) cls[l] = p.xl[((size_t)b * p.T + p.P) * L + l];
+    float mean, rstd;
+    ln_small<L>(cls, p.ca0_g, p.ca0_b, hn, mean, rstd);
+    float a = p.ca1_b[lane];
+#pragma unroll
+    for (int l = 0; l < L; ++l) a += p.ca1_w[lane * L + l] * hn[l];
+    const float t3 = p.ca3_b[pi] + wave_sum(p.ca3_w[pi * 64 + lane] * gelu_erf(a));
+    ln_small<L>(cls, p.gl0_g, p.gl0_b, gn, mean, rstd);
+    float t = p.gl1_b[0];
+#pragma unroll
+    for (int l = 0; l < L; ++l) t += p.gl1_w[l] * gn[l];
+    if (lane == 0) {
+      const float im = sigmoidf_(t3), gw = sigmoidf_(t);
+      gate_s[0] = im; gate_s[1] = gw;
+      p.imp[b * p.P + pi] = im;
+      if (pi == 0) p.gw[b] = gw;
+    }
+    __syncthreads();
+    return;
+  }
+  const int side = wave >> 2, quarter = wave & 3;
+  // lane l owns element l of the per-prompt vectors while they are formed; they are then spread with lane shuffles
   const float pr_l = p.xl[((size_t)b * p.T + pi) * L + ll_];
-  const float* wq = wave == 0 ? p.wgq : p.wlq;
-  float q_l = (wave == 0 ? p.bgq : p.blq)[ll_];
+  const float* wq = side == 0 ? p.wgq : p.wlq;
+  float q_l = (side == 0 ? p.bgq : p.blq)[ll_];
 #pragma unroll
   for (int l = 0; l < L; ++l) q_l = __builtin_fmaf(wq[ll_ * L + l], __shfl(pr_l, l, 64), q_l);
   q_l *= p.scale;                                        // scale folded into the query
   float q[L], c[L], lse;
 #pragma unroll
   for (int l = 0; l < L; ++l) q[l] = __shfl(q_l, l, 64);
-  if (wave == 0) cross_one<L>(q, p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L, p.T - (2 * p.P + 2), lane, c, lse);
-  else cross_one<L>(q, p.ll + (size_t)b * p.N * L, p.N, lane, c, lse);
+  const float* base = side == 0 ? p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L : p.ll + (size_t)b * p.N * L;
+  const int n = side == 0 ? p.T - (2 * p.P + 2) : p.N;
+  const int per = (n + 3) >> 2, lo = quarter * per, cnt = min(per, n - lo);
+  if (cnt > 0) {
+    cross_one<L>(q, base + (size_t)lo * L, cnt, lane, c, lse);
+  } else {
+    lse = -INFINITY;
+#pragma unroll
+    for (int l = 0; l < L; ++l) c[l] = 0.f;
+  }
   float c_l = 0.f;
 #pragma unroll
   for (int l = 0; l < L; ++l) c_l = (lane == l) ? c[l] : c_l;
-  if (wave == 1) {
-    if (lane < L) { cl_s[lane] = c_l; p.ql[o + lane] = q_l; p.cl[o + lane] = c_l; }
-    if (lane == 0) p.lse_l[b * p.P + pi] = lse;
-  }
+  if (lane < L) part_c[wave][lane] = c_l;
+  if (lane == 0) part_lse[wave] = lse;
+  if (wave == 4 && lane < L) p.ql[o + lane] = q_l;
   __syncthreads();
-  if (wave == 0) {
-    const float gw = p.gw[b], im = p.imp[b * p.P + pi];
-    if (lane < L) {
-      p.enh[o + lane] = (gw * c_l + (1.f - gw) * cl_s[lane]) * im;
-      p.prm[o + lane] = pr_l; p.qg[o + lane] = q_l; p.cg[o + lane] = c_l;
+  if (wave != 0) return;
+  float cs[2], ls[2];
+#pragma unroll
+  for (int sd = 0; sd < 2; ++sd) {                       // fixed-order merge of the four quarters (quarter 0 is never empty)
+    float m = part_lse[4 * sd];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) m = fmaxf(m, part_lse[4 * sd + k]);
+    float st = 0.f, acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float w = __expf(part_lse[4 * sd + k] - m);  // empty quarter: exp(-inf) = 0
+      st += w;
+      acc = __builtin_fmaf(w, part_c[4 * sd + k][ll_], acc);
     }
-    if (lane == 0) p.lse_g[b * p.P + pi] = lse;
+    cs[sd] = acc / st;
+    ls[sd] = m + __logf(st);
   }
+  const float im = gate_s[0], gw = gate_s[1];
+  if (lane < L) {
+    const float e = (gw * cs[0] + (1.f - gw) * cs[1]) * im;
+    p.enh[o + lane] = e;
+    if (p.enh16 != nullptr) {                          // split-bf16 form [hi | lo | hi] (elementwise.hip: pack_split_bf16_kernel)
+      bf16* d16 = p.enh16 + ((size_t)b * p.T + pi) * p.ld16 + p.col16;
+      const bf16 hi = (bf16)e;
+      d16[lane] = hi; d16[L + lane] = (bf16)(e - (float)hi); d16[2 * L + lane] = hi;
+    }
+    p.prm[o + lane] = pr_l; p.qg[o + lane] = q_l; p.cg[o + lane] = cs[0]; p.cl[o + lane] = cs[1];
+  }
+  if (lane == 0) { p.lse_g[b * p.P + pi] = ls[0]; p.lse_l[b * p.P + pi] = ls[1]; }
 }
 
 // ---- backward, prompt side: same workgroup shape as the forward (wave 0 global, wave 1 local)
@@ -345,6 +373,7 @@ static void fill_gpa(GpaArgs& a, const gvk_gpa_desc* d) {
   a.dqg = d->dqg; a.dql = d->dql; a.dcg = d->dcg; a.dcl = d->dcl; a.delta_g = d->delta_g; a.delta_l = d->delta_l; a.dprm = d->dprm;
   a.dcls = d->dcls; a.gate_partials = d->gate_partials; a.dzx = d->dzx; a.dzl = d->dzl;
   a.B = d->B; a.T = d->T; a.N = d->N; a.P = d->P; a.scale = d->scale;
+  a.enh16 = (bf16*)d->enh16; a.ld16 = d->ld16; a.col16 = d->col16;
 }
 
 }  // namespace gvk
@@ -375,11 +404,10 @@ extern "C" int gvk_gpa_fwd(const gvk_gpa_desc* d, void* stream) {
   GpaArgs a{};
   fill_gpa(a, d);
   hipStream_t s = (hipStream_t)stream;
-  GVK_GPA_LAUNCH(gpa_gates_fwd_kernel, dim3(d->B), dim3(64), 0);
-  rc = check_launch("gpa_gates_fwd");
-  if (rc) return rc;
-  GVK_GPA_LAUNCH(gpa_cross_fwd_kernel, dim3(d->P, d->B), dim3(128), 0);
-  return check_launch("gpa_cross_fwd");
+  GVK_REQUIRE(d->enh16 == nullptr || (d->ld16 >= d->col16 + 3 * d->L && d->col16 >= 0), "gvk_gpa_fwd: enh16 slot out of range");
+  GVK_REQUIRE(d->P <= 64, "gvk_gpa_fwd: P=%d > 64", d->P);
+  GVK_GPA_LAUNCH(gpa_fwd_kernel, dim3(d->P, d->B), dim3(576), 0);
+  return check_launch("gpa_fwd");
 }
 
 extern "C" int gvk_gpa_bwd(const gvk_gpa_desc* d, void* stream) {

@@ -181,6 +181,8 @@ static int check_proj(const gvk_rowproj_desc* pj, int C, const char* who) {
 }
 static int launch_proj(DownArgs& a, const gvk_rowproj_desc* pj, hipStream_t s, const char* who) {
   a.w = pj->w; a.bias = pj->bias; a.y = pj->y; a.z = pj->z; a.act = pj->act; a.w_layout = pj->w_layout;
+  a.ysplit = (bf16*)pj->y_split; a.ysplit_ld = pj->ld_split; a.ysplit_col = pj->col_split;
+  GVK_REQUIRE(pj->y_split == nullptr || (pj->col_split >= 0 && pj->col_split + 3 * pj->L <= pj->ld_split), "%s: y_split slot out of range", who);
   int rc = launch_side_down(a, pj->L, s);                 // 16-row tiles on the fp32 matrix cores (sidepass.hip) where they apply
   if (rc == 1) rc = launch_row_down(a, pj->L, s);
   if (rc == 1) return set_error(-2, "%s: the fused projection covers L in {4, 8, 16, 20} and C >= 128 (got L=%d, C=%d): use gvk_skinny_down", who, pj->L, a.C);

@@ -289,6 +289,11 @@ __device__ __forceinline__ void row_down_pass(const DownArgs& p, float* Wc, floa
       if (r < n) {
         if (p.z) p.z[(size_t)rows[r] * L + lane] = zz;
         if (p.y) p.y[(size_t)rows[r] * L + lane] = yv;
+        if (p.ysplit != nullptr) {                       // elementwise.hip: pack_split_bf16_kernel, activation side
+          bf16* d16 = p.ysplit + (size_t)rows[r] * p.ysplit_ld + p.ysplit_col;
+          const bf16 hi = (bf16)yv;
+          d16[lane] = hi; d16[L + lane] = (bf16)(yv - (float)hi); d16[2 * L + lane] = hi;
+        }
       }
     }
     if (p.w2 != nullptr) {

@@ -29,8 +29,6 @@ int check_launch(const char* what) {
 // ---- launch plans ---------------------------------------------------------------------------------------------------------
 struct Plan {
   std::vector<std::function<void()>> nodes;
-  hipStream_t first = nullptr;            // stream of the first recorded launch: the main stream of the step
-  bool has_first = false;
   std::vector<hipEvent_t> events;
   ~Plan() {
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
@@ -44,17 +42,42 @@ static bool g_plan_timing = false;      // gvk_plan_set_timing: events of plans 
 bool plan_recording() { return g_rec != nullptr; }
 void plan_push(std::function<void()>&& node) { g_rec->nodes.push_back(std::move(node)); }
 
+// ---- LDS exclusion ------------------------------------------------------------------------------------------------------------
+// A workgroup that asks for `pad` bytes of (unused) dynamic LDS only fits on a CU with that much LDS free: with the pad above
+// 160 KiB - (a backbone workgroup's LDS) the side kernels of a registered stream never share a CU with a GEMM / attention
+// workgroup -- they take idle CUs or wait a tile -- instead of slowing the slowest tile of every backbone kernel.
+struct PadStream { hipStream_t s; unsigned pad; };
+static std::vector<PadStream> g_pad_streams;
+static std::mutex g_pad_mu;
+static std::vector<const void*> g_pad_kernels;    // kernels whose dynamic-LDS limit has been raised
+unsigned stream_lds_pad(hipStream_t stream, const void* kernel, unsigned lds) {
+  if (g_pad_streams.empty()) return 0;
+  for (const PadStream& ps : g_pad_streams)
+    if (ps.s == stream) {
+      std::lock_guard<std::mutex> lk(g_pad_mu);
+      bool known = false;
+      for (const void* k : g_pad_kernels) known |= k == kernel;
+      if (!known) {
+        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + ps.pad));
+        if (e != hipSuccess) fprintf(stderr, "gaviko_hip: hipFuncSetAttribute(%u B dynamic LDS): %s\n", lds + ps.pad, hipGetErrorString(e));
+        g_pad_kernels.push_back(kernel);
+      }
+      return ps.pad;
+    }
+  return 0;
+}
+
 __global__ void nop_kernel() {}
-// Diagnostics (GAVIKO_HIP_ABLATE=sidenop, refused by bench.py without --allow-ablate): every launch on a stream other than the plan's
-// first keeps its place, stream and events but runs an empty kernel -- separates what the side streams cost the main one in dispatch
-// and synchronisation from what they cost in CUs and bandwidth.  Results are garbage.
+// Diagnostics (GAVIKO_HIP_ABLATE=sidenop|locnop|gpanop, refused by bench.py without --allow-ablate): every launch on a stream the
+// engine registered with gvk_plan_nop_stream keeps its place, stream and events but runs an empty kernel -- separates what the side
+// streams cost the main one in dispatch and synchronisation from what they cost in CUs and bandwidth.  Results are garbage.
+static std::vector<hipStream_t> g_nop_streams;
 void plan_push_launch(hipStream_t stream, std::function<void()>&& node) {
-  static const bool sidenop = [] { const char* e = getenv("GAVIKO_HIP_ABLATE"); return e && strstr(e, "sidenop"); }();
-  if (!g_rec->has_first) { g_rec->first = stream; g_rec->has_first = true; }
-  if (sidenop && stream != g_rec->first) {
-    g_rec->nodes.push_back([=]() { hipLaunchKernelGGL(nop_kernel, dim3(1), dim3(64), 0, stream); });
-    return;
-  }
+  for (hipStream_t s : g_nop_streams)
+    if (s == stream) {
+      g_rec->nodes.push_back([=]() { hipLaunchKernelGGL(nop_kernel, dim3(1), dim3(64), 0, stream); });
+      return;
+    }
   g_rec->nodes.push_back(std::move(node));
 }
 
@@ -77,6 +100,21 @@ __global__ void scale_kernel(float* x, float alpha, long n) {
   if (i < n) x[i] *= alpha;
 }
 }  // namespace gvk
+
+extern "C" int gvk_stream_set_lds_pad(void* stream, int bytes) {
+  using namespace gvk;
+  GVK_REQUIRE(bytes >= 0 && bytes <= 128 * 1024, "gvk_stream_set_lds_pad: %d bytes out of range", bytes);
+  std::lock_guard<std::mutex> lk(g_pad_mu);
+  for (PadStream& ps : g_pad_streams)
+    if (ps.s == (hipStream_t)stream) { ps.pad = (unsigned)bytes; return 0; }
+  g_pad_streams.push_back({(hipStream_t)stream, (unsigned)bytes});
+  return 0;
+}
+
+extern "C" int gvk_plan_nop_stream(void* stream) {
+  gvk::g_nop_streams.push_back((hipStream_t)stream);
+  return 0;
+}
 
 extern "C" int gvk_plan_begin(void) {
   using namespace gvk;
@@ -228,7 +266,7 @@ extern "C" int gvk_scale_f32(float* x, float alpha, long n, void* stream) {
 }
 
 extern "C" const char* gvk_last_error(void) { return gvk::g_err; }
-extern "C" int gvk_abi_version(void) { return 5; }
+extern "C" int gvk_abi_version(void) { return 6; }
 
 extern "C" int gvk_device_check(void) {
   int dev = 0;

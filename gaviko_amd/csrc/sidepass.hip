@@ -499,6 +499,7 @@ int launch_side_down(const DownArgs& a, int L, hipStream_t s) {
   const int ngw = groups_per_wave(a.C);
   if (!side_enabled() || L != kSL || ngw == 0 || a.mode < 0 || a.mode > 2 || (a.w2 != nullptr && a.L2 > 64)) return 1;
   if (a.mode != 0 && (a.w2 != nullptr || a.drop_thresh != 0u)) return 1;
+  if (a.ysplit != nullptr) return 1;                     // the split-bf16 operand copy is written by the row-per-wave kernel only
   static const bool ln_modes = getenv("GAVIKO_HIP_SIDE_LN") != nullptr && getenv("GAVIKO_HIP_SIDE_LN")[0] == '1';   // A/B switch, see DESIGN.md section 7
   if (a.mode != 0 && !ln_modes) return 1;
   const dim3 grid((a.M + 15) / 16), block(64 * kSW);

@@ -694,6 +694,31 @@ extern "C" int gvk_skinny_down(const gvk_skinny_down_desc* d, void* stream) {
   }
 }
 
+namespace gvk {
+// out[b*T + p][:] += (enh[b][p][:] - lat[b*T + p][:]) . W^T for the P prompt rows of every sample: when the up-projection of the plain
+// latents rides a GEMM (K-concatenation), only the prompt rows -- whose latents the GPA replaces (gaviko.py:183-187) -- are left to fix.
+__global__ __launch_bounds__(256) void prompt_up_fix_kernel(const float* __restrict__ enh, const float* __restrict__ lat, const float* __restrict__ w,
+                                                            float* __restrict__ out, int T, int P, int C, int L) {
+  __shared__ float dl[64];
+  const int b = blockIdx.y, pi = blockIdx.x;
+  const size_t row = (size_t)b * T + pi;
+  if ((int)threadIdx.x < L) dl[threadIdx.x] = enh[((size_t)b * P + pi) * L + threadIdx.x] - lat[row * L + threadIdx.x];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f;
+    for (int l = 0; l < L; ++l) a = __builtin_fmaf(dl[l], w[(size_t)c * L + l], a);
+    out[row * C + c] += a;
+  }
+}
+}  // namespace gvk
+
+extern "C" int gvk_prompt_up_fix(const float* enh, const float* lat, const float* w, float* out, int B, int T, int P, int C, int L, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(enh && lat && w && out && B > 0 && P > 0 && P <= T && C > 0 && L > 0 && L <= 64, "gvk_prompt_up_fix: bad arguments");
+  GVK_LAUNCH(prompt_up_fix_kernel, dim3(P, B), dim3(256), 0, (hipStream_t)stream, enh, lat, w, out, T, P, C, L);
+  return check_launch("prompt_up_fix");
+}
+
 extern "C" int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(d && d->lat && d->w && d->out, "gvk_skinny_up: null pointer");

@@ -20,6 +20,7 @@ struct DownArgs {
   //   mode 3: QuickGELU applied to the input rows before the projection (DVPT share_MLP, dvpt.py:38)
   int mode;
   bf16* y16;
+  bf16* ysplit; int ysplit_ld, ysplit_col;                // row-per-wave kernel: split-bf16 copy [hi | lo | hi] of y into spare K columns of a GEMM operand
   const float* dy; const float* mean_in; const float* rstd_in; const float* dres; float* dx; bf16* dx16;
 };
 

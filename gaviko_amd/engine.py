@@ -195,6 +195,12 @@ class Engine:
         self._fuse_proj = (kind == "gaviko" and not self.fp32 and ops.rowproj_supported(self.Lat, dim)
                            and os.environ.get("GAVIKO_HIP_FUSE_PROJ", "1") != "0")
         self._fuse_local = kind == "gaviko" and ops.side_tile_supported(self.Lat, dim)
+        # GPA up-projection as K-concatenation of the MLP's second Linear: 64 spare K columns carry the rank-L product in split-bf16 form,
+        # A' = [act | lat_hi | lat_lo | lat_hi | 1 | 1], W' = [W_fc2 | Wup_hi | Wup_hi | Wup_lo | b_hi | b_lo] (fp32-grade: the dropped
+        # lo.lo term is 2^-16 relative), so x + ff(x) + proj_up(.) (gaviko.py:187 after vision_transformer.py:34) is ONE GEMM and the
+        # main stream loses a full read-modify-write pass over the token stream per layer
+        self._fuse_up = (kind == "gaviko" and not self.fp32 and 3 * self.Lat + 2 <= 64 and os.environ.get("GAVIKO_HIP_FUSE_UP", "1") != "0")
+        self.ldx = self.mlp + 64 if self._fuse_up else self.mlp      # row stride of the MLP hidden buffers
         self._marks = []
         self.plan_marks = {}                # plan id -> [(name, event id)]
         self._bucket_marks = {}             # (stream kind, layer) -> event of the pass being issued / recorded: gradients of that layer final
@@ -266,7 +272,12 @@ class Engine:
             for tag, nm in (("qkv", self.names.qkv_weight(i)), ("out", self.names.attn(i) + ".to_out.0.weight"),
                             ("fc1", self.names.mlp(i) + ".net.1.weight"), ("fc2", self.names.mlp(i) + ".net.4.weight")):
                 src = self._d(nm).contiguous()
-                if stale:
+                if stale and tag == "fc2" and self._fuse_up:
+                    buf = w.get(f"fc2{i}")
+                    if buf is None:
+                        buf = w[f"fc2{i}"] = torch.zeros((self.C, self.ldx), dtype=self.adt, device=src.device)
+                    buf[:, :self.mlp].copy_(src)                 # columns mlp.. are packed from the trainable proj_up inside every step
+                elif stale:
                     w[f"{tag}{i}"] = ops.to_operand(src, None if self.fp32 else w.get(f"{tag}{i}"), self.adt)   # fp32: the parameter itself
                 if need_dgrad and (stale or not self._have_dgrad):
                     w[f"{tag}{i}_t"] = ops.transpose_operand(src, w.get(f"{tag}{i}_t"), self.adt)
@@ -317,8 +328,10 @@ class Engine:
         ws["qkv"] = [z(M, 3 * C, bf16) for _ in range(nsave)]
         ws["ctx"] = [z(M, C, bf16) for _ in range(nsave)]
         ws["lse"] = [torch.zeros((B, self.heads, T), device=device) for _ in range(nsave)]
-        ws["pre"] = [z(M, self.mlp, bf16) for _ in range(nsave)] if train else [None]
-        ws["act"] = z(M, self.mlp, bf16)
+        ws["pre"] = [z(M, self.ldx, bf16) for _ in range(nsave)] if train else [None]
+        ws["act"] = z(M, self.ldx, bf16)
+        if self._fuse_up:
+            ws["act"][:, self.mlp + 3 * self.Lat: self.mlp + 3 * self.Lat + 2] = 1.0     # the two bias columns (b_hi, b_lo); the rest of the slot stays 0
         ws["stat"] = [[torch.zeros(M, device=device) for _ in range(4)] for _ in range(nsave)]   # mean1, rstd1, mean2, rstd2
         ws["pooled"] = torch.zeros((B, C), device=device)
         if self.kind == "gaviko":
@@ -416,6 +429,11 @@ class Engine:
             # (confining the side streams to a CU subset with hipExtStreamCreateWithCUMask was measured: 676 -> 170-260 volumes/s for
             #  every mask shape tried -- masked queues are far slower to dispatch on this runtime)
             st = self._streams[name] = torch.cuda.Stream(priority=SIDE_STREAM_PRIORITY)
+            pad = int(os.environ.get(f"GAVIKO_HIP_LDS_PAD_{name.upper()}", os.environ.get("GAVIKO_HIP_LDS_PAD", "0")))
+            if pad:
+                L.check(L.load().gvk_stream_set_lds_pad(st.cuda_stream, pad), "gvk_stream_set_lds_pad")
+            if "sidenop" in _ABLATE or f"{name}nop" in _ABLATE:
+                L.load().gvk_plan_nop_stream(st.cuda_stream)
         return st
 
     def _ev_record(self, stream):
@@ -610,6 +628,12 @@ class Engine:
             loc, gpa = self._stream("loc"), self._stream("gpa")
             self._wait("loc", None)                                  # Lc[0] written by the patch GEMM
             self._wait("gpa", None)
+            fuse_up = self._fuse_up and sv["bdrop"] <= 0             # (dropout behind fc2 must not touch the up-projection)
+            if fuse_up and "noside" not in _ABLATE:
+                with torch.cuda.stream(gpa):                         # the trainable half of W': off the main stream, once per step
+                    for i in range(self.depth):
+                        pre, _ = self._gpa_names(i)
+                        ops.pack_split_bf16(d(pre + ".proj_up.weight"), self._w16[f"fc2{i}"], self.mlp, C, b=d(pre + ".proj_up.bias"), weight_side=True)
         for i in range(self.depth):
             si = i if train else 0
             gi, go = (i, i + 1) if train else (i & 1, (i + 1) & 1)
@@ -646,13 +670,23 @@ class Engine:
                 self._wait("gpa", "loc")                             # ll ready (the MWSA chain projects its own L')
                 with torch.cuda.stream(gpa):
                     self._gpa_fwd_latents(ws, i, si, ws["G1"][si], ws["Lc"][go], M, B, False)
-            self._mlp_block_fwd(ws, i, si, ws["G1"][si], gout, Mi, train, sv["bdrop"])
+            up_in_fc2 = gaviko and fused and fuse_up
+            # fc2 carries proj_up of the PLAIN latents of every row (ready right behind the LayerNorm); the GPA has the two GEMMs' time
+            # to finish, and only the P prompt rows it replaces are fixed up afterwards
+            self._mlp_block_fwd(ws, i, si, ws["G1"][si], gout, Mi, train, sv["bdrop"],
+                                up_in_fc2=up_in_fc2)
             if self.kind == "adaptformer":
                 self._adapter_fwd_up(ws, i, si, gout, Mi)
             if self.kind == "dvpt":
                 self._dvpt_fwd_up(ws, i, si, gout, Mi)
             self._mark(f"f{i}:mlp")
-            if gaviko:
+            if gaviko and up_in_fc2:
+                self._wait(None, "gpa")                              # enh ready
+                if "noside" not in _ABLATE:
+                    pre, _ = self._gpa_names(i)
+                    g = ws["gp"][si]
+                    ops.prompt_up_fix(g["enh"], g["xl"], d(pre + ".proj_up.weight"), ws["G"][go], B, self.T, self.P, C, self.Lat)
+            elif gaviko:
                 self._wait(None, "gpa")                              # enh ready
                 self._gpa_fwd_up(ws, i, si, ws["G"][go], M)
             self._mark(f"f{i}:end")
@@ -715,22 +749,25 @@ class Engine:
         if fused:
             pre, _ = self._gpa_names(i)
             g = ws["gp"][si]
+            split = dict(y_split=ws["act"], col_split=self.mlp) if self._fuse_up else {}      # the plain latents ride fc2 (self._fuse_up)
             ops.layernorm_fwd_proj(g1, d(m + ".net.0.weight"), d(m + ".net.0.bias"), M, C, y16=ws["xn"], mean=st[2], rstd=st[3],
-                                   w=d(pre + ".proj_down.0.weight"), bias=d(pre + ".proj_down.0.bias"), z=g["zx"], y=g["xl"], act=1, w_layout=0)
+                                   w=d(pre + ".proj_down.0.weight"), bias=d(pre + ".proj_down.0.bias"), z=g["zx"], y=g["xl"], act=1, w_layout=0,
+                                   **split)
         else:
             ops.layernorm_fwd(g1, d(m + ".net.0.weight"), d(m + ".net.0.bias"), M, C, y16=ws["xn"], mean=st[2], rstd=st[3])
 
-    def _mlp_block_fwd(self, ws, i, si, g1, gout, M, train, pdrop=0.0):
+    def _mlp_block_fwd(self, ws, i, si, g1, gout, M, train, pdrop=0.0, up_in_fc2=False):
         nm, w, d, C = self.names, self._w16, self._d, self.C
         m = nm.mlp(i)
         if self._keep_inputs:
             ops.copy_(ws["sav"]["xn2"][si], ws["xn"])
         self._gemm(ws["xn"], w[f"fc1{i}"], M, ws["pre"][si] if train else None, epilogue=ops.EPI_BIAS_GELU_BF16, out1=ws["act"],
                     bias=d(m + ".net.1.bias"),           # inference keeps no pre-activation (out0 = NULL)
-                    drop_p=pdrop, seed=SEED_LAYER + 8 * i + 2, seed_ptr=ws["seed"])
+                    ldo=self.ldx, drop_p=pdrop, seed=SEED_LAYER + 8 * i + 2, seed_ptr=ws["seed"])
         if self._keep_inputs:
             ops.copy_(ws["sav"]["act"][si], ws["act"])
         self._gemm(ws["act"], w[f"fc2{i}"], M, gout, epilogue=ops.EPI_BIAS_RES_F32, bias=d(m + ".net.4.bias"), res=g1,
+                   K=self.ldx if up_in_fc2 else self.mlp,      # the GPA latents ride this GEMM as 64 extra K columns (self._fuse_up)
                    drop_p=pdrop, seed=SEED_LAYER + 8 * i + 3, seed_ptr=ws["seed"])
 
     # ---- GAViKO side paths --------------------------------------------------------------------------------------
@@ -775,7 +812,7 @@ class Engine:
         ops.skinny_down(x=lnew, w=d(pre + ".proj_down.0.weight"), bias=d(pre + ".proj_down.0.bias"), z=g["zl"], y=g["ll"], M=B * self.N,
                         C=self.C, L=self.Lat, act=1, w_layout=0)
 
-    def _gpa_fwd_latents(self, ws, i, si, g1, lnew, M, B, project):
+    def _gpa_fwd_latents(self, ws, i, si, g1, lnew, M, B, project, enh16=None):
         if "noside" in _ABLATE:
             return
         pre, names = self._gpa_names(i)
@@ -785,9 +822,10 @@ class Engine:
             ops.skinny_down(x=g1, w=d(pre + ".proj_down.0.weight"), bias=d(pre + ".proj_down.0.bias"), z=g["zx"], y=g["xl"], M=M, C=C, L=Lt,
                             act=1, w_layout=0)
             self._gpa_down_local(ws, i, si, lnew, B)
+        slot = {} if enh16 is None else dict(enh16=enh16, ld16=enh16.shape[-1], col16=self.mlp)
         ops.gpa_fwd(xl=g["xl"], ll=g["ll"], B=B, T=self.T, N=self.N, P=self.P, L=Lt, scale=Lt ** -0.5,
                     imp=g["imp"], gw=g["gw"], enh=g["enh"], prm=g["prm"], qg=g["qg"], ql=g["ql"], cg=g["cg"], cl=g["cl"],
-                    lse_g=g["lse_g"], lse_l=g["lse_l"], **{k: d(v) for k, v in names.items()})
+                    lse_g=g["lse_g"], lse_l=g["lse_l"], **slot, **{k: d(v) for k, v in names.items()})
 
     def _gpa_fwd_up(self, ws, i, si, gout, M):
         pre, _ = self._gpa_names(i)
@@ -954,7 +992,7 @@ class Engine:
             ssf = self.kind == "ssf"
             if ssf:                                                          # fc2 + ssf_2: dy = dGout, y = G[i+1] - G1[i]
                 self._ssf_linear_grad(ws, gv, m, 2, dGout, ws["G"][i + 1], M, C, y1=ws["G1"][i])
-            self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i],
+            self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i], ldaux=self.ldx,
                        drop_p=pd_, seed=SEED_LAYER + 8 * i + 2, seed_ptr=ws["seed"])
             if ssf:                                                          # fc1 + ssf_1: dy = d(pre-activation), y = saved pre-activation
                 self._ssf_linear_grad(ws, gv, m, 1, ws["dpre"], ws["pre"][i], M, self.mlp)

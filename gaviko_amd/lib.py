@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # side streams wrapped around onto the main stream's queue (tools/bench_reducer.py).  Must be set before the first HIP call.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-ABI_VERSION = 5                                   # gvk_abi_version() of the library these declarations describe
+ABI_VERSION = 6                                   # gvk_abi_version() of the library these declarations describe
 LIB_PATH = os.environ.get("GAVIKO_HIP_LIB") or os.path.join(_HERE, "libgaviko_hip.so")     # override: A/B runs of two builds
 
 
@@ -53,8 +53,8 @@ GpaDesc = _struct("GpaDesc",
                   ["xl", "ll", "ca0_g", "ca0_b", "ca1_w", "ca1_b", "ca3_w", "ca3_b", "gl0_g", "gl0_b", "gl1_w", "gl1_b",
                    "wgq", "bgq", "wlq", "blq", "imp", "gw", "enh", "prm", "qg", "ql", "cg", "cl", "lse_g", "lse_l",
                    "dcomb", "zx", "zl", "dimp", "dgw_part", "dqg", "dql", "dcg", "dcl", "delta_g", "delta_l", "dprm",
-                   "dcls", "gate_partials", "dzx", "dzl"],
-                  ["B", "T", "N", "P", "L"], ["scale"])
+                   "dcls", "gate_partials", "dzx", "dzl", "enh16"],
+                  ["B", "T", "N", "P", "L", "ld16", "col16"], ["scale"])
 SsfColgradDesc = _struct("SsfColgradDesc", ["dy", "y0", "y1", "pos", "s", "t", "ds", "dt", "scratch"],
                          ["M", "N", "ld_dy", "ld_y", "dy_f32", "y0_f32", "rows_in", "rows_out", "row_off"])
 DvptDesc = _struct("DvptDesc", ["z", "enh", "lse", "dcomb", "gate", "bu", "colsum_dy", "delta", "dz", "dgate"], ["B", "T", "P", "L", "C"], ["scale"])
@@ -62,7 +62,7 @@ AdamDesc = _struct("AdamDesc", ["ptr_tab", "blk_tab", "grad", "m", "v", "norm_sq
                    ["lr", "beta1", "beta2", "eps", "bias_c1", "bias_c2", "max_norm"])
 LossDesc = _struct("LossDesc", ["logits", "target", "weights", "loss", "dlogits", "meter"], ["B", "K", "kind", "reduction"], ["gamma", "eps"], i64=["ignore_index"])
 DropoutDesc = _struct("DropoutDesc", ["x", "out32", "out16", "seed_ptr"], ["M", "N", "ld", "rows_in", "rows_out", "row_off"], ["drop_p"], ["seed"])
-RowProjDesc = _struct("RowProjDesc", ["w", "bias", "y", "z"], ["L", "w_layout", "act"])
+RowProjDesc = _struct("RowProjDesc", ["w", "bias", "y", "z", "y_split"], ["L", "w_layout", "act", "ld_split", "col_split"])
 ReduceJob = _struct("ReduceJob", ["a", "b", "out", "a2"], ["M", "J", "L", "accumulate", "M2"])
 HeadDesc = _struct("HeadDesc", ["g", "ln_gamma", "ln_beta", "wh", "bh", "logits", "pooled", "dlogits", "dg", "dwh", "dbh"],
                    ["B", "T", "C", "K", "r0", "R", "accumulate"])
@@ -84,6 +84,8 @@ SIGNATURES = {
     "gvk_copy_f32_strided": [_P, _P, _I, _I, _I, _P],
     "gvk_cast_f32_bf16": [_P, _P, _L, _P],
     "gvk_transpose_cast_f32_bf16": [_P, _P, _I, _I, _P],
+    "gvk_pack_split_bf16": [_P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "gvk_prompt_up_fix": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gvk_patchify_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gvk_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "gvk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
@@ -151,7 +153,7 @@ NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, [
              "gvk_plan_begin": (C.c_int, []), "gvk_plan_end": (C.c_int, []), "gvk_plan_abort": (C.c_int, []),
              "gvk_plan_size": (C.c_int, [C.c_int]), "gvk_plan_replay": (C.c_int, [C.c_int]), "gvk_plan_free": (C.c_int, [C.c_int]),
              "gvk_plan_event_record": (C.c_int, [_P]), "gvk_plan_event_wait": (C.c_int, [_P, C.c_int]),
-             "gvk_plan_event_record_fenced": (C.c_int, [_P]), "gvk_plan_event_stream_wait": (C.c_int, [C.c_int, C.c_int, _P]),
+             "gvk_plan_event_record_fenced": (C.c_int, [_P]), "gvk_plan_nop_stream": (C.c_int, [_P]), "gvk_stream_set_lds_pad": (C.c_int, [_P, C.c_int]), "gvk_plan_event_stream_wait": (C.c_int, [C.c_int, C.c_int, _P]),
              "gvk_plan_set_timing": (C.c_int, [C.c_int]),
              "gvk_plan_event_elapsed": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)])}
 STRUCTS = {"gvk_gemm_desc": GemmDesc, "gvk_skinny_down_desc": SkinnyDownDesc, "gvk_skinny_up_desc": SkinnyUpDesc,

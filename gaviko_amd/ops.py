@@ -81,6 +81,24 @@ def cast_bf16(x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     return out
 
 
+def pack_split_bf16(a, dst, col0, rows, b=None, weight_side=False):
+    """Split-bf16 packing (hi + lo) of a narrow fp32 operand into 3*ca + 2 spare K columns of a bf16 GEMM operand (gaviko_hip.h)."""
+    _chk(a, torch.float32, "pack a", rows * a.shape[-1])
+    _chk(dst, torch.bfloat16, "pack dst", rows * dst.shape[-1])
+    _chk(b, torch.float32, "pack b", rows)
+    L.check(L.load().gvk_pack_split_bf16(L.ptr(a), a.shape[-1], L.ptr(b), L.ptr(dst), dst.shape[-1], col0, rows, int(weight_side), L.stream_ptr()),
+            "gvk_pack_split_bf16")
+
+
+def prompt_up_fix(enh, lat, w, out, B, T, P, C_, L_):
+    """out rows b*T + p (p < P) += (enh[b][p] - lat[b*T + p]) . w^T (gaviko_hip.h: gvk_prompt_up_fix)."""
+    _chk(enh, torch.float32, "prompt_up_fix enh", B * P * L_)
+    _chk(lat, torch.float32, "prompt_up_fix lat", B * T * L_)
+    _chk(w, torch.float32, "prompt_up_fix w", C_ * L_)
+    _chk(out, torch.float32, "prompt_up_fix out", B * T * C_)
+    L.check(L.load().gvk_prompt_up_fix(L.ptr(enh), L.ptr(lat), L.ptr(w), L.ptr(out), B, T, P, C_, L_, L.stream_ptr()), "gvk_prompt_up_fix")
+
+
 def copy_(dst: torch.Tensor, src: torch.Tensor) -> None:
     """Stream-ordered device copy of src into dst (same dtype, contiguous; dst may be larger)."""
     if dst.dtype != src.dtype or not dst.is_contiguous() or not src.is_contiguous() or dst.numel() < src.numel():
@@ -199,15 +217,18 @@ def rowproj_supported(L_: int, C_: int) -> bool:
     return L_ in (4, 8, 16, 20) and C_ % 4 == 0 and 128 <= C_ <= 1024
 
 
-def _rowproj(M, C_, w, y, bias, z, L_, w_layout, act):
+def _rowproj(M, C_, w, y, bias, z, L_, w_layout, act, y_split=None, col_split=0):
     _chk(w, torch.float32, "rowproj w", L_ * C_)
     _chk(y, torch.float32, "rowproj y", M * L_)
     _chk(bias, torch.float32, "rowproj bias", L_)
     _chk(z, torch.float32, "rowproj z", M * L_)
-    return L.RowProjDesc(w=L.ptr(w), bias=L.ptr(bias), y=L.ptr(y), z=L.ptr(z), L=L_, w_layout=w_layout, act=act)
+    _chk(y_split, torch.bfloat16, "rowproj y_split", 0 if y_split is None else M * y_split.shape[-1])
+    return L.RowProjDesc(w=L.ptr(w), bias=L.ptr(bias), y=L.ptr(y), z=L.ptr(z), y_split=L.ptr(y_split), L=L_, w_layout=w_layout, act=act,
+                         ld_split=0 if y_split is None else y_split.shape[-1], col_split=col_split)
 
 
-def layernorm_fwd_proj(x, gamma, beta, M, C_, *, y16, mean=None, rstd=None, eps=1e-5, w, y, bias=None, z=None, L_=ROWPROJ_L, w_layout=0, act=0):
+def layernorm_fwd_proj(x, gamma, beta, M, C_, *, y16, mean=None, rstd=None, eps=1e-5, w, y, bias=None, z=None, L_=ROWPROJ_L, w_layout=0, act=0,
+                       y_split=None, col_split=0):
     """LayerNorm forward + rank-L projection of the raw input rows (one pass over x)."""
     _chk(x, torch.float32, "ln x", M * C_)
     _chk(gamma, torch.float32, "ln gamma", C_)
@@ -215,7 +236,7 @@ def layernorm_fwd_proj(x, gamma, beta, M, C_, *, y16, mean=None, rstd=None, eps=
     _chk(y16, torch.bfloat16, "ln y16", M * C_)
     _chk(mean, torch.float32, "ln mean", M)
     _chk(rstd, torch.float32, "ln rstd", M)
-    d = _rowproj(M, C_, w, y, bias, z, L_, w_layout, act)
+    d = _rowproj(M, C_, w, y, bias, z, L_, w_layout, act, y_split, col_split)
     L.check(L.load().gvk_layernorm_fwd_proj(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y16), L.ptr(mean), L.ptr(rstd), M, C_, eps,
                                             C.byref(d), L.stream_ptr()), "gvk_layernorm_fwd_proj")
 
@@ -302,7 +323,7 @@ def _desc(cls, what, **kw):
         v = kw.pop(name, None)
         if ctype is C.c_void_p:
             if v is not None:
-                _chk(v, torch.int64 if name == "seed_ptr" else torch.bfloat16 if name == "out_bf16" else torch.float32, f"{what}.{name}")
+                _chk(v, torch.int64 if name == "seed_ptr" else torch.bfloat16 if name in ("out_bf16", "enh16") else torch.float32, f"{what}.{name}")
             setattr(d, name, L.ptr(v))
         elif v is not None:
             setattr(d, name, v)

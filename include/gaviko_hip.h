@@ -22,7 +22,7 @@ extern "C" {
 const char* gvk_last_error(void);
 /* returns 950 when the code object loaded on the current device is gfx950, else <0 */
 int gvk_device_check(void);
-int gvk_abi_version(void);   /* 3 */
+int gvk_abi_version(void);   /* 6 */
 
 /* ------------------------------------------------------------------ launch plans
  * The reference drives its step from the Python interpreter (train.py:296-319: one autograd node per op).  Here one
@@ -42,6 +42,11 @@ int gvk_plan_event_record(void* stream);           /* -> event id within the pla
 int gvk_plan_event_wait(void* stream, int event);
 /* gvk_plan_event_record with the system-scope fence kept (events that peer devices' reads are ordered behind: all-reduce buckets) */
 int gvk_plan_event_record_fenced(void* stream);
+/* LDS exclusion: every later launch of this library on `stream` asks for `bytes` of extra (unused) dynamic LDS, so its workgroups only
+   fit on CUs with that much LDS free -- keeps side-stream kernels off the CUs the backbone GEMM / attention workgroups occupy */
+int gvk_stream_set_lds_pad(void* stream, int bytes);
+/* diagnostics only: launches recorded on `stream` from now on are replaced by an empty kernel (contention studies; results are garbage) */
+int gvk_plan_nop_stream(void* stream);
 /* issued immediately (not recorded): `stream` waits for event `event` of plan `plan` as recorded by its most recent replay */
 int gvk_plan_event_stream_wait(int plan, int event, void* stream);
 /* measurement: milliseconds between two events of a replayed plan.  Events carry timestamps only in plans recorded after
@@ -125,6 +130,12 @@ int gvk_copy_async(void* dst, const void* src, size_t bytes, void* stream);
  * (out [cols][rows]) for the dgrad operand of frozen weights. */
 int gvk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream);
 int gvk_transpose_cast_f32_bf16(const float* in, void* out, int rows, int cols, void* stream);
+/* Split-bf16 packing of a narrow fp32 operand into 3 ca + 2 spare K columns (from col0) of a bf16 GEMM operand dst [rows][ld_dst]:
+ * x = hi + lo (hi = bf16(x), lo = bf16(x - hi)); activation side (weight_side 0) writes [a_hi | a_lo | a_hi], weight side writes
+ * [w_hi | w_hi | w_lo | b_hi | b_lo] (b f32 [rows] or NULL; it meets two constant-1 columns of the activation operand).  The GPA
+ * up-projection (gaviko.py:187, x + proj_up(.)) then rides the MLP's second Linear (vision_transformer.py:34) as K-concatenation,
+ * A' = [act | lat_hi | lat_lo | lat_hi | 1 | 1], W' = [W_fc2 | Wup_hi | Wup_hi | Wup_lo | b_hi | b_lo], at ~2^-16 relative accuracy. */
+int gvk_pack_split_bf16(const float* a, int ca, const float* b, void* dst, int ld_dst, int col0, int rows, int weight_side, void* stream);
 /* im2col of non-overlapping 3-D patches, fp32 volume -> bf16 rows [B*n_patches][pd*ph*pw]
  * (K order (kd,kh,kw) == Conv3d weight.flatten(1); vision_transformer.py:126-128,150-151). */
 int gvk_patchify_bf16(const float* img, void* out, int B, int D, int H, int W, int pd, int ph, int pw, void* stream);
@@ -150,7 +161,10 @@ int gvk_layernorm_bwd_affine(const float* dy, const float* x, const float* mean,
 typedef struct gvk_rowproj_desc {
   const float* w; const float* bias;       /* bias [L] or NULL */
   float* y; float* z;                      /* y [M][L]; z [M][L] pre-activation or NULL */
+  void* y_split;                           /* optional: split-bf16 copy [hi | lo | hi] of y (gvk_pack_split_bf16, activation side) into columns
+                                              col_split .. col_split + 3L - 1 of a bf16 [M][ld_split] GEMM operand */
   int32_t L, w_layout, act;                /* act: 0 none, 1 QuickGELU */
+  int32_t ld_split, col_split;
 } gvk_rowproj_desc;
 int gvk_layernorm_fwd_proj(const float* x, const float* gamma, const float* beta, void* y_bf16, float* mean, float* rstd,
                            int M, int C, float eps, const gvk_rowproj_desc* proj, void* stream);
@@ -224,6 +238,9 @@ typedef struct gvk_skinny_up_desc {
   uint64_t seed;
 } gvk_skinny_up_desc;
 int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream);
+/* out f32 [B*T][C] rows b*T + p (p < P) += (enh[b][p] - lat[b*T + p]) . w^T, w f32 [C][L]: the prompt rows of the GPA up-projection
+ * (gaviko.py:183-187) when the plain-latent part rides the MLP GEMM as K-concatenation (gvk_pack_split_bf16) */
+int gvk_prompt_up_fix(const float* enh, const float* lat, const float* w, float* out, int B, int T, int P, int C, int L, void* stream);
 
 /* outer: out[l][c] (transposed=0) or out[c][l] (transposed=1) (+)= sum_m narrow[m][l] * wide'[m][c];
  *        colsum[c] (+)= sum_m wide'[m][c] (optional).  wide' = LN(wide) when mean/rstd(/gamma/beta) are given, times the
@@ -296,7 +313,9 @@ typedef struct gvk_gpa_desc {
   float* dimp; float* dgw_part;
   float* dqg; float* dql; float* dcg; float* dcl; float* delta_g; float* delta_l; float* dprm;
   float* dcls; float* gate_partials; float* dzx; float* dzl;
-  int32_t B, T, N, P, L;
+  void* enh16;            /* optional (fwd): split-bf16 copy [hi | lo | hi] of enh[b][p][:] (gvk_pack_split_bf16, activation side) into row
+                             b*T + p, columns col16 .. col16 + 3L - 1 of a [B*T][ld16] GEMM operand */
+  int32_t B, T, N, P, L, ld16, col16;
   float scale;
 } gvk_gpa_desc;
 int gvk_gpa_fwd(const gvk_gpa_desc* d, void* stream);
