@@ -24,6 +24,28 @@
 
 namespace gvk {
 
+// Streaming accesses of the [M][C] tensors (read or written once per launch).  -DGVK_SIDE_NT=1 marks them non-temporal, to keep the
+// 12 MB a pass moves from evicting the backbone kernels' operands from the per-XCD L2: measured 660 vs 681 volumes/s -- worse (the next
+// side kernel re-reads the same rows from L2 / the MALL a few tens of microseconds later), so the plain form is the default.
+#ifndef GVK_SIDE_NT
+#define GVK_SIDE_NT 0
+#endif
+__device__ __forceinline__ f32x4 ld_stream(const float* p) {
+#if GVK_SIDE_NT
+  return __builtin_nontemporal_load((const f32x4*)p);
+#else
+  return *(const f32x4*)p;
+#endif
+}
+__device__ __forceinline__ void st_stream(float* p, const f32x4 v) {
+#if GVK_SIDE_NT
+  __builtin_nontemporal_store(v, (f32x4*)p);
+#else
+  *(f32x4*)p = v;
+#endif
+}
+
+
 namespace {
 constexpr int kSW = 8;                 // waves per workgroup
 constexpr int kSL = 20;                // latent width these kernels are built for (configs/gaviko.yaml prompt_latent_dim / local_dim)
@@ -79,10 +101,10 @@ __global__ __launch_bounds__(64 * kSW, NGW <= 3 ? 4 : 2) void side_down_kernel(D
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       col[gi][h] = 32 * (ok[gi] ? g : 0) + 16 * h + 4 * kq;
-      x[gi][h] = *(const f32x4*)(p.x + (size_t)row * C + col[gi][h]);
+      x[gi][h] = ld_stream(p.x + (size_t)row * C + col[gi][h]);
       if constexpr (MODE == 2) {
-        dyv[gi][h] = *(const f32x4*)(p.dy + (size_t)row * C + col[gi][h]);
-        drs[gi][h] = p.dres != nullptr ? *(const f32x4*)(p.dres + (size_t)row * C + col[gi][h]) : zero4();
+        dyv[gi][h] = ld_stream(p.dy + (size_t)row * C + col[gi][h]);
+        drs[gi][h] = p.dres != nullptr ? ld_stream(p.dres + (size_t)row * C + col[gi][h]) : zero4();
       }
     }
   }
@@ -235,7 +257,7 @@ __global__ __launch_bounds__(64 * kSW, NGW <= 3 ? 4 : 2) void side_down_kernel(D
         for (int e = 0; e < 4; ++e) o[e] = rstd * (dyv[gi][h][e] - m1 - x[gi][h][e] * m2) + drs[gi][h][e];
         x[gi][h] = o;
         if (rv && ok[gi]) {
-          *(f32x4*)(p.dx + (size_t)row * C + col[gi][h]) = o;
+          st_stream(p.dx + (size_t)row * C + col[gi][h], o);
           if (p.dx16 != nullptr) {
             const bf16x4 hh = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
             *(bf16x4*)(p.dx16 + (size_t)row * C + col[gi][h]) = hh;
@@ -333,9 +355,9 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
     cc[pi] = 32 * (ok[pi] ? pp : 0) + 8 * kq;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      bs[pi][j] = base != nullptr ? *(const f32x4*)(base + (size_t)row * C + cc[pi] + 4 * j) : zero4();
-      if constexpr (LNB) xs[pi][j] = *(const f32x4*)(p.ln_x + (size_t)row * C + cc[pi] + 4 * j);
-      if constexpr (LNM == 2) ys[pi][j] = *(const f32x4*)(q.dy + (size_t)row * C + cc[pi] + 4 * j);
+      bs[pi][j] = base != nullptr ? ld_stream(base + (size_t)row * C + cc[pi] + 4 * j) : zero4();
+      if constexpr (LNB) xs[pi][j] = ld_stream(p.ln_x + (size_t)row * C + cc[pi] + 4 * j);
+      if constexpr (LNM == 2) ys[pi][j] = ld_stream(q.dy + (size_t)row * C + cc[pi] + 4 * j);
     }
   }
   {
@@ -395,7 +417,7 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
           for (int e = 0; e < 4; ++e) v[e] *= drop_scale(p.seed, (unsigned long long)row * C + cc[pi] + 4 * j + e, p.drop_thresh, p.inv_keep);
         }
         v += bs[pi][j];
-        if (rvalid && ok[pi]) *(f32x4*)(p.out + (size_t)row * C + cc[pi] + 4 * j) = v;
+        if (rvalid && ok[pi]) st_stream(p.out + (size_t)row * C + cc[pi] + 4 * j, v);
       }
       acc[pi][j] = v;
     }
@@ -426,7 +448,7 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = rs * (acc[pi][j][e] - s1 - xs[pi][j][e] * s2) + bs[pi][j][e];
           if constexpr (LNM == 2) o += ys[pi][j];
-          *(f32x4*)(p.out + (size_t)row * C + cc[pi] + 4 * j) = o;
+          st_stream(p.out + (size_t)row * C + cc[pi] + 4 * j, o);
           acc[pi][j] = o;
         }
         if (LNM == 2 && p.out16 != nullptr) {
