@@ -51,6 +51,9 @@ GEMM_MARKS = None
 # Dispatch priority of the side-chain streams (negative = higher).  Measured: -1 drops the step rate from 448 to 274 volumes/s
 # (priority queues serialise against the captured graph's main queue on this runtime), so the default stays 0.
 SIDE_STREAM_PRIORITY = int(os.environ.get("GAVIKO_HIP_SIDE_PRIORITY", "0"))
+# MWSA backward chain held behind the layer's attention backward: measured 669 vs 688 volumes/s -- the chain then slows the dgrad GEMMs
+# of the next layer by as much as it slowed the attention kernels before (start->fc1d 82 -> 98 us); opt-in only
+_LOC_SHIFT = os.environ.get("GAVIKO_HIP_LOC_SHIFT", "0") == "1"
 _EPI_NAMES = {0: "store_bf16", 1: "bias_res_f32", 2: "bias_gelu_bf16", 3: "patch_f32", 4: "gelu_bwd_bf16", 5: "store_f32", 6: "bias_res_f32_bf16",
               7: "bias_relu_bf16", 8: "relu_bwd_bf16"}
 
@@ -998,7 +1001,9 @@ class Engine:
                 self._ssf_linear_grad(ws, gv, m, 1, ws["dpre"], ws["pre"][i], M, self.mlp)
             if bb:                                                           # fc1: db = colsum(dpre), dW = dpre^T . LN2(G1)
                 self._bb_linear_grads(ws, gv, bb, m + ".net.1", ws["dpre"], ws["dpre"], ws["sav"]["xn2"][i] if sv["wgrad"] else None, M, self.mlp, C)
+            self._mark(f"b{i}:fc2d") if False else None
             self._gemm(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
+            self._mark(f"b{i}:fc1d")
             if bb:
                 self._bb_ln_grads(ws, gv, bb, m + ".net.0", ws["dx32"], ws["G1"][i], st[2], st[3], M)
             if ssf:                                                          # LN2 + ssf_0
@@ -1026,12 +1031,12 @@ class Engine:
                     self._ev_wait(torch.cuda.current_stream(), dz_ready)
                     self._gpa_bwd_scatter_g(ws, i, dGin, M)                  # dG1 += dzx.Wd (+ bf16 copy)
                 self._mark(f"b{i}:scatter")
-                self._ev_wait(loc, dz_ready)
-                with torch.cuda.stream(loc):
-                    self._gpa_bwd_scatter_l(ws, i, ws["dL"][par], B, par)    # dL += dzl.Wd (dL[par] was written on this stream)
-                    scl_done = self._ev_record(loc)
-                    self._mwsa_bwd(ws, sv, gv, i, ws["dL"][par], ws["dL"][par ^ 1], B)
-                    self._bucket_mark("loc", i)
+                # The MWSA chain of this layer (~170 us of kernels against ~290 us of backbone work per layer) runs beside the attention
+                # backward, which it slows by 21 % (tools/plan_marks.py, locnop ablation); GAVIKO_HIP_LOC_SHIFT=1 holds it back until that
+                # is through (not a gain, see _LOC_SHIFT)
+                shift = _LOC_SHIFT and i > lo
+                if not shift:
+                    self._mwsa_chain_bwd(ws, sv, gv, i, par, B, loc, dz_ready)
             # main stream, attention block: dG0 = dG1 + LN'(qkv^T(attn'(out^T(dG1))))
             if ssf:                                                          # to_out + ssf_2: dy = dG1, y = G1[i] - G[i]
                 self._ssf_linear_grad(ws, gv, a, 2, dGin, ws["G1"][i], M, C, y1=ws["G"][i])
@@ -1041,8 +1046,12 @@ class Engine:
             if bb:                                                           # to_out: db = colsum(dG1), dW = dG1^T . ctx
                 self._bb_linear_grads(ws, gv, bb, a + ".to_out.0", dy_at, ws["dG16"], ws["ctx"][i], M, C, C)
             self._gemm(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
+            self._mark(f"b{i}:outd")
             ops.attention_bwd(ws["qkv"][i], ws["ctx"][i], ws["dctx"], ws["lse"][i], ws["delta"], ws["dqkv"], B, T, self.heads, 64 ** -0.5,
                               drop_p=pd_, seed=SEED_LAYER + 8 * i, seed_ptr=ws["seed"])
+            self._mark(f"b{i}:attnb")
+            if gaviko and shift:
+                self._mwsa_chain_bwd(ws, sv, gv, i, par, B, loc, self._ev_record(torch.cuda.current_stream()))
             if self.kind == "melo":
                 self._melo_bwd(ws, gv, i, M)
             if ssf:                                                          # to_qkv + ssf_1: dy = dqkv, y = saved qkv
@@ -1076,7 +1085,7 @@ class Engine:
                 # layer i+1's scatter read -- ordered by making the GPA stream (not the main one) wait for THAT long finished kernel.
                 if prev_scl is not None:
                     self._ev_wait(gpa, prev_scl)
-                prev_scl = scl_done
+                prev_scl = self._scl_done
                 self._wait("gpa", None)                                      # the next layer's GPA backward needs this dG[i]
             if self.kind == "evp":
                 self._evp_bwd_layer(ws, gv, i, dGout, B)
@@ -1199,6 +1208,15 @@ class Engine:
                       M=M, C=self.C, L=self.Lat, w_layout=1, accumulate=1)
         if self.fp32:
             ops.copy_(ws["dG16"], dG1)
+
+    def _mwsa_chain_bwd(self, ws, sv, gv, i, par, B, loc, after):
+        """Local stream: dL += dzl . Wd (GPA's share), then the MWSA backward of layer i; starts once event `after` is reached."""
+        self._ev_wait(loc, after)
+        with torch.cuda.stream(loc):
+            self._gpa_bwd_scatter_l(ws, i, ws["dL"][par], B, par)            # dL[par] was written on this stream
+            self._scl_done = self._ev_record(loc)
+            self._mwsa_bwd(ws, sv, gv, i, ws["dL"][par], ws["dL"][par ^ 1], B)
+            self._bucket_mark("loc", i)
 
     def _gpa_bwd_scatter_l(self, ws, i, dLnew, B, par):
         """MWSA chain: dL += dzl . Wd."""
