@@ -7,47 +7,10 @@
 // instead of stored (20-MAC dot products against an L2-resident 240 KB/sample q|k|v matrix).
 // Backward is split in a query-side pass (dq, delta) and a key-side pass over the REVERSE window (dk, dv): no atomics.
 #include "common.hpp"
+#include "window_args.hpp"
 #include "../../include/gaviko_hip.h"
 
 namespace gvk {
-
-__device__ __forceinline__ unsigned int hash_u32_w(unsigned long long seed, unsigned long long idx) {
-  unsigned long long x = idx * 0x9E3779B97F4A7C15ull + seed;
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  return (unsigned int)x;
-}
-
-struct WinArgs {
-  const float* qkv;   // [B*N][3L]
-  float* ctx;         // [B*N][L]
-  float* lse;         // [B*N]
-  const float* dctx;  // bwd
-  float* delta;       // bwd scratch [B*N]
-  float* dqkv;        // bwd out [B*N][3L]
-  int B, D, H, W, kd, kh, kw;
-  float scale;
-  unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;
-};
-
-struct Win {   // forward window of a query / reverse window of a key, per axis [lo, lo+n)
-  int d0, nd, h0, nh, w0, nw;
-  __device__ __forceinline__ int count() const { return nd * nh * nw; }
-  __device__ __forceinline__ int index(int kk, int H, int W) const {
-    const int ww = kk % nw, t = kk / nw, hh = t % nh, dd = t / nh;
-    return ((d0 + dd) * H + (h0 + hh)) * W + (w0 + ww);
-  }
-};
-__device__ __forceinline__ void axis_fwd(int q, int k, int n, int& lo, int& cnt) {
-  const int a = max(0, q - k / 2), b = min(n, q - k / 2 + k);
-  lo = a; cnt = b - a;
-}
-__device__ __forceinline__ void axis_rev(int key, int k, int n, int& lo, int& cnt) {
-  // queries q with  q - k/2 <= key < q - k/2 + k   <=>   key - (k - 1 - k/2) <= q <= key + k/2
-  const int a = max(0, key - (k - 1 - k / 2)), b = min(n - 1, key + k / 2);
-  lo = a; cnt = b - a + 1;
-}
 
 template <int L>
 __global__ __launch_bounds__(256) void win_fwd_kernel(WinArgs p) {
@@ -237,6 +200,10 @@ extern "C" int gvk_window_attn_fwd(const gvk_window_attn_desc* d, void* stream) 
   WinArgs a{};
   fill(a, d);
   hipStream_t s = (hipStream_t)stream;
+  {
+    const int rc = launch_win_mfma_fwd(a, d->L, s);
+    if (rc != 1) return rc;
+  }
   const int grid = (d->B * d->D * d->H * d->W + 3) / 4;
   GVK_WIN_DISPATCH(win_fwd_kernel, "gvk_window_attn_fwd");
   return check_launch("window_attn_fwd");
@@ -249,6 +216,10 @@ extern "C" int gvk_window_attn_bwd(const gvk_window_attn_desc* d, void* stream) 
   WinArgs a{};
   fill(a, d);
   hipStream_t s = (hipStream_t)stream;
+  {
+    const int rc = launch_win_mfma_bwd(a, d->L, s);
+    if (rc != 1) return rc;
+  }
   const int grid = (d->B * d->D * d->H * d->W + 3) / 4;
   GVK_WIN_DISPATCH(win_bwd_q_kernel, "gvk_window_attn_bwd");
   int rc = check_launch("window_attn_bwd/q");
