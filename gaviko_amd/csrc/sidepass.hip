@@ -322,14 +322,22 @@ __global__ __launch_bounds__(64 * kSW, NGW <= 3 ? 4 : 2) void side_down_kernel(D
 
 // ---- up projection ------------------------------------------------------------------------------------------------------------------
 struct Up2Args {                                        // optional down-projection of the rows side_up has just written
-  const float* w; const float* bias; float* z; float* y; int act;            // w [kSL][C]; z / y [M][kSL]
+  const float* w; const float* bias; float* z; float* y; int act;            // w [kSL][C] (wl 0) or [C][kSL] (wl 1); z / y [M][kSL]
   const float* dy;                                                           // LNM 2: the LayerNorm output gradient [M][C]
+  // LNM 3: a second rank-L term added behind the LayerNorm backward, out = base + LN'(lat . W^T) + lat2 . W2up^T  (w2up [kSL][C]), and the
+  // down-projection above reads the rows through a dropout mask (the MWSA backward across a layer boundary, engine._mwsa_chain_bwd)
+  const float* lat2; const float* w2up;
+  int wl;
+  unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;
 };
 
 // NPW = 32-column pairs per wave, WL = weight layout (0: w [C][L], 1: w [L][C]).  LNM selects the epilogue on v = lat . W^T:
 //   0: out = base + dropout(v + bias)            1: out = base + LN'(v; ln_x, mean, rstd, gamma)            (gvk_skinny_up)
 //   2: out = base + LN'(dy; ln_x, mean, rstd, gamma) + v, + bf16 copy     (gvk_layernorm_bwd_up: the MLP block's LayerNorm backward and GPA's
 //      dG1 += dzx . W_d in one pass over the row, engine._backward_segment)
+//   3: out = base + LN'(v; ...) + lat2 . W2up^T, then y2 = (out o dropout mask) . W3^T: three launches of the MWSA backward in one pass --
+//      layer i+1's dL_in = dL_out + LN'(dlat . Wd) (gaviko.py:231), layer i's GPA share dL += dzl . Wd_gpa (:156) and layer i's
+//      dctx = proj_drop'(dL) . Wup (:242-243) -- the local-stream gradient is read once and written once instead of 3 + 2 times
 template <int NPW, int WL, int LNM>
 __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpArgs p, Up2Args q) {
   constexpr bool LNB = LNM != 0;
@@ -382,6 +390,11 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
   if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
   [[maybe_unused]] float mu = 0.f, rs = 0.f;
   if constexpr (LNB) { mu = p.ln_mean[row]; rs = p.ln_rstd[row]; }
+  [[maybe_unused]] float lb2[kK4];                       // LNM 3: the second latent row (v2 = lat2 . W2up^T is formed late, where it is added)
+  if constexpr (LNM == 3) {
+#pragma unroll
+    for (int s = 0; s < kK4; ++s) lb2[s] = q.lat2[(size_t)row * kSL + kq * kK4 + s];
+  }
   // ---- D[column a of tile j][token row] = sum over the latent index
   f32x4 acc[NPW][2];
 #pragma unroll
@@ -441,6 +454,16 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
     s2 /= (float)C;
 #pragma unroll
     for (int pi = 0; pi < NPW; ++pi) {
+      [[maybe_unused]] f32x4 v2[2];
+      if constexpr (LNM == 3) {                          // lat2 . W2up^T (w2up [kSL][C]) for these columns; every lane takes part in the MFMAs
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = cc[pi] - 8 * kq + 8 * (a >> 2) + 4 * j + (a & 3);
+          v2[j] = zero4();
+#pragma unroll
+          for (int s = 0; s < kK4; ++s) v2[j] = mfma4(q.w2up[(size_t)(kq * kK4 + s) * C + c], lb2[s], v2[j]);
+        }
+      }
       if (rvalid && ok[pi]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -448,6 +471,7 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = rs * (acc[pi][j][e] - s1 - xs[pi][j][e] * s2) + bs[pi][j][e];
           if constexpr (LNM == 2) o += ys[pi][j];
+          if constexpr (LNM == 3) o += v2[j];
           st_stream(p.out + (size_t)row * C + cc[pi] + 4 * j, o);
           acc[pi][j] = o;
         }
@@ -459,28 +483,39 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
         }
       }
     }
-  } else {
+  }
+  if constexpr (LNM == 0 || LNM == 3) {
     if (q.w != nullptr) {
       // second projection of the rows just written: A operand = the output piece itself (token row a, k <-> column cc + 4 j + e), B operand
-      // W2[n][cc + 4 j + e]
-      f32x4 d2[2] = {zero4(), zero4()}, w2f[NPW][2][2];
+      // W2[n][cc + 4 j + e]; rows / column groups past the end contribute zeros
+      if (q.drop_thresh != 0u && q.seed_ptr != nullptr) q.seed += *q.seed_ptr;
+      f32x4 d2[2] = {zero4(), zero4()};
 #pragma unroll
-      for (int pi = 0; pi < NPW; ++pi)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          w2f[pi][j][0] = load_w_down<0>(q.w, C, a, cc[pi] + 4 * j);
-          w2f[pi][j][1] = load_w_down<0>(q.w, C, 16 + a, cc[pi] + 4 * j);
-        }
-#pragma unroll
-      for (int pi = 0; pi < NPW; ++pi)
+      for (int pi = 0; pi < NPW; ++pi) {
+        f32x4 w2f[2][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const f32x4 ov = ok[pi] ? acc[pi][j] : zero4();
-#pragma unroll
-          for (int e = 0; e < 4; ++e) d2[0] = mfma4(ov[e], w2f[pi][j][0][e], d2[0]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) d2[1] = mfma4(ov[e], w2f[pi][j][1][e], d2[1]);
+          if (q.wl == 0) {
+            w2f[j][0] = load_w_down<0>(q.w, C, a, cc[pi] + 4 * j);
+            w2f[j][1] = load_w_down<0>(q.w, C, 16 + a, cc[pi] + 4 * j);
+          } else {
+            w2f[j][0] = load_w_down<1>(q.w, C, a, cc[pi] + 4 * j);
+            w2f[j][1] = load_w_down<1>(q.w, C, 16 + a, cc[pi] + 4 * j);
+          }
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x4 ov = (ok[pi] && rvalid) ? acc[pi][j] : zero4();
+          if (q.drop_thresh != 0u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] *= drop_scale(q.seed, (unsigned long long)row * C + cc[pi] + 4 * j + e, q.drop_thresh, q.inv_keep);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d2[0] = mfma4(ov[e], w2f[j][0][e], d2[0]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d2[1] = mfma4(ov[e], w2f[j][1][e], d2[1]);
+        }
+      }
       part[wave][0][lane] = d2[0];
       part[wave][1][lane] = d2[1];
       __syncthreads();
@@ -535,18 +570,28 @@ int launch_side_down(const DownArgs& a, int L, hipStream_t s) {
   return check_launch("side_down");
 }
 
-int launch_side_up(const UpArgs& a, int L, const float* w2, const float* bias2, float* z2, float* y2, int L2, int act2, hipStream_t s, const float* ln_dy) {
+int launch_side_up(const UpArgs& a, int L, const float* w2, const float* bias2, float* z2, float* y2, int L2, int act2, hipStream_t s, const float* ln_dy,
+                   const UpExtra* ex) {
   const int npw = groups_per_wave(a.C);
   const bool lnb = a.ln_x != nullptr, ext = a.alpha_ptr != nullptr || a.gg_x != nullptr;
   if (!side_enabled() || L != kSL || npw == 0 || ext) return 1;       // DVPT's gate / GELU' epilogue: row-per-wave kernel (see launch_side_down)
-  if (w2 != nullptr && (lnb || L2 != kSL)) return set_error(-2, "side_up: the fused second projection takes the plain epilogue and L2 = %d", kSL);
+  if (w2 != nullptr && ((lnb && ex == nullptr) || L2 != kSL))
+    return set_error(-2, "side_up: the fused second projection takes the plain epilogue (or the layer-boundary form) and L2 = %d", kSL);
   if (ln_dy != nullptr && !lnb) return set_error(-2, "side_up: ln_dy needs the LayerNorm operands (ln_x, mean, rstd, gamma)");
-  Up2Args q{w2, bias2, z2, y2, act2, ln_dy};
-  const int lnm = ln_dy != nullptr ? 2 : (lnb ? 1 : 0);
+  if (ex != nullptr && (!lnb || ln_dy != nullptr || w2 == nullptr || ex->lat2 == nullptr || ex->w2up == nullptr || a.w_layout != 1))
+    return set_error(-2, "side_up: the layer-boundary form needs the LayerNorm operands, lat2 / w2up, a second projection and w_layout 1");
+  Up2Args q{};
+  q.w = w2; q.bias = bias2; q.z = z2; q.y = y2; q.act = act2; q.dy = ln_dy;
+  if (ex != nullptr) {
+    q.lat2 = ex->lat2; q.w2up = ex->w2up; q.wl = ex->w2_layout;
+    q.seed = ex->seed2; q.seed_ptr = ex->seed_ptr; q.drop_thresh = ex->drop2_thresh; q.inv_keep = ex->inv_keep2;
+  }
+  const int lnm = ex != nullptr ? 3 : ln_dy != nullptr ? 2 : (lnb ? 1 : 0);
   const dim3 grid((a.M + 15) / 16), block(64 * kSW);
 #define GVK_SU(N_, W_, B_) GVK_LAUNCH((side_up_kernel<N_, W_, B_>), grid, block, 0, s, a, q)
 #define GVK_SU_N(W_, B_) { if (npw == 1) GVK_SU(1, W_, B_); else if (npw == 3) GVK_SU(3, W_, B_); else GVK_SU(4, W_, B_); }
-  if (a.w_layout == 0) { if (lnm == 2) GVK_SU_N(0, 2) else if (lnm == 1) GVK_SU_N(0, 1) else GVK_SU_N(0, 0) }
+  if (lnm == 3) GVK_SU_N(1, 3)
+  else if (a.w_layout == 0) { if (lnm == 2) GVK_SU_N(0, 2) else if (lnm == 1) GVK_SU_N(0, 1) else GVK_SU_N(0, 0) }
   else { if (lnm == 2) GVK_SU_N(1, 2) else if (lnm == 1) GVK_SU_N(1, 1) else GVK_SU_N(1, 0) }
 #undef GVK_SU_N
 #undef GVK_SU

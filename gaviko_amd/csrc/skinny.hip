@@ -735,6 +735,16 @@ extern "C" int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream) {
   static const bool mfma_only = getenv("GAVIKO_HIP_SKINNY_MFMA") != nullptr;
   a.alpha_ptr = d->alpha_ptr; a.gg_x = d->gg_x;
   GVK_REQUIRE(d->w2 == nullptr || ((d->z2 || d->y2) && d->L2 > 0), "gvk_skinny_up: the second projection needs z2 or y2 and L2");
+  if (d->lat_b != nullptr) {                            // the layer-boundary form: 16-row-tile kernel only
+    GVK_REQUIRE(d->w_b && d->ln_x && d->w2 && (d->w2_layout == 0 || d->w2_layout == 1), "gvk_skinny_up: lat_b needs w_b, the LayerNorm operands and w2");
+    UpExtra ex{};
+    ex.lat2 = d->lat_b; ex.w2up = d->w_b; ex.w2_layout = d->w2_layout;
+    ex.seed2 = d->seed2; ex.seed_ptr = (const unsigned long long*)d->seed_ptr; ex.drop2_thresh = drop_threshold(d->drop2_p);
+    ex.inv_keep2 = d->drop2_p > 0.f ? 1.f / (1.f - d->drop2_p) : 1.f;
+    const int rc = launch_side_up(a, d->L, d->w2, d->bias2, d->z2, d->y2, d->L2, d->act2, s, nullptr, &ex);
+    if (rc == 1) return set_error(-2, "gvk_skinny_up: lat_b is built for L = 20 and C in {192, 768, 1024} (got L=%d, C=%d)", d->L, d->C);
+    return rc;
+  }
   if (!mfma_only) {
     const int rc = launch_side_up(a, d->L, d->w2, d->bias2, d->z2, d->y2, d->L2, d->act2, s);
     if (rc != 1) return rc;

@@ -43,7 +43,14 @@ int launch_row_up(const UpArgs& a, int L, hipStream_t s);
 // has just written with a second weight w2 [L2][C] (+ bias2, activation act2) into z2 / y2 [M][L2].
 int launch_side_down(const DownArgs& a, int L, hipStream_t s);
 // ln_dy (with a's LayerNorm operands): out = base + LN'(ln_dy) + lat . W^T instead of base + LN'(lat . W^T)
+// ex (with a's LayerNorm operands and w2): out = base + LN'(lat . W^T) + ex->lat2 . ex->w2up^T, and the second projection (w2 in layout
+// ex->w2_layout, 0: [L][C], 1: [C][L]) reads the rows through the dropout mask (ex->seed2, ex->drop2_*)
+struct UpExtra {
+  const float* lat2; const float* w2up;        // [M][L], [L][C]
+  int w2_layout;
+  unsigned long long seed2; const unsigned long long* seed_ptr; unsigned int drop2_thresh; float inv_keep2;
+};
 int launch_side_up(const UpArgs& a, int L, const float* w2, const float* bias2, float* z2, float* y2, int L2, int act2, hipStream_t s,
-                   const float* ln_dy = nullptr);
+                   const float* ln_dy = nullptr, const UpExtra* ex = nullptr);
 
 }  // namespace gvk

@@ -198,6 +198,8 @@ class Engine:
         self._fuse_proj = (kind == "gaviko" and not self.fp32 and ops.rowproj_supported(self.Lat, dim)
                            and os.environ.get("GAVIKO_HIP_FUSE_PROJ", "1") != "0")
         self._fuse_local = kind == "gaviko" and ops.side_tile_supported(self.Lat, dim)
+        self._fuse_bnd = self._fuse_local and os.environ.get("GAVIKO_HIP_FUSE_BOUNDARY", "1") != "0"
+        self._mwsa_pending = None
         # GPA up-projection as K-concatenation of the MLP's second Linear: 64 spare K columns carry the rank-L product in split-bf16 form,
         # A' = [act | lat_hi | lat_lo | lat_hi | 1 | 1], W' = [W_fc2 | Wup_hi | Wup_hi | Wup_lo | b_hi | b_lo] (fp32-grade: the dropped
         # lo.lo term is 2^-16 relative), so x + ff(x) + proj_up(.) (gaviko.py:187 after vision_transformer.py:34) is ONE GEMM and the
@@ -1105,6 +1107,7 @@ class Engine:
                 dGout = other
                 ops.to_operand(dGout, ws["dG16"], self.adt)
         if gaviko:
+            self._mwsa_flush(ws, B, loc)
             self._wait(None, "gpa")
             self._wait(None, "loc")
         if last and sv.get("bb"):
@@ -1212,13 +1215,51 @@ class Engine:
             ops.copy_(ws["dG16"], dG1)
 
     def _mwsa_chain_bwd(self, ws, sv, gv, i, par, B, loc, after):
-        """Local stream: dL += dzl . Wd (GPA's share), then the MWSA backward of layer i; starts once event `after` is reached."""
+        """Local stream: dL += dzl . Wd (GPA's share), then the MWSA backward of layer i; starts once event `after` is reached.
+        The last step of a layer's MWSA backward (dL_in = dL_out + LN'(dlat . Wd)) is deferred to the start of the next-lower layer's
+        chain, where ONE kernel does it together with that layer's scatter and its first down-projection (self._fuse_bnd)."""
         self._ev_wait(loc, after)
         with torch.cuda.stream(loc):
-            self._gpa_bwd_scatter_l(ws, i, ws["dL"][par], B, par)            # dL[par] was written on this stream
+            pend, fused = self._mwsa_pending, False
+            if pend is not None and self._fuse_bnd and "noside" not in _ABLATE and "loc_noupdown" not in _ABLATE:
+                self._mwsa_boundary(ws, sv, pend, i, par, B)
+                fused = True
+            else:
+                if pend is not None:
+                    self._mwsa_final(ws, pend, B)
+                self._gpa_bwd_scatter_l(ws, i, ws["dL"][par], B, par)        # dL[par] was written on this stream
             self._scl_done = self._ev_record(loc)
-            self._mwsa_bwd(ws, sv, gv, i, ws["dL"][par], ws["dL"][par ^ 1], B)
+            self._mwsa_bwd(ws, sv, gv, i, ws["dL"][par], ws["dL"][par ^ 1], B, have_dctx=fused, defer_final=True)
+            self._mwsa_pending = i
             self._bucket_mark("loc", i)
+
+    def _mwsa_flush(self, ws, B, loc):
+        """End of a backward plan: the deferred last step of the lowest layer of the sweep."""
+        if self._mwsa_pending is not None:
+            with torch.cuda.stream(loc):
+                self._mwsa_final(ws, self._mwsa_pending, B)
+            self._mwsa_pending = None
+
+    def _mwsa_final(self, ws, j, B):
+        """dL_in = dL_out + LN'(dlat . Wd) of layer j (gaviko.py:231): the rank-L product never touches HBM."""
+        if "noside" in _ABLATE or "loc_noupdown" in _ABLATE:
+            return
+        pre = f"transformer.local_attns.{j // self.share}"
+        d, m, par = self._d, ws["mw"][j], (self.depth - 1 - j) & 1
+        ops.skinny_up(lat=ws["bw"]["dlat"], w=d(pre + ".proj_down.weight"), res=ws["dL"][par], out=ws["dL"][par ^ 1], ln_x=ws["Lc"][j],
+                      ln_mean=m["mean"], ln_rstd=m["rstd"], ln_gamma=d(pre + ".norm.weight"), M=B * self.N, C=self.C, L=self.Lat, w_layout=1)
+
+    def _mwsa_boundary(self, ws, sv, j, i, par, B):
+        """Layer j = i + 1's last step, layer i's GPA scatter and layer i's dctx = proj_drop'(dL) . Wup in one pass over the local-stream
+        gradient (gvk_skinny_up with lat_b): dL[par] = dL[par ^ 1] + LN'(dlat_j . Wd_j) + dzl_i . Wd_gpa_i;  dctx_i = (dL[par] o mask_i) . Wup_i."""
+        pj, pi_ = f"transformer.local_attns.{j // self.share}", f"transformer.local_attns.{i // self.share}"
+        gpre, _ = self._gpa_names(i)
+        d, m, bw = self._d, ws["mw"][j], ws["bw"]
+        ops.skinny_up(lat=bw["dlat"], w=d(pj + ".proj_down.weight"), res=ws["dL"][par ^ 1], out=ws["dL"][par], ln_x=ws["Lc"][j],
+                      ln_mean=m["mean"], ln_rstd=m["rstd"], ln_gamma=d(pj + ".norm.weight"), M=B * self.N, C=self.C, L=self.Lat, w_layout=1,
+                      lat_b=bw["dzl"][par], w_b=d(gpre + ".proj_down.0.weight"),
+                      w2=d(pi_ + ".proj_up.weight"), z2=bw["dctx"], L2=self.Lat, act2=0, w2_layout=1,
+                      drop2_p=sv["proj_drop"], seed2=2 * i + 1, seed_ptr=ws["seed"])
 
     def _gpa_bwd_scatter_l(self, ws, i, dLnew, B, par):
         """MWSA chain: dL += dzl . Wd."""
@@ -1542,7 +1583,7 @@ class Engine:
     def _offset_of(self, name) -> int:
         return (self._flat_grad["views"][name].data_ptr() - self._flat_grad["buf"].data_ptr()) // 4
 
-    def _mwsa_bwd(self, ws, sv, gv, i, dLout, dLin, B):
+    def _mwsa_bwd(self, ws, sv, gv, i, dLout, dLin, B, have_dctx=False, defer_final=False):
         if "noside" in _ABLATE:
             return
         s = i // self.share
@@ -1554,7 +1595,7 @@ class Engine:
         acc = self._acc(i)
         pd, seed_p, seed_a, sp = sv["proj_drop"], 2 * i + 1, 2 * i, ws["seed"]
         wup = d(pre + ".proj_up.weight")
-        if "loc_noupdown" not in _ABLATE:
+        if "loc_noupdown" not in _ABLATE and not have_dctx:
             ops.skinny_down(x=dLout, w=wup, y=bw["dctx"], M=BN, C=C, L=Lt, act=0, w_layout=1, drop_p=pd, seed=seed_p, seed_ptr=sp)
         if "loc_noouter" not in _ABLATE:
           ops.outer_reduce(narrow=m["ctx"], wide=dLout, scratch=sc, out=gv[pre + ".proj_up.weight"], colsum=gv[pre + ".proj_up.bias"],
@@ -1578,6 +1619,6 @@ class Engine:
           ops.ln_lowrank_affine(bw["Q"], bw["S"], wd, g_, b_, gv[pre + ".proj_down.weight"], gv[pre + ".norm.weight"], gv[pre + ".norm.bias"],
                               gv[pre + ".proj_down.bias"], Lt, C, accumulate=bool(acc))
         # dL_in = dL_out + LN'(dlat . Wd): the rank-L product never touches HBM
-        if "loc_noupdown" not in _ABLATE:
+        if "loc_noupdown" not in _ABLATE and not defer_final:
           ops.skinny_up(lat=bw["dlat"], w=wd, res=dLout, out=dLin, ln_x=lin, ln_mean=m["mean"], ln_rstd=m["rstd"], ln_gamma=g_, M=BN, C=C, L=Lt,
                       w_layout=1)

@@ -232,10 +232,16 @@ typedef struct gvk_skinny_up_desc {
   /* optional second projection of the rows just written (plain epilogue only): z2 = out[m] . W2^T + bias2, y2 = act2(z2); W2 [L2][C]
      (GPA's proj_down of the new local tokens, gaviko.py:156, rides on the MWSA up-projection that produces them, gaviko.py:242) */
   const float* w2; const float* bias2; float* z2; float* y2;
+  /* optional, with the LayerNorm-backward epilogue, w_layout 1 and w2 (L = 20 tile kernels only): a second rank-L term behind it,
+     out = base + LN'(lat . W^T) + lat_b . W_b^T (W_b [L][C]), and the second projection reads `out` through the dropout mask (drop2_p, seed2):
+     z2 = (out o mask) . W2^T with W2 in w2_layout (0: [L2][C], 1: [C][L2]).  One pass for three steps of the MWSA backward across a layer
+     boundary: dL_in = dL_out + LN'(dlat . Wd) of layer i+1 (gaviko.py:231), dL += dzl . Wd_gpa of layer i (:156), dctx = proj_drop'(dL) . Wup
+     of layer i (:242-243) */
+  const float* lat_b; const float* w_b;
   int32_t M, C, L, T, P, w_layout, accumulate;
-  int32_t L2, act2;
-  float drop_p;
-  uint64_t seed;
+  int32_t L2, act2, w2_layout;
+  float drop_p, drop2_p;
+  uint64_t seed, seed2;
 } gvk_skinny_up_desc;
 int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream);
 /* out f32 [B*T][C] rows b*T + p (p < P) += (enh[b][p] - lat[b*T + p]) . w^T, w f32 [C][L]: the prompt rows of the GPA up-projection

@@ -447,3 +447,32 @@ def test_layernorm_bwd_up_matches_two_kernels(dev, M, C):
     dx2 = torch.zeros(M, C, device=dev); dx216 = torch.zeros(M, C, dtype=torch.bfloat16, device=dev)
     ops.layernorm_bwd_up(dyd, xd, md, rd, gd, M, C, dx=dx2, dres=dresd, dx16=dx216, lat=latd, w=wd.t().contiguous(), L_=L, w_layout=0)
     assert (dx2 - dx).abs().max().item() < 2e-6 * sc
+
+
+@pytest.mark.parametrize("M,C,p", [(4000, 768, 0.2), (2000, 192, 0.0), (1000, 1024, 0.2), (37, 768, 0.2)])
+def test_skinny_up_layer_boundary_form_matches_three_kernels(dev, M, C, p):
+    """gvk_skinny_up with lat_b: out = res + LN'(lat . W^T) + lat_b . W_b^T and z2 = (out o dropout mask) . W2^T in one pass, against the
+    three launches it replaces in the MWSA backward (LayerNorm-backward up-projection, accumulate up-projection, dropout down-projection)."""
+    from gaviko_amd import ops
+    Lat = 20
+    f = lambda t: t.float().to(dev).contiguous()
+    lat, lat_b = f(_rand((M, Lat), 1)), f(_rand((M, Lat), 2))
+    wd, wb, wup = f(_rand((Lat, C), 3, 0.1)), f(_rand((Lat, C), 4, 0.1)), f(_rand((C, Lat), 5, 0.1))
+    res, x = f(_rand((M, C), 6)), f(_rand((M, C), 7, 2.0))
+    gamma = f(1 + 0.3 * _rand((C,), 8))
+    mean = x.mean(-1).contiguous()
+    rstd = (x.var(-1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    seed = torch.full((1,), 77, dtype=torch.int64, device=dev)
+    # the three kernels
+    out3 = torch.empty_like(res)
+    ops.skinny_up(lat=lat, w=wd, res=res, out=out3, ln_x=x, ln_mean=mean, ln_rstd=rstd, ln_gamma=gamma, M=M, C=C, L=Lat, w_layout=1)
+    ops.skinny_up(lat=lat_b, w=wb, out=out3, M=M, C=C, L=Lat, w_layout=1, accumulate=1)
+    z3 = torch.zeros((M, Lat), device=dev)
+    ops.skinny_down(x=out3, w=wup, y=z3, M=M, C=C, L=Lat, act=0, w_layout=1, drop_p=p, seed=5, seed_ptr=seed)
+    # one kernel
+    out1, z1 = torch.empty_like(res), torch.zeros((M, Lat), device=dev)
+    ops.skinny_up(lat=lat, w=wd, res=res, out=out1, ln_x=x, ln_mean=mean, ln_rstd=rstd, ln_gamma=gamma, M=M, C=C, L=Lat, w_layout=1,
+                  lat_b=lat_b, w_b=wb, w2=wup, z2=z1, L2=Lat, act2=0, w2_layout=1, drop2_p=p, seed2=5, seed_ptr=seed)
+    torch.cuda.synchronize()
+    _close(out1, out3.double().cpu(), 2e-6, "boundary out")
+    _close(z1, z3.double().cpu(), 2e-5, "boundary dctx")
