@@ -329,6 +329,10 @@ struct Up2Args {                                        // optional down-project
   const float* lat2; const float* w2up;
   int wl;
   unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;
+  // LNM 0, optional: the NEXT layer's MWSA entry on the rows just written (gaviko.py:231-232 of layer i+1 behind :242 of layer i):
+  // lat = LayerNorm(out; g3, b3) . W3^T + bias3 (W3 [kSL][C]; mean3 / rstd3 saved), y4 = lat . W4^T (W4 [L4][kSL], L4 <= 64)
+  const float* w3; const float* bias3; const float* g3; const float* b3; float* mean3; float* rstd3; float* y3;
+  const float* w4; float* y4; int L4; float eps3;
 };
 
 // NPW = 32-column pairs per wave, WL = weight layout (0: w [C][L], 1: w [L][C]).  LNM selects the epilogue on v = lat . W^T:
@@ -343,6 +347,8 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
   constexpr bool LNB = LNM != 0;
   __shared__ float red[kSW][16][2];
   __shared__ f32x4 part[kSW][2][64];
+  __shared__ float yrow3[LNM == 0 ? 16 : 1][33];        // LNM 0: the next layer's latent rows of this tile, and its second-stage weight
+  __shared__ float w4s[LNM == 0 ? 64 * 33 : 1];
   const int lane = lane_id(), wave = wave_id();
   const int a = lane & 15, kq = lane >> 4;              // A operand: weight row a of a column tile; B operand / D: token row a
   const int C = p.C, NP = C >> 5;
@@ -539,6 +545,96 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
       }
     }
   }
+  if constexpr (LNM == 0) {
+    if (q.w3 != nullptr) {
+      // ---- the next layer's LayerNorm + proj_down (+ qkv) of the rows in acc: two-pass statistics like torch's LayerNorm
+      for (int t = threadIdx.x; t < q.L4 * kSL; t += 64 * kSW) {
+        const int j = t / kSL, l = t - j * kSL;
+        w4s[j * 33 + l] = q.w4[t];
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int pi = 0; pi < NPW; ++pi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) s += ok[pi] ? (acc[pi][j][0] + acc[pi][j][1]) + (acc[pi][j][2] + acc[pi][j][3]) : 0.f;
+      s = kq_sum(s);
+      __syncthreads();                                   // the second projection is done with `part` / nobody still reads `red`
+      if (kq == 0) red[wave][a][0] = s;
+      __syncthreads();
+      float mean = 0.f;
+#pragma unroll
+      for (int w = 0; w < kSW; ++w) mean += red[w][a][0];
+      mean /= (float)C;
+      float qs = 0.f;
+#pragma unroll
+      for (int pi = 0; pi < NPW; ++pi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = acc[pi][j][e] - mean; qs += ok[pi] ? d * d : 0.f; }
+      qs = kq_sum(qs);
+      if (kq == 0) red[wave][a][1] = qs;
+      __syncthreads();
+      float var = 0.f;
+#pragma unroll
+      for (int w = 0; w < kSW; ++w) var += red[w][a][1];
+      const float rstd = rsqrtf(var / (float)C + q.eps3);
+      if (wave == 0 && kq == 0 && rvalid) {
+        if (q.mean3) q.mean3[row] = mean;
+        if (q.rstd3) q.rstd3[row] = rstd;
+      }
+      f32x4 d3[2] = {zero4(), zero4()};
+#pragma unroll
+      for (int pi = 0; pi < NPW; ++pi) {
+        f32x4 w3f[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          w3f[j][0] = load_w_down<0>(q.w3, C, a, cc[pi] + 4 * j);
+          w3f[j][1] = load_w_down<0>(q.w3, C, 16 + a, cc[pi] + 4 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x4 g4 = *(const f32x4*)(q.g3 + cc[pi] + 4 * j), b4 = *(const f32x4*)(q.b3 + cc[pi] + 4 * j);
+          f32x4 xn;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xn[e] = ok[pi] ? (acc[pi][j][e] - mean) * rstd * g4[e] + b4[e] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d3[0] = mfma4(xn[e], w3f[j][0][e], d3[0]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d3[1] = mfma4(xn[e], w3f[j][1][e], d3[1]);
+        }
+      }
+      part[wave][0][lane] = d3[0];
+      part[wave][1][lane] = d3[1];
+      __syncthreads();
+      if (wave < 2) {
+        f32x4 t = part[0][wave][lane];
+#pragma unroll
+        for (int w = 1; w < kSW; ++w) t += part[w][wave][lane];
+        const int n = 16 * wave + a;
+        if (n < kSL) {
+          const float b = q.bias3 != nullptr ? q.bias3[n] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * kq + e, m = row0 + r;
+            const float yy = t[e] + b;
+            yrow3[r][n] = yy;
+            if (m < p.M && q.y3) q.y3[(size_t)m * kSL + n] = yy;
+          }
+        }
+      }
+      if (q.w4 != nullptr) {                             // y4[m][j] = sum_l lat[m][l] W4[j][l]
+        __syncthreads();
+        for (int t = threadIdx.x; t < 16 * q.L4; t += 64 * kSW) {
+          const int r = t / q.L4, j = t - r * q.L4, m = row0 + r;
+          float v = 0.f;
+#pragma unroll
+          for (int l = 0; l < kSL; ++l) v = __builtin_fmaf(yrow3[r][l], w4s[j * 33 + l], v);
+          if (m < p.M) q.y4[(size_t)m * q.L4 + j] = v;
+        }
+      }
+    }
+  }
 }
 
 static bool side_enabled() {
@@ -571,7 +667,7 @@ int launch_side_down(const DownArgs& a, int L, hipStream_t s) {
 }
 
 int launch_side_up(const UpArgs& a, int L, const float* w2, const float* bias2, float* z2, float* y2, int L2, int act2, hipStream_t s, const float* ln_dy,
-                   const UpExtra* ex) {
+                   const UpExtra* ex, const UpNext* nx) {
   const int npw = groups_per_wave(a.C);
   const bool lnb = a.ln_x != nullptr, ext = a.alpha_ptr != nullptr || a.gg_x != nullptr;
   if (!side_enabled() || L != kSL || npw == 0 || ext) return 1;       // DVPT's gate / GELU' epilogue: row-per-wave kernel (see launch_side_down)
@@ -587,6 +683,12 @@ int launch_side_up(const UpArgs& a, int L, const float* w2, const float* bias2, 
     q.seed = ex->seed2; q.seed_ptr = ex->seed_ptr; q.drop_thresh = ex->drop2_thresh; q.inv_keep = ex->inv_keep2;
   }
   const int lnm = ex != nullptr ? 3 : ln_dy != nullptr ? 2 : (lnb ? 1 : 0);
+  if (nx != nullptr) {
+    if (lnm != 0 || !nx->w || !nx->g || !nx->b || !nx->lat || (nx->w2 != nullptr && (!nx->y2 || nx->L2 <= 0 || nx->L2 > 64)))
+      return set_error(-2, "side_up: the next-layer stage takes the plain epilogue, w / gamma / beta / lat and L2 <= 64");
+    q.w3 = nx->w; q.bias3 = nx->bias; q.g3 = nx->g; q.b3 = nx->b; q.mean3 = nx->mean; q.rstd3 = nx->rstd; q.y3 = nx->lat;
+    q.w4 = nx->w2; q.y4 = nx->y2; q.L4 = nx->L2; q.eps3 = nx->eps > 0.f ? nx->eps : 1e-5f;
+  }
   const dim3 grid((a.M + 15) / 16), block(64 * kSW);
 #define GVK_SU(N_, W_, B_) GVK_LAUNCH((side_up_kernel<N_, W_, B_>), grid, block, 0, s, a, q)
 #define GVK_SU_N(W_, B_) { if (npw == 1) GVK_SU(1, W_, B_); else if (npw == 3) GVK_SU(3, W_, B_); else GVK_SU(4, W_, B_); }

@@ -745,6 +745,13 @@ extern "C" int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream) {
     if (rc == 1) return set_error(-2, "gvk_skinny_up: lat_b is built for L = 20 and C in {192, 768, 1024} (got L=%d, C=%d)", d->L, d->C);
     return rc;
   }
+  if (d->nx_w != nullptr) {                             // the next layer's MWSA entry on the produced rows: 16-row-tile kernel only
+    GVK_REQUIRE(d->ln_x == nullptr && d->lat_b == nullptr, "gvk_skinny_up: nx_w takes the plain epilogue");
+    UpNext nx{d->nx_w, d->nx_bias, d->nx_ln_gamma, d->nx_ln_beta, d->nx_mean, d->nx_rstd, d->nx_lat, d->nx_w2, d->nx_y2, d->nx_L2, d->nx_eps};
+    const int rc = launch_side_up(a, d->L, d->w2, d->bias2, d->z2, d->y2, d->L2, d->act2, s, nullptr, nullptr, &nx);
+    if (rc == 1) return set_error(-2, "gvk_skinny_up: nx_w is built for L = 20 and C in {192, 768, 1024} (got L=%d, C=%d)", d->L, d->C);
+    return rc;
+  }
   if (!mfma_only) {
     const int rc = launch_side_up(a, d->L, d->w2, d->bias2, d->z2, d->y2, d->L2, d->act2, s);
     if (rc != 1) return rc;

@@ -50,7 +50,13 @@ struct UpExtra {
   int w2_layout;
   unsigned long long seed2; const unsigned long long* seed_ptr; unsigned int drop2_thresh; float inv_keep2;
 };
+// nx (plain epilogue only): the next layer's MWSA entry on the rows just written: lat = LayerNorm(out; g, b) . w^T + bias (w [L][C], statistics
+// saved), y2 = lat . w2^T (w2 [L2][L], L2 <= 64)
+struct UpNext {
+  const float* w; const float* bias; const float* g; const float* b; float* mean; float* rstd; float* lat; const float* w2; float* y2;
+  int L2; float eps;
+};
 int launch_side_up(const UpArgs& a, int L, const float* w2, const float* bias2, float* z2, float* y2, int L2, int act2, hipStream_t s,
-                   const float* ln_dy = nullptr, const UpExtra* ex = nullptr);
+                   const float* ln_dy = nullptr, const UpExtra* ex = nullptr, const UpNext* nx = nullptr);
 
 }  // namespace gvk

@@ -199,6 +199,7 @@ class Engine:
                            and os.environ.get("GAVIKO_HIP_FUSE_PROJ", "1") != "0")
         self._fuse_local = kind == "gaviko" and ops.side_tile_supported(self.Lat, dim)
         self._fuse_bnd = self._fuse_local and os.environ.get("GAVIKO_HIP_FUSE_BOUNDARY", "1") != "0"
+        self._fuse_next = self._fuse_local and os.environ.get("GAVIKO_HIP_FUSE_NEXT", "1") != "0"
         self._mwsa_pending = None
         # GPA up-projection as K-concatenation of the MLP's second Linear: 64 spare K columns carry the rank-L product in split-bf16 form,
         # A' = [act | lat_hi | lat_lo | lat_hi | 1 | 1], W' = [W_fc2 | Wup_hi | Wup_hi | Wup_lo | b_hi | b_lo] (fp32-grade: the dropped
@@ -777,6 +778,8 @@ class Engine:
 
     # ---- GAViKO side paths --------------------------------------------------------------------------------------
     def _mwsa_fwd(self, ws, sv, i, si, lin, lout, gpa_local=False):
+        """MWSA of layer i on the local stream (gaviko.py:229-244).  With self._fuse_next the up-projection kernel of layer i also runs layer
+        i+1's entry (LayerNorm + proj_down + qkv of the rows it writes), so only layer 0 launches the entry kernel itself."""
         if "noside" in _ABLATE:
             return
         s = i // self.share
@@ -784,7 +787,8 @@ class Engine:
         d, C, Lt, B = self._d, self.C, self.Lat, ws["B"]
         BN = B * self.N
         m = ws["mw"][si]
-        if "loc_noupdown" not in _ABLATE:
+        chained = self._fuse_next and gpa_local and "loc_noupdown" not in _ABLATE
+        if "loc_noupdown" not in _ABLATE and not (chained and i > 0):
           ops.skinny_down(x=lin, w=d(pre + ".proj_down.weight"), bias=d(pre + ".proj_down.bias"), ln_gamma=d(pre + ".norm.weight"),
                         ln_beta=d(pre + ".norm.bias"), mean=m["mean"], rstd=m["rstd"], y=m["lat"], w2=d(pre + ".qkv.weight"), y2=m["qkv"],
                         M=BN, C=C, L=Lt, L2=3 * Lt, act=0, w_layout=0, eps=1e-5)
@@ -797,6 +801,12 @@ class Engine:
             gpre, _ = self._gpa_names(i)
             g = ws["gp"][si]
             second = dict(w2=d(gpre + ".proj_down.0.weight"), bias2=d(gpre + ".proj_down.0.bias"), z2=g["zl"], y2=g["ll"], L2=Lt, act2=1)
+        if chained and i + 1 < self.depth:                  # layer i+1's norm + proj_down + qkv of the same rows
+            nx = f"transformer.local_attns.{(i + 1) // self.share}"
+            mn = ws["mw"][si + 1 if sv["train"] else 0]
+            second.update(nx_w=d(nx + ".proj_down.weight"), nx_bias=d(nx + ".proj_down.bias"), nx_ln_gamma=d(nx + ".norm.weight"),
+                          nx_ln_beta=d(nx + ".norm.bias"), nx_mean=mn["mean"], nx_rstd=mn["rstd"], nx_lat=mn["lat"], nx_w2=d(nx + ".qkv.weight"),
+                          nx_y2=mn["qkv"], nx_L2=3 * Lt, nx_eps=1e-5)
         if "loc_noupdown" not in _ABLATE:
           ops.skinny_up(lat=m["ctx"], w=d(pre + ".proj_up.weight"), bias=d(pre + ".proj_up.bias"), res=lin, out=lout, M=BN, C=C, L=Lt,
                       w_layout=0, drop_p=sv["proj_drop"], seed=2 * i + 1, seed_ptr=ws["seed"], **second)

@@ -42,8 +42,10 @@ SkinnyDownDesc = _struct("SkinnyDownDesc",
                          ["x", "w", "bias", "ln_gamma", "ln_beta", "mean", "rstd", "z", "y", "w2", "y2", "seed_ptr"],
                          ["M", "C", "L", "L2", "act", "w_layout", "act_in"], ["eps", "drop_p"], ["seed"])
 SkinnyUpDesc = _struct("SkinnyUpDesc", ["lat", "w", "bias", "res", "out", "lat_override", "seed_ptr", "ln_x", "ln_mean", "ln_rstd", "ln_gamma", "out_bf16",
-                                        "alpha_ptr", "gg_x", "w2", "bias2", "z2", "y2", "lat_b", "w_b"],
-                       ["M", "C", "L", "T", "P", "w_layout", "accumulate", "L2", "act2", "w2_layout"], ["drop_p", "drop2_p"], ["seed", "seed2"])
+                                        "alpha_ptr", "gg_x", "w2", "bias2", "z2", "y2", "lat_b", "w_b",
+                                        "nx_w", "nx_bias", "nx_ln_gamma", "nx_ln_beta", "nx_mean", "nx_rstd", "nx_lat", "nx_w2", "nx_y2"],
+                       ["M", "C", "L", "T", "P", "w_layout", "accumulate", "L2", "act2", "w2_layout", "nx_L2"], ["drop_p", "drop2_p", "nx_eps"],
+                       ["seed", "seed2"])
 OuterDesc = _struct("OuterDesc", ["narrow", "wide", "lat_override", "mean", "rstd", "ln_gamma", "ln_beta", "scratch", "out", "colsum", "seed_ptr",
                                   "narrow2", "wide2"],
                     ["M", "C", "L", "T", "P", "transposed", "accumulate", "wide_act", "M2"], ["drop_p"], ["seed"])

@@ -238,9 +238,15 @@ typedef struct gvk_skinny_up_desc {
      boundary: dL_in = dL_out + LN'(dlat . Wd) of layer i+1 (gaviko.py:231), dL += dzl . Wd_gpa of layer i (:156), dctx = proj_drop'(dL) . Wup
      of layer i (:242-243) */
   const float* lat_b; const float* w_b;
+  /* optional, plain epilogue (L = 20 tile kernels only): the NEXT layer's MWSA entry on the rows just written (gaviko.py:231-232 of layer
+     i+1 behind :242 of layer i), so the local stream is read once per layer instead of twice:
+     nx_lat = LayerNorm(out; nx_ln_gamma, nx_ln_beta, nx_eps) . nx_w^T + nx_bias (nx_w [L][C]; nx_mean / nx_rstd [M] saved),
+     nx_y2 = nx_lat . nx_w2^T (nx_w2 [nx_L2][L], nx_L2 <= 64: the qkv projection) */
+  const float* nx_w; const float* nx_bias; const float* nx_ln_gamma; const float* nx_ln_beta; float* nx_mean; float* nx_rstd; float* nx_lat;
+  const float* nx_w2; float* nx_y2;
   int32_t M, C, L, T, P, w_layout, accumulate;
-  int32_t L2, act2, w2_layout;
-  float drop_p, drop2_p;
+  int32_t L2, act2, w2_layout, nx_L2;
+  float drop_p, drop2_p, nx_eps;
   uint64_t seed, seed2;
 } gvk_skinny_up_desc;
 int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream);

@@ -476,3 +476,34 @@ def test_skinny_up_layer_boundary_form_matches_three_kernels(dev, M, C, p):
     torch.cuda.synchronize()
     _close(out1, out3.double().cpu(), 2e-6, "boundary out")
     _close(z1, z3.double().cpu(), 2e-5, "boundary dctx")
+
+
+@pytest.mark.parametrize("M,C,p", [(4000, 768, 0.2), (2000, 192, 0.0), (1000, 1024, 0.0), (37, 768, 0.2)])
+def test_skinny_up_with_next_layer_entry_matches_two_kernels(dev, M, C, p):
+    """gvk_skinny_up with nx_w: the up-projection (+ residual, dropout, GPA's second projection) and the NEXT layer's LayerNorm + proj_down +
+    qkv of the rows it writes, against the up kernel followed by the entry kernel (gvk_skinny_down with the LayerNorm input)."""
+    from gaviko_amd import ops
+    Lat = 20
+    f = lambda t: t.float().to(dev).contiguous()
+    lat, wup, bup, res = f(_rand((M, Lat), 1)), f(_rand((C, Lat), 2, 0.2)), f(_rand((C,), 3, 0.1)), f(_rand((M, C), 4))
+    w2, b2 = f(_rand((Lat, C), 5, 0.1)), f(_rand((Lat,), 6, 0.1))
+    wd, bd, g, b = f(_rand((Lat, C), 7, 0.1)), f(_rand((Lat,), 8, 0.1)), f(1 + 0.3 * _rand((C,), 9)), f(_rand((C,), 10, 0.2))
+    wqkv = f(_rand((3 * Lat, Lat), 11, 0.3))
+    seed = torch.full((1,), 91, dtype=torch.int64, device=dev)
+    mk = lambda *s_: torch.zeros(s_, device=dev)
+    up = dict(lat=lat, w=wup, bias=bup, res=res, M=M, C=C, L=Lat, w_layout=0, drop_p=p, seed=3, seed_ptr=seed, w2=w2, bias2=b2, L2=Lat, act2=1)
+    out_a, z_a, y_a = mk(M, C), mk(M, Lat), mk(M, Lat)
+    ops.skinny_up(out=out_a, z2=z_a, y2=y_a, **up)
+    mean_a, rstd_a, lat_a, qkv_a = mk(M), mk(M), mk(M, Lat), mk(M, 3 * Lat)
+    ops.skinny_down(x=out_a, w=wd, bias=bd, ln_gamma=g, ln_beta=b, mean=mean_a, rstd=rstd_a, y=lat_a, w2=wqkv, y2=qkv_a, M=M, C=C, L=Lat, L2=3 * Lat,
+                    act=0, w_layout=0, eps=1e-5)
+    out_b, z_b, y_b = mk(M, C), mk(M, Lat), mk(M, Lat)
+    mean_b, rstd_b, lat_b, qkv_b = mk(M), mk(M), mk(M, Lat), mk(M, 3 * Lat)
+    ops.skinny_up(out=out_b, z2=z_b, y2=y_b, nx_w=wd, nx_bias=bd, nx_ln_gamma=g, nx_ln_beta=b, nx_mean=mean_b, nx_rstd=rstd_b, nx_lat=lat_b,
+                  nx_w2=wqkv, nx_y2=qkv_b, nx_L2=3 * Lat, nx_eps=1e-5, **up)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b) and torch.equal(y_a, y_b)
+    _close(mean_b, mean_a.double().cpu(), 2e-6, "next mean")
+    _close(rstd_b, rstd_a.double().cpu(), 2e-6, "next rstd")
+    _close(lat_b, lat_a.double().cpu(), 1e-5, "next lat")
+    _close(qkv_b, qkv_a.double().cpu(), 1e-5, "next qkv")
