@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64 * kSW, NGW <= 3 ? 4 : 2) void side_down_kernel(D
   const int lane = lane_id(), wave = wave_id();
   const int i = lane & 15, kq = lane >> 4;
   const int C = p.C, NG = C >> 5;                       // groups of 32 columns; wave w owns groups w, w + 8, ...
-  const int row0 = blockIdx.x * 16;
+  const int row0 = (blockIdx.x + p.tile_off) * 16;
   const int row = min(row0 + i, p.M - 1);
   const bool ln = MODE == 0 && p.ln_g != nullptr;
   // ---- every load of the tile goes out first: the rows, the weight fragments, the LayerNorm affine
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
   const int lane = lane_id(), wave = wave_id();
   const int a = lane & 15, kq = lane >> 4;              // A operand: weight row a of a column tile; B operand / D: token row a
   const int C = p.C, NP = C >> 5;
-  const int row0 = blockIdx.x * 16;
+  const int row0 = (blockIdx.x + p.tile_off) * 16;
   const int row = min(row0 + a, p.M - 1);
   const bool rvalid = row0 + a < p.M;
   const float* __restrict__ base = p.accumulate ? p.out : p.res;
@@ -637,6 +637,13 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
   }
 }
 
+// diagnostics (GAVIKO_HIP_SIDE_CHUNKS = k): a launch is issued as k back-to-back launches over row ranges -- the same work at 1/k of the
+// concurrency, to see whether the backbone kernels suffer from the side kernels' bandwidth BURST or from their total work
+static int side_chunks() {
+  static const int k = getenv("GAVIKO_HIP_SIDE_CHUNKS") ? max(1, atoi(getenv("GAVIKO_HIP_SIDE_CHUNKS"))) : 1;
+  return k;
+}
+
 static bool side_enabled() {
   static const bool on = getenv("GAVIKO_HIP_SIDE") == nullptr || getenv("GAVIKO_HIP_SIDE")[0] != '0';   // A/B switch: 0 = the row-per-wave kernels
   return on;
@@ -655,14 +662,20 @@ int launch_side_down(const DownArgs& a, int L, hipStream_t s) {
   if (a.ysplit != nullptr) return 1;                     // the split-bf16 operand copy is written by the row-per-wave kernel only
   static const bool ln_modes = getenv("GAVIKO_HIP_SIDE_LN") != nullptr && getenv("GAVIKO_HIP_SIDE_LN")[0] == '1';   // A/B switch, see DESIGN.md section 7
   if (a.mode != 0 && !ln_modes) return 1;
-  const dim3 grid((a.M + 15) / 16), block(64 * kSW);
-#define GVK_SD(N_, W_, M_) GVK_LAUNCH((side_down_kernel<N_, W_, M_>), grid, block, 0, s, a)
+  const int tiles = (a.M + 15) / 16, chunks = side_chunks(), per = (tiles + chunks - 1) / chunks;
+  const dim3 block(64 * kSW);
+  DownArgs ac = a;
+  for (int t0 = 0; t0 < tiles; t0 += per) {
+  ac.tile_off = t0;
+  const dim3 grid(min(per, tiles - t0));
+#define GVK_SD(N_, W_, M_) GVK_LAUNCH((side_down_kernel<N_, W_, M_>), grid, block, 0, s, ac)
 #define GVK_SD_N(W_, M_) { if (ngw == 1) GVK_SD(1, W_, M_); else if (ngw == 3) GVK_SD(3, W_, M_); else GVK_SD(4, W_, M_); }
   if (a.mode == 0) { if (a.w_layout == 0) GVK_SD_N(0, 0) else GVK_SD_N(1, 0) }
   else if (a.mode == 1) { if (a.w_layout == 0) GVK_SD_N(0, 1) else GVK_SD_N(1, 1) }
   else { if (a.w_layout == 0) GVK_SD_N(0, 2) else GVK_SD_N(1, 2) }
 #undef GVK_SD_N
 #undef GVK_SD
+  }
   return check_launch("side_down");
 }
 
@@ -689,14 +702,20 @@ int launch_side_up(const UpArgs& a, int L, const float* w2, const float* bias2, 
     q.w3 = nx->w; q.bias3 = nx->bias; q.g3 = nx->g; q.b3 = nx->b; q.mean3 = nx->mean; q.rstd3 = nx->rstd; q.y3 = nx->lat;
     q.w4 = nx->w2; q.y4 = nx->y2; q.L4 = nx->L2; q.eps3 = nx->eps > 0.f ? nx->eps : 1e-5f;
   }
-  const dim3 grid((a.M + 15) / 16), block(64 * kSW);
-#define GVK_SU(N_, W_, B_) GVK_LAUNCH((side_up_kernel<N_, W_, B_>), grid, block, 0, s, a, q)
+  const int tiles = (a.M + 15) / 16, chunks = side_chunks(), per = (tiles + chunks - 1) / chunks;
+  const dim3 block(64 * kSW);
+  UpArgs ac = a;
+  for (int t0 = 0; t0 < tiles; t0 += per) {
+  ac.tile_off = t0;
+  const dim3 grid(min(per, tiles - t0));
+#define GVK_SU(N_, W_, B_) GVK_LAUNCH((side_up_kernel<N_, W_, B_>), grid, block, 0, s, ac, q)
 #define GVK_SU_N(W_, B_) { if (npw == 1) GVK_SU(1, W_, B_); else if (npw == 3) GVK_SU(3, W_, B_); else GVK_SU(4, W_, B_); }
   if (lnm == 3) GVK_SU_N(1, 3)
   else if (a.w_layout == 0) { if (lnm == 2) GVK_SU_N(0, 2) else if (lnm == 1) GVK_SU_N(0, 1) else GVK_SU_N(0, 0) }
   else { if (lnm == 2) GVK_SU_N(1, 2) else if (lnm == 1) GVK_SU_N(1, 1) else GVK_SU_N(1, 0) }
 #undef GVK_SU_N
 #undef GVK_SU
+  }
   return check_launch("side_up");
 }
 

@@ -20,6 +20,7 @@ struct DownArgs {
   //   mode 3: QuickGELU applied to the input rows before the projection (DVPT share_MLP, dvpt.py:38)
   int mode;
   bf16* y16;
+  int tile_off;                                            // sidepass.hip: first 16-row tile of this launch (chunked launches, GAVIKO_HIP_SIDE_CHUNKS)
   bf16* ysplit; int ysplit_ld, ysplit_col;                // row-per-wave kernel: split-bf16 copy [hi | lo | hi] of y into spare K columns of a GEMM operand
   const float* dy; const float* mean_in; const float* rstd_in; const float* dres; float* dx; bf16* dx16;
 };
@@ -28,6 +29,7 @@ struct UpArgs {
   const float* lat; const float* w; const float* bias;    // lat [M][L]; w [C][L] (layout 0) or [L][C] (layout 1)
   const float* res; float* out;                           // out = res + (...)  (res may be NULL / alias out); accumulate: out += (...)
   const float* lat_override; int T, P;                    // rows with (m % T) < P read lat_override[(m / T) * P + m % T][:]
+  int tile_off;                                            // sidepass.hip: first 16-row tile of this launch
   const float* ln_x; const float* ln_mean; const float* ln_rstd; const float* ln_g;   // optional LayerNorm-backward epilogue
   bf16* out16;                                            // optional bf16 copy of `out` (the next dgrad GEMM's operand)
   const float* alpha_ptr;                                 // optional device scalar: v = alpha * (lat . W + bias)   (DVPT prompt_gate)
