@@ -51,6 +51,7 @@ GEMM_MARKS = None
 # Dispatch priority of the side-chain streams (negative = higher).  Measured: -1 drops the step rate from 448 to 274 volumes/s
 # (priority queues serialise against the captured graph's main queue on this runtime), so the default stays 0.
 SIDE_STREAM_PRIORITY = int(os.environ.get("GAVIKO_HIP_SIDE_PRIORITY", "0"))
+_SIDE_STREAMS = {}                       # (device index, kind) -> the process-wide side stream of that kind
 # MWSA backward chain held behind the layer's attention backward: measured 669 vs 688 volumes/s -- the chain then slows the dgrad GEMMs
 # of the next layer by as much as it slowed the attention kernels before (start->fc1d 82 -> 98 us); opt-in only
 _LOC_SHIFT = os.environ.get("GAVIKO_HIP_LOC_SHIFT", "0") == "1"
@@ -432,9 +433,17 @@ class Engine:
     def _stream(self, name):
         st = self._streams.get(name)
         if st is None:
+            # One side stream of each kind per DEVICE, shared by every engine of the process (train + eval models, a test suite's many
+            # models): engines run their steps one after another, and every stream of their own would eventually alias hardware queues
+            # (tools/bench_reducer.py: the 5th model of a process ran 14.8 ms steps instead of 5.9).
+            key = (torch.cuda.current_device(), name)
+            st = _SIDE_STREAMS.get(key)
+            if st is not None:
+                self._streams[name] = st
+                return st
             # (confining the side streams to a CU subset with hipExtStreamCreateWithCUMask was measured: 676 -> 170-260 volumes/s for
             #  every mask shape tried -- masked queues are far slower to dispatch on this runtime)
-            st = self._streams[name] = torch.cuda.Stream(priority=SIDE_STREAM_PRIORITY)
+            st = self._streams[name] = _SIDE_STREAMS[key] = torch.cuda.Stream(priority=SIDE_STREAM_PRIORITY)
             pad = int(os.environ.get(f"GAVIKO_HIP_LDS_PAD_{name.upper()}", os.environ.get("GAVIKO_HIP_LDS_PAD", "0")))
             if pad:
                 L.check(L.load().gvk_stream_set_lds_pad(st.cuda_stream, pad), "gvk_stream_set_lds_pad")
@@ -963,6 +972,8 @@ class Engine:
         """Layers hi, hi-1, ..., lo of the backward sweep (+ the head when `first`, + the embedding rows when `last`).
         ws['dG'][0] always holds the gradient of the global stream at a layer boundary, ws['dG'][1] the mid-layer one;
         the local-stream gradient ping-pongs with the layer parity."""
+        if first:
+            self._mwsa_pending = None
         nm, w, d = self.names, self._w16, self._d
         B, C, T, M = sv["B"], self.C, self.T, sv["B"] * self.T
         gaviko = self.kind == "gaviko"
@@ -1117,7 +1128,8 @@ class Engine:
                 dGout = other
                 ops.to_operand(dGout, ws["dG16"], self.adt)
         if gaviko:
-            self._mwsa_flush(ws, B, loc)
+            if last:                                                         # (the deferred step crosses segment boundaries like layer boundaries)
+                self._mwsa_flush(ws, B, loc)
             self._wait(None, "gpa")
             self._wait(None, "loc")
         if last and sv.get("bb"):
