@@ -108,9 +108,9 @@ __global__ __launch_bounds__(64 * kSW, NGW <= 3 ? 4 : 2) void side_down_kernel(D
       }
     }
   }
-  if constexpr (MODE != 2) {                             // MODE 2 holds three wide streams: its weight fragments are fetched after the row math
-#pragma unroll
-    for (int gi = 0; gi < NGW; ++gi)
+  if constexpr (MODE == 0) {                             // the LayerNorm modes hold two or three wide streams: their weight fragments are fetched
+#pragma unroll                                           // where the projection consumes them (128 VGPRs = two workgroups per CU, or the 259 tiles
+    for (int gi = 0; gi < NGW; ++gi)                     //  of M = 4132 need a second round)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         wf[gi][h][0] = load_w_down<WL>(p.w, C, i, col[gi][h]);
@@ -264,13 +264,6 @@ __global__ __launch_bounds__(64 * kSW, NGW <= 3 ? 4 : 2) void side_down_kernel(D
           }
         }
       }
-#pragma unroll
-    for (int gi = 0; gi < NGW; ++gi)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        wf[gi][h][0] = load_w_down<WL>(p.w, C, i, col[gi][h]);
-        wf[gi][h][1] = load_w_down<WL>(p.w, C, 16 + i, col[gi][h]);
-      }
   }
   // ---- projection: this wave's share of the sum over C (groups past the end contribute zeros)
   f32x4 acc[2] = {zero4(), zero4()};
@@ -279,6 +272,10 @@ __global__ __launch_bounds__(64 * kSW, NGW <= 3 ? 4 : 2) void side_down_kernel(D
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const f32x4 xv = ok[gi] ? x[gi][h] : zero4();
+      if constexpr (MODE != 0) {
+        wf[gi][h][0] = load_w_down<WL>(p.w, C, i, col[gi][h]);
+        wf[gi][h][1] = load_w_down<WL>(p.w, C, 16 + i, col[gi][h]);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[0] = mfma4(xv[e], wf[gi][h][0][e], acc[0]);
 #pragma unroll
@@ -304,6 +301,11 @@ __global__ __launch_bounds__(64 * kSW, NGW <= 3 ? 4 : 2) void side_down_kernel(D
         if (m < p.M) {
           if (p.z) p.z[(size_t)m * kSL + n] = zz;
           if (p.y) p.y[(size_t)m * kSL + n] = yy;
+          if (p.ysplit != nullptr) {                     // split-bf16 copy [hi | lo | hi] into spare K columns of a GEMM operand (elementwise.hip)
+            bf16* d16 = p.ysplit + (size_t)m * p.ysplit_ld + p.ysplit_col;
+            const bf16 hi = (bf16)yy;
+            d16[n] = hi; d16[kSL + n] = (bf16)(yy - (float)hi); d16[2 * kSL + n] = hi;
+          }
         }
       }
     }
@@ -659,9 +661,10 @@ int launch_side_down(const DownArgs& a, int L, hipStream_t s) {
   const int ngw = groups_per_wave(a.C);
   if (!side_enabled() || L != kSL || ngw == 0 || a.mode < 0 || a.mode > 2 || (a.w2 != nullptr && a.L2 > 64)) return 1;
   if (a.mode != 0 && (a.w2 != nullptr || a.drop_thresh != 0u)) return 1;
-  if (a.ysplit != nullptr) return 1;                     // the split-bf16 operand copy is written by the row-per-wave kernel only
-  static const bool ln_modes = getenv("GAVIKO_HIP_SIDE_LN") != nullptr && getenv("GAVIKO_HIP_SIDE_LN")[0] == '1';   // A/B switch, see DESIGN.md section 7
-  if (a.mode != 0 && !ln_modes) return 1;
+  // A/B switch, see DESIGN.md section 7b: '1' = both LayerNorm modes on the tile kernels, 'f' = the forward one (MODE 1), 'b' = the backward one
+  static const char ln_sel = getenv("GAVIKO_HIP_SIDE_LN") != nullptr ? getenv("GAVIKO_HIP_SIDE_LN")[0] : 'f';
+  if (a.mode == 1 && !(ln_sel == '1' || ln_sel == 'f')) return 1;
+  if (a.mode == 2 && !(ln_sel == '1' || ln_sel == 'b')) return 1;
   const int tiles = (a.M + 15) / 16, chunks = side_chunks(), per = (tiles + chunks - 1) / chunks;
   const dim3 block(64 * kSW);
   DownArgs ac = a;
