@@ -160,11 +160,13 @@ __global__ __launch_bounds__(576) void gpa_fwd_kernel(GpaArgs p) {
   if (lane == 0) { p.lse_g[b * p.P + pi] = ls[0]; p.lse_l[b * p.P + pi] = ls[1]; }
 }
 
-// ---- backward, prompt side: same workgroup shape as the forward (wave 0 global, wave 1 local)
+// ---- backward, prompt side: same workgroup shape as the forward -- eight waves, waves 0-3 a quarter each of the global tokens, waves 4-7 of
+// the local tokens (dq is a plain sum over tokens: the quarters' partial sums are added through LDS in a fixed order); wave 0 finishes.
 template <int L>
-__global__ __launch_bounds__(128) void gpa_cross_bwd_p_kernel(GpaArgs p) {
-  __shared__ float dpr_s[L];
+__global__ __launch_bounds__(512) void gpa_cross_bwd_p_kernel(GpaArgs p) {
+  __shared__ float dq_s[8][L], dpr_s[L];
   const int b = blockIdx.y, pi = blockIdx.x, wave = wave_id(), lane = lane_id();
+  const int side = wave >> 2, quarter = wave & 3;
   const size_t o = ((size_t)b * p.P + pi) * L;
   const float gw = p.gw[b], im = p.imp[b * p.P + pi];
   const int ll_ = lane < L ? lane : 0;
@@ -174,29 +176,34 @@ __global__ __launch_bounds__(128) void gpa_cross_bwd_p_kernel(GpaArgs p) {
   const float fused_l = gw * cg_l + (1.f - gw) * cl_l;
   const float df_l = denh_l * im;
   const float dcg_l = gw * df_l, dcl_l = (1.f - gw) * df_l;
-  const float dc_l = wave == 0 ? dcg_l : dcl_l;
-  const float del = wave_sum(in ? dc_l * (wave == 0 ? cg_l : cl_l) : 0.f);
-  const float q_l = (wave == 0 ? p.qg : p.ql)[o + ll_];
+  const float dc_l = side == 0 ? dcg_l : dcl_l;
+  const float del = wave_sum(in ? dc_l * (side == 0 ? cg_l : cl_l) : 0.f);
+  const float q_l = (side == 0 ? p.qg : p.ql)[o + ll_];
   float dc[L], q[L], dq[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) { dc[l] = __shfl(dc_l, l, 64); q[l] = __shfl(q_l, l, 64); }
-  if (wave == 0) cross_dq<L>(q, dc, p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L, p.T - (2 * p.P + 2), lane, p.lse_g[b * p.P + pi], del, dq);
-  else cross_dq<L>(q, dc, p.ll + (size_t)b * p.N * L, p.N, lane, p.lse_l[b * p.P + pi], del, dq);
-  // unscaled-query gradients (q_scaled = scale * (W prompt + b)), and this query path's share of the prompt latent gradient
-  const float* wq = wave == 0 ? p.wgq : p.wlq;
-  float dpr_l = 0.f, dq_l = 0.f;
+  const float* base = side == 0 ? p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L : p.ll + (size_t)b * p.N * L;
+  const int n = side == 0 ? p.T - (2 * p.P + 2) : p.N;
+  const int per = (n + 3) >> 2, lo = quarter * per, cnt = max(0, min(per, n - lo));
+  cross_dq<L>(q, dc, base + (size_t)lo * L, cnt, lane, (side == 0 ? p.lse_g : p.lse_l)[b * p.P + pi], del, dq);   // cnt = 0: zeros
+  float dq_l = 0.f;
 #pragma unroll
-  for (int j = 0; j < L; ++j) {
-    dq[j] *= p.scale;
-    dpr_l = __builtin_fmaf(wq[j * L + ll_], dq[j], dpr_l);
-    dq_l = (lane == j) ? dq[j] : dq_l;
-  }
-  if (wave == 1) {
+  for (int j = 0; j < L; ++j) dq_l = (lane == j) ? dq[j] : dq_l;
+  if (in) dq_s[wave][lane] = dq_l;
+  __syncthreads();
+  if (quarter != 0) return;                              // waves 0 (global) and 4 (local) carry on with the summed dq of their side
+  dq_l = in ? ((dq_s[wave][ll_] + dq_s[wave + 1][ll_]) + (dq_s[wave + 2][ll_] + dq_s[wave + 3][ll_])) * p.scale : 0.f;
+  // unscaled-query gradients (q_scaled = scale * (W prompt + b)), and this query path's share of the prompt latent gradient
+  const float* wq = side == 0 ? p.wgq : p.wlq;
+  float dpr_l = 0.f;
+#pragma unroll
+  for (int j = 0; j < L; ++j) dpr_l = __builtin_fmaf(wq[j * L + ll_], __shfl(dq_l, j, 64), dpr_l);
+  if (side == 1) {
     if (in) { dpr_s[lane] = dpr_l; p.dql[o + lane] = dq_l; p.dcl[o + lane] = dcl_l; }
     if (lane == 0) p.delta_l[b * p.P + pi] = del;
   }
-  __syncthreads();
-  if (wave == 0) {
+  __syncthreads();                                       // (waves 0 and 4 only: the others have left)
+  if (side == 0) {
     if (in) { p.dqg[o + lane] = dq_l; p.dcg[o + lane] = dcg_l; p.dprm[o + lane] = dpr_l + dpr_s[lane]; }
     const float dimp = wave_sum(in ? denh_l * fused_l : 0.f);
     const float dgw = wave_sum(in ? df_l * (cg_l - cl_l) : 0.f);
@@ -206,11 +213,13 @@ __global__ __launch_bounds__(128) void gpa_cross_bwd_p_kernel(GpaArgs p) {
 
 // ---- gates backward: one wave per sample; recomputes the tiny forward.  Per-sample parameter-gradient partials are
 // written to gate_partials[b][:] in the order [ca0_g L | ca0_b L | ca1_w 64L | ca1_b 64 | ca3_w 64P | ca3_b P | gl0_g L | gl0_b L | gl1_w L | gl1_b 1].
+// (device body: runs on ONE wave -- the extra workgroup per sample of gpa_bwd_tok_kernel, whose other waves have left, so the barriers below
+//  only order this wave's own LDS traffic)
 template <int L>
-__global__ __launch_bounds__(64) void gpa_gates_bwd_kernel(GpaArgs p) {
+__device__ __forceinline__ void gpa_gates_bwd_body(const GpaArgs& p, const int b, const int lane, float (&dcls)[L]) {
   __shared__ float a1_s[64], da1_s[64], dpre3_s[64], dhn_s[64][L + 1];
   __shared__ float w3_s[64][65];                           // ca3_w rows (q < P), +1 pad
-  const int b = blockIdx.x, lane = threadIdx.x, P = p.P;
+  const int P = p.P;
   const int n_gate = 4 * L + 64 * L + 64 + 64 * P + P + L + 1;
   float* out = p.gate_partials + (size_t)b * n_gate;
   float* o_ca0g = out; float* o_ca0b = out + L; float* o_ca1w = out + 2 * L; float* o_ca1b = o_ca1w + 64 * L;
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(64) void gpa_gates_bwd_kernel(GpaArgs p) {
   float* o_gl1w = o_gl0b + L; float* o_gl1b = o_gl1w + L;
   // One wave per sample on a busy chip: every dependent round trip to memory costs microseconds, so EVERYTHING this kernel reads is
   // requested here, before the first use (the loop form interleaved loads with stores to `out` and paid ~8 round trips: 24 us).
-  float w1[L], cls[L], hn[L], gn[L], dcls[L];
+  float w1[L], cls[L], hn[L], gn[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) { w1[l] = p.ca1_w[lane * L + l]; cls[l] = p.xl[((size_t)b * p.T + P) * L + l]; dcls[l] = 0.f; }
   for (int q = 0; q < P && q < 64; ++q) w3_s[q][lane] = p.ca3_w[q * 64 + lane];
@@ -298,6 +307,21 @@ template <int L>
 __global__ __launch_bounds__(256) void gpa_bwd_tok_kernel(GpaArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.y, P = p.P;
+  if (blockIdx.x == gridDim.x - 1) {
+    // The extra workgroup of every sample: the two gates' backward (one wave; gaviko.py:160-170) and, with it, the CLS row -- the only token
+    // row the gates' gradient reaches, and one that attends to nothing (t = P < 2P + 2), so dz = (dcomb + dcls) o QuickGELU'(z) is all of it.
+    // This used to be a launch of its own BETWEEN the prompt-side and the token-side kernels: 16 us + a dispatch on the chain the backbone
+    // stream waits for.
+    if (threadIdx.x >= 64) return;
+    float dcls[L];
+    gpa_gates_bwd_body<L>(p, b, (int)threadIdx.x, dcls);
+    const size_t row = (size_t)b * p.T + P;
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int l = 0; l < L; ++l) p.dzx[row * L + l] = (p.dcomb[row * L + l] + dcls[l]) * quick_gelu_grad(p.zx[row * L + l]);
+    }
+    return;
+  }
   float* q_s = (float*)smem;              // [2][P][L]  scaled queries (global, local)
   float* dc_s = q_s + 2 * P * L;          // [2][P][L]  dctx
   float* ls_s = dc_s + 2 * P * L;         // [2][P]     lse
@@ -318,6 +342,7 @@ __global__ __launch_bounds__(256) void gpa_bwd_tok_kernel(GpaArgs p) {
   if (r >= p.T + p.N) return;                              // (whole quads leave together)
   const bool is_local = r >= p.T;
   const int t = is_local ? r - p.T : r;
+  if (!is_local && t == P) return;                         // the CLS row belongs to the gates' workgroup
   const size_t row = is_local ? (size_t)b * p.N + t : (size_t)b * p.T + t;
   const float* lat = (is_local ? p.ll : p.xl) + row * L;
   float tok[L], g[L];
@@ -350,11 +375,7 @@ __global__ __launch_bounds__(256) void gpa_bwd_tok_kernel(GpaArgs p) {
       for (int l = 0; l < L; ++l) g[l] = p.dprm[((size_t)b * P + t) * L + l];     // prompt rows only feed the queries
     } else {
 #pragma unroll
-      for (int l = 0; l < L; ++l) g[l] += p.dcomb[row * L + l];                  // cls / image rows pass through proj_up
-      if (t == P) {
-#pragma unroll
-        for (int l = 0; l < L; ++l) g[l] += p.dcls[b * L + l];
-      }
+      for (int l = 0; l < L; ++l) g[l] += p.dcomb[row * L + l];                  // image rows pass through proj_up
     }
   }
   const float* z = (is_local ? p.zl : p.zx) + row * L;
@@ -420,14 +441,11 @@ extern "C" int gvk_gpa_bwd(const gvk_gpa_desc* d, void* stream) {
   GpaArgs a{};
   fill_gpa(a, d);
   hipStream_t s = (hipStream_t)stream;
-  GVK_GPA_LAUNCH(gpa_cross_bwd_p_kernel, dim3(d->P, d->B), dim3(128), 0);
+  GVK_GPA_LAUNCH(gpa_cross_bwd_p_kernel, dim3(d->P, d->B), dim3(512), 0);
   rc = check_launch("gpa_cross_bwd_p");
   if (rc) return rc;
-  GVK_GPA_LAUNCH(gpa_gates_bwd_kernel, dim3(d->B), dim3(64), 0);
-  rc = check_launch("gpa_gates_bwd");
-  if (rc) return rc;
   const int lds = (4 * d->P * d->L + 4 * d->P) * 4;
-  GVK_GPA_LAUNCH(gpa_bwd_tok_kernel, dim3((d->T + d->N + 63) / 64, d->B), dim3(256), lds);
+  GVK_GPA_LAUNCH(gpa_bwd_tok_kernel, dim3((d->T + d->N + 63) / 64 + 1, d->B), dim3(256), lds);   // + the gates' workgroup of every sample
   return check_launch("gpa_bwd_tok");
 }
 

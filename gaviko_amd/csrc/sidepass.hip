@@ -390,9 +390,11 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = cc[pi] - 8 * kq + 8 * (a >> 2) + 4 * j + (a & 3);      // weight row fed to A-operand row a of column tile j
+      if constexpr (LNM != 2) {                          // LNM 2 forms its rank-L term late, where it is added (three wide streams are live until then)
 #pragma unroll
-      for (int s = 0; s < kK4; ++s)
-        wa[pi][j][s] = WL == 0 ? p.w[(size_t)c * kSL + kq * kK4 + s] : p.w[(size_t)(kq * kK4 + s) * C + c];
+        for (int s = 0; s < kK4; ++s)
+          wa[pi][j][s] = WL == 0 ? p.w[(size_t)c * kSL + kq * kK4 + s] : p.w[(size_t)(kq * kK4 + s) * C + c];
+      }
       if constexpr (!LNB) vec[pi][j] = p.bias != nullptr ? *(const f32x4*)(p.bias + cc[pi] + 4 * j) : zero4();
     }
   if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
@@ -410,8 +412,10 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       acc[pi][j] = zero4();
+      if constexpr (LNM != 2) {
 #pragma unroll
-      for (int s = 0; s < kK4; ++s) acc[pi][j] = mfma4(wa[pi][j][s], lb[s], acc[pi][j]);
+        for (int s = 0; s < kK4; ++s) acc[pi][j] = mfma4(wa[pi][j][s], lb[s], acc[pi][j]);
+      }
     }
   // ---- epilogue: lane = token row a, columns cc + (4 j + e)
   [[maybe_unused]] float s1 = 0.f, s2 = 0.f;
@@ -425,7 +429,6 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float dh = (LNM == 2 ? ys[pi][j][e] : v[e]) * gam[e], xh = (xs[pi][j][e] - mu) * rs;
-          if constexpr (LNM == 2) ys[pi][j][e] = v[e];                 // the rank-L term, added after the LayerNorm backward
           v[e] = dh;
           xs[pi][j][e] = xh;
           s1 += ok[pi] ? dh : 0.f;
@@ -472,14 +475,23 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
           for (int s = 0; s < kK4; ++s) v2[j] = mfma4(q.w2up[(size_t)(kq * kK4 + s) * C + c], lb2[s], v2[j]);
         }
       }
+      if constexpr (LNM == 2) {                          // the rank-L term lat . W^T, formed here (weights fetched at use)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = cc[pi] - 8 * kq + 8 * (a >> 2) + 4 * j + (a & 3);
+          v2[j] = zero4();
+#pragma unroll
+          for (int s = 0; s < kK4; ++s)
+            v2[j] = mfma4(WL == 0 ? p.w[(size_t)c * kSL + kq * kK4 + s] : p.w[(size_t)(kq * kK4 + s) * C + c], lb[s], v2[j]);
+        }
+      }
       if (rvalid && ok[pi]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           f32x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = rs * (acc[pi][j][e] - s1 - xs[pi][j][e] * s2) + bs[pi][j][e];
-          if constexpr (LNM == 2) o += ys[pi][j];
-          if constexpr (LNM == 3) o += v2[j];
+          if constexpr (LNM == 2 || LNM == 3) o += v2[j];
           st_stream(p.out + (size_t)row * C + cc[pi] + 4 * j, o);
           acc[pi][j] = o;
         }
