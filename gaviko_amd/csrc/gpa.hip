@@ -211,6 +211,50 @@ __global__ __launch_bounds__(512) void gpa_cross_bwd_p_kernel(GpaArgs p) {
   }
 }
 
+// ---- backward, prompt side, two-wave form (wave 0 global, wave 1 local): GAVIKO_HIP_GPA_BWD_WAVES=2
+template <int L>
+__global__ __launch_bounds__(128) void gpa_cross_bwd_p2_kernel(GpaArgs p) {
+  __shared__ float dpr_s[L];
+  const int b = blockIdx.y, pi = blockIdx.x, wave = wave_id(), lane = lane_id();
+  const size_t o = ((size_t)b * p.P + pi) * L;
+  const float gw = p.gw[b], im = p.imp[b * p.P + pi];
+  const int ll_ = lane < L ? lane : 0;
+  const bool in = lane < L;
+  const float denh_l = p.dcomb[((size_t)b * p.T + pi) * L + ll_];
+  const float cg_l = p.cg[o + ll_], cl_l = p.cl[o + ll_];
+  const float fused_l = gw * cg_l + (1.f - gw) * cl_l;
+  const float df_l = denh_l * im;
+  const float dcg_l = gw * df_l, dcl_l = (1.f - gw) * df_l;
+  const float dc_l = wave == 0 ? dcg_l : dcl_l;
+  const float del = wave_sum(in ? dc_l * (wave == 0 ? cg_l : cl_l) : 0.f);
+  const float q_l = (wave == 0 ? p.qg : p.ql)[o + ll_];
+  float dc[L], q[L], dq[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) { dc[l] = __shfl(dc_l, l, 64); q[l] = __shfl(q_l, l, 64); }
+  if (wave == 0) cross_dq<L>(q, dc, p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L, p.T - (2 * p.P + 2), lane, p.lse_g[b * p.P + pi], del, dq);
+  else cross_dq<L>(q, dc, p.ll + (size_t)b * p.N * L, p.N, lane, p.lse_l[b * p.P + pi], del, dq);
+  // unscaled-query gradients (q_scaled = scale * (W prompt + b)), and this query path's share of the prompt latent gradient
+  const float* wq = wave == 0 ? p.wgq : p.wlq;
+  float dpr_l = 0.f, dq_l = 0.f;
+#pragma unroll
+  for (int j = 0; j < L; ++j) {
+    dq[j] *= p.scale;
+    dpr_l = __builtin_fmaf(wq[j * L + ll_], dq[j], dpr_l);
+    dq_l = (lane == j) ? dq[j] : dq_l;
+  }
+  if (wave == 1) {
+    if (in) { dpr_s[lane] = dpr_l; p.dql[o + lane] = dq_l; p.dcl[o + lane] = dcl_l; }
+    if (lane == 0) p.delta_l[b * p.P + pi] = del;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    if (in) { p.dqg[o + lane] = dq_l; p.dcg[o + lane] = dcg_l; p.dprm[o + lane] = dpr_l + dpr_s[lane]; }
+    const float dimp = wave_sum(in ? denh_l * fused_l : 0.f);
+    const float dgw = wave_sum(in ? df_l * (cg_l - cl_l) : 0.f);
+    if (lane == 0) { p.dimp[b * p.P + pi] = dimp; p.dgw_part[b * p.P + pi] = dgw; p.delta_g[b * p.P + pi] = del; }
+  }
+}
+
 // ---- gates backward: one wave per sample; recomputes the tiny forward.  Per-sample parameter-gradient partials are
 // written to gate_partials[b][:] in the order [ca0_g L | ca0_b L | ca1_w 64L | ca1_b 64 | ca3_w 64P | ca3_b P | gl0_g L | gl0_b L | gl1_w L | gl1_b 1].
 // (device body: runs on ONE wave -- the extra workgroup per sample of gpa_bwd_tok_kernel, whose other waves have left, so the barriers below
@@ -441,7 +485,9 @@ extern "C" int gvk_gpa_bwd(const gvk_gpa_desc* d, void* stream) {
   GpaArgs a{};
   fill_gpa(a, d);
   hipStream_t s = (hipStream_t)stream;
-  GVK_GPA_LAUNCH(gpa_cross_bwd_p_kernel, dim3(d->P, d->B), dim3(512), 0);
+  static const bool two_waves = getenv("GAVIKO_HIP_GPA_BWD_WAVES") != nullptr && getenv("GAVIKO_HIP_GPA_BWD_WAVES")[0] == '2';   // A/B switch
+  if (two_waves) { GVK_GPA_LAUNCH(gpa_cross_bwd_p2_kernel, dim3(d->P, d->B), dim3(128), 0); }
+  else { GVK_GPA_LAUNCH(gpa_cross_bwd_p_kernel, dim3(d->P, d->B), dim3(512), 0); }
   rc = check_launch("gpa_cross_bwd_p");
   if (rc) return rc;
   const int lds = (4 * d->P * d->L + 4 * d->P) * 4;
