@@ -17,6 +17,7 @@ are device-agnostic so the N>1 path is covered by world_size-2 `gloo` tests on C
 """
 from __future__ import annotations
 
+import os
 import re
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -74,6 +75,9 @@ class GradReducer:
         if mode not in ("events", "segments"):
             raise ValueError("GradReducer: mode must be 'events' or 'segments'")
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # a single rank has nothing to exchange; GAVIKO_DP_FORCE_COLLECTIVES=1 issues the collectives anyway (identity over one rank) so that the
+        # whole ordering machinery -- and RCCL itself -- can be exercised on a one-GPU box (tests/test_distributed_gpu.py)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("GAVIKO_DP_FORCE_COLLECTIVES", "0") == "1")
         self.group = group
         self.mode = mode
         self.ranges, self.kinds = plan_buckets(names, numels, depth, share_factor, layers_per_bucket, kinds=True)
@@ -82,7 +86,7 @@ class GradReducer:
         self._done_upto = None
 
     def _reduce(self, flat: torch.Tensor, s: int, e: int):
-        if self.world == 1:
+        if not self.active:
             return
         piece = flat[s:e]
         if flat.is_cuda:
@@ -102,10 +106,10 @@ class GradReducer:
         """mode 'events': every bucket is all-reduced on the collective stream behind the event the engine recorded for it.
         marks: {(kind, ready_layer): event handle}; waiter(stream, handle) makes `stream` wait for that event.  Called once per step,
         after the whole backward has been ENQUEUED -- the GPU still runs it, and each collective starts when its bucket is final."""
-        if self.world > 1 and flat.is_cuda and self._stream is None:
+        if self.active and flat.is_cuda and self._stream is None:
             self._stream = torch.cuda.Stream(device=flat.device)
         for (ready, s, e), kind in zip(self.ranges, self.kinds):
-            if self.world == 1:
+            if not self.active:
                 continue
             piece = flat[s:e]
             if not flat.is_cuda:

@@ -80,3 +80,64 @@ def test_two_process_event_ordered_reduction_bitwise(dev, tmp_path, share):
         outs.append(out)
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"DP-OK {rank} replayed" in out, out[-3000:]
+
+
+
+RCCL_CHILD = textwrap.dedent('''
+    import os, sys
+    import torch, torch.distributed as dist
+    sys.path.insert(0, os.environ["GVK_ROOT"])
+    from gaviko_amd.registry import build_model
+    from gaviko_amd.utils import synth
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1)           # backend "nccl" IS RCCL on ROCm
+        probe = torch.ones(4, device=dev)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+    except Exception as e:                                                # no RCCL on this box: nothing to test
+        print("RCCL-UNAVAILABLE", repr(e)[:200], flush=True)
+        sys.exit(0)
+    cfg = dict(image_size=160, image_patch_size=16, frames=120, frame_patch_size=12, num_classes=5, channels=1, pool="cls", dim_head=64,
+               dropout=0.0, emb_dropout=0.0, backbone="vit-t16", method="gaviko", num_prompts=8, prompt_latent_dim=20, local_dim=20,
+               local_k=(3, 6, 6), DHW=(10, 10, 10), attn_drop=0.0, proj_drop=0.0, freeze_vit=True, share_factor=1, fp16=False)
+    m = build_model(cfg)
+    filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    m.to(dev).train()
+    x = torch.from_numpy(synth.volumes(0, 2)).to(dev); y = torch.from_numpy(synth.labels(0, 2)).to(dev)
+
+    def grads():
+        for p in m.parameters():
+            p.grad = None
+        torch.nn.functional.cross_entropy(m(x), y).backward()
+        torch.cuda.synchronize()
+        return m._engine().flat_grad.clone()
+
+    want = [grads() for _ in range(4)][-1]
+    red = m.make_reducer(layers_per_bucket=4)
+    assert red.mode == "events" and red.world == 1 and red.active
+    for it in range(5):                                                   # eager x2, record, replay x2: RCCL kernels behind the plan's events
+        got = grads()
+        assert torch.equal(got, want), (it, (got - want).abs().max().item())
+    assert m._engine()._last_run[0] == "replayed"
+    print("RCCL-OK", flush=True)
+    dist.destroy_process_group()
+''')
+
+
+def test_rccl_collectives_behind_plan_events_on_one_rank(dev, tmp_path):
+    """RCCL itself (backend "nccl") on the one GPU this box has: a single-rank process group with the collectives forced on
+    (GAVIKO_DP_FORCE_COLLECTIVES=1: an all-reduce over one rank is the identity).  Every bucket's all-reduce is issued on the collective
+    stream behind the event of the stream that finalises it, eagerly and from the replayed plan; the gradients must not change by a bit."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GVK_ROOT=ROOT, GAVIKO_DP_FORCE_COLLECTIVES="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", RCCL_CHILD], env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=420)
+    if "RCCL-UNAVAILABLE" in p.stdout:
+        pytest.skip("RCCL could not be initialised on this box: " + p.stdout.strip().splitlines()[-1])
+    assert p.returncode == 0 and "RCCL-OK" in p.stdout, p.stdout[-3000:]
