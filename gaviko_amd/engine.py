@@ -51,6 +51,9 @@ GEMM_MARKS = None
 # Dispatch priority of the side-chain streams (negative = higher).  Measured: -1 drops the step rate from 448 to 274 volumes/s
 # (priority queues serialise against the captured graph's main queue on this runtime), so the default stays 0.
 SIDE_STREAM_PRIORITY = int(os.environ.get("GAVIKO_HIP_SIDE_PRIORITY", "0"))
+# Patch embedding as one implicit GEMM (csrc/patch_gemm.hip) instead of the im2col kernel + GEMM: correct and bit-identical, but 74-79 us
+# against 54 us for the pair -- opt-in
+_PATCH_IMPLICIT = os.environ.get("GAVIKO_HIP_PATCH_IMPLICIT", "0") == "1"
 _SIDE_STREAMS = {}                       # (device index, kind) -> the process-wide side stream of that kind
 # MWSA backward chain held behind the layer's attention backward: measured 669 vs 688 volumes/s -- the chain then slows the dgrad GEMMs
 # of the next layer by as much as it slowed the attention kernels before (start->fc1d 82 -> 98 us); opt-in only
@@ -605,10 +608,21 @@ class Engine:
         marking = GEMM_MARKS is not None and self._recording  # bench.py: time the whole patch-embed stage (im2col + GEMM + scatter)
         cur = torch.cuda.current_stream()
         pe0 = self._ev_record(cur) if marking else None
-        ops.patchify(ws["img"], ws["cols"], self.patch)
         pos = d(nm.root + "pos_embedding")[0]
         G0 = ws["G"][0]
-        if self.kind == "evp":
+        # implicit GEMM straight from the fp32 volume (csrc/patch_gemm.hip) wherever nothing else needs the im2col matrix: not EVP (reads
+        # the raw embedding), not a trainable patch conv (its weight gradient contracts over the im2col rows), not the fp32 path
+        conv_trains = self.p[nm.conv() + ".weight"].requires_grad
+        implicit = (_PATCH_IMPLICIT and not self.fp32 and self.kind != "evp" and not conv_trains and C % 128 == 0 and self.patch[2] == 16
+                    and (self.patch[1] * self.patch[2]) % 64 == 0)
+        if implicit:
+            ops.patch_embed(ws["img"], w["conv"], d(nm.conv() + ".bias"), pos[1:], G0, ws["Lc"][0] if self.kind == "gaviko" else None,
+                            self.patch, C, T, self.row_off)
+        else:
+            ops.patchify(ws["img"], ws["cols"], self.patch)
+        if implicit:
+            pass
+        elif self.kind == "evp":
             # the raw patch embedding is needed on its own (embedding_generator reads it, evp.py:347-348): conv -> xc, tokens = xc + pos
             ops.gemm_nt(ws["cols"], w["conv"], B * N, ws["xc"], epilogue=ops.EPI_STORE_F32, bias=d(nm.conv() + ".bias"))
             ops.rows_patch(G0, ws["xc"], pos[1:], B, T, N, C, 1, False)

@@ -90,6 +90,22 @@ def pack_split_bf16(a, dst, col0, rows, b=None, weight_side=False):
             "gvk_pack_split_bf16")
 
 
+def patch_embed(img, w, bias, pos, out0, out1, patch, C_, rows_out, row_off):
+    """Conv3d(kernel = stride = patch) + bias + position rows, scattered into the token rows of out0 (and densely into out1): one implicit
+    GEMM over the fp32 volume (gaviko_hip.h: gvk_patch_embed_bf16)."""
+    B, _, D, H, W = img.shape
+    pd, ph, pw = patch
+    n = (D // pd) * (H // ph) * (W // pw)
+    _chk(img, torch.float32, "patch_embed img")
+    _chk(w, torch.bfloat16, "patch_embed w", C_ * pd * ph * pw)
+    _chk(bias, torch.float32, "patch_embed bias", C_)
+    _chk(pos, torch.float32, "patch_embed pos", n * C_)
+    _chk(out0, torch.float32, "patch_embed out0", B * rows_out * C_)
+    _chk(out1, torch.float32, "patch_embed out1", B * n * C_)
+    L.check(L.load().gvk_patch_embed_bf16(L.ptr(img), L.ptr(w), L.ptr(bias), L.ptr(pos), L.ptr(out0), L.ptr(out1), B, D, H, W, pd, ph, pw, C_,
+                                          rows_out, row_off, L.stream_ptr()), "gvk_patch_embed_bf16")
+
+
 def prompt_up_fix(enh, lat, w, out, B, T, P, C_, L_):
     """out rows b*T + p (p < P) += (enh[b][p] - lat[b*T + p]) . w^T (gaviko_hip.h: gvk_prompt_up_fix)."""
     _chk(enh, torch.float32, "prompt_up_fix enh", B * P * L_)

@@ -139,6 +139,12 @@ int gvk_pack_split_bf16(const float* a, int ca, const float* b, void* dst, int l
 /* im2col of non-overlapping 3-D patches, fp32 volume -> bf16 rows [B*n_patches][pd*ph*pw]
  * (K order (kd,kh,kw) == Conv3d weight.flatten(1); vision_transformer.py:126-128,150-151). */
 int gvk_patchify_bf16(const float* img, void* out, int B, int D, int H, int W, int pd, int ph, int pw, void* stream);
+/* The same Conv3d (kernel = stride = patch; vision_transformer.py:126-128,150-157) as ONE implicit GEMM: the A operand is gathered from the
+ * fp32 volume inside the kernel (no im2col matrix), w bf16 [C][pd*ph*pw] = Conv3d.weight.flatten(1), epilogue = GVK_EPI_PATCH_F32:
+ * out0 f32 [B*rows_out][C] rows b*rows_out + row_off + t = patch(b, t) . w^T + bias + pos[t] (pos f32 [n_tokens][C]); out1 (optional)
+ * f32 [B*n_tokens][C] receives the same rows densely (GAViKO's local stream, gaviko.py:532-548).  pw = 16, ph*pw % 64 == 0, C % 128 == 0. */
+int gvk_patch_embed_bf16(const float* img, const void* w, const float* bias, const float* pos, float* out0, float* out1, int B, int D, int H,
+                         int W, int pd, int ph, int pw, int C, int rows_out, int row_off, void* stream);
 
 /* ------------------------------------------------------------------ LayerNorm (eps 1e-5; vision_transformer.py:30,49,77)
  * fwd: x f32 [M][C] -> y bf16 [M][C] (MFMA operand) and/or y32 f32; saves mean/rstd f32 [M] (either may be NULL). */

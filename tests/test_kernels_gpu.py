@@ -103,6 +103,37 @@ def test_patch_embed_path(dev):
     assert (Lo[: B * 1000].view(B, 1000, C_).cpu().double() - ref).abs().max().item() < 5e-4
 
 
+@pytest.mark.parametrize("B,C_,P", [(2, 768, 32), (3, 128, 0), (1, 1024, 8)])
+def test_patch_embed_implicit_gemm(dev, B, C_, P):
+    """gvk_patch_embed_bf16 (A operand gathered from the fp32 volume inside the GEMM) == conv3d + flatten/transpose + pos, scattered into
+    rows [P+1 ..] of every sample and densely into the second output -- and bit-identical to the im2col kernel + PATCH GEMM it replaces."""
+    from gaviko_amd import ops
+    from gaviko_amd.utils import synth
+    img = torch.from_numpy(synth.volumes(7, B))
+    w = _rand((C_, 1, 12, 16, 16), 41, math.sqrt(3.0 / 3072) * 1.7)
+    bias = _rand((C_,), 42, 0.05)
+    pos = _rand((1000, C_), 43, 0.3)
+    wb = _bf16_round(w)
+    ref = torch.nn.functional.conv3d(_bf16_round(img).double(), wb.double(), bias.double(), stride=(12, 16, 16))
+    ref = ref.flatten(2).transpose(1, 2) + pos.double()
+    T = P + 1 + 1000
+    W = wb.reshape(C_, 3072).to(dev).bfloat16().contiguous()
+    G = torch.full((ops.pad_rows(B * T), C_), -5.0, dtype=torch.float32, device=dev)
+    Lo = torch.zeros((ops.pad_rows(B * 1000), C_), dtype=torch.float32, device=dev)
+    ops.patch_embed(img.to(dev), W, bias.to(dev), pos.to(dev).contiguous(), G, Lo, (12, 16, 16), C_, T, P + 1)
+    g = G[: B * T].view(B, T, C_).cpu().double()
+    assert (g[:, P + 1:] - ref).abs().max().item() < 5e-4
+    assert (g[:, : P + 1] == -5.0).all()
+    assert (Lo[: B * 1000].view(B, 1000, C_).cpu().double() - ref).abs().max().item() < 5e-4
+    # the two-kernel form: same products, same accumulation order per tile -> the same bits
+    cols = ops.act_zeros(B * 1000, 3072, torch.bfloat16, dev)
+    ops.patchify(img.to(dev), cols, (12, 16, 16))
+    G2 = torch.full((ops.pad_rows(B * T), C_), -5.0, dtype=torch.float32, device=dev)
+    ops.gemm_nt(cols, W, B * 1000, G2, epilogue=ops.EPI_PATCH_F32, bias=bias.to(dev), pos=pos.to(dev).contiguous(), rows_in=1000, rows_out=T,
+                row_off=P + 1, tile=128128)
+    assert torch.equal(G[: B * T], G2[: B * T])
+
+
 @pytest.mark.parametrize("M,C_", [(1033, 768), (77, 192), (515, 1024), (9, 384)])
 def test_layernorm_fwd_bwd(dev, M, C_):
     from gaviko_amd import ops
