@@ -56,14 +56,23 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(GemmArgs p, PatchGeom g
   // two register sets: the voxels of tile t+2 are requested while tile t is multiplied and tile t+1 waits to be converted -- one k-tile of
   // MFMAs (~1 us) does not cover an HBM round trip, two do
   f32x4 avA[2][4], avB[2][4];
-  auto gather = [&](int kt, f32x4 (&av)[2][4]) {
-    const int k0 = kt * BK;
-    const int kd = k0 / slice, kh0 = (k0 - kd * slice) / g.pw + 2 * half;
-    const float* s = asrc + ((size_t)kd * g.H + kh0) * g.W;
+  // k-tiles are gathered in order, so the source pointer just walks: +4 image rows per tile, and a jump to the next depth slice after
+  // every slice / 64 tiles (no per-tile index arithmetic)
+  // (two persistent pointers, one per run: an address formed in a temporary made hipcc drain the vector-memory queue -- vmcnt(0) -- in
+  //  front of every gather, because the temporary landed in registers of the in-flight register set)
+  const float* cur0 = asrc + (size_t)(2 * half) * g.W;
+  const float* cur1 = cur0 + g.W;
+  const int tps = slice / BK;                          // k-tiles per depth slice
+  const size_t step_tile = (size_t)(BK / g.pw) * g.W, step_slice = (size_t)(g.H - g.ph) * g.W;
+  int in_slice = 0;
+  auto gather = [&](int, f32x4 (&av)[2][4]) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int c = 0; c < 4; ++c) av[0][c] = *(const f32x4*)(cur0 + 4 * c);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) av[r][c] = *(const f32x4*)(s + (size_t)r * g.W + 4 * c);
+    for (int c = 0; c < 4; ++c) av[1][c] = *(const f32x4*)(cur1 + 4 * c);
+    size_t adv = step_tile;
+    if (++in_slice == tps) { in_slice = 0; adv += step_slice; }
+    cur0 += adv; cur1 += adv;
   };
   auto commit = [&](int buf, const f32x4 (&av)[2][4]) {   // 32 k-values of this thread's row -> four swizzled 16-byte chunks
     char* sA = smem + buf * STAGE + arow * ROWB;
