@@ -4,8 +4,8 @@
 //
 // The im2col + GEMM pair it replaces wrote 24.6 MB of bf16 patch rows per 4 volumes and read them back (19 us + 35 us).  Here the A operand
 // is gathered from the fp32 volume inside the GEMM: the K axis in Conv3d.weight.flatten(1) order is (kd, kh, kw), so one 64-wide k-tile of
-// one token is FOUR runs of 16 contiguous voxels (kh .. kh+3 of one depth slice) -- two lanes per token row, each fetching two 64-byte runs
-// as 8 x global_load_dwordx4, converting to bf16 and writing four 16-byte chunks into the same swizzled LDS image the other GEMM kernels use
+// one token is FOUR runs of 16 contiguous voxels (kh .. kh+3 of one depth slice) -- four lanes per run, each thread fetching its quarter of
+// one run of eight token rows (8 x global_load_dwordx4), converting to bf16 and writing half-chunks into the same swizzled LDS image the other GEMM kernels use
 // (LDS-DMA cannot convert, so this operand goes through registers; the weight tile still arrives by LDS-DMA).  Three LDS stages, gathers
 // and weight tiles requested two k-tiles ahead behind counted vmcnt waits.  128 x 128 x 64 tiles, four waves, v_mfma_f32_16x16x32_bf16, the shared PATCH
 // epilogue (bias + position rows + scatter to token rows row_off.. of every sample, optional second copy).
@@ -43,49 +43,39 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(GemmArgs p, PatchGeom g
   const int wm = wave >> 1, wn = wave & 1;
   const int l15 = lane & 15, lq = lane >> 4;
 
-  // ---- A gather: thread = (token row, half of the k-tile); rows past M re-read the last token (never stored)
-  const int arow = threadIdx.x >> 1, half = threadIdx.x & 1;
-  const float* asrc;
-  {
-    const int m = min(m0 + arow, p.M - 1);
+  // ---- A gather.  Four lanes per 64-byte run (quarter q = tid & 3), the four runs of a token row on 16 consecutive lanes: a wave's load
+  // instruction touches 16 cache lines (with two lanes per token row it touched 64 and the address path, not HBM, set the pace).  A thread
+  // serves the SAME (run, quarter) of eight token rows 16 apart; rows past M re-read the last token (never stored).
+  const int quarter = threadIdx.x & 3, run = (threadIdx.x >> 2) & 3, arow0 = threadIdx.x >> 4;       // rows arow0 + 16 i
+  unsigned int aoff[8];                                  // element offsets into the volume (49 MB per 4 volumes: 32 bits are plenty)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = min(m0 + arow0 + 16 * i, p.M - 1);
     const int b = m / g.ntok, idx = m - b * g.ntok;
     const int td = idx / (g.gh * g.gw), r2 = idx - td * (g.gh * g.gw), th = r2 / g.gw, tw = r2 - th * g.gw;
-    asrc = g.img + (((size_t)b * g.D + (size_t)td * g.pd) * g.H + (size_t)th * g.ph) * g.W + (size_t)tw * g.pw;
+    aoff[i] = (unsigned int)((((size_t)b * g.D + (size_t)td * g.pd) * g.H + (size_t)th * g.ph + run) * g.W + (size_t)tw * g.pw + 4 * quarter);
   }
   const int slice = g.ph * g.pw;                       // k values per depth slice of a patch (a multiple of 64: a k-tile never straddles two)
-  // two register sets: the voxels of tile t+2 are requested while tile t is multiplied and tile t+1 waits to be converted -- one k-tile of
-  // MFMAs (~1 us) does not cover an HBM round trip, two do
-  f32x4 avA[2][4], avB[2][4];
-  // k-tiles are gathered in order, so the source pointer just walks: +4 image rows per tile, and a jump to the next depth slice after
-  // every slice / 64 tiles (no per-tile index arithmetic)
-  // (two persistent pointers, one per run: an address formed in a temporary made hipcc drain the vector-memory queue -- vmcnt(0) -- in
-  //  front of every gather, because the temporary landed in registers of the in-flight register set)
-  const float* cur0 = asrc + (size_t)(2 * half) * g.W;
-  const float* cur1 = cur0 + g.W;
-  const int tps = slice / BK;                          // k-tiles per depth slice
-  const size_t step_tile = (size_t)(BK / g.pw) * g.W, step_slice = (size_t)(g.H - g.ph) * g.W;
+  // k-tiles are gathered in order, so the offsets just walk: +4 image rows per tile, and a jump to the next depth slice after every
+  // slice / 64 tiles.  Two register sets: the voxels of tile t+2 are requested while tile t is multiplied and tile t+1 waits to be converted.
+  f32x4 avA[8], avB[8];
+  const int tps = slice / BK;
+  const unsigned int step_tile = (unsigned int)((BK / g.pw) * g.W), step_slice = (unsigned int)((g.H - g.ph) * g.W);
+  unsigned int walk = 0u;
   int in_slice = 0;
-  auto gather = [&](int, f32x4 (&av)[2][4]) {
+  auto gather = [&](int, f32x4 (&av)[8]) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) av[0][c] = *(const f32x4*)(cur0 + 4 * c);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) av[1][c] = *(const f32x4*)(cur1 + 4 * c);
-    size_t adv = step_tile;
-    if (++in_slice == tps) { in_slice = 0; adv += step_slice; }
-    cur0 += adv; cur1 += adv;
+    for (int i = 0; i < 8; ++i) av[i] = *(const f32x4*)(g.img + (size_t)(aoff[i] + walk));
+    walk += step_tile;
+    if (++in_slice == tps) { in_slice = 0; walk += step_slice; }
   };
-  auto commit = [&](int buf, const f32x4 (&av)[2][4]) {   // 32 k-values of this thread's row -> four swizzled 16-byte chunks
-    char* sA = smem + buf * STAGE + arow * ROWB;
-    const int sw = swz_a128(arow);
+  auto commit = [&](int buf, const f32x4 (&av)[8]) {    // four k-values per row: half a swizzled 16-byte chunk
+    char* sA = smem + buf * STAGE + arow0 * ROWB + (((run * 2 + (quarter >> 1)) ^ swz_a128(arow0)) << 4) + (quarter & 1) * 8;
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const f32x4 lo = av[r][2 * c], hi = av[r][2 * c + 1];
-        const bf16x8 h8 = {(bf16)lo[0], (bf16)lo[1], (bf16)lo[2], (bf16)lo[3], (bf16)hi[0], (bf16)hi[1], (bf16)hi[2], (bf16)hi[3]};
-        const int chunk = (2 * half + r) * 2 + c;
-        *(bf16x8*)(sA + ((chunk ^ sw) << 4)) = h8;
-      }
+    for (int i = 0; i < 8; ++i) {
+      const bf16x4 h4 = {(bf16)av[i][0], (bf16)av[i][1], (bf16)av[i][2], (bf16)av[i][3]};
+      *(bf16x4*)(sA + i * 16 * ROWB) = h4;               // swz_a128(row + 16) == swz_a128(row)
+    }
   };
   // ---- W tile by LDS-DMA (gemm_nt_kernel's mapping: 8 rows per 1-KiB wave instruction, source-side XOR swizzle)
   const bf16* __restrict__ Wg = p.W + (size_t)n0 * p.ldw;
@@ -117,7 +107,7 @@ __global__ __launch_bounds__(256) void patch_gemm_kernel(GemmArgs p, PatchGeom g
   if (nt > 1) __builtin_amdgcn_s_waitcnt(0x0070 | 12); else __builtin_amdgcn_s_waitcnt(0x0070);     // lgkmcnt(0) + vmcnt(12 | 0)
   __builtin_amdgcn_s_barrier();
   // one k-tile: `nxt` holds tile t+1 (requested one tile ago), `fill` is free for tile t+2
-  auto ktile = [&](const int t, const int buf, f32x4 (&nxt)[2][4], f32x4 (&fill)[2][4]) {
+  auto ktile = [&](const int t, const int buf, f32x4 (&nxt)[8], f32x4 (&fill)[8]) {
     const int b1 = buf == 2 ? 0 : buf + 1, b2 = b1 == 2 ? 0 : b1 + 1;
     if (t + 2 < nt) {                                    // (buffer b2 was last read one barrier ago)
       gather(t + 2, fill);
