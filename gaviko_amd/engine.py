@@ -40,6 +40,11 @@ PLAN_TIMING = os.environ.get("GAVIKO_HIP_PLAN_TIMING") is not None
 # Timing ablations (tools/ablate_streams.py) -- the RESULTS ARE WRONG with either switch; they only answer "where does the step go":
 #   nowait: the main stream skips its waits on the side chains;  noside: the MWSA / GPA chains are not launched at all.
 _ABLATE = set(filter(None, os.environ.get("GAVIKO_HIP_ABLATE", "").split(",")))
+
+
+def _on(tag: str) -> bool:
+    """False when the timing ablation `tag` is switched on (GAVIKO_HIP_ABLATE, diagnostics only: bench.py refuses it without --allow-ablate)."""
+    return tag not in _ABLATE
 # Site seeds of the backbone's own nn.Dropout modules (added to the device epoch word): embedding, VPT prompts of layer i, and per layer
 # {+0 attention probabilities, +1 to_out, +2 after GELU, +3 after fc2}.  The MWSA sites use 2*i and 2*i + 1.
 SEED_EMB, SEED_PROMPT, SEED_LAYER = 900, 950, 1000
@@ -621,7 +626,7 @@ class Engine:
         else:
             ops.patchify(ws["img"], ws["cols"], self.patch)
         if implicit:
-            pass
+            pass                                              # tokens are already in place
         elif self.kind == "evp":
             # the raw patch embedding is needed on its own (embedding_generator reads it, evp.py:347-348): conv -> xc, tokens = xc + pos
             ops.gemm_nt(ws["cols"], w["conv"], B * N, ws["xc"], epilogue=ops.EPI_STORE_F32, bias=d(nm.conv() + ".bias"))
@@ -803,22 +808,21 @@ class Engine:
     def _mwsa_fwd(self, ws, sv, i, si, lin, lout, gpa_local=False):
         """MWSA of layer i on the local stream (gaviko.py:229-244).  With self._fuse_next the up-projection kernel of layer i also runs layer
         i+1's entry (LayerNorm + proj_down + qkv of the rows it writes), so only layer 0 launches the entry kernel itself."""
-        if "noside" in _ABLATE:
+        if not _on("noside"):
             return
-        s = i // self.share
-        pre = f"transformer.local_attns.{s}"
+        pre = f"transformer.local_attns.{i // self.share}"
         d, C, Lt, B = self._d, self.C, self.Lat, ws["B"]
         BN = B * self.N
         m = ws["mw"][si]
-        chained = self._fuse_next and gpa_local and "loc_noupdown" not in _ABLATE
-        if "loc_noupdown" not in _ABLATE and not (chained and i > 0):
-          ops.skinny_down(x=lin, w=d(pre + ".proj_down.weight"), bias=d(pre + ".proj_down.bias"), ln_gamma=d(pre + ".norm.weight"),
-                        ln_beta=d(pre + ".norm.bias"), mean=m["mean"], rstd=m["rstd"], y=m["lat"], w2=d(pre + ".qkv.weight"), y2=m["qkv"],
-                        M=BN, C=C, L=Lt, L2=3 * Lt, act=0, w_layout=0, eps=1e-5)
-        if "nowin" not in _ABLATE:
-          ops.window_attn_fwd(qkv=m["qkv"], ctx=m["ctx"], lse=m["lse"], B=B, D=self.grid[0], H=self.grid[1], W=self.grid[2],
-                              kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt, scale=C ** -0.5, drop_p=sv["attn_drop"],
-                              seed=2 * i, seed_ptr=ws["seed"])
+        chained = self._fuse_next and gpa_local and _on("loc_noupdown")
+        if _on("loc_noupdown") and not (chained and i > 0):
+            ops.skinny_down(x=lin, w=d(pre + ".proj_down.weight"), bias=d(pre + ".proj_down.bias"), ln_gamma=d(pre + ".norm.weight"),
+                            ln_beta=d(pre + ".norm.bias"), mean=m["mean"], rstd=m["rstd"], y=m["lat"], w2=d(pre + ".qkv.weight"), y2=m["qkv"],
+                            M=BN, C=C, L=Lt, L2=3 * Lt, act=0, w_layout=0, eps=1e-5)
+        if _on("nowin"):
+            ops.window_attn_fwd(qkv=m["qkv"], ctx=m["ctx"], lse=m["lse"], B=B, D=self.grid[0], H=self.grid[1], W=self.grid[2],
+                                kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt, scale=C ** -0.5, drop_p=sv["attn_drop"],
+                                seed=2 * i, seed_ptr=ws["seed"])
         second = {}
         if gpa_local:                                       # ll = QuickGELU(proj_down(L')) (gaviko.py:156) of the rows this launch produces
             gpre, _ = self._gpa_names(i)
@@ -830,9 +834,9 @@ class Engine:
             second.update(nx_w=d(nx + ".proj_down.weight"), nx_bias=d(nx + ".proj_down.bias"), nx_ln_gamma=d(nx + ".norm.weight"),
                           nx_ln_beta=d(nx + ".norm.bias"), nx_mean=mn["mean"], nx_rstd=mn["rstd"], nx_lat=mn["lat"], nx_w2=d(nx + ".qkv.weight"),
                           nx_y2=mn["qkv"], nx_L2=3 * Lt, nx_eps=1e-5)
-        if "loc_noupdown" not in _ABLATE:
-          ops.skinny_up(lat=m["ctx"], w=d(pre + ".proj_up.weight"), bias=d(pre + ".proj_up.bias"), res=lin, out=lout, M=BN, C=C, L=Lt,
-                      w_layout=0, drop_p=sv["proj_drop"], seed=2 * i + 1, seed_ptr=ws["seed"], **second)
+        if _on("loc_noupdown"):
+            ops.skinny_up(lat=m["ctx"], w=d(pre + ".proj_up.weight"), bias=d(pre + ".proj_up.bias"), res=lin, out=lout, M=BN, C=C, L=Lt,
+                          w_layout=0, drop_p=sv["proj_drop"], seed=2 * i + 1, seed_ptr=ws["seed"], **second)
 
     def _gpa_names(self, i):
         s = i // self.share
@@ -1302,9 +1306,9 @@ class Engine:
         if "noside" in _ABLATE:
             return
         pre, _ = self._gpa_names(i)
-        if "loc_noupdown" not in _ABLATE:
-          ops.skinny_up(lat=ws["bw"]["dzl"][par], w=self._d(pre + ".proj_down.0.weight"), out=dLnew, M=B * self.N, C=self.C, L=self.Lat, w_layout=1,
-                      accumulate=1)
+        if _on("loc_noupdown"):
+            ops.skinny_up(lat=ws["bw"]["dzl"][par], w=self._d(pre + ".proj_down.0.weight"), out=dLnew, M=B * self.N, C=self.C, L=self.Lat,
+                          w_layout=1, accumulate=1)
 
     # ---- AdaptFormer (adaptformer.py:58-78, 93-97): r = up(ReLU(down(LN_a(x)))), x_out = ff(x) + x + r -----------------------
     def _adapter_prefix(self, i):
@@ -1620,41 +1624,42 @@ class Engine:
         return (self._flat_grad["views"][name].data_ptr() - self._flat_grad["buf"].data_ptr()) // 4
 
     def _mwsa_bwd(self, ws, sv, gv, i, dLout, dLin, B, have_dctx=False, defer_final=False):
-        if "noside" in _ABLATE:
+        """MWSA backward of layer i on the local stream.  have_dctx: the layer-boundary kernel already produced dctx (_mwsa_boundary);
+        defer_final: the last step (dL_in) is left to the next-lower layer's boundary kernel (_mwsa_chain_bwd).  The `_on(...)` guards are
+        the timing ablations of DESIGN.md section 7b.3."""
+        if not _on("noside"):
             return
-        s = i // self.share
-        pre = f"transformer.local_attns.{s}"
-        d, C, Lt, N = self._d, self.C, self.Lat, self.N
-        BN = B * N
+        pre = f"transformer.local_attns.{i // self.share}"
+        d, C, Lt = self._d, self.C, self.Lat
+        BN = B * self.N
         m, bw, sc = ws["mw"][i], ws["bw"], ws["scratch_l"]
         lin = ws["Lc"][i]
         acc = self._acc(i)
         pd, seed_p, seed_a, sp = sv["proj_drop"], 2 * i + 1, 2 * i, ws["seed"]
-        wup = d(pre + ".proj_up.weight")
-        if "loc_noupdown" not in _ABLATE and not have_dctx:
-            ops.skinny_down(x=dLout, w=wup, y=bw["dctx"], M=BN, C=C, L=Lt, act=0, w_layout=1, drop_p=pd, seed=seed_p, seed_ptr=sp)
-        if "loc_noouter" not in _ABLATE:
-          ops.outer_reduce(narrow=m["ctx"], wide=dLout, scratch=sc, out=gv[pre + ".proj_up.weight"], colsum=gv[pre + ".proj_up.bias"],
-                         M=BN, C=C, L=Lt, transposed=1, accumulate=acc, drop_p=pd, seed=seed_p, seed_ptr=sp)
-        if "nowin" not in _ABLATE:
+        if _on("loc_noupdown") and not have_dctx:
+            ops.skinny_down(x=dLout, w=d(pre + ".proj_up.weight"), y=bw["dctx"], M=BN, C=C, L=Lt, act=0, w_layout=1, drop_p=pd, seed=seed_p,
+                            seed_ptr=sp)
+        if _on("loc_noouter"):
+            ops.outer_reduce(narrow=m["ctx"], wide=dLout, scratch=sc, out=gv[pre + ".proj_up.weight"], colsum=gv[pre + ".proj_up.bias"],
+                             M=BN, C=C, L=Lt, transposed=1, accumulate=acc, drop_p=pd, seed=seed_p, seed_ptr=sp)
+        if _on("nowin"):
             ops.window_attn_bwd(qkv=m["qkv"], ctx=m["ctx"], lse=m["lse"], dctx=bw["dctx"], delta=bw["wdelta"], dqkv=bw["dqkv"], B=B,
                                 D=self.grid[0], H=self.grid[1], W=self.grid[2], kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt,
                                 scale=C ** -0.5, drop_p=sv["attn_drop"], seed=seed_a, seed_ptr=sp)
-        wqkv = d(pre + ".qkv.weight")
-        if "loc_nosmall" not in _ABLATE:
-            ops.skinny_down(x=bw["dqkv"], w=wqkv, y=bw["dlat"], M=BN, C=3 * Lt, L=Lt, act=0, w_layout=1)
+        if _on("loc_nosmall"):
+            ops.skinny_down(x=bw["dqkv"], w=d(pre + ".qkv.weight"), y=bw["dlat"], M=BN, C=3 * Lt, L=Lt, act=0, w_layout=1)
         wd = d(pre + ".proj_down.weight")
         g_, b_ = d(pre + ".norm.weight"), d(pre + ".norm.bias")
-        # Q[l][c] = sum_m dlat[m][l] xhat[m][c], S[l] = sum_m dlat[m][l]  ->  dWd, dbd, dgamma, dbeta in one tiny kernel
-        if "loc_noouter" not in _ABLATE:
-          ops.outer_reduce(narrow=bw["dlat"], wide=lin, mean=m["mean"], rstd=m["rstd"], scratch=sc, out=bw["Q"], M=BN, C=C, L=Lt, transposed=0,
-                         accumulate=0)
-        # qkv weight gradient (dqkv^T . lat) and S[l] = sum_m dlat[m][l] in one two-stage reduction
-        if "loc_nosmall" not in _ABLATE:
-          ops.reduce_batch([(bw["dqkv"], m["lat"], gv[pre + ".qkv.weight"], acc), (bw["dlat"], None, bw["S"], 0)], ws["rscratch_l"])
-          ops.ln_lowrank_affine(bw["Q"], bw["S"], wd, g_, b_, gv[pre + ".proj_down.weight"], gv[pre + ".norm.weight"], gv[pre + ".norm.bias"],
-                              gv[pre + ".proj_down.bias"], Lt, C, accumulate=bool(acc))
-        # dL_in = dL_out + LN'(dlat . Wd): the rank-L product never touches HBM
-        if "loc_noupdown" not in _ABLATE and not defer_final:
-          ops.skinny_up(lat=bw["dlat"], w=wd, res=dLout, out=dLin, ln_x=lin, ln_mean=m["mean"], ln_rstd=m["rstd"], ln_gamma=g_, M=BN, C=C, L=Lt,
-                      w_layout=1)
+        if _on("loc_noouter"):
+            # Q[l][c] = sum_m dlat[m][l] xhat[m][c], S[l] = sum_m dlat[m][l]  ->  dWd, dbd, dgamma, dbeta in one tiny kernel
+            ops.outer_reduce(narrow=bw["dlat"], wide=lin, mean=m["mean"], rstd=m["rstd"], scratch=sc, out=bw["Q"], M=BN, C=C, L=Lt,
+                             transposed=0, accumulate=0)
+        if _on("loc_nosmall"):
+            # qkv weight gradient (dqkv^T . lat) and S[l] = sum_m dlat[m][l] in one two-stage reduction
+            ops.reduce_batch([(bw["dqkv"], m["lat"], gv[pre + ".qkv.weight"], acc), (bw["dlat"], None, bw["S"], 0)], ws["rscratch_l"])
+            ops.ln_lowrank_affine(bw["Q"], bw["S"], wd, g_, b_, gv[pre + ".proj_down.weight"], gv[pre + ".norm.weight"],
+                                  gv[pre + ".norm.bias"], gv[pre + ".proj_down.bias"], Lt, C, accumulate=bool(acc))
+        if _on("loc_noupdown") and not defer_final:
+            # dL_in = dL_out + LN'(dlat . Wd): the rank-L product never touches HBM
+            ops.skinny_up(lat=bw["dlat"], w=wd, res=dLout, out=dLin, ln_x=lin, ln_mean=m["mean"], ln_rstd=m["rstd"], ln_gamma=g_, M=BN, C=C,
+                          L=Lt, w_layout=1)
