@@ -5,7 +5,7 @@
 // GEMMs and the flash-attention kernels running beside them on the other streams pay for (removing the window
 // kernels alone returned 4.5 % of the step).  Here the window is a MASK over dense 16 x 16 tiles instead:
 //
-//   workgroup = 16 consecutive tokens (queries; keys in the key-side backward) of one sample, eight waves; wave w takes every eighth
+//   workgroup = 16 consecutive tokens (queries; keys in the key-side backward) of one sample, four waves; wave w takes every fourth
 //   16-token partner block of the d-planes the block's windows reach (6-7 planes x 100 tokens at local_k = 6,6,6: ~40 blocks, of which
 //   the 216-key windows fill about a third -- the matrix cores do not care);
 //   S^T[key][query] = K . Q^T is five v_mfma_f32_16x16x4_f32 (L = 20 = 5 x 4) with both operands read straight from global memory as
@@ -26,7 +26,7 @@ namespace {
 
 constexpr int kL = 20;            // latent width this file is built for
 constexpr int kRow = 3 * kL;      // floats per token row of q | k | v
-constexpr int kSplit = 8;         // waves per 16-token block
+constexpr int kSplit = 4;         // waves per 16-token block (in the step: 4 -> 714, 8 -> 710, 16 -> 702, 2 -> 668 volumes/s; isolated 8 is the fastest)
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 // reductions over the four 16-lane groups of a wave (same lane % 16)
