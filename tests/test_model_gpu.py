@@ -421,3 +421,20 @@ def test_wrong_volume_shape_and_unsupported_modes_fail_loudly(dev):
     from gaviko_amd.registry import build_model
     with pytest.raises(NotImplementedError):
         build_model(dict(BASE, backbone="vit-t16", method="evp", input_type="laplacian"))
+
+
+@pytest.mark.parametrize("backbone,share", [("vit-t16", 1), ("vit-t16", 2), ("vit-b16", 1)])
+def test_gaviko_eval_forward_equals_train_forward_without_dropout(dev, backbone, share):
+    """The inference workspace ping-pongs the streams and re-uses ONE set of MWSA buffers for every layer (the up-projection kernel of layer i
+    writes layer i+1's latents into it); with every dropout at p = 0 it must give the training forward's logits bit for bit, eagerly and
+    replayed."""
+    from gaviko_amd.utils import synth
+    m, cfg = build("gaviko", backbone, dict(GAVIKO, share_factor=share), dev)
+    x = torch.from_numpy(synth.volumes(3, 2)).to(dev)
+    m.train()
+    train_logits = [m(x).detach().clone() for _ in range(3)][-1]
+    m.eval()
+    with torch.no_grad():
+        outs = [m(x).detach().clone() for _ in range(4)]
+    for o in outs:
+        assert torch.equal(o, train_logits)
