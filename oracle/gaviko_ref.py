@@ -35,10 +35,12 @@ def window_mask(DHW, local_k, dtype=torch.float32) -> Tensor:
     return m
 
 
-def local_self_attention(sd: SD, prefix: str, x: Tensor, mask: Optional[Tensor], taps=None) -> Tensor:
+def local_self_attention(sd: SD, prefix: str, x: Tensor, mask: Optional[Tensor], taps=None, drop_attn: Optional[Tensor] = None,
+                         drop_proj: Optional[Tensor] = None) -> Tensor:
     """LocalSelfAttention.forward (gaviko.py:229-244).  Single head over the local_dim latent;
     scale is dim**-0.5 of the *model* dim (gaviko.py:201), qkv has no bias (205, 272).
-    attn_drop / proj_drop are identity here (parity runs use p=0, SURVEY 7 'Hard parts')."""
+    attn_drop / proj_drop (gaviko.py:238,242) are identity unless explicit scale masks (0 or 1/(1-p), what nn.Dropout multiplies by) are
+    handed in: torch's RNG stream cannot be matched, so a test runs this with the masks the kernels drew (tests/dropmask.py)."""
     c = x.shape[-1]
     lat = F.linear(layer_norm(sd, prefix + ".norm", x), sd[prefix + ".proj_down.weight"], sd[prefix + ".proj_down.bias"])
     q, k, v = F.linear(lat, sd[prefix + ".qkv.weight"]).chunk(3, dim=-1)
@@ -46,10 +48,13 @@ def local_self_attention(sd: SD, prefix: str, x: Tensor, mask: Optional[Tensor],
     if mask is not None:
         attn = attn + mask.unsqueeze(0)
     attn = attn.softmax(dim=-1)
+    if drop_attn is not None:
+        attn = attn * drop_attn
     ctx = attn @ v
     if taps is not None:
         taps[prefix + ".ctx"] = ctx
-    return F.linear(ctx, sd[prefix + ".proj_up.weight"], sd[prefix + ".proj_up.bias"])
+    out = F.linear(ctx, sd[prefix + ".proj_up.weight"], sd[prefix + ".proj_up.bias"])
+    return out if drop_proj is None else out * drop_proj
 
 
 def _quick_gelu(x: Tensor) -> Tensor:
@@ -115,7 +120,9 @@ def gaviko_forward(sd: SD, img: Tensor, cfg: dict, taps: Optional[dict] = None) 
         taps["embed.local"] = loc
     for i in range(depth):
         s = i // share                                         # 299
-        loc = local_self_attention(sd, f"transformer.local_attns.{s}", loc, mask, taps) + loc       # 301
+        masks = cfg.get("_masks") or {}
+        loc = local_self_attention(sd, f"transformer.local_attns.{s}", loc, mask, taps, masks.get(("mwsa_attn", i)),
+                                   masks.get(("mwsa_proj", i))) + loc                                # 301
         g = attention(sd, f"transformer.attns.{i}", g, heads, None) + g                              # 302
         if taps is not None:
             taps[f"layer{i}.local"] = loc

@@ -44,3 +44,9 @@ def attn_mask(seed: int, B: int, H: int, T: int, p: float) -> np.ndarray:
             x ^= x >> np.uint32(16)
             out[bh] = np.where(x >= np.uint32(threshold(p)), inv_keep(p), np.float32(0))
     return out.reshape(B, H, T, T)
+
+
+def window_attn_mask(seed: int, B: int, N: int, p: float) -> np.ndarray:
+    """scale mask [B, N, N] of the MWSA attention probabilities (csrc/window_*.hip: index (b*N + i) * N + j)."""
+    idx = np.arange(B * N * N, dtype=np.uint64).reshape(B, N, N)
+    return np.where(hash_u32(seed, idx) >= np.uint32(threshold(p)), inv_keep(p), np.float32(0)).astype(np.float32)

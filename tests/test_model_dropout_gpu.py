@@ -146,3 +146,57 @@ def test_fp32_path_with_live_dropout_is_exact_against_the_oracle(dev, method, ex
             if e > worst:
                 worst, who = e, k
     assert worst < 5e-4, (worst, who)
+
+
+@pytest.mark.parametrize("share", [1, 2])
+def test_gaviko_step_with_live_mwsa_dropouts_matches_oracle_with_the_same_masks(dev, share):
+    """GAViKO trains with LocalSelfAttention's attn_drop / proj_drop live (gaviko.py:513-528 keeps only the backbone in eval; the shipped config
+    has 0.2 / 0.2 and bench.py times exactly that).  The masks are regenerated on the host from the device seed word (window attention: layer
+    seed 2i, projection: 2i + 1) and the ORACLE is run with them: forward and every gradient -- including the chained MWSA kernels that carry
+    a dropout mask across a layer boundary -- against the reference arithmetic."""
+    from gaviko_amd.registry import build_model
+    from gaviko_amd.utils import synth
+    p = 0.2
+    cfg = dict(BASE, backbone="vit-t16", method="gaviko", num_prompts=8, prompt_latent_dim=20, local_dim=20, local_k=(3, 6, 6), DHW=(10, 10, 10),
+               attn_drop=p, proj_drop=p, freeze_vit=True, share_factor=share, fp16=False)
+    cfg["dropout"] = cfg["emb_dropout"] = 0.0
+    m = build_model(cfg)
+    filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    m.to(dev).train()
+    B, N = 2, 1000
+    x = torch.from_numpy(synth.volumes(0, B))
+    y = torch.from_numpy(synth.labels(0, B))
+    for _ in range(4):                                                   # eager, eager, recorded, replayed
+        for q in m.parameters():
+            q.grad = None
+        logits = m(x.to(dev))
+        torch.nn.functional.cross_entropy(logits, y.to(dev)).backward()
+        torch.cuda.synchronize()
+    eng = m._engine()
+    assert eng._last_run[0] == "replayed"
+    word = int(eng._ws["seed"].item())
+    t = lambda a: torch.from_numpy(a)  # noqa: E731
+    masks = {}
+    for i in range(eng.depth):
+        masks[("mwsa_attn", i)] = t(dropmask.window_attn_mask(2 * i + word, B, N, p))
+        masks[("mwsa_proj", i)] = t(dropmask.rows_mask(2 * i + 1 + word, B * N, eng.C, p)).view(B, N, eng.C)
+    keep = masks[("mwsa_proj", 3)].gt(0).float().mean().item()
+    assert abs(keep - (1 - p)) < 0.01
+    osd = {k: v.detach().cpu().clone().requires_grad_(oracle.trainable("gaviko", k)) for k, v in m.state_dict().items()}
+    ologits = oracle.FORWARD["gaviko"](osd, x, dict(cfg, _masks=masks), None)
+    torch.nn.functional.cross_entropy(ologits, y).backward()
+    lg = logits.detach().cpu()
+    scale = ologits.abs().max().item()
+    assert (lg - ologits.detach()).abs().max().item() < 1.5e-2 * scale, (lg, ologits)
+    plain = oracle.FORWARD["gaviko"]({k: v.detach() for k, v in osd.items()}, x, cfg, None)
+    assert (plain - ologits.detach()).abs().max().item() > 3 * (lg - ologits.detach()).abs().max().item()      # the masks matter
+    errs = []
+    for k, q in m.named_parameters():
+        if not q.requires_grad or osd[k].grad is None:
+            continue
+        want = osd[k].grad
+        wn = want.norm().item()
+        errs.append((abs(q.grad.norm().item() - wn) / max(wn, 1e-12), k))
+    e = np.array([v[0] for v in errs])
+    assert len(e) > 20 and np.median(e) < 1.5e-2 and np.percentile(e, 90) < 5e-2 and e.max() < 0.15, sorted(errs, reverse=True)[:5]
