@@ -148,8 +148,9 @@ def test_fp32_path_with_live_dropout_is_exact_against_the_oracle(dev, method, ex
     assert worst < 5e-4, (worst, who)
 
 
-@pytest.mark.parametrize("share", [1, 2])
-def test_gaviko_step_with_live_mwsa_dropouts_matches_oracle_with_the_same_masks(dev, share):
+@pytest.mark.parametrize("backbone,B,P_,lk,share", [("vit-t16", 2, 8, (3, 6, 6), 1), ("vit-t16", 2, 8, (3, 6, 6), 2),
+                                                     ("vit-b16", 4, 32, (6, 6, 6), 1)])           # the last one IS BASELINE cfg2 / bench.py
+def test_gaviko_step_with_live_mwsa_dropouts_matches_oracle_with_the_same_masks(dev, backbone, B, P_, lk, share):
     """GAViKO trains with LocalSelfAttention's attn_drop / proj_drop live (gaviko.py:513-528 keeps only the backbone in eval; the shipped config
     has 0.2 / 0.2 and bench.py times exactly that).  The masks are regenerated on the host from the device seed word (window attention: layer
     seed 2i, projection: 2i + 1) and the ORACLE is run with them: forward and every gradient -- including the chained MWSA kernels that carry
@@ -157,14 +158,14 @@ def test_gaviko_step_with_live_mwsa_dropouts_matches_oracle_with_the_same_masks(
     from gaviko_amd.registry import build_model
     from gaviko_amd.utils import synth
     p = 0.2
-    cfg = dict(BASE, backbone="vit-t16", method="gaviko", num_prompts=8, prompt_latent_dim=20, local_dim=20, local_k=(3, 6, 6), DHW=(10, 10, 10),
+    cfg = dict(BASE, backbone=backbone, method="gaviko", num_prompts=P_, prompt_latent_dim=20, local_dim=20, local_k=lk, DHW=(10, 10, 10),
                attn_drop=p, proj_drop=p, freeze_vit=True, share_factor=share, fp16=False)
     cfg["dropout"] = cfg["emb_dropout"] = 0.0
     m = build_model(cfg)
     filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
     m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
     m.to(dev).train()
-    B, N = 2, 1000
+    N = 1000
     x = torch.from_numpy(synth.volumes(0, B))
     y = torch.from_numpy(synth.labels(0, B))
     for _ in range(4):                                                   # eager, eager, recorded, replayed
