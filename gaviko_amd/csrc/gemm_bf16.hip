@@ -251,10 +251,14 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
       if (wide != 0 && a.N % 256 == 0 && a.drop_thresh == 0u && t256 >= wide_lo() && t256 <= 256 && (EPI != GVK_EPI_GELU_BWD_BF16 || wide_bwd))
         tile = (wide == 256 || a.K < 128) ? 256256 : 8256256;
     }
-    static const long t128_lo = getenv("GAVIKO_HIP_GEMM_T128LO") ? atol(getenv("GAVIKO_HIP_GEMM_T128LO")) : 96;
-    if (bm == 64 && bn == 128 && t128 >= t128_lo && t128 <= 256 && a.K >= 512 && a.drop_thresh == 0u) {
-      if (n768 == 3128) tile = 3128128;
+    // N = 768-type shapes (64 x 128 by the fill rule above) with K >= 512 run THREE LDS stages: as 128 x 128 tiles at one workgroup per CU
+    // when those fill at least half the chip (M = 4132: 198 tiles), as 64 x 128 tiles below that (M = 2066: 102 tiles of 128 rows would leave
+    // 60 % of the CUs idle; 198 tiles of 64: 465 -> 488 volumes/s at B = 2, while at B = 4 the small tile costs 6 %)
+    static const long t64_hi = getenv("GAVIKO_HIP_GEMM_T64HI") ? atol(getenv("GAVIKO_HIP_GEMM_T64HI")) : 130;
+    if (bm == 64 && bn == 128 && t128 <= 256 && a.K >= 512 && a.drop_thresh == 0u) {
+      if (n768 == 3128) tile = t128 <= t64_hi ? 3064128 : 3128128;
       else if (n768 == 128) tile = 128128;
+      else if (n768 == 3064) tile = 3064128;
     }
   }
   if (a.drop_thresh != 0u) {
@@ -274,6 +278,7 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     case 8256256: return launch_gemm8p(a, EPI, 0, stream);      // eight-phase kernel, LDS-DMA issued in the load sections (default)
     case 7256256: return launch_gemm8p(a, EPI, 1, stream);      // ... issued inside the MFMA clusters (2546 vs 2426 cycles per k-tile)
     case 3128128: return launch_gemm<128, 128, EPI, false, 3>(a, stream);
+    case 3064128: return launch_gemm<64, 128, EPI, false, 3>(a, stream);     // 64 x 128 with three stages (A/B switch GAVIKO_HIP_GEMM_N768=3064)
     case 256256:
       if constexpr (EPI == GVK_EPI_STORE_BF16 || EPI == GVK_EPI_BIAS_GELU_BF16 || EPI == GVK_EPI_GELU_BWD_BF16) return launch_gemm<256, 256, EPI, false, 2, 8>(a, stream);
       else return set_error(-2, "gvk_gemm_nt_bf16: the 256x256 tile is built for STORE_BF16, BIAS_GELU_BF16 and GELU_BWD_BF16");
