@@ -59,6 +59,83 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
+// The same with the GPA prompt fix of the PREVIOUS layer applied on the way in: rows with (row % T) < P first receive
+// x[row] += (enh[b][p] - lat[row]) . Wup^T (Wup [C][L]; gaviko.py:183-187 -- the plain latents already rode the fc2 GEMM, elementwise.hip)
+// and are written back, then every row is normalised as usual.  Saves the separate 128-row fix launch on the backbone stream.
+__global__ __launch_bounds__(256) void ln_fwd_fix_kernel(float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         bf16* __restrict__ y16, float* __restrict__ mean_o, float* __restrict__ rstd_o, int M, int C,
+                                                         float eps, const float* __restrict__ enh, const float* __restrict__ lat,
+                                                         const float* __restrict__ wup, int T, int P, int L) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = lane_id();
+  float* xr = x + (size_t)row * C;
+  f32x4 v[kMaxChunks];
+#pragma unroll
+  for (int k = 0; k < kMaxChunks; ++k) {
+    const int c = k * 256 + lane * 4;
+    v[k] = (c < C) ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int b = row / T, t = row - b * T;
+  if (t < P) {                                           // wave-uniform: a prompt row
+    // the lane's four columns are four CONSECUTIVE rows of Wup [C][L]: 4 L contiguous floats, read as float4s (L % 4 == 0) -- element j of
+    // that run belongs to column c + j / L, latent j % L
+    const float dl = lane < L ? enh[((size_t)b * P + t) * L + lane] - lat[(size_t)row * L + lane] : 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxChunks; ++k) {
+      const int c = k * 256 + lane * 4;
+      if (c < C) {
+        const f32x4* wr = (const f32x4*)(wup + (size_t)c * L);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 4; ++e) {
+          float acc = 0.f;
+          for (int l4 = 0; l4 < L / 4; ++l4) {
+            const f32x4 w4 = wr[e * (L / 4) + l4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_fmaf(__shfl(dl, 4 * l4 + u, 64), w4[u], acc);
+          }
+          a[e] = acc;
+        }
+        v[k] += a;
+        *(f32x4*)(xr + c) = v[k];
+      }
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < kMaxChunks; ++k) s += v[k][0] + v[k][1] + v[k][2] + v[k][3];
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < kMaxChunks; ++k) {
+    const int c = k * 256 + lane * 4;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[k][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) {
+    if (mean_o) mean_o[row] = mean;
+    if (rstd_o) rstd_o[row] = rstd;
+  }
+#pragma unroll
+  for (int k = 0; k < kMaxChunks; ++k) {
+    const int c = k * 256 + lane * 4;
+    if (c < C) {
+      const f32x4 g = *(const f32x4*)(gamma + c);
+      const f32x4 bb = *(const f32x4*)(beta + c);
+      bf16x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (bf16)((v[k][e] - mean) * rstd * g[e] + bb[e]);
+      *(bf16x4*)(y16 + (size_t)row * C + c) = h;
+    }
+  }
+}
+
 // dx = dres + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
@@ -157,6 +234,17 @@ extern "C" int gvk_layernorm_fwd(const float* x, const float* gamma, const float
   GVK_LAUNCH(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16*)y_bf16, y_f32, mean,
                      rstd, M, C, eps);
   return check_launch("layernorm_fwd");
+}
+
+extern "C" int gvk_layernorm_fwd_fix(float* x, const float* gamma, const float* beta, void* y_bf16, float* mean, float* rstd, int M, int C, float eps,
+                                     const float* enh, const float* lat, const float* wup, int T, int P, int L, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(x && gamma && beta && y_bf16 && enh && lat && wup, "gvk_layernorm_fwd_fix: null pointer");
+  GVK_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 256 * kMaxChunks, "gvk_layernorm_fwd_fix: C=%d must be a multiple of 4 and <= 1024", C);
+  GVK_REQUIRE(T > 0 && P > 0 && P <= T && L > 0 && L <= 64 && L % 4 == 0 && M % T == 0, "gvk_layernorm_fwd_fix: need 0 < P <= T, L <= 64 and a multiple of 4, M a multiple of T");
+  GVK_LAUNCH(ln_fwd_fix_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16*)y_bf16, mean, rstd, M, C,
+             eps > 0.f ? eps : 1e-5f, enh, lat, wup, T, P, L);
+  return check_launch("layernorm_fwd_fix");
 }
 
 extern "C" int gvk_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,

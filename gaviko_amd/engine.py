@@ -59,6 +59,9 @@ SIDE_STREAM_PRIORITY = int(os.environ.get("GAVIKO_HIP_SIDE_PRIORITY", "0"))
 # Patch embedding as one implicit GEMM (csrc/patch_gemm.hip) instead of the im2col kernel + GEMM: correct and bit-identical, but 74-79 us
 # against 54 us for the pair -- opt-in
 _PATCH_IMPLICIT = os.environ.get("GAVIKO_HIP_PATCH_IMPLICIT", "0") == "1"
+# GPA prompt fix inside the next layer's first LayerNorm (gvk_layernorm_fwd_fix) instead of its own 128-row launch: measured 709-711 vs
+# 719-721 volumes/s -- the 128 prompt rows' waves become the tail of a 4132-row kernel; opt-in
+_FIX_IN_LN = os.environ.get("GAVIKO_HIP_FIX_IN_LN", "0") == "1"
 _SIDE_STREAMS = {}                       # (device index, kind) -> the process-wide side stream of that kind
 # MWSA backward chain held behind the layer's attention backward: measured 669 vs 688 volumes/s -- the chain then slows the dgrad GEMMs
 # of the next layer by as much as it slowed the attention kernels before (start->fc1d 82 -> 98 us); opt-in only
@@ -668,6 +671,7 @@ class Engine:
                     for i in range(self.depth):
                         pre, _ = self._gpa_names(i)
                         ops.pack_split_bf16(d(pre + ".proj_up.weight"), self._w16[f"fc2{i}"], self.mlp, C, b=d(pre + ".proj_up.bias"), weight_side=True)
+        pending_fix = None
         for i in range(self.depth):
             si = i if train else 0
             gi, go = (i, i + 1) if train else (i & 1, (i + 1) & 1)
@@ -686,7 +690,10 @@ class Engine:
             self._mark(f"f{i}:start")
             if self.kind == "evp":
                 self._evp_add_prompt(ws, i, si, ws["G"][gi], B)               # x[:, 1:] += prompt_i (evp.py:235-238)
-            self._attn_block_fwd(ws, i, si, ws["G"][gi], ws["G1"][si], Mi, sv["bdrop"])
+            if gaviko and pending_fix is not None:
+                self._wait(None, "gpa")                              # the previous layer's enh
+            self._attn_block_fwd(ws, i, si, ws["G"][gi], ws["G1"][si], Mi, sv["bdrop"], fix=pending_fix if gaviko and _on("noside") else None)
+            pending_fix = None
             self._mark(f"f{i}:attn")
             fused = gaviko and self._fuse_proj
             if gaviko and not fused:
@@ -715,11 +722,16 @@ class Engine:
                 self._dvpt_fwd_up(ws, i, si, gout, Mi)
             self._mark(f"f{i}:mlp")
             if gaviko and up_in_fc2:
-                self._wait(None, "gpa")                              # enh ready
-                if "noside" not in _ABLATE:
-                    pre, _ = self._gpa_names(i)
-                    g = ws["gp"][si]
-                    ops.prompt_up_fix(g["enh"], g["xl"], d(pre + ".proj_up.weight"), ws["G"][go], B, self.T, self.P, C, self.Lat)
+                # the P prompt rows still lack (enh - xl) . Wup^T: the next layer's first LayerNorm applies it on the way in (one launch less
+                # on this stream); the last layer has no successor and launches the 128-row fix itself
+                pre, _ = self._gpa_names(i)
+                g = ws["gp"][si]
+                pending_fix = dict(enh=g["enh"], lat=g["xl"], wup=d(pre + ".proj_up.weight"))
+                if i + 1 == self.depth or not _FIX_IN_LN:
+                    self._wait(None, "gpa")                          # enh ready
+                    if _on("noside"):
+                        ops.prompt_up_fix(pending_fix["enh"], pending_fix["lat"], pending_fix["wup"], ws["G"][go], B, self.T, self.P, C, self.Lat)
+                    pending_fix = None
             elif gaviko:
                 self._wait(None, "gpa")                              # enh ready
                 self._gpa_fwd_up(ws, i, si, ws["G"][go], M)
@@ -763,11 +775,15 @@ class Engine:
         if sv["pdrop"] > 0:
             ops.dropout_rows(g, sv["pdrop"], SEED_PROMPT + i, ws["seed"], out32=g, M=sv["B"] * self.P, N=self.C, rows_in=self.P, rows_out=T, row_off=1)
 
-    def _attn_block_fwd(self, ws, i, si, gin, g1, M, pdrop=0.0):
+    def _attn_block_fwd(self, ws, i, si, gin, g1, M, pdrop=0.0, fix=None):
         nm, w, d, C = self.names, self._w16, self._d, self.C
         a = nm.attn(i)
         st = ws["stat"][si]
-        ops.layernorm_fwd(gin, d(a + ".norm.weight"), d(a + ".norm.bias"), M, C, y16=ws["xn"], mean=st[0], rstd=st[1])
+        if fix is not None:                                  # + the previous layer's GPA prompt fix, applied to gin in place
+            ops.layernorm_fwd_fix(gin, d(a + ".norm.weight"), d(a + ".norm.bias"), M, C, y16=ws["xn"], mean=st[0], rstd=st[1], T=self.T, P=self.P,
+                                  L_=self.Lat, **fix)
+        else:
+            ops.layernorm_fwd(gin, d(a + ".norm.weight"), d(a + ".norm.bias"), M, C, y16=ws["xn"], mean=st[0], rstd=st[1])
         if self._keep_inputs:
             ops.copy_(ws["sav"]["xn1"][si], ws["xn"])
         self._gemm(ws["xn"], w[f"qkv{i}"], M, ws["qkv"][si], epilogue=ops.EPI_STORE_BF16, bias=self._eff.get(a + ".to_qkv.bias"))

@@ -89,6 +89,7 @@ SIGNATURES = {
     "gvk_pack_split_bf16": [_P, _I, _P, _P, _I, _I, _I, _I, _P],
     "gvk_patch_embed_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "gvk_prompt_up_fix": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gvk_layernorm_fwd_fix": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _I, _I, _I, _P],
     "gvk_patchify_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gvk_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "gvk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],

@@ -106,6 +106,21 @@ def patch_embed(img, w, bias, pos, out0, out1, patch, C_, rows_out, row_off):
                                           rows_out, row_off, L.stream_ptr()), "gvk_patch_embed_bf16")
 
 
+def layernorm_fwd_fix(x, gamma, beta, M, C_, *, y16, mean, rstd, enh, lat, wup, T, P, L_, eps=1e-5):
+    """LayerNorm forward (bf16 output) that first applies the previous layer's GPA prompt fix to rows (m % T) < P of x, in place."""
+    _chk(x, torch.float32, "ln_fix x", M * C_)
+    _chk(gamma, torch.float32, "ln_fix gamma", C_)
+    _chk(beta, torch.float32, "ln_fix beta", C_)
+    _chk(y16, torch.bfloat16, "ln_fix y16", M * C_)
+    _chk(mean, torch.float32, "ln_fix mean", M)
+    _chk(rstd, torch.float32, "ln_fix rstd", M)
+    _chk(enh, torch.float32, "ln_fix enh", (M // T) * P * L_)
+    _chk(lat, torch.float32, "ln_fix lat", M * L_)
+    _chk(wup, torch.float32, "ln_fix wup", C_ * L_)
+    L.check(L.load().gvk_layernorm_fwd_fix(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y16), L.ptr(mean), L.ptr(rstd), M, C_, eps, L.ptr(enh),
+                                           L.ptr(lat), L.ptr(wup), T, P, L_, L.stream_ptr()), "gvk_layernorm_fwd_fix")
+
+
 def prompt_up_fix(enh, lat, w, out, B, T, P, C_, L_):
     """out rows b*T + p (p < P) += (enh[b][p] - lat[b*T + p]) . w^T (gaviko_hip.h: gvk_prompt_up_fix)."""
     _chk(enh, torch.float32, "prompt_up_fix enh", B * P * L_)

@@ -150,6 +150,11 @@ int gvk_patch_embed_bf16(const float* img, const void* w, const float* bias, con
  * fwd: x f32 [M][C] -> y bf16 [M][C] (MFMA operand) and/or y32 f32; saves mean/rstd f32 [M] (either may be NULL). */
 int gvk_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
                       float* mean, float* rstd, int M, int C, float eps, void* stream);
+/* gvk_layernorm_fwd (bf16 output) with the GPA prompt fix of the previous layer applied on the way in: rows with (m % T) < P first receive
+ * x[m] += (enh[m / T][m % T] - lat[m]) . wup^T (wup f32 [C][L]; gaviko.py:183-187 when the plain-latent part rode the MLP GEMM) and are
+ * written back; then every row is normalised.  Replaces gvk_prompt_up_fix + gvk_layernorm_fwd at a layer boundary. */
+int gvk_layernorm_fwd_fix(float* x, const float* gamma, const float* beta, void* y_bf16, float* mean, float* rstd, int M, int C, float eps,
+                          const float* enh, const float* lat, const float* wup, int T, int P, int L, void* stream);
 /* bwd (input gradient only -- frozen affine): dx = dres + LN'(dy); dres may be NULL; dx_bf16 (optional) = bf16 copy. */
 int gvk_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                       const float* dres, float* dx, void* dx_bf16, int M, int C, void* stream);
