@@ -454,7 +454,8 @@ class Engine:
                 return st
             # (confining the side streams to a CU subset with hipExtStreamCreateWithCUMask was measured: 676 -> 170-260 volumes/s for
             #  every mask shape tried -- masked queues are far slower to dispatch on this runtime)
-            st = self._streams[name] = _SIDE_STREAMS[key] = torch.cuda.Stream(priority=SIDE_STREAM_PRIORITY)
+            prio = int(os.environ.get(f"GAVIKO_HIP_{name.upper()}_PRIORITY", SIDE_STREAM_PRIORITY))     # per-stream A/B switch
+            st = self._streams[name] = _SIDE_STREAMS[key] = torch.cuda.Stream(priority=prio)
             pad = int(os.environ.get(f"GAVIKO_HIP_LDS_PAD_{name.upper()}", os.environ.get("GAVIKO_HIP_LDS_PAD", "0")))
             if pad:
                 L.check(L.load().gvk_stream_set_lds_pad(st.cuda_stream, pad), "gvk_stream_set_lds_pad")
