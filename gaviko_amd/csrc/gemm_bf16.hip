@@ -256,7 +256,11 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     // 60 % of the CUs idle; 198 tiles of 64: 465 -> 488 volumes/s at B = 2, while at B = 4 the small tile costs 6 %)
     static const long t64_hi = getenv("GAVIKO_HIP_GEMM_T64HI") ? atol(getenv("GAVIKO_HIP_GEMM_T64HI")) : 130;
     if (bm == 64 && bn == 128 && t128 <= 256 && a.K >= 512 && a.drop_thresh == 0u) {
-      if (n768 == 3128) tile = t128 <= t64_hi ? 3064128 : 3128128;
+      // GAVIKO_HIP_GEMM_K2=1: the same tile on EIGHT waves that split every k-tile (gemm_k2_bf16.hip) -- two waves per SIMD instead of one.
+      // Measured: isolated 32.7 vs 35.9 us (fc2), 23.6 vs 25.2 (qkv dgrad), equal elsewhere; 709-715 vs 713 volumes/s on the step: the loop is
+      // bound by LDS bandwidth (64 KB of fragment reads + 32 KB of LDS-DMA writes per k-tile), not by the single wave's latency chain.  Opt-in.
+      static const bool k2 = getenv("GAVIKO_HIP_GEMM_K2") != nullptr && getenv("GAVIKO_HIP_GEMM_K2")[0] == '1';
+      if (n768 == 3128) tile = t128 <= t64_hi ? 3064128 : (k2 && gemm_k2_supports(EPI) && a.K >= 192 ? 9128128 : 3128128);
       else if (n768 == 128) tile = 128128;
       else if (n768 == 3064) tile = 3064128;
     }
@@ -277,6 +281,7 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
   switch (tile) {
     case 8256256: return launch_gemm8p(a, EPI, 0, stream);      // eight-phase kernel, LDS-DMA issued in the load sections (default)
     case 7256256: return launch_gemm8p(a, EPI, 1, stream);      // ... issued inside the MFMA clusters (2546 vs 2426 cycles per k-tile)
+    case 9128128: return launch_gemm_k2(a, EPI, stream);         // 128 x 128, eight waves splitting every k-tile, three LDS stages
     case 3128128: return launch_gemm<128, 128, EPI, false, 3>(a, stream);
     case 3064128: return launch_gemm<64, 128, EPI, false, 3>(a, stream);     // 64 x 128 with three stages (A/B switch GAVIKO_HIP_GEMM_N768=3064)
     case 256256:

@@ -333,3 +333,35 @@ def test_gemm_eight_phase_kernel(dev, M, N, K, tile8):
     o = ops.act_zeros(M, N, torch.float32, dev)
     ops.gemm_nt(A, W, M, o, epilogue=ops.EPI_STORE_F32, tile=tile8)
     assert (o[:M] - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [(4132, 768, 3072), (4132, 768, 3136), (4132, 768, 768), (1033, 768, 192), (300, 256, 256), (130, 512, 2304)])
+def test_gemm_split_k_eight_wave_tile(dev, M, N, K):
+    """tile 9128128 (gemm_k2_bf16.hip: 128 x 128 on eight waves, waves 0-3 / 4-7 multiplying the two 32-wide halves of every k-tile, partial
+    tiles summed through LDS): its three epilogues against torch in float32 and against the four-wave kernel (the k halves are summed in a
+    different order, so equal to fp32 rounding, not bit for bit), repeated -- a wrong LDS-DMA / barrier ordering is a race."""
+    from gaviko_amd import ops
+    gen = torch.Generator().manual_seed(11 * M + N + K)
+    A = ops.act_zeros(M, K, torch.bfloat16, dev); A[:M] = torch.randn(M, K, generator=gen).bfloat16().to(dev)
+    W = (torch.randn(N, K, generator=gen) / K ** 0.5).bfloat16().to(dev)
+    bias = torch.randn(N, generator=gen).to(dev)
+    res = ops.act_zeros(M, N, torch.float32, dev); res[:M] = torch.randn(M, N, generator=gen).to(dev)
+    ref = A[:M].float() @ W.float().t()
+    cases = ((ops.EPI_STORE_BF16, dict(), torch.bfloat16, ref), (ops.EPI_STORE_F32, dict(), torch.float32, ref),
+             (ops.EPI_BIAS_RES_F32, dict(bias=bias, res=res), torch.float32, ref + bias + res[:M]))
+    first = {}
+    for rep in range(4):
+        for epi, kw, dt, want in cases:
+            o = ops.act_zeros(M, N, dt, dev)
+            ops.gemm_nt(A, W, M, o, epilogue=epi, tile=9128128, **kw)
+            got = o.float()
+            tol = (1.2e-2 if dt == torch.bfloat16 else 2e-3) * max(1.0, want.abs().max().item())
+            assert (got[:M] - want).abs().max().item() < tol, (epi, rep)
+            assert not got[M:].any(), "rows >= M must not be written"
+            if rep == 0:
+                first[epi] = got.clone()
+                o4 = ops.act_zeros(M, N, dt, dev)
+                ops.gemm_nt(A, W, M, o4, epilogue=epi, tile=128128, **kw)
+                assert (got - o4.float()).abs().max().item() < (1.6e-2 if dt == torch.bfloat16 else 1e-4) * max(1.0, want.abs().max().item())
+            else:
+                assert torch.equal(got, first[epi]), "not reproducible from launch to launch"
