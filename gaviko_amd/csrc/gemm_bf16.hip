@@ -257,10 +257,11 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     static const long t64_hi = getenv("GAVIKO_HIP_GEMM_T64HI") ? atol(getenv("GAVIKO_HIP_GEMM_T64HI")) : 130;
     if (bm == 64 && bn == 128 && t128 <= 256 && a.K >= 512 && a.drop_thresh == 0u) {
       // GAVIKO_HIP_GEMM_K2=1: the same tile on EIGHT waves that split every k-tile (gemm_k2_bf16.hip) -- two waves per SIMD instead of one.
-      // Measured: isolated 32.7 vs 35.9 us (fc2), 23.6 vs 25.2 (qkv dgrad), equal elsewhere; 709-715 vs 713 volumes/s on the step: the loop is
-      // bound by LDS bandwidth (64 KB of fragment reads + 32 KB of LDS-DMA writes per k-tile), not by the single wave's latency chain.  Opt-in.
+      // Measured: isolated 32.7 vs 35.9 us (fc2), 23.6 vs 25.2 (qkv dgrad), equal elsewhere; 709-715 vs 713 volumes/s on the step: the
+      // single wave's latency chain is not what bounds the loop.  Opt-in.
       static const bool k2 = getenv("GAVIKO_HIP_GEMM_K2") != nullptr && getenv("GAVIKO_HIP_GEMM_K2")[0] == '1';
-      if (n768 == 3128) tile = t128 <= t64_hi ? 3064128 : (k2 && gemm_k2_supports(EPI) && a.K >= 192 ? 9128128 : 3128128);
+      static const bool k4 = getenv("GAVIKO_HIP_GEMM_K4") != nullptr && getenv("GAVIKO_HIP_GEMM_K4")[0] == '1';       // gemm_k4_bf16.hip, A/B switch
+      if (n768 == 3128) tile = t128 <= t64_hi ? 3064128 : (k4 && gemm_k4_supports(EPI) ? 4128128 : k2 && gemm_k2_supports(EPI) && a.K >= 192 ? 9128128 : 3128128);
       else if (n768 == 128) tile = 128128;
       else if (n768 == 3064) tile = 3064128;
     }
@@ -281,6 +282,7 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
   switch (tile) {
     case 8256256: return launch_gemm8p(a, EPI, 0, stream);      // eight-phase kernel, LDS-DMA issued in the load sections (default)
     case 7256256: return launch_gemm8p(a, EPI, 1, stream);      // ... issued inside the MFMA clusters (2546 vs 2426 cycles per k-tile)
+    case 4128128: return launch_gemm_k4(a, EPI, stream);         // 128 x 128, eight waves = 2 column halves x 4 k quarters (128 x 64 per wave)
     case 9128128: return launch_gemm_k2(a, EPI, stream);         // 128 x 128, eight waves splitting every k-tile, three LDS stages
     case 3128128: return launch_gemm<128, 128, EPI, false, 3>(a, stream);
     case 3064128: return launch_gemm<64, 128, EPI, false, 3>(a, stream);     // 64 x 128 with three stages (A/B switch GAVIKO_HIP_GEMM_N768=3064)

@@ -153,5 +153,8 @@ bool gemm8p_supports(int epilogue);
 // gemm_k2_bf16.hip: the 128 x 128 tile on eight waves that split every k-tile between them (STORE_BF16, BIAS_RES_F32, STORE_F32)
 int launch_gemm_k2(const GemmArgs& a, int epilogue, hipStream_t stream);
 bool gemm_k2_supports(int epilogue);
+// gemm_k4_bf16.hip: the 128 x 128 tile on eight waves = 2 column halves x 4 k quarters, 128 x 64 per wave (same three epilogues)
+int launch_gemm_k4(const GemmArgs& a, int epilogue, hipStream_t stream);
+bool gemm_k4_supports(int epilogue);
 
 }  // namespace gvk

@@ -11,9 +11,8 @@
 // summed through LDS once, after the main loop (64 KB, fixed order), and waves 0-3 run the shared epilogue.
 //
 // Result: correct, reproducible, 0-9 % faster in isolation, NO gain inside the step -- the second wave per SIMD
-// does not help because the k-tile is bound by LDS bandwidth (fragment reads + LDS-DMA writes: ~96 KB per k-tile and CU), which this form
-// leaves unchanged; only a larger per-wave tile (fewer fragment bytes per MFMA, as in gemm8p_bf16.hip) would.  Selected by tile code
-// 9128128 or GAVIKO_HIP_GEMM_K2=1.
+// does not help: the single wave's latency chain is not what bounds the k-tile (nor are the LDS bytes: gemm_k4_bf16.hip).  Selected by
+// tile code 9128128 or GAVIKO_HIP_GEMM_K2=1.
 #include "gemm_epilogue.hpp"
 #include "../../include/gaviko_hip.h"
 

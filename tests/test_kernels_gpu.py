@@ -335,10 +335,11 @@ def test_gemm_eight_phase_kernel(dev, M, N, K, tile8):
     assert (o[:M] - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("tilek", [9128128, 4128128])
 @pytest.mark.parametrize("M,N,K", [(4132, 768, 3072), (4132, 768, 3136), (4132, 768, 768), (1033, 768, 192), (300, 256, 256), (130, 512, 2304)])
-def test_gemm_split_k_eight_wave_tile(dev, M, N, K):
-    """tile 9128128 (gemm_k2_bf16.hip: 128 x 128 on eight waves, waves 0-3 / 4-7 multiplying the two 32-wide halves of every k-tile, partial
-    tiles summed through LDS): its three epilogues against torch in float32 and against the four-wave kernel (the k halves are summed in a
+def test_gemm_split_k_eight_wave_tile(dev, M, N, K, tilek):
+    """tiles 9128128 (gemm_k2_bf16.hip: 128 x 128 on eight waves, waves 0-3 / 4-7 multiplying the two 32-wide halves of every k-tile) and
+    4128128 (gemm_k4_bf16.hip: 2 column halves x 4 k quarters, 128 x 64 per wave), partial tiles summed through LDS: their three epilogues against torch in float32 and against the four-wave kernel (the k halves are summed in a
     different order, so equal to fp32 rounding, not bit for bit), repeated -- a wrong LDS-DMA / barrier ordering is a race."""
     from gaviko_amd import ops
     gen = torch.Generator().manual_seed(11 * M + N + K)
@@ -353,7 +354,7 @@ def test_gemm_split_k_eight_wave_tile(dev, M, N, K):
     for rep in range(4):
         for epi, kw, dt, want in cases:
             o = ops.act_zeros(M, N, dt, dev)
-            ops.gemm_nt(A, W, M, o, epilogue=epi, tile=9128128, **kw)
+            ops.gemm_nt(A, W, M, o, epilogue=epi, tile=tilek, **kw)
             got = o.float()
             tol = (1.2e-2 if dt == torch.bfloat16 else 2e-3) * max(1.0, want.abs().max().item())
             assert (got[:M] - want).abs().max().item() < tol, (epi, rep)
