@@ -1,8 +1,8 @@
 // bf16 MFMA GEMM, 128 x 128 workgroup tile with the k axis split FOUR ways: eight waves = 2 column halves x 4 k quarters, every wave
 // holding a 128 x 64 accumulator tile (8 x 4 MFMA tiles, 128 VGPRs).
 //
-// Why: the N = 768 GEMMs of the model (M = 4132: 198 tiles of 128 x 128, one per CU) are bound by LDS BANDWIDTH, not by MFMA issue and not by
-// latency (removing the steady-state LDS-DMA takes fc1 dgrad from 33.0 to 25.4 us; a second wave per SIMD at the
+// Hypothesis tested: the N = 768 GEMMs of the model (M = 4132: 198 tiles of 128 x 128, one per CU) are bound by LDS bandwidth rather than by MFMA
+// issue or by latency (removing the steady-state LDS-DMA takes fc1 dgrad from 33.0 to 25.4 us; a second wave per SIMD at the
 // same per-wave tile changes nothing).  With 64 x 64 per wave a 64-wide k-tile costs 64 KB of fragment reads + 32 KB of LDS-DMA writes per
 // CU; with 128 x 64 per wave the fragment reads drop to 48 KB (every wave reads ALL 128 activation rows but only 64 weight rows, for a
 // quarter of the k range) -- the per-wave tile of gemm8p_bf16.hip on a workgroup tile that still gives 198 workgroups.  The price is the
