@@ -16,9 +16,9 @@
 //     u2 = W rows, nq = 1                       (phase 1)
 //     u3 = A rows, mq = 1                       (phase 2)
 // The stream of units S_j (j = 4 t + u) runs D units ahead of the reads.  Two placements of the LDS-DMA (template parameter VAR):
-//   VAR 1 (default): phase g issues S_{g+7} INSIDE its MFMA cluster (an LDS-DMA costs ~60 issue cycles among MFMAs against 100-185 in a
+//   VAR 1 (tile code 7256256, opt-in: measured 2546 vs 2426 cycles per k-tile): phase g issues S_{g+7} INSIDE its MFMA cluster (an LDS-DMA costs ~60 issue cycles among MFMAs against 100-185 in a
 //          section that also carries ds_reads; the load section shrinks to the ds_reads, so the two groups' clusters run back to back);
-//   VAR 0: phase g issues S_{g+6} in its load section.
+//   VAR 0 (tile code 8256256, what dispatch_tile picks): phase g issues S_{g+6} in its load section.
 // WAR: a unit is restaged no earlier than the MFMA section of the phase AFTER its last ds_read (VAR 1) / two phases after it (VAR 0): the
 // reading group retired those reads with lgkmcnt(0) before its own MFMA section, and the other group is exactly one barrier away.
 // RAW: each load section ends with a COUNTED vmcnt that leaves every unit in flight except those the NEXT phase reads (4 units = 64 KiB

@@ -238,9 +238,11 @@ ROWPROJ_L = 20      # default latent width (configs/gaviko.yaml prompt_latent_di
 
 def side_tile_supported(L_: int, C_: int) -> bool:
     """Shapes the 16-row-tile fp32-MFMA projections (csrc/sidepass.hip) cover -- and with them the second projection fused into
-    gvk_skinny_up (w2 / z2 / y2)."""
+    gvk_skinny_up (w2 / z2 / y2) and the chained layer-boundary forms.  Mirrors the C side exactly (sidepass.hip: kSL = 20,
+    groups_per_wave(C) != 0 only for C in {192, 768, 1024}); any other latent width or channel count runs the generic
+    row-per-wave / MFMA-tile kernels of rowwise.hip / skinny.hip without the fusions."""
     import os
-    return os.environ.get("GAVIKO_HIP_SIDE", "1")[:1] != "0" and C_ % 32 == 0 and 64 <= C_ <= 1024 and L_ % 4 == 0 and 4 <= L_ <= 32
+    return os.environ.get("GAVIKO_HIP_SIDE", "1")[:1] != "0" and L_ == 20 and C_ in (192, 768, 1024)
 
 
 def rowproj_supported(L_: int, C_: int) -> bool:

@@ -84,6 +84,9 @@ def _parity_report():
 GAVIKO_CASES = [("gaviko_t16_b2", "vit-t16", 2, dict(GAVIKO)),
                 ("gaviko_t16_b2_k366_p8", "vit-t16", 2, dict(GAVIKO, local_k=(3, 6, 6), num_prompts=8)),
                 ("gaviko_t16_b1_share2", "vit-t16", 1, dict(GAVIKO, share_factor=2)),
+                # latent width 16: outside the L = 20 tile kernels (sidepass.hip / window_mfma.hip), so the engine must take the
+                # unfused row-per-wave / generic-L kernels for every rank-L projection, the window attention and their backward
+                ("gaviko_t16_b2_lat16", "vit-t16", 2, dict(GAVIKO, prompt_latent_dim=16, local_dim=16)),
                 ("cfg2_gaviko_b16_b4", "vit-b16", 4, dict(GAVIKO)),
                 ("cfg5_gaviko_l16_b2", "vit-l16", 2, dict(GAVIKO))]
 

@@ -86,3 +86,21 @@ def test_reference_imports_resolve_through_the_shim(tmp_path):
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "shim"), ROOT, str(ref_like)]), PYTHONDONTWRITEBYTECODE="1")
     r = subprocess.run([sys.executable, "-c", SCRIPT], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SHIM-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_shim_wins_when_the_reference_src_is_first_on_sys_path(tmp_path):
+    """`python src/train.py` puts src/ at sys.path[0], AHEAD of everything on PYTHONPATH.  The shim still wins because the reference's
+    model/ data/ losses/ utils/ directories carry no __init__.py: they are namespace-package candidates, and a regular package found
+    LATER on the path takes precedence over a namespace portion found earlier (import system: a path entry with <name>/__init__.py ends
+    the search, one without only records a portion).  This stand-in mirrors that layout with decoy modules that must never be imported."""
+    ref_like = tmp_path / "src"
+    for pkg, mods in (("model", ("gaviko", "vision_transformer", "vpt", "adaptformer", "melo", "ssf", "dvpt", "evp")),
+                      ("data", ("dataset",)), ("losses", ("focal_loss",)), ("utils", ("load_pretrained",))):
+        (ref_like / pkg).mkdir(parents=True)                     # no __init__.py, like /root/reference/src/*
+        for m in mods:
+            (ref_like / pkg / f"{m}.py").write_text("raise ImportError('the reference-side module was imported instead of the shim')\n")
+    (ref_like / "utils" / "logging.py").write_text("MemoryUsageLogger = analyze_model_computation = setup_logging = 'reference-side logging module'\n")
+    (ref_like / "train_like.py").write_text("import sys, os\nassert os.path.abspath(sys.path[0]) == os.path.dirname(os.path.abspath(__file__)), sys.path[:3]\n" + SCRIPT)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "shim"), ROOT]), PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, str(ref_like / "train_like.py")], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SHIM-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -18,9 +18,9 @@ def test_training_loop_end_to_end(dev, tmp_path, method):
     h = res["history"]
     assert all(torch.isfinite(torch.tensor(e["train_loss"])) for e in h)
     if method == "bitfit":
-        # 76 k bias parameters, 8 steps, live dropout: the epoch losses move by +-1 % with the dropout draws (measured over seeds:
-        # 1.203 .. 1.238 around 1.22), so "lower than epoch 0" is a coin flip here -- require a sane, stable loss instead
-        assert max(abs(e["train_loss"] - h[0]["train_loss"]) for e in h) < 0.05 * h[0]["train_loss"], h
+        # 76 k bias parameters under live dropout + random augmentation: the epoch MEANS move by +-1 % with the draws, so the loop run only
+        # has to stay finite here; that bitfit LEARNS is asserted deterministically in test_bitfit_learns_on_a_fixed_batch below
+        pass
     else:
         assert min(e["train_loss"] for e in h[1:]) < h[0]["train_loss"], h   # it learns something on 8 volumes
     assert os.path.exists(res["checkpoint"]) and os.path.exists(res["results_csv"])
@@ -39,6 +39,38 @@ def test_training_loop_end_to_end(dev, tmp_path, method):
     if h[-1]["val_acc"] > max(e["val_acc"] for e in h[:-1]):
         assert torch.equal(a, b)
     assert torch.isfinite(b).all()
+
+
+def test_bitfit_learns_on_a_fixed_batch(dev):
+    """`--method bitfit` (train.py:131-137: biases + head train) with every dropout off and one fixed batch: the step is deterministic, so
+    "the loss falls and the bias tensors move" is a hard assertion -- a no-op optimizer or zeroed bias gradients fail it."""
+    from gaviko_amd.optim import FusedAdamOneCycle
+    from gaviko_amd.registry import build_model
+    from gaviko_amd.utils import synth
+    model = build_model(_tiny_cfg("bitfit"))
+    filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    model.to(dev).train()
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+    assert names and all(("bias" in k) or ("head" in k) for k in names)
+    before = {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
+    x = torch.from_numpy(synth.volumes(0, 4)).to(dev)
+    y = torch.from_numpy(synth.labels(0, 4)).to(dev)
+    steps = 12
+    opt = FusedAdamOneCycle(model, lr=2e-3, eps=1e-8, max_norm=1.0, max_lr=2e-3, total_steps=steps, pct_start=0.3, div_factor=10, final_div_factor=1000)
+    hist = []
+    for _ in range(steps):
+        loss = torch.nn.functional.cross_entropy(model(x), y)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        hist.append(loss.item())
+    assert all(torch.isfinite(torch.tensor(hist))), hist
+    assert hist[-1] < hist[0] - 1e-3 and min(hist[1:]) < hist[0], hist
+    after = dict(model.named_parameters())
+    moved = [k for k in names if (after[k].detach() - before[k]).abs().max().item() > 0]
+    backbone_bias = [k for k in moved if "head" not in k]
+    assert len(moved) == len(names) and backbone_bias, (len(moved), len(names))
 
 
 def _tiny_cfg(method, **kw):
