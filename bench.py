@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: MRI volumes/sec (fwd+bwd), ViT-B/16 --method gaviko, synthetic 120x160x160 volumes.
 
-  python bench.py --gpus N --steps K --warmup W            (N=1)
+  python bench.py --gpus N --steps K --warmup W            (any N: for N > 1 without a launcher's RANK / WORLD_SIZE in the environment
+                                                            this process starts the N ranks itself -- see spawn_ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 A "step" = one pass of the hot path over one batch: forward, loss seed, backward of every trainable tensor (frozen ViT,
@@ -12,7 +13,9 @@ Weak scaling: 4 volumes per GPU (BASELINE.json configs[1]).
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     -- the dominant kernel (the bf16 MFMA GEMM class with the largest total time), timed per launch by HIP event
                   pairs on its launch stream inside a second, instrumented copy of the step's launch plans (same
-                  three-stream schedule as the timed region; the bracket's own cost is calibrated and subtracted)
+                  three-stream schedule as the timed region).  `achieved` uses the RAW event-pair time (it agrees with the
+                  rocprofv3 kernel duration of the same launches) and the ALGORITHMIC flops (padding columns of the
+                  K-concatenated operand excluded); the cost of an empty event pair is reported as `event_pair_us`, not subtracted
   cpu_baseline -- the oracle (CPU restatement of the reference, fp32 torch) timed on this host's cores on one batch.
 """
 from __future__ import annotations
@@ -102,6 +105,9 @@ def cpu_baseline(backbone, batch):
                       f"{times[0]:.1f} s, best of {len(times) - 1} timed step(s) ({', '.join(f'{t:.1f}' for t in times[1:])} s)"}
 
 
+# newest committed PMC summary first; each records the sha of the GEMM sources it was measured on and is ignored when that differs
+PMC_TRAFFIC_FILE = next((f for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))),
+                        "r03_pmc_traffic.json")
 GEMM_SOURCES = ("gemm_bf16.hip", "gemm8p_bf16.hip", "gemm_epilogue.hpp", "common.hpp")
 
 
@@ -116,11 +122,11 @@ def gemm_source_hash():
 
 
 def pmc_traffic(name, stats):
-    """HBM-side bytes per launch of the dominant GEMM from the committed PMC passes (profiles/r01_pmc_traffic.json, produced
+    """HBM-side bytes per launch of the dominant GEMM from the committed PMC passes (profiles/r0N_pmc_traffic.json, produced
     by tools/pmc_traffic.py from two `rocprofv3 --pmc` runs of this same command: FETCH_SIZE and WRITE_SIZE, KiB units, reads
     x2 on gfx950).  PMC counters cannot be read from inside the process, so the figure is the last profiled one; it is only
     attached when the kernel instantiation (epilogue id) is used by exactly one GEMM shape of this run, else traffic stays null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_TRAFFIC_FILE)
     m = re.match(r"gemm_nt_bf16\[(\w+)\]", name)
     if not (m and os.path.exists(path)):
         return {}
@@ -146,8 +152,52 @@ def pmc_traffic(name, stats):
     cl = hits[0].get("clusters") or [hits[0]]
     if len(cl) != len(same):
         return {}
-    return {"traffic": cl[same.index(name)]["total_bytes"], "traffic_source": f"profiles/r02_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB; GEMM sources {doc.get('gemm_source_sha')})",
+    return {"traffic": cl[same.index(name)]["total_bytes"], "traffic_source": f"profiles/{PMC_TRAFFIC_FILE} (2*FETCH_SIZE + WRITE_SIZE, KiB; GEMM sources {doc.get('gemm_source_sha')})",
             "algorithmic_bytes": alg_bytes(stats[name]["shape"])}
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher: start the N ranks as FRESH child processes (never a re-exec) -- this parent has not
+    touched the GPU (importing torch does not initialise HIP) and never will.  Every child gets RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT like torch.distributed.run would set them and runs this same file; rank 0's stdout (the one JSON line)
+    is relayed, stderr of every rank passes through.  Returns the exit code (first failing rank's, else 0)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GAVIKO_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs between processes on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    rc, out0 = 0, ""
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                    for q in sorted(pending):
+                        procs[q].terminate()                      # the exact child processes started above
+            if pending:
+                time.sleep(0.05)                                  # (rank 0 prints one short line at the very end: its pipe cannot fill up)
+        if procs[0].stdout is not None:
+            out0 = procs[0].stdout.read()
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
 
 
 def main():
@@ -160,17 +210,30 @@ def main():
     ap.add_argument("--loss", default="ce", choices=["ce", "focal", "ce-torch"])   # ce-torch: torch's own op, for A/B only
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--launch-check", action="store_true", help="every rank reports its launcher environment and exits before any GPU call (tests)")
     ap.add_argument("--allow-ablate", action="store_true", help="diagnostics only: run with GAVIKO_HIP_ABLATE set; the output line is marked INVALID")
     args = ap.parse_args()
     if os.environ.get("GAVIKO_HIP_ABLATE") and not args.allow_ablate:
         raise SystemExit("bench.py: GAVIKO_HIP_ABLATE is set -- the timing ablations compute WRONG results, so this is not a benchmark; unset it "
                          "(or pass --allow-ablate: the line is then marked INVALID)")
 
+    if args.gpus > 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        raise SystemExit(spawn_ranks(args.gpus))              # bare `python bench.py --gpus N`: the ranks are started here, before any GPU call
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        rec = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GAVIKO_BENCH_CHILD")}
+        rec["gpu_initialised"] = bool(torch.cuda.is_initialized())
+        path = os.environ.get("GAVIKO_BENCH_LAUNCH_LOG")
+        if path:
+            with open(f"{path}.{rank}", "w") as f:
+                json.dump(rec, f)
+        if rank == 0:
+            print(json.dumps({"launch_check": rec, "n_gpus": world}))
+        return
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
     # Rehearsal switches (not used by the driver): GAVIKO_BENCH_REHEARSAL=1 runs every rank on cuda:0 over gloo, so that the
     # whole multi-rank flow (bucketed backward, all-reduce, instrumented pass) can be exercised on a one-GPU box.
     rehearsal = os.environ.get("GAVIKO_BENCH_REHEARSAL") == "1"
@@ -283,13 +346,15 @@ def main():
                                   "algorithmic_bytes": pe["bytes"], "note": "im2col(bf16) + MFMA GEMM with fused bias/pos/scatter epilogue"}
         if stats:
             name, s = max(stats.items(), key=lambda kv: kv[1]["total_ms"])
-            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(s["flops_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12, 2),
-                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(s["flops_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                               "traffic": None, "avg_launch_us": round(s["avg_ms"] * 1e3, 2), "launches": s["n"],
-                               "flop_per_launch": s["flops_per_launch"], "shape": s["shape"],
-                               "timing": f"HIP event pairs on the launch stream inside the replayed plan, bracket cost "
-                                         f"{s['overhead_ms'] * 1e3:.1f} us subtracted"}
+            raw_us, pair_us = s["avg_ms"] * 1e3, s["overhead_ms"] * 1e3
+            tf = s["flops_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None, "avg_launch_us": round(raw_us, 2), "launches": s["n"],
+                               "flop_per_launch": s["flops_per_launch"], "shape": s["shape"], "event_pair_us": round(pair_us, 2),
+                               "avg_launch_us_minus_event_pair": round(max(raw_us - pair_us, 0.0), 2),
+                               "timing": "RAW HIP event pairs on the launch stream inside the replayed plan (nothing subtracted; an empty "
+                                         "pair costs event_pair_us); flop_per_launch = 2*M*N*K_algorithmic (padding columns of the "
+                                         "K-concatenated fc2 operand excluded); cross-check: profiles/r03_kernel_stats_by_shape.csv"}
             out["roofline"].update(pmc_traffic(name, stats))
             out["gemm_classes"] = {k: {"avg_us": round(v["avg_ms"] * 1e3, 2), "n": v["n"], "tflops": round(v["flops_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12, 1)}
                                    for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])}

@@ -231,21 +231,26 @@ class Engine:
         self._flat_grad = None
         self._saved = None
 
-    def _gemm(self, a, w, M, out0, **kw):
+    def _gemm(self, a, w, M, out0, alg_k=None, **kw):
+        """One NT GEMM launch.  alg_k: the ALGORITHMIC contraction length when the operand carries padding columns (fc2 with the
+        K-concatenated GPA up-projection: 3072 + 20 of 3136 columns are products the reference computes, the split-bf16 copies and the
+        zero padding are not) -- only the bench instrumentation reads it, for flop_per_launch."""
         if GEMM_MARKS is None or not self._recording:
             return ops.gemm_nt(a, w, M, out0, **kw)
-        N, K = w.shape
+        N, K = w.shape[0], int(kw.get("K") or w.shape[1])
+        ka = int(alg_k) if alg_k is not None else K
         key = f"gemm_nt_bf16[{_EPI_NAMES[kw['epilogue']]}] M={M} N={N} K={K}"
         cur = torch.cuda.current_stream()
         e0 = self._ev_record(cur)
         ops.gemm_nt(a, w, M, out0, **kw)
         e1 = self._ev_record(cur)
-        self._gemm_marks.append((key, 2.0 * M * N * K, [M, N, K], None, e0, e1))
+        self._gemm_marks.append((key, 2.0 * M * N * ka, [M, N, K], None, e0, e1))
 
     def collect_gemm_marks(self, acc=None):
         """After a sync: add the event-pair durations of the last replay of every instrumented plan to `acc`
-        ({class: {"ms": [...], "flops", "shape", "bytes"}}).  An empty event pair recorded at the head of each plan measures the
-        cost of the bracketing itself, which is subtracted."""
+        ({class: {"ms": [...], "flops", "shape", "bytes", "overhead_ms"}}).  Durations are RAW event-pair times (they agree with the
+        rocprofv3 kernel durations of the same launches, profiles/r02_bench_kernel_stats.csv); the empty event pair recorded at the head
+        of each plan is reported beside them as `overhead_ms`, never subtracted."""
         import ctypes
         acc = {} if acc is None else acc
         lib, ms = L.load(), ctypes.c_float()
@@ -257,7 +262,7 @@ class Engine:
                     overhead = ms.value
                     continue
                 rec = acc.setdefault(key, {"ms": [], "flops": flops, "shape": shape, "bytes": nbytes, "overhead_ms": overhead})
-                rec["ms"].append(max(ms.value - overhead, 0.0))
+                rec["ms"].append(ms.value)
         return acc
 
     # ------------------------------------------------------------------ weights
@@ -819,6 +824,7 @@ class Engine:
             ops.copy_(ws["sav"]["act"][si], ws["act"])
         self._gemm(ws["act"], w[f"fc2{i}"], M, gout, epilogue=ops.EPI_BIAS_RES_F32, bias=d(m + ".net.4.bias"), res=g1,
                    K=self.ldx if up_in_fc2 else self.mlp,      # the GPA latents ride this GEMM as 64 extra K columns (self._fuse_up)
+                   alg_k=self.mlp + self.Lat if up_in_fc2 else None,
                    drop_p=pdrop, seed=SEED_LAYER + 8 * i + 3, seed_ptr=ws["seed"])
 
     # ---- GAViKO side paths --------------------------------------------------------------------------------------

@@ -66,6 +66,15 @@ def _worker(rank, world, port, ret):
     dist.all_gather(gathered, mine)
     want = sum(gathered) / world
     ok = torch.allclose(flat, want, atol=1e-6)
+    # the event-ordered form (one plan, grouped collectives): same result bit for bit, and every event it waits for is one the engine records
+    flat2 = mine.clone()
+    waited = []
+    marks = {(k, r): (k, r) for k in ("loc", "gpa") for r in (8, 4, 0)}
+    marks[("main", -1)] = ("main", -1)
+    red.reduce_marked(flat2, marks, lambda stream, ev: waited.append(ev))
+    ok = ok and torch.equal(flat2, flat)
+    groups = red.ready_groups()
+    ok = ok and [g[0] for g in groups] == [8, 4, -1] and sorted(i for _, m in groups for i in m) == list(range(len(red.ranges)))
     fired = {l: n for l, n in done if n}
     if rank == 0:
         ret["ok"], ret["fired"] = bool(ok), fired
@@ -83,3 +92,26 @@ def test_bucketed_mean_allreduce_world2_gloo():
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret["ok"]
     assert set(ret["fired"]) == {8, 4, 0}          # buckets go out at their lowest layer, the rest at finish()
+
+
+def test_bench_starts_its_own_ranks_when_run_bare(tmp_path):
+    """`python bench.py --gpus N` with no launcher environment (the form the driver uses) must start N fresh rank processes itself,
+    before any GPU call, with torch.distributed.run's variables, and relay rank 0's line.  --launch-check stops every rank before
+    it touches a device, so this runs on CPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["GAVIKO_BENCH_LAUNCH_LOG"] = str(tmp_path / "rank")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--launch-check"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 3 and line["launch_check"]["RANK"] == "0" and line["launch_check"]["MASTER_ADDR"] == "127.0.0.1"
+    recs = [json.load(open(f"{tmp_path / 'rank'}.{k}")) for k in range(3)]
+    assert [x["RANK"] for x in recs] == ["0", "1", "2"] and [x["LOCAL_RANK"] for x in recs] == ["0", "1", "2"]
+    assert len({x["MASTER_PORT"] for x in recs}) == 1 and all(x["WORLD_SIZE"] == "3" and not x["gpu_initialised"] for x in recs)
+    # under a launcher (RANK set) it must NOT spawn again
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0 and json.loads(r2.stdout.strip().splitlines()[-1])["launch_check"]["GAVIKO_BENCH_CHILD"] is None

@@ -141,3 +141,15 @@ def test_rccl_collectives_behind_plan_events_on_one_rank(dev, tmp_path):
     if "RCCL-UNAVAILABLE" in p.stdout:
         pytest.skip("RCCL could not be initialised on this box: " + p.stdout.strip().splitlines()[-1])
     assert p.returncode == 0 and "RCCL-OK" in p.stdout, p.stdout[-3000:]
+
+
+def test_bench_bare_two_ranks_rehearsal(dev, tmp_path):
+    """The driver's multi-GPU command form, `python bench.py --gpus 2 ...` with no launcher: bench.py starts both ranks itself.  On a
+    one-GPU box the ranks share cuda:0 over gloo (GAVIKO_BENCH_REHEARSAL=1); the line must report two ranks and a sane rate."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GAVIKO_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["value"] > 0 and line["scaling"] == "weak"
