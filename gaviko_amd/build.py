@@ -73,6 +73,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if r.returncode:
             print(r.stdout + r.stderr, file=sys.stderr)
             raise RuntimeError("link of libgaviko_hip.so failed")
+        # a kernel template whose host stub was silently dropped by the compiler shows up only as an undefined symbol at load time:
+        # resolve every symbol now (fresh interpreter, RTLD_NOW) so that such a build fails HERE and not on the GPU box
+        r = subprocess.run([sys.executable, "-c", f"import ctypes, os; ctypes.CDLL({LIB!r}, mode=os.RTLD_NOW)"], capture_output=True, text=True)
+        if r.returncode:
+            print(r.stdout + r.stderr, file=sys.stderr)
+            raise RuntimeError("libgaviko_hip.so does not load (undefined symbol?)")
     return LIB
 
 

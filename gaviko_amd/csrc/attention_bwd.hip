@@ -5,40 +5,38 @@
 //              dP[q][key] are computed with the KEY on the MFMA lane, so their accumulators are directly the B operands
 //              of dV^T += dO^T.P and dK^T += Q^T.dS (Q / dO tiles are read row-wise for S, dP and 4x16-transposed
 //              (ds_read_b64_tr_b16) for the two gradient products -- one LDS image serves both).
-//   dq pass:   workgroup = 128 queries, sweeping 64-key tiles exactly like the forward: S^T, dP^T with the QUERY on the
+//   dq pass:   workgroup = 128 queries, sweeping key tiles exactly like the forward: S^T, dP^T with the QUERY on the
 //              lane, dQ^T += K^T.dS^T with K^T gathered by transposed reads of the row-major K tile.
-// The row constants (-lse/scale) are preloaded into the S accumulators, so P = exp2(c * S') needs no subtraction.
-#include "common.hpp"
-#include "dropout.hpp"
+// Round 3 (same diet as the forward, attention_fwd.hip): both kernels were bound by vector issue -- per 32 x 32 score block ~100-120
+// VALU instructions beside 12-16 MFMAs, half of them the row constants (S - lse, dP - delta), the x scale and key / row masks that
+// hipcc had hoisted into per-tile v_cmp / v_cndmask chains.  Now
+//   * the q block ARRIVES pre-scaled by scale*log2(e) (the qkv projection's epilogue, gvk_gemm_desc.scale_cols), exactly as the forward
+//     read it: P = exp2(S') with no multiply, and the three kernels recompute bit-identical scores -- an in-kernel pre-scale of whichever
+//     operand sits in registers (Q in one pass, K in the other) made P inconsistent with the forward's lse and cost 8x on the deepest
+//     gradients of the adaptformer fixture;  dQ = scale . dS.K is the gradient of the UNSCALED q, dK = dS^T.Q' / log2(e);
+//   * S' = S - lse*log2(e) (+ the mask as -3e38) and dP' = dP - delta come out of the matrix pipe: one extra MFMA each over an
+//     augmented contraction (attention_common.hpp), no v_fma / v_sub / v_cndmask per score: a score costs v_exp, v_mul, and its
+//     share of two v_cvt_pk;
+//   * key / query tiles of 96 rows when they pad the sequence less than 128 (T = 1033: 1056 instead of 1152 / 1088), waves whose 32
+//     rows lie wholly past the sequence only help staging;
+//   * staging by LDS-DMA through buffer resources with SCALAR tile offsets (no per-tile vector address arithmetic);
+//   * dQ / dK / dV leave through LDS as whole 128-byte rows.
+#include "attention_common.hpp"
 #include "../../include/gaviko_hip.h"
 
 namespace gvk {
 
-// A/B switch (compile-time, tools/gpu experiments): raise the wave's priority around its MFMA clusters so that, of the two waves a SIMD
-// hosts (two workgroups per CU), the one in a matrix phase issues first and the other fills the gaps with its softmax VALU work
-#ifdef GVK_ATTN_PRIO
-#define GVK_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define GVK_PRIO(x)
-#endif
-
-__device__ __forceinline__ int swz_b(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
-
-constexpr int kQT = 64;                 // query rows staged per barrier pair (two 32-row MFMA sub-blocks)
-constexpr int kTileQ = kQT * 128;       // bytes of a [kQT][64] bf16 tile
-
-// With attention-probability dropout (mask M, 1/keep folded in): O = (P.M) V, so dV^T += dO^T.(P.M), dS = P.(M.dP - delta) and
-// delta = rowsum(dO.O) is unchanged; the mask is regenerated from (b*H + head, query, key) exactly as the forward drew it.
-struct AttnDrop { unsigned long long seed; const unsigned long long* seed_ptr; unsigned int thresh; float inv_keep; };
-
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+// QT: query rows staged per barrier pair (3 or 4 sub-blocks of 32)
+template <int QT, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
-                                                            bf16* __restrict__ dqkv, int T, int H, int ld_qkv, int ld_o, float scale,
-                                                            float scale_log2e, AttnDrop dr) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][Q tile | dO tile | lse' kQT f32 | delta kQT f32]
-  constexpr int kBuf = 2 * kTileQ + 2 * kQT * 4;
+                                                            bf16* __restrict__ dqkv, int T, int H, int ld_qkv, int ld_o, float dk_scale,
+                                                            AttnDrop dr) {
+  constexpr int NSB = QT / 32;
+  constexpr int kTileQ = QT * 128;                // bytes of a [QT][64] bf16 tile
+  constexpr int kBuf = 2 * kTileQ + 2 * 128 * 4;  // Q tile | dO tile | lse 128 f32 | delta 128 f32
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][kBuf]
   int bh, kblk;
   xcd_group_block(blockIdx.x, (T + 127) / 128, gridDim.x / ((T + 127) / 128), bh, kblk);   // all key blocks of a (batch, head) on one XCD
   const int b = bh / H, head = bh - b * H, k0 = kblk * 128;
@@ -46,9 +44,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
   const int r31 = lane & 31, hh = lane >> 5;
   const int inner = H * 64;
   const bf16* qbase = qkv + (size_t)b * T * ld_qkv + head * 64;
-  const bf16* dobase = d_o + (size_t)b * T * ld_o + head * 64;
-  const float* lse_b = lse + ((size_t)b * H + head) * T;
-  const float* del_b = delta + ((size_t)b * H + head) * T;
+  const bool active = k0 + wave * 32 < T;          // a wave whose 32 keys all lie past the sequence only stages tiles
 
   // K, V fragments of this wave's 32 keys: B operands (col = key, k = d)
   const int key = k0 + wave * 32 + r31;
@@ -59,156 +55,141 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16* __restri
     kf[ks] = *(const bf16x8*)(qbase + inner + (size_t)keyc * ld_qkv + 16 * ks + 8 * hh);
     vf[ks] = *(const bf16x8*)(qbase + 2 * inner + (size_t)keyc * ld_qkv + 16 * ks + 8 * hh);
   }
-
   [[maybe_unused]] unsigned int akey = 0u;
   if constexpr (DROP) akey = attn_key(dr.seed + *dr.seed_ptr, b * H + head);
-  const float inv_scale = 1.0f / scale;
+
+  // staging: Q rows (from qkv), dO rows, lse / delta (one 4-byte LDS-DMA per wave: waves 0,1 the two 64-row halves of lse, waves 2,3 of delta)
+  const int nqt = (T + QT - 1) / QT;
+  const int nB = (int)gridDim.x / (((T + 127) / 128) * H);
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, nB * T * ld_qkv * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)d_o, 0, nB * T * ld_o * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(wave < 2 ? lse : delta), 0, nB * H * T * 4, 0x00020000);
+  const int rsub = lane >> 3, slot = lane & 7;
+  int voq[NSB], voq_last[NSB], vod[NSB], vod_last[NSB];
+#pragma unroll
+  for (int r = 0; r < NSB; ++r) {
+    const int row = r * 32 + wave * 8 + rsub;
+    const int col = head * 64 + ((slot ^ attn_swz(row)) << 3);
+    const int over = max((nqt - 1) * QT + row - (T - 1), 0);      // rows past the end step back to row T-1 (finite; masked by the row flag)
+    voq[r] = ((b * T + row) * ld_qkv + col) * 2;
+    voq_last[r] = ((b * T + row - over) * ld_qkv + col) * 2;
+    vod[r] = ((b * T + row) * ld_o + col) * 2;
+    vod_last[r] = ((b * T + row - over) * ld_o + col) * 2;
+  }
+  const int lrow = (wave & 1) * 64 + lane;                         // row of the tile whose constant this lane fetches
+  const int vol = ((b * H + head) * T + lrow) * 4;
+  const int vol_last = ((b * H + head) * T + lrow - max((nqt - 1) * QT + lrow - (T - 1), 0)) * 4;
   auto stage = [&](int buf, int qt) {
     char* sQ = smem + buf * kBuf;
     char* sD = sQ + kTileQ;
-    float* sL = (float*)(sD + kTileQ);
+    char* sL = sD + kTileQ;
+    const bool last = qt == nqt - 1;
+    // (the scalar offsets go through plain ints: with the template parameter inside the builtin's argument list hipcc's HOST pass dropped
+    //  the whole kernel stub without a diagnostic -- an undefined symbol at load time)
+    const int soq = qt * QT * ld_qkv * 2, sod = qt * QT * ld_o * 2, sol = qt * QT * 4;
 #pragma unroll
-    for (int r = 0; r < kQT / 32; ++r) {
-      const int row = r * 32 + wave * 8 + (lane >> 3), slot = lane & 7;
-      const int q = min(qt * kQT + row, T - 1);
-      const int chunk = slot ^ swz_b(row);
-      glds16(qbase + (size_t)q * ld_qkv + chunk * 8, sQ + (r * 32 + wave * 8) * 128);
-      glds16(dobase + (size_t)q * ld_o + chunk * 8, sD + (r * 32 + wave * 8) * 128);
+    for (int r = 0; r < NSB; ++r) {
+      const int vq = last ? voq_last[r] : voq[r], vd = last ? vod_last[r] : vod[r];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (GVK_LDS void*)(sQ + (r * 32 + wave * 8) * 128), 16, vq, soq, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (GVK_LDS void*)(sD + (r * 32 + wave * 8) * 128), 16, vd, sod, 0, 0);
     }
-    // The row constants ride on the LDS-DMA too (4-byte form, 64 rows per instruction; every wave writes the same 256 bytes: benign, and it
-    // keeps the per-wave vmcnt identical).  As ORDINARY loads they made hipcc wait vmcnt(0) at their first use -- right here, draining the
-    // Q / dO requests issued two lines above: one exposed L2 round trip per 64-row tile (SQ_WAIT_ANY 0.41 of the wave cycles).
-    {
-      const int qq = min(qt * kQT + lane, T - 1);
-      __builtin_amdgcn_global_load_lds((const GVK_GLOBAL void*)(lse_b + qq), (GVK_LDS void*)sL, 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((const GVK_GLOBAL void*)(del_b + qq), (GVK_LDS void*)(sL + kQT), 4, 0, 0);
-    }
+    const int vl = last ? vol_last : vol;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (GVK_LDS void*)(sL + (wave >> 1) * 512 + (wave & 1) * 256), 4, vl, sol, 0, 0);
   };
 
   f32x16 dkt[2], dvt[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) { dkt[i] = f32x16{}; dvt[i] = f32x16{}; }
-
-  const int nqt = (T + kQT - 1) / kQT;
+  const bf16x8 sel_s = aug_sel_first(true, hh);      // [1, 1, 1, 1, 0...]: the query side carries -3e38 only in rows past the sequence
+  const bf16x8 sel_d = aug_sel_second(hh);           // [0, 0, 0, 0, 1, 1, 1, 0]
   const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
   stage(0, 0);
   __syncthreads();
   for (int qt = 0; qt < nqt; ++qt) {
     const int buf = qt & 1;
     if (qt + 1 < nqt) stage(buf ^ 1, qt + 1);
-    const char* sQ0 = smem + buf * kBuf;
-    const char* sD0 = sQ0 + kTileQ;
-    const float* sL0 = (const float*)(sD0 + kTileQ);
+    if (active) {
+      const char* sQ0 = smem + buf * kBuf;
+      const char* sD0 = sQ0 + kTileQ;
+      const float* sL0 = (const float*)(sD0 + kTileQ);
 #pragma unroll
-    for (int sub = 0; sub < kQT / 32; ++sub) {
-      if (qt * kQT + sub * 32 >= T) break;                 // wave-uniform: sub-block entirely past the sequence
-      const char* sQ = sQ0 + sub * 32 * 128;               // (32 rows = a multiple of the swizzle period 16)
-      const char* sD = sD0 + sub * 32 * 128;
-      const float* sL = sL0 + sub * 32;
-      // S'[q][key] = Q.K^T - lse/scale ;  dP[q][key] = dO.V^T
-      f32x16 s, dp;
-      const int rows_left = T - (qt * kQT + sub * 32);       // query rows of this sub-block inside the sequence (wave-uniform)
+      for (int sub = 0; sub < NSB; ++sub) {
+        const int qrow0 = qt * QT + sub * 32;
+        if (qrow0 >= T) break;                               // wave-uniform: sub-block entirely past the sequence
+        const char* sQ = sQ0 + sub * 32 * 128;               // (32 rows = a multiple of the swizzle period 16)
+        const char* sD = sD0 + sub * 32 * 128;
+        // constant side of the augmented MFMAs: this lane's query row r31 -> [-lse*log2e pieces, row >= T ? -3e38 : 0, -delta pieces, 0]
+        const float l2 = sL0[sub * 32 + r31] * 1.44269504088896340736f;
+        const float dl = DROP ? 0.f : sL0[128 + sub * 32 + r31];   // with dropout delta is subtracted after the mask (dS = P.(M.dP - delta))
+        const bf16x8 qaug = aug_const(l2, qrow0 + r31 >= T, dl, hh);
+        // S'[q][key] = Q'.K^T - lse2 ;  dP'[q][key] = dO.V^T - delta
+        f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qaug, sel_s, f32x16{}, 0, 0, 0);
+        f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qaug, sel_d, f32x16{}, 0, 0, 0);
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 l4 = *(const f32x4*)(sL + 8 * g4 + 4 * hh);
+        for (int ks = 0; ks < 4; ++ks) {
+          const int chunk = 2 * ks + hh;
+          const bf16x8 qa = *(const bf16x8*)(sQ + r31 * 128 + ((chunk ^ attn_swz(r31)) << 4));
+          const bf16x8 da = *(const bf16x8*)(sD + r31 * 128 + ((chunk ^ attn_swz(r31)) << 4));
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
+        }
+        // P = exp2(S');  dS = P * dP'
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[4 * g4 + e] = -l4[e] * inv_scale;
-      }
-      if (rows_left < 32) {                                  // rows >= T: P = exp2(-inf) = 0
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (8 * g4 + 4 * hh + e >= rows_left) s[4 * g4 + e] = -INFINITY;
-      }
-      dp = f32x16{};
-      GVK_PRIO(1);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int chunk = 2 * ks + hh;
-        const bf16x8 qa = *(const bf16x8*)(sQ + r31 * 128 + ((chunk ^ swz_b(r31)) << 4));
-        const bf16x8 da = *(const bf16x8*)(sD + r31 * 128 + ((chunk ^ swz_b(r31)) << 4));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
-      }
-      GVK_PRIO(0);
-      // P = exp2(c * S');  dS = P * (dP - delta[q]) -- two scores per packed instruction (these loops, not the MFMAs, fill the SIMD)
-      const f32x2 sc2 = {scale_log2e, scale_log2e};
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const f32x4 d4 = *(const f32x4*)(sL + kQT + 8 * g4 + 4 * hh);
-#pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-          const f32x2 a = f32x2{s[4 * g4 + e], s[4 * g4 + e + 1]} * sc2;
-          f32x2 pr = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-          f32x2 dpv = {dp[4 * g4 + e], dp[4 * g4 + e + 1]};
-          f32x2 pd = pr;                                      // the P that multiplies dO in dV: dropped and rescaled under DROP
+        for (int r = 0; r < 16; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(s[r]);
           if constexpr (DROP) {
-            const unsigned int qq = (unsigned int)(qt * kQT + sub * 32 + 8 * g4 + 4 * hh + e);
-            const f32x2 mm = {attn_drop_scale(akey, qq * (unsigned int)T + (unsigned int)key, dr.thresh, dr.inv_keep),
-                              attn_drop_scale(akey, (qq + 1u) * (unsigned int)T + (unsigned int)key, dr.thresh, dr.inv_keep)};
-            pd = pr * mm;
-            dpv = dpv * mm;
+            const unsigned int qq = (unsigned int)(qrow0 + (r & 3) + 8 * (r >> 2) + 4 * hh);
+            const float mm = attn_drop_scale(akey, qq * (unsigned int)T + (unsigned int)key, dr.thresh, dr.inv_keep);
+            const float dlr = sL0[128 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
+            s[r] = pr * mm;                                  // the P that multiplies dO in dV: dropped and rescaled
+            dp[r] = pr * (dp[r] * mm - dlr);
+          } else {
+            s[r] = pr;
+            dp[r] = pr * dp[r];
           }
-          const f32x2 ds = pr * (dpv - f32x2{d4[e], d4[e + 1]});
-          s[4 * g4 + e] = pd[0]; s[4 * g4 + e + 1] = pd[1];
-          dp[4 * g4 + e] = ds[0]; dp[4 * g4 + e + 1] = ds[1];
+        }
+        // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]   (k = q, accumulator row order)
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk) {
+          bf16x8 pf, dsf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { pf[j] = (bf16)s[8 * sk + j]; dsf[j] = (bf16)dp[8 * sk + j]; }
+          const int q0r = 16 * sk + 4 * (g >> 1);
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
+            const int ra = q0r + tq, rb = q0r + 8 + tq;
+            const int oa = ra * 128 + ((chunk ^ attn_swz(ra)) << 4) + (tp & 1) * 8;
+            const int ob = rb * 128 + ((chunk ^ attn_swz(rb)) << 4) + (tp & 1) * 8;
+            const bf16x4 da0 = lds_read_tr16(sD + oa), da1 = lds_read_tr16(sD + ob);
+            const bf16x4 qa0 = lds_read_tr16(sQ + oa), qa1 = lds_read_tr16(sQ + ob);
+            const bf16x8 dof = {da0[0], da0[1], da0[2], da0[3], da1[0], da1[1], da1[2], da1[3]};
+            const bf16x8 qf = {qa0[0], qa0[1], qa0[2], qa0[3], qa1[0], qa1[1], qa1[2], qa1[3]};
+            dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dvt[db], 0, 0, 0);
+            dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, dsf, dkt[db], 0, 0, 0);
+          }
         }
       }
-      // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]   (k = q, accumulator row order)
-      GVK_PRIO(1);
-#pragma unroll
-      for (int sk = 0; sk < 2; ++sk) {
-        bf16x8 pf, dsf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { pf[j] = (bf16)s[8 * sk + j]; dsf[j] = (bf16)dp[8 * sk + j]; }
-        const int q0r = 16 * sk + 4 * (g >> 1);
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
-          const int ra = q0r + tq, rb = q0r + 8 + tq;
-          const int oa = ra * 128 + ((chunk ^ swz_b(ra)) << 4) + (tp & 1) * 8;
-          const int ob = rb * 128 + ((chunk ^ swz_b(rb)) << 4) + (tp & 1) * 8;
-          const bf16x4 da0 = lds_read_tr16(sD + oa), da1 = lds_read_tr16(sD + ob);
-          const bf16x4 qa0 = lds_read_tr16(sQ + oa), qa1 = lds_read_tr16(sQ + ob);
-          const bf16x8 dof = {da0[0], da0[1], da0[2], da0[3], da1[0], da1[1], da1[2], da1[3]};
-          const bf16x8 qf = {qa0[0], qa0[1], qa0[2], qa0[3], qa1[0], qa1[1], qa1[2], qa1[3]};
-          dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dvt[db], 0, 0, 0);
-          dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, dsf, dkt[db], 0, 0, 0);
-        }
-      }
-      GVK_PRIO(0);
     }
     __syncthreads();
   }
-  if (key < T) {
-    bf16* dk_row = dqkv + ((size_t)b * T + key) * ld_qkv + inner + head * 64;
-    bf16* dv_row = dk_row + inner;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int d = db * 32 + 8 * g4 + 4 * hh;
-        bf16x4 ok = {(bf16)(dkt[db][4 * g4] * scale), (bf16)(dkt[db][4 * g4 + 1] * scale), (bf16)(dkt[db][4 * g4 + 2] * scale),
-                     (bf16)(dkt[db][4 * g4 + 3] * scale)};
-        bf16x4 ov = {(bf16)dvt[db][4 * g4], (bf16)dvt[db][4 * g4 + 1], (bf16)dvt[db][4 * g4 + 2], (bf16)dvt[db][4 * g4 + 3]};
-        *(bf16x4*)(dk_row + d) = ok;
-        *(bf16x4*)(dv_row + d) = ov;
-      }
-  }
+  if (!active) return;
+  const int kw = k0 + wave * 32;
+  bf16* dk_rows = dqkv + ((size_t)b * T + kw) * ld_qkv + inner + head * 64;
+  store_rows_t(dkt, dk_scale, smem + wave * 8192, dk_rows, (size_t)ld_qkv, T - kw, lane);
+  store_rows_t(dvt, 1.0f, smem + wave * 8192 + 4096, dk_rows + inner, (size_t)ld_qkv, T - kw, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
-constexpr int kKB2 = 64;
-constexpr int kTile64 = 64 * 128;
-
 // Runs FIRST: it also produces delta[b][h][q] = sum_d dO * O for its own queries (the rows are in its registers anyway) and leaves
 // it in memory for the dK/dV pass, so no separate row-sum kernel sits on the critical path.
-template <bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd, const bf16* __restrict__ d_o,
+template <int KB, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd, const bf16* __restrict__ d_o,
                                                           const float* __restrict__ lse, float* __restrict__ delta,
                                                           bf16* __restrict__ dqkv, int T, int H, int ld_qkv, int ld_o, float scale,
-                                                          float scale_log2e, AttnDrop dr) {
+                                                          AttnDrop dr) {
+  constexpr int NKB = KB / 32;
+  constexpr int kTileBytes = KB * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][K tile | V tile]
   int bh, qblk;
   xcd_group_block(blockIdx.x, (T + 127) / 128, gridDim.x / ((T + 127) / 128), bh, qblk);
@@ -217,126 +198,137 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
   const int r31 = lane & 31, hh = lane >> 5;
   const int inner = H * 64;
   const bf16* base = qkv + (size_t)b * T * ld_qkv + head * 64;
-  const bf16* kbase = base + inner;
-  const bf16* vbase = base + 2 * inner;
+  const bool active = q0 + wave * 32 < T;
   const int q = q0 + wave * 32 + r31;
   const int qc = min(q, T - 1);
   bf16x8 qf[4], dof[4];
   float del = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    qf[ks] = *(const bf16x8*)(base + (size_t)qc * ld_qkv + 16 * ks + 8 * hh);
+    qf[ks] = *(const bf16x8*)(base + (size_t)qc * ld_qkv + 16 * ks + 8 * hh);           // Q' = q * scale * log2(e)
     dof[ks] = *(const bf16x8*)(d_o + ((size_t)b * T + qc) * ld_o + head * 64 + 16 * ks + 8 * hh);
     const bf16x8 of = *(const bf16x8*)(o_fwd + ((size_t)b * T + qc) * ld_o + head * 64 + 16 * ks + 8 * hh);
 #pragma unroll
     for (int j = 0; j < 8; ++j) del += (float)of[j] * (float)dof[ks][j];
   }
-  del += __shfl_xor(del, 32, 64);                         // the two half-waves hold the two halves of the 64-wide row
+  del = half_sum(del);                                    // the two half-waves hold the two halves of the 64-wide row
   if (hh == 0 && q < T) delta[((size_t)b * H + head) * T + q] = del;
   [[maybe_unused]] unsigned int akey = 0u, qoff = 0u;
   if constexpr (DROP) {
     akey = attn_key(dr.seed + *dr.seed_ptr, b * H + head);
     qoff = (unsigned int)q * (unsigned int)T;
   }
-  const float sinit = -lse[((size_t)b * H + head) * T + qc] / scale;
+  // constant side of the augmented MFMAs (this lane's query): [-lse*log2e pieces, -3e38, -delta pieces, 0]
+  const float l2 = lse[((size_t)b * H + head) * T + qc] * 1.44269504088896340736f;
+  const bf16x8 qaug = aug_const(l2, true, DROP ? 0.f : del, hh);
+  const bf16x8 sel_d = aug_sel_second(hh);
 
-  auto stage = [&](int buf, int kt) {
-    char* sK = smem + buf * 2 * kTile64;
-    char* sV = sK + kTile64;
-    const int rsub = lane >> 3, slot = lane & 7;
+  const int nkt = (T + KB - 1) / KB;
+  const int nB = (int)gridDim.x / (((T + 127) / 128) * H);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, nB * T * ld_qkv * 2, 0x00020000);
+  const int rsub = lane >> 3, slot = lane & 7;
+  int vo[NKB], vo_last[NKB];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int row = r * 32 + wave * 8 + rsub;
-      const int key = min(kt * kKB2 + row, T - 1);
-      const int chunk = slot ^ swz_b(row);
-      glds16(kbase + (size_t)key * ld_qkv + chunk * 8, sK + (r * 32 + wave * 8) * 128);
-      glds16(vbase + (size_t)key * ld_qkv + chunk * 8, sV + (r * 32 + wave * 8) * 128);
+  for (int r = 0; r < NKB; ++r) {
+    const int row = r * 32 + wave * 8 + rsub;
+    const int col = inner + head * 64 + ((slot ^ attn_swz(row)) << 3);
+    vo[r] = ((b * T + row) * ld_qkv + col) * 2;
+    vo_last[r] = ((b * T + row - max((nkt - 1) * KB + row - (T - 1), 0)) * ld_qkv + col) * 2;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* sK = smem + buf * 2 * kTileBytes;
+    char* sV = sK + kTileBytes;
+#pragma unroll
+    for (int r = 0; r < NKB; ++r) {
+      const int v = (kt == nkt - 1) ? vo_last[r] : vo[r];
+      const int so = kt * KB * ld_qkv * 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (GVK_LDS void*)(sK + (r * 32 + wave * 8) * 128), 16, v, so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (GVK_LDS void*)(sV + (r * 32 + wave * 8) * 128), 16, v, so + inner * 2, 0, 0);
     }
   };
 
   f32x16 dqt[2];
   dqt[0] = f32x16{};
   dqt[1] = f32x16{};
-  const int nkt = (T + kKB2 - 1) / kKB2;
   const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
   stage(0, 0);
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nkt) stage(buf ^ 1, kt + 1);
-    const char* sK = smem + buf * 2 * kTile64;
-    const char* sV = sK + kTile64;
+    if (active) {
+      const char* sK = smem + buf * 2 * kTileBytes;
+      const char* sV = sK + kTileBytes;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      f32x16 st, dpt;
+      for (int kb = 0; kb < NKB; ++kb) {
+        const int row = kb * 32 + r31;
+        const bf16x8 sel_s = aug_sel_first(kt * KB + row >= T, hh);        // [1, 1, 1, key >= T, 0...]
+        f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel_s, qaug, f32x16{}, 0, 0, 0);
+        f32x16 dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel_d, qaug, f32x16{}, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[r] = sinit;
-      dpt = f32x16{};
-      const int row = kb * 32 + r31;
-      GVK_PRIO(1);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int chunk = 2 * ks + hh;
-        const int off = row * 128 + ((chunk ^ swz_b(row)) << 4);
-        const bf16x8 ka = *(const bf16x8*)(sK + off);
-        const bf16x8 va = *(const bf16x8*)(sV + off);
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], st, 0, 0, 0);
-        dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dpt, 0, 0, 0);
-      }
-      GVK_PRIO(0);
-      if (kt == nkt - 1) {                                 // wave-uniform: only the last tile holds keys >= T
+        for (int ks = 0; ks < 4; ++ks) {
+          const int chunk = 2 * ks + hh;
+          const int off = row * 128 + ((chunk ^ attn_swz(row)) << 4);
+          const bf16x8 ka = *(const bf16x8*)(sK + off);
+          const bf16x8 va = *(const bf16x8*)(sV + off);
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], st, 0, 0, 0);
+          dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dpt, 0, 0, 0);
+        }
+        // dS^T = exp2(S'^T) * dP'^T
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = kt * kKB2 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          st[r] = (key < T) ? st[r] : -INFINITY;
+          float dpv = dpt[r];
+          if constexpr (DROP) {
+            const int key = kt * KB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            dpv = dpv * attn_drop_scale(akey, qoff + (unsigned int)key, dr.thresh, dr.inv_keep) - del;
+          }
+          st[r] = __builtin_amdgcn_exp2f(st[r]) * dpv;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 dsf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dsf[j] = (bf16)st[8 * s + j];
+          const int key0 = kb * 32 + 16 * s + 4 * (g >> 1);
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
+            const int ra = key0 + tq, rb = key0 + 8 + tq;
+            const bf16x4 ka0 = lds_read_tr16(sK + ra * 128 + ((chunk ^ attn_swz(ra)) << 4) + (tp & 1) * 8);
+            const bf16x4 ka1 = lds_read_tr16(sK + rb * 128 + ((chunk ^ attn_swz(rb)) << 4) + (tp & 1) * 8);
+            const bf16x8 kt8 = {ka0[0], ka0[1], ka0[2], ka0[3], ka1[0], ka1[1], ka1[2], ka1[3]};
+            dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt8, dsf, dqt[db], 0, 0, 0);
+          }
         }
       }
-      const f32x2 sc2 = {scale_log2e, scale_log2e}, del2 = {del, del};
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {                                                                     // dS^T, two scores per packed op
-        f32x2 dpv = {dpt[r], dpt[r + 1]};
-        if constexpr (DROP) {
-          const int key = kt * kKB2 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;          // r even: r + 1 is the next key
-          dpv = dpv * f32x2{attn_drop_scale(akey, qoff + (unsigned int)key, dr.thresh, dr.inv_keep),
-                            attn_drop_scale(akey, qoff + (unsigned int)key + 1u, dr.thresh, dr.inv_keep)};
-        }
-        const f32x2 a = f32x2{st[r], st[r + 1]} * sc2;
-        const f32x2 ds = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} * (dpv - del2);
-        st[r] = ds[0];
-        st[r + 1] = ds[1];
-      }
-      GVK_PRIO(1);
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 dsf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dsf[j] = (bf16)st[8 * s + j];
-        const int key0 = kb * 32 + 16 * s + 4 * (g >> 1);
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
-          const int ra = key0 + tq, rb = key0 + 8 + tq;
-          const bf16x4 ka0 = lds_read_tr16(sK + ra * 128 + ((chunk ^ swz_b(ra)) << 4) + (tp & 1) * 8);
-          const bf16x4 ka1 = lds_read_tr16(sK + rb * 128 + ((chunk ^ swz_b(rb)) << 4) + (tp & 1) * 8);
-          const bf16x8 kt8 = {ka0[0], ka0[1], ka0[2], ka0[3], ka1[0], ka1[1], ka1[2], ka1[3]};
-          dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt8, dsf, dqt[db], 0, 0, 0);
-        }
-      }
-      GVK_PRIO(0);
     }
     __syncthreads();
   }
-  if (q < T) {
-    bf16* dq_row = dqkv + ((size_t)b * T + q) * ld_qkv + head * 64;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        bf16x4 o = {(bf16)(dqt[db][4 * g4] * scale), (bf16)(dqt[db][4 * g4 + 1] * scale), (bf16)(dqt[db][4 * g4 + 2] * scale),
-                    (bf16)(dqt[db][4 * g4 + 3] * scale)};
-        *(bf16x4*)(dq_row + db * 32 + 8 * g4 + 4 * hh) = o;
-      }
+  if (!active) return;
+  const int qw = q0 + wave * 32;
+  store_rows_t(dqt, scale, smem + wave * 4096, dqkv + ((size_t)b * T + qw) * ld_qkv + head * 64, (size_t)ld_qkv, T - qw, lane);
+}
+
+template <int KB, bool DROP>
+static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int T, int H,
+                           int ld_qkv, int ld_out, float scale, AttnDrop dr, hipStream_t s) {
+  const float dk_scale = 0.69314718055994530942f;      // dK = scale . dS^T.Q = dS^T.Q' / log2(e)
+  const dim3 grid(((T + 127) / 128) * H * B);
+  constexpr unsigned lds_kv = 2 * (2 * KB * 128 + 2 * 128 * 4), lds_q = 2 * 2 * KB * 128;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<KB, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkdv_kernel<KB, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+    if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(attn_bwd): %s", hipGetErrorString(e));
+    attr = true;
   }
+  GVK_LAUNCH((attn_bwd_dq_kernel<KB, DROP>), grid, dim3(256), lds_q, s, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H,
+             ld_qkv, ld_out, scale, dr);
+  int rc = check_launch("attention_bwd/dq");
+  if (rc) return rc;
+  GVK_LAUNCH((attn_bwd_dkdv_kernel<KB, DROP>), grid, dim3(256), lds_kv, s, (const bf16*)qkv, (const bf16*)dout, lse, (const float*)delta, (bf16*)dqkv, T, H,
+             ld_qkv, ld_out, dk_scale, dr);
+  return check_launch("attention_bwd/dkdv");
 }
 
 }  // namespace gvk
@@ -351,28 +343,16 @@ extern "C" int gvk_attention_bwd_bf16_dropout(const void* qkv, const void* out, 
               "gvk_attention_bwd_bf16: head dim is fixed at 64; ld_qkv=%d ld_out=%d inconsistent with H=%d", ld_qkv, ld_out, H);
   GVK_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed_ptr != nullptr), "gvk_attention_bwd_bf16: drop_p in [0,1) and a seed word");
   GVK_REQUIRE(drop_p == 0.f || (int64_t)T * T < (int64_t)1 << 32, "gvk_attention_bwd_bf16: the dropout mask index (query*T + key) is 32-bit");
+  GVK_REQUIRE((int64_t)B * T * ld_qkv * 2 < (int64_t)1 << 31, "gvk_attention_bwd_bf16: the qkv tensor must stay below 2 GiB (32-bit buffer offsets)");
   const AttnDrop dr{seed, (const unsigned long long*)seed_ptr, drop_threshold_u32(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f};
   hipStream_t s = (hipStream_t)stream;
-  const float sl2 = scale * 1.44269504088896340736f;
-  const dim3 grid(((T + 127) / 128) * H * B);
-  const unsigned lds_kv = 2 * (2 * kTileQ + 2 * kQT * 4), lds_q = 2 * 2 * kTile64;
-  int rc;
-  if (drop_p > 0.f) {
-    GVK_LAUNCH(attn_bwd_dq_kernel<true>, grid, dim3(256), lds_q, s, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H,
-               ld_qkv, ld_out, scale, sl2, dr);
-    rc = check_launch("attention_bwd/dq");
-    if (rc) return rc;
-    GVK_LAUNCH(attn_bwd_dkdv_kernel<true>, grid, dim3(256), lds_kv, s, (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H, ld_qkv,
-               ld_out, scale, sl2, dr);
-    return check_launch("attention_bwd/dkdv");
-  }
-  GVK_LAUNCH(attn_bwd_dq_kernel<false>, grid, dim3(256), lds_q, s, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H,
-             ld_qkv, ld_out, scale, sl2, dr);
-  rc = check_launch("attention_bwd/dq");
-  if (rc) return rc;
-  GVK_LAUNCH(attn_bwd_dkdv_kernel<false>, grid, dim3(256), lds_kv, s, (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H, ld_qkv,
-             ld_out, scale, sl2, dr);
-  return check_launch("attention_bwd/dkdv");
+  // tile of 96 rows when it pads the sequence less than 128 does (T = 1033: 1056 against 1152)
+  int kb = ((T + 95) / 96 * 96 < (T + 127) / 128 * 128) ? 96 : 128;
+  if (getenv("GAVIKO_HIP_ATTN_KB") && (atoi(getenv("GAVIKO_HIP_ATTN_KB")) == 96 || atoi(getenv("GAVIKO_HIP_ATTN_KB")) == 128)) kb = atoi(getenv("GAVIKO_HIP_ATTN_KB"));
+  if (drop_p > 0.f)      // the dropout variants carry the mask arithmetic: 96-row tiles only (the 128-row form would spill registers)
+    return launch_attn_bwd<96, true>(qkv, out, dout, lse, delta, dqkv, B, T, H, ld_qkv, ld_out, scale, dr, s);
+  return kb == 96 ? launch_attn_bwd<96, false>(qkv, out, dout, lse, delta, dqkv, B, T, H, ld_qkv, ld_out, scale, dr, s)
+                  : launch_attn_bwd<128, false>(qkv, out, dout, lse, delta, dqkv, B, T, H, ld_qkv, ld_out, scale, dr, s);
 }
 
 extern "C" int gvk_attention_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,

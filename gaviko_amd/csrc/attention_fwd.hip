@@ -2,51 +2,53 @@
 // Replaces vision_transformer.py:63-71 (q.k^T * scale -> softmax -> .v and both einops rearranges): the [B,h,T,T]
 // score tensor is never materialised, only the per-row log-sum-exp is saved for the backward.
 //
-// One workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 queries.
+// One workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 queries; two workgroups share a CU.
 // S^T[key][query] = K.Q^T with v_mfma_f32_32x32x16_bf16 (A = K rows from LDS, B = Q kept in registers), so a lane
-// holds ONE query column: the online-softmax max/sum are lane-local plus one exchange between the two 32-lane
-// halves.  The S^T accumulator is then reused in place as the B operand of O^T[d][query] += V^T.P^T (its k order
-// is the accumulator row order; the V^T fragment is gathered in that same order with ds_read_b64_tr_b16 from the
-// row-major [key][d] V tile), so nothing is transposed through memory.
-// LDS tile rows are 64 bf16 = 128 B; 16-B chunk c of row r sits at chunk c ^ swz(r), swz(r) = bit1(r)<<2 | bits3:2(r)
+// holds ONE query column: the online-softmax max is lane-local plus one exchange between the two 32-lane halves.
+// The S^T accumulator is then reused in place as the B operand of O^T[d][query] += V^T.P^T (its k order is the
+// accumulator row order; the V^T fragment is gathered in that same order with ds_read_b64_tr_b16 from the row-major
+// [key][d] V tile), so nothing is transposed through memory.
+//
+// Round 3: the kernel was bound by the SIMD's VECTOR ISSUE, not by the matrix pipe (356 VALU instructions per 128-key tile
+// and wave beside 32 MFMAs; profiles/r02_attention_fwd_stamps.txt), so the per-score VALU work moved onto the matrix pipe:
+//   * the q block ARRIVES pre-scaled by scale*log2(e): the qkv projection's epilogue applies the factor in fp32 before its one rounding to
+//     bf16 (gvk_gemm_desc.scale_cols; gvk_qkv_prescale_bf16 for callers that hold a raw q block), so a score needs no multiply and the
+//     forward and both backward passes see bit-identical Q' operands (their P must agree: the backward subtracts the forward's lse);
+//   * the running-max subtraction and the key mask are a FIFTH MFMA per 32-key block over an augmented contraction:
+//     A_aug[key] = [1, 1, 1, key >= T, 0...], B_aug[query] = [-m_hi, -m_mid, -m_lo, -3e38, 0...] (m split into three bf16
+//     pieces = exact to fp32), i.e. S' = K.Q'^T - m  arrives in the accumulator ready for v_exp_f32 -- no v_fma, no v_cndmask;
+//   * the running maximum is only raised when a tile exceeds it by more than kThr (log2 units): the O / l rescale and the
+//     rebuild of B_aug sit in a wave-uniform slow path that a few tiles per workgroup take (P <= 2^kThr stays harmless: bf16
+//     keeps fp32's exponent range and the accumulators are fp32);
+//   * row sums either as v_add_f32 (VAR bit 0 clear) or as a third "d block" of the PV product with an all-ones A operand;
+//   * 96-key tiles when they pad the sequence less than 128-key tiles do (T = 1033: 11 x 96 = 1056 keys instead of 1152);
+//   * O leaves through LDS as whole 128-byte rows (16 B per lane) instead of 8-byte pieces at a 1.5 KB row stride.
+// LDS tile rows are 64 bf16 = 128 B; 16-B chunk c of row r sits at chunk c ^ attn_swz(r), attn_swz(r) = bit1(r)<<2 | bits3:2(r)
 // -- conflict-free for both the ds_read_b128 row reads and the 4x16 transposed reads.
-#include "common.hpp"
-#include "dropout.hpp"
+#include "attention_common.hpp"
 #include "../../include/gaviko_hip.h"
 
 namespace gvk {
 
-// A/B switch (compile-time, tools/gpu experiments): raise the wave's priority around its MFMA clusters so that, of the two waves a SIMD
-// hosts (two workgroups per CU), the one in a matrix phase issues first and the other fills the gaps with its softmax VALU work
-// tools/probe/probe_attn.hip compiles this file with GVK_STAMPS: shader-clock stamps of ONE steady-state key tile (kt == 4) of the four-wave kernel,
+// tools/probe/probe_attn.hip compiles this file with GVK_STAMPS: shader-clock stamps of ONE steady-state key tile (kt == 4),
 // written through dr.seed_ptr (unused without dropout) as uint64 [workgroup][wave][8].  Compiled out of the library.
 #ifdef GVK_STAMPS
 #define GVK_ASTAMP(k) if (kt == 4) st_[k] = __builtin_amdgcn_s_memtime();
 #else
 #define GVK_ASTAMP(k)
 #endif
-#ifdef GVK_ATTN_PRIO
-#define GVK_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define GVK_PRIO(x)
-#endif
 
-__device__ __forceinline__ int swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+constexpr int kQB = 128;          // queries per workgroup
+constexpr float kThr = 8.0f;      // the running max is raised only when a tile exceeds it by more than this (log2 units)
 
-constexpr int kQB = 128;   // queries per workgroup
-constexpr int kKB = 128;   // keys per staged tile (4 MFMA key blocks of 32): one barrier pair per 128 keys
-constexpr int kTileBytes = kKB * 128;
-
-// attention-probability dropout (vision_transformer.py:68, live for the unfrozen-backbone methods): the softmax statistics are taken
-// of the undropped scores, the dropped and rescaled P feeds the P.V product; mask element (b*H + head, query, key) -- dropout.hpp
-struct AttnDrop { unsigned long long seed; const unsigned long long* seed_ptr; unsigned int thresh; float inv_keep; };
-
-// RS: K / V tiles staged through registers (global_load_dwordx4 at the top of a tile, ds_write_b128 in front of its closing barrier) instead
-// of by LDS-DMA: issuing the eight 1-KiB LDS-DMA instructions of a tile holds the wave's instruction stream for ~650 cycles of a ~3900-cycle
-// tile (tools/probe/probe_attn.py), and this kernel is bound by the SIMD's vector issue, not by latency.
-template <bool DROP, bool RS>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse,
-                                                       int T, int H, int ld_qkv, int ld_out, float scale_log2e, AttnDrop dr) {
+// VAR bit 0: row sums on the matrix pipe (ones operand);  bit 1: the next tile's LDS-DMA spread behind the S^T MFMA groups
+template <int KB, bool DROP, int VAR>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse,
+                                                       int T, int H, int ld_qkv, int ld_out, AttnDrop dr) {
+  constexpr int NKB = KB / 32;                 // MFMA key blocks per staged tile
+  constexpr int kTileBytes = KB * 128;
+  constexpr bool ONES = (VAR & 1) != 0 && !DROP;
+  constexpr bool SPREAD = (VAR & 2) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K tile | V tile]
   int bh, qb;
   xcd_group_block(blockIdx.x, (T + kQB - 1) / kQB, gridDim.x / ((T + kQB - 1) / kQB), bh, qb);   // all query blocks of a (batch, head) on one XCD
@@ -55,216 +57,200 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   const int r31 = lane & 31, hh = lane >> 5;
   const int inner = H * 64;
   const bf16* base = qkv + (size_t)b * T * ld_qkv + head * 64;
-  const bf16* kbase = base + inner;
-  const bf16* vbase = base + 2 * inner;
+  // a wave whose 32 query rows all lie past the sequence (the last query block of T = 1033 has 9 real rows) only stages tiles
+  const bool active = q0 + wave * 32 < T;
 
-  // Q fragments: B operand, col = query (lane&31), k = d = 16*ks + 8*hh + j
+  // Q' fragments (q * scale * log2(e), see the header): B operand, col = query (lane&31), k = d = 16*ks + 8*hh + j
   const int qrow = min(q0 + wave * 32 + r31, T - 1);
   bf16x8 qf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(base + (size_t)qrow * ld_qkv + 16 * ks + 8 * hh);
 
-  // K / V staging: lane-private source pointers advanced by one tile per call (the straightforward form recomputed a clamped 64-bit
-  // address per 16-byte piece: ~100 VALU instructions per tile in a kernel whose softmax is VALU-bound).  Only the last tile can
-  // reach past the sequence; it clamps its rows to T-1 (finite data that the key mask then ignores).
+  // K / V staging by LDS-DMA through a buffer resource: the per-lane byte offsets of a tile's pieces never change (NKB VGPRs), the tile
+  // advances through the instruction's SCALAR offset -- no vector address arithmetic inside the loop (the 64-bit per-lane pointers of the
+  // previous form cost 28 VALU instructions per tile).  Only the last tile can reach past the sequence; its pieces use a second, clamped
+  // offset set (rows past the end step back to row T-1: finite data that the key mask then ignores), so every access is in bounds.
   const int rsub = lane >> 3, slot = lane & 7;
-  const bf16* kp[kKB / 32];
-  const bf16* vp[kKB / 32];
+  const int nkt = (T + KB - 1) / KB;
+  const int nB = (int)gridDim.x / (((T + kQB - 1) / kQB) * H);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, nB * T * ld_qkv * 2, 0x00020000);
+  int vo[NKB], vo_last[NKB];
 #pragma unroll
-  for (int r = 0; r < kKB / 32; ++r) {
+  for (int r = 0; r < NKB; ++r) {
     const int row = r * 32 + wave * 8 + rsub;
-    kp[r] = kbase + (size_t)row * ld_qkv + ((slot ^ swz(row)) << 3);
-    vp[r] = kp[r] + inner;
+    const int col = inner + head * 64 + ((slot ^ attn_swz(row)) << 3);
+    vo[r] = ((b * T + row) * ld_qkv + col) * 2;
+    const int over = max((nkt - 1) * KB + row - (T - 1), 0);
+    vo_last[r] = ((b * T + row - over) * ld_qkv + col) * 2;
   }
-  const size_t tile_step = (size_t)kKB * ld_qkv;
-  const int nkt = (T + kKB - 1) / kKB;
-  auto stage = [&](int buf, int kt) {
+  const int tile_step = KB * ld_qkv * 2;       // bytes
+  // one 32-row slice (K and V) of tile kt into buffer buf
+  auto stage_piece = [&](int buf, int kt, int r) {
     char* sK = smem + buf * 2 * kTileBytes;
     char* sV = sK + kTileBytes;
-    if (kt == nkt - 1) {
-#pragma unroll
-      for (int r = 0; r < kKB / 32; ++r) {
-        const int row = r * 32 + wave * 8 + rsub;
-        const int over = max(kt * kKB + row - (T - 1), 0);            // rows past the end step back to row T-1
-        glds16(kp[r] - (size_t)over * ld_qkv, sK + (r * 32 + wave * 8) * 128);
-        glds16(vp[r] - (size_t)over * ld_qkv, sV + (r * 32 + wave * 8) * 128);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < kKB / 32; ++r) {
-        glds16(kp[r], sK + (r * 32 + wave * 8) * 128);
-        glds16(vp[r], sV + (r * 32 + wave * 8) * 128);
-        kp[r] += tile_step;
-        vp[r] += tile_step;
-      }
-    }
-  };
-  // register staging (RS): the same source addresses and the same LDS image, in two halves
-  [[maybe_unused]] u32x4 kreg[kKB / 32], vreg[kKB / 32];
-  [[maybe_unused]] auto fetch = [&](int kt) {
-#pragma unroll
-    for (int r = 0; r < kKB / 32; ++r) {
-      const int row = r * 32 + wave * 8 + rsub;
-      const int over = (kt == nkt - 1) ? max(kt * kKB + row - (T - 1), 0) : 0;
-      kreg[r] = *(const u32x4*)(kp[r] - (size_t)over * ld_qkv);
-      vreg[r] = *(const u32x4*)(vp[r] - (size_t)over * ld_qkv);
-      kp[r] += tile_step;
-      vp[r] += tile_step;
-    }
-  };
-  [[maybe_unused]] auto commit = [&](int buf) {
-    char* sK = smem + buf * 2 * kTileBytes;
-    char* sV = sK + kTileBytes;
-#pragma unroll
-    for (int r = 0; r < kKB / 32; ++r) {
-      *(u32x4*)(sK + (r * 32 + wave * 8) * 128 + lane * 16) = kreg[r];
-      *(u32x4*)(sV + (r * 32 + wave * 8) * 128 + lane * 16) = vreg[r];
-    }
+    const int v = (kt == nkt - 1) ? vo_last[r] : vo[r];
+    const int so = kt * tile_step;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (GVK_LDS void*)(sK + (r * 32 + wave * 8) * 128), 16, v, so, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (GVK_LDS void*)(sV + (r * 32 + wave * 8) * 128), 16, v, so + inner * 2, 0, 0);
   };
 
   f32x16 ot[2];
   ot[0] = f32x16{};
   ot[1] = f32x16{};
-  float m_run = -INFINITY, l_run = 0.f;
+  [[maybe_unused]] f32x16 lt = f32x16{};       // ONES: every register of every lane holds the query's running row sum
+  float m_run = 0.f;                           // log2 domain; set by the first tile
+  [[maybe_unused]] float l_run = 0.f;
+  bf16x8 qa = aug_const(0.f, true, 0.f, hh);     // constant side of the augmented MFMA: [-m pieces, -3e38 | 0...]
   [[maybe_unused]] unsigned int akey = 0u, qoff = 0u;
   if constexpr (DROP) {
     akey = attn_key(dr.seed + *dr.seed_ptr, b * H + head);
     qoff = (unsigned int)(q0 + wave * 32 + r31) * (unsigned int)T;
   }
+  [[maybe_unused]] const bf16 one_ = (bf16)1.0f;
+  [[maybe_unused]] const bf16x8 ones = {one_, one_, one_, one_, one_, one_, one_, one_};
 
 #ifdef GVK_STAMPS
   unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-  if constexpr (RS) { fetch(0); commit(0); } else { stage(0, 0); }
+#pragma unroll
+  for (int r = 0; r < NKB; ++r) stage_piece(0, 0, r);
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     GVK_ASTAMP(0)
-    if (kt + 1 < nkt) {
-      if constexpr (RS) fetch(kt + 1); else stage(buf ^ 1, kt + 1);
+    if constexpr (!SPREAD) {
+      if (kt + 1 < nkt) {
+#pragma unroll
+        for (int r = 0; r < NKB; ++r) stage_piece(buf ^ 1, kt + 1, r);
+      }
     }
     GVK_ASTAMP(1)
-    const char* sK = smem + buf * 2 * kTileBytes;
-    const char* sV = sK + kTileBytes;
+    if (active) {
+      const char* sK = smem + buf * 2 * kTileBytes;
+      const char* sV = sK + kTileBytes;
 
-    // ---- S^T = K . Q^T   (kKB/32 key blocks of 32).  The K fragments of block kb+1 are read from LDS while the four MFMAs of block kb
-    //      run: left to itself the compiler issued every ds_read right before its MFMA and waited lgkmcnt(0) in between (16 exposed
-    //      LDS round trips per tile).
-    constexpr int NKB = kKB / 32;
-    f32x16 st[NKB];
-    bf16x8 kfr[2][4];
-    auto load_k = [&](int kb, bf16x8 (&dst)[4]) {
-      const int row = kb * 32 + r31;
+      // ---- S' = K . Q'^T - m   (NKB key blocks of 32, five MFMAs each).  The K fragments of block kb+1 are read from LDS while the
+      //      MFMAs of block kb run.
+      f32x16 st[NKB];
+      bf16x8 kfr[2][4];
+      auto load_k = [&](int kb, bf16x8 (&dst)[4]) {
+        const int row = kb * 32 + r31;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const bf16x8*)(sK + row * 128 + (((2 * ks + hh) ^ swz(row)) << 4));
-    };
-    load_k(0, kfr[0]);
+        for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const bf16x8*)(sK + row * 128 + (((2 * ks + hh) ^ attn_swz(row)) << 4));
+      };
+      load_k(0, kfr[0]);
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      if (kb + 1 < NKB) load_k(kb + 1, kfr[(kb + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      st[kb] = f32x16{};
-      GVK_PRIO(1);
+      for (int kb = 0; kb < NKB; ++kb) {
+        if (kb + 1 < NKB) load_k(kb + 1, kfr[(kb + 1) & 1]);
+        const bf16x8 ka = aug_sel_first(kt * KB + kb * 32 + r31 >= T, hh);      // selector side: [1, 1, 1, key >= T, 0...]
+        __builtin_amdgcn_sched_barrier(0);
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qa, f32x16{}, 0, 0, 0);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb & 1][ks], qf[ks], st[kb], 0, 0, 0);
-      GVK_PRIO(0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    GVK_ASTAMP(2)
-    // ---- online softmax in the log2 domain.  VALU budget per score: max, fma, exp2, add (the scale is folded into the fma,
-    //      the key mask is applied on the last tile only) -- this block, not the MFMAs, was the largest share of the kernel.
-    if (kt == nkt - 1) {                                  // wave-uniform: only the last tile can contain keys >= T
+        for (int ks = 0; ks < 4; ++ks) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb & 1][ks], qf[ks], st[kb], 0, 0, 0);
+        if constexpr (SPREAD) {
+          if (kt + 1 < nkt) stage_piece(buf ^ 1, kt + 1, kb);       // behind this block's MFMAs: the DMA issue overlaps their execution
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      GVK_ASTAMP(2)
+      // ---- running maximum (log2 domain).  d = tile max of S' = (tile max of the scores) - m_run
+      float d = st[0][0];
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
+        for (int r = (kb == 0 ? 1 : 0); r < 16; ++r) d = fmaxf(d, st[kb][r]);
+      d = half_max(d);
+      if (kt == 0 || __builtin_amdgcn_ballot_w64(d > kThr) != 0ull) {
+        // slow path (wave-uniform): raise the maximum, bring this tile's S' and the accumulated O / l to the new scale.  Tile 0 takes
+        // it with m_run = 0 as the subtracted value and O = l = 0.
+        const float m_new = (kt == 0) ? d : m_run + fmaxf(d, 0.f);
+        const float delta = m_new - m_run;
+        const float alpha = (kt == 0) ? 0.f : __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[kb][r] -= delta;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ot[db][r] *= alpha;
+        if constexpr (ONES) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) lt[r] *= alpha;
+        } else {
+          l_run *= alpha;
+        }
+        m_run = m_new;
+        qa = aug_const(m_run, true, 0.f, hh);
+      }
+      // ---- probabilities and O^T += V^T . P^T, software-pipelined over the 32-key blocks: the exp2 / conversion of block kb+1 is issued
+      //      right BEHIND the MFMAs of block kb, so the VALU work runs while the matrix pipe executes them.  P^T goes straight from the
+      //      accumulator registers into the B operand; V^T fragments of block kb+1 are gathered (ds_read_b64_tr_b16) before the MFMAs of
+      //      block kb are issued.
+      [[maybe_unused]] float psum = 0.f;
+      auto exp_block = [&](int kb) {
+#pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = kt * kKB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          st[kb][r] = (key < T) ? st[kb][r] : -INFINITY;
+          float p = __builtin_amdgcn_exp2f(st[kb][r]);
+          if constexpr (!ONES) psum += p;                     // statistics of the undropped probabilities
+          if constexpr (DROP) {
+            const int key = kt * KB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            p *= attn_drop_scale(akey, qoff + (unsigned int)key, dr.thresh, dr.inv_keep);
+          }
+          st[kb][r] = p;
         }
+      };
+      auto cvt_block = [&](int kb, bf16x8 (&pf)[2]) {
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[sb][j] = (bf16)st[kb][8 * sb + j];
+      };
+      GVK_ASTAMP(3)
+      const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+      bf16x8 vfr[2][2][2], pfr[2][2];                         // [block parity][16-key step][d half], [block parity][16-key step]
+      auto load_v = [&](int kb, bf16x8 (&dst)[2][2]) {
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+          const int key0 = kb * 32 + 16 * sb + 4 * (g >> 1);   // lane half hh == g>>1
+          const int ra = key0 + tq, rb = key0 + 8 + tq;
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
+            const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((chunk ^ attn_swz(ra)) << 4) + (tp & 1) * 8);
+            const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((chunk ^ attn_swz(rb)) << 4) + (tp & 1) * 8);
+            dst[sb][db] = bf16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+          }
+        }
+      };
+      load_v(0, vfr[0]);
+      exp_block(0);
+      cvt_block(0, pfr[0]);
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        if (kb + 1 < NKB) load_v(kb + 1, vfr[(kb + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+          for (int db = 0; db < 2; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kb & 1][sb][db], pfr[kb & 1][sb], ot[db], 0, 0, 0);
+          if constexpr (ONES) lt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pfr[kb & 1][sb], lt, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 1 < NKB) {                                   // VALU of the next block, behind the MFMAs just issued
+          exp_block(kb + 1);
+          cvt_block(kb + 1, pfr[(kb + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (!ONES) l_run += psum;
+    } else if constexpr (SPREAD) {
+      if (kt + 1 < nkt) {
+#pragma unroll
+        for (int r = 0; r < NKB; ++r) stage_piece(buf ^ 1, kt + 1, r);
+      }
     }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;   // scale > 0 commutes with max
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
-    m_run = m_new;
-    // Software pipeline over the four 32-key blocks: the exp2 / row-sum / bf16 conversion of block kb+1 is issued right BEHIND the four
-    // PV MFMAs of block kb, so the VALU work runs while the matrix pipe executes them (written as "all exps, then all MFMAs" hipcc
-    // sank every exp in front of the one MFMA that consumes it: 1936 cycles for this section against 512 of MFMA + ~1200 of VALU;
-    // tools/probe/probe_attn.py).  Two scores per v_pk_fma_f32 / v_pk_add_f32.
-    f32x2 psum2 = {0.f, 0.f};
-    const f32x2 sc2 = {scale_log2e, scale_log2e}, nm2 = {-m_new, -m_new};
-    auto exp_block = [&](int kb) {
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const f32x2 a = __builtin_elementwise_fma(f32x2{st[kb][r], st[kb][r + 1]}, sc2, nm2);
-        f32x2 p2 = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-        psum2 += p2;                                        // statistics of the undropped probabilities
-        if constexpr (DROP) {
-          const int key = kt * kKB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;        // r even: r + 1 is the next key
-          p2 = p2 * f32x2{attn_drop_scale(akey, qoff + (unsigned int)key, dr.thresh, dr.inv_keep),
-                          attn_drop_scale(akey, qoff + (unsigned int)key + 1u, dr.thresh, dr.inv_keep)};
-        }
-        st[kb][r] = p2[0];
-        st[kb][r + 1] = p2[1];
-      }
-    };
-    auto cvt_block = [&](int kb, bf16x8 (&pf)[2]) {
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[sb][j] = (bf16)st[kb][8 * sb + j];
-    };
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ot[db][r] *= alpha;
-
-    GVK_ASTAMP(3)
-    // ---- O^T += V^T . P^T : P^T straight from the accumulator registers as the B operand; V^T fragments of block kb+1 are gathered
-    //      (ds_read_b64_tr_b16) before the MFMAs of block kb are issued
-    const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-    bf16x8 vfr[2][2][2], pfr[2][2];                         // [block parity][16-key step][d half], [block parity][16-key step]
-    auto load_v = [&](int kb, bf16x8 (&dst)[2][2]) {
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb) {
-        const int key0 = kb * 32 + 16 * sb + 4 * (g >> 1);   // lane half hh == g>>1
-        const int ra = key0 + tq, rb = key0 + 8 + tq;
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
-          const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((chunk ^ swz(ra)) << 4) + (tp & 1) * 8);
-          const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((chunk ^ swz(rb)) << 4) + (tp & 1) * 8);
-          dst[sb][db] = bf16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
-        }
-      }
-    };
-    load_v(0, vfr[0]);
-    exp_block(0);
-    cvt_block(0, pfr[0]);
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      if (kb + 1 < NKB) load_v(kb + 1, vfr[(kb + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      GVK_PRIO(1);
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-        for (int db = 0; db < 2; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[kb & 1][sb][db], pfr[kb & 1][sb], ot[db], 0, 0, 0);
-      GVK_PRIO(0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (kb + 1 < NKB) {                                   // VALU of the next block, behind the four MFMAs just issued
-        exp_block(kb + 1);
-        cvt_block(kb + 1, pfr[(kb + 1) & 1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    l_run = l_run * alpha + (psum2[0] + psum2[1]);
     GVK_ASTAMP(4)
-    if constexpr (RS) { if (kt + 1 < nkt) commit(buf ^ 1); }   // the other buffer was last read one barrier ago
     __syncthreads();
     GVK_ASTAMP(5)
   }
@@ -276,257 +262,95 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   }
 #endif
 
-  // ---- epilogue: O[q][d] = O^T / l ; lse = ln(sum exp(s*scale))
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  const int q = q0 + wave * 32 + r31;
-  if (q < T) {
-    bf16* orow = out + ((size_t)b * T + q) * ld_out + head * 64;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        bf16x4 o = {(bf16)(ot[db][4 * g4 + 0] * inv), (bf16)(ot[db][4 * g4 + 1] * inv), (bf16)(ot[db][4 * g4 + 2] * inv),
-                    (bf16)(ot[db][4 * g4 + 3] * inv)};
-        *(bf16x4*)(orow + db * 32 + 8 * g4 + 4 * hh) = o;
-      }
-    if (hh == 0 && lse != nullptr) lse[((size_t)b * H + head) * T + q] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
-  }
-}
-
-
-// ---- eight-wave form: two groups of four waves share every staged K / V tile (256 queries per workgroup, one workgroup per CU) and run the
-// same program ONE BARRIER APART.  A tile is two phases,
-//     P1 = S^T = K.Q^T (16 MFMAs) | running max, rescale factor, O *= alpha        P2 = exp2, row sums, bf16 P | O^T += V^T.P^T (16 MFMAs)
-// so while one group is in the MFMA half of a phase the other is in a VALU half (the 4-wave kernel leaves that overlap to two unrelated
-// workgroups that happen to share a CU and mostly move in lockstep: 30 us = 0.17 of the bf16 peak).  Waves w and w+4 share a SIMD.
-// LDS: THREE K|V buffers; tile t+2 is requested at the start of P2(t) -- its buffer (tile t-1) was last read in the other group's P2(t-1),
-// which ended at the barrier this phase began with -- and every wave waits vmcnt(0) at the end of P1(t+1), one barrier (group 0) or two
-// (group 1) before any wave reads the tile.
-constexpr int kQB8 = 256;
-
-template <bool DROP>
-__global__ __launch_bounds__(512) void attn_fwd8_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse,
-                                                        int T, int H, int ld_qkv, int ld_out, float scale_log2e, AttnDrop dr) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [3 buffers][K tile | V tile]
-  int bh, qb;
-  xcd_group_block(blockIdx.x, (T + kQB8 - 1) / kQB8, gridDim.x / ((T + kQB8 - 1) / kQB8), bh, qb);
-  const int b = bh / H, head = bh - b * H, q0 = qb * kQB8;
-  const int lane = lane_id(), wave = wave_id();
-  const int grp = wave >> 2, sw = wave & 3;              // group (phase offset) and the wave's 32-query slice inside the group's 128
-  const int r31 = lane & 31, hh = lane >> 5;
-  const int inner = H * 64;
-  const bf16* base = qkv + (size_t)b * T * ld_qkv + head * 64;
-  const bf16* kbase = base + inner;
-
-  const int qme = q0 + grp * 128 + sw * 32 + r31;
-  const int qrow = min(qme, T - 1);
-  bf16x8 qf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(base + (size_t)qrow * ld_qkv + 16 * ks + 8 * hh);
-
-  // staging: 8 waves x 8 rows = 64 rows per pass, two passes per 128-key tile and operand
-  const int rsub = lane >> 3, slot = lane & 7;
-  const int nkt = (T + kKB - 1) / kKB;
-  auto stage = [&](int kt) {
-    char* sK = smem + (kt % 3) * 2 * kTileBytes;
-    char* sV = sK + kTileBytes;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int row = r * 64 + wave * 8 + rsub;
-      const int key = min(kt * kKB + row, T - 1);                       // rows past the end re-read row T-1 (masked below)
-      const bf16* kp = kbase + (size_t)key * ld_qkv + ((slot ^ swz(row)) << 3);
-      glds16(kp, sK + (r * 64 + wave * 8) * 128);
-      glds16(kp + inner, sV + (r * 64 + wave * 8) * 128);
-    }
-  };
-
-  f32x16 ot[2];
-  ot[0] = f32x16{};
-  ot[1] = f32x16{};
-  float m_run = -INFINITY, l_run = 0.f;
-  [[maybe_unused]] unsigned int akey = 0u, qoff = 0u;
-  if constexpr (DROP) {
-    akey = attn_key(dr.seed + *dr.seed_ptr, b * H + head);
-    qoff = (unsigned int)qme * (unsigned int)T;
-  }
-  constexpr int NKB = kKB / 32;
-
-  stage(0);
-  if (nkt > 1) stage(1);
-  __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
-  __builtin_amdgcn_s_barrier();
-  if (grp == 1) __builtin_amdgcn_s_barrier();            // the stagger
-  for (int kt = 0; kt < nkt; ++kt) {
-    const char* sK = smem + (kt % 3) * 2 * kTileBytes;
-    const char* sV = sK + kTileBytes;
-    // ================= P1: S^T = K . Q^T, then the running max and the rescale of O
-    f32x16 st[NKB];
-    bf16x8 kfr[2][4];
-    auto load_k = [&](int kb, bf16x8 (&dst)[4]) {
-      const int row = kb * 32 + r31;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const bf16x8*)(sK + row * 128 + (((2 * ks + hh) ^ swz(row)) << 4));
-    };
-    load_k(0, kfr[0]);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      if (kb + 1 < NKB) load_k(kb + 1, kfr[(kb + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      st[kb] = f32x16{};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb & 1][ks], qf[ks], st[kb], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    if (kt == nkt - 1) {                                  // wave-uniform: only the last tile can contain keys >= T
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt * kKB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          st[kb][r] = (key < T) ? st[kb][r] : -INFINITY;
-        }
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ot[db][r] *= alpha;
-    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's share of tile kt+1 (requested one phase ago) has landed
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ================= P2: probabilities, row sums, O^T += V^T . P^T
-    if (kt + 2 < nkt) stage(kt + 2);
-    f32x2 psum2 = {0.f, 0.f};
-    const f32x2 sc2 = {scale_log2e, scale_log2e}, nm2 = {-m_new, -m_new};
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const f32x2 a = __builtin_elementwise_fma(f32x2{st[kb][r], st[kb][r + 1]}, sc2, nm2);
-        const f32x2 p2 = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-        st[kb][r] = p2[0];
-        st[kb][r + 1] = p2[1];
-        psum2 += p2;
-      }
-    l_run = l_run * alpha + (psum2[0] + psum2[1]);
-    if constexpr (DROP) {
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt * kKB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          st[kb][r] *= attn_drop_scale(akey, qoff + (unsigned int)key, dr.thresh, dr.inv_keep);
-        }
-    }
-    const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-    bf16x8 vfr[2][2];
-    auto load_v = [&](int step, bf16x8 (&dst)[2]) {
-      const int kb = step >> 1, sb = step & 1;
-      const int key0 = kb * 32 + 16 * sb + 4 * (g >> 1);
-      const int ra = key0 + tq, rb = key0 + 8 + tq;
-#pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
-        const bf16x4 va = lds_read_tr16(sV + ra * 128 + ((chunk ^ swz(ra)) << 4) + (tp & 1) * 8);
-        const bf16x4 vb = lds_read_tr16(sV + rb * 128 + ((chunk ^ swz(rb)) << 4) + (tp & 1) * 8);
-        dst[db] = bf16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
-      }
-    };
-    load_v(0, vfr[0]);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int step = 0; step < 2 * NKB; ++step) {
-      if (step + 1 < 2 * NKB) load_v(step + 1, vfr[(step + 1) & 1]);
-      const int kb = step >> 1, sb = step & 1;
-      bf16x8 pf;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[kb][8 * sb + j];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int db = 0; db < 2; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[step & 1][db], pf, ot[db], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();            // balance the barrier count
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  if (qme < T) {
-    bf16* orow = out + ((size_t)b * T + qme) * ld_out + head * 64;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        bf16x4 o = {(bf16)(ot[db][4 * g4 + 0] * inv), (bf16)(ot[db][4 * g4 + 1] * inv), (bf16)(ot[db][4 * g4 + 2] * inv),
-                    (bf16)(ot[db][4 * g4 + 3] * inv)};
-        *(bf16x4*)(orow + db * 32 + 8 * g4 + 4 * hh) = o;
-      }
-    if (hh == 0 && lse != nullptr) lse[((size_t)b * H + head) * T + qme] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
-  }
+  // ---- epilogue: O[q][d] = O^T / l through a wave-private 4 KB LDS image (32 rows of 128 B, 16-B chunk c of row q at c ^ (q & 7)),
+  //      then whole rows out: 8 lanes x 16 B per row, 8 rows per store instruction.  lse = ln(sum exp(s*scale))
+  if (!active) return;                         // (the last barrier of the loop is behind every wave: the K / V buffers are free)
+  float l_tot;
+  if constexpr (ONES) l_tot = lt[0];
+  else l_tot = half_sum(l_run);
+  const int qw = q0 + wave * 32;
+  store_rows_t(ot, 1.0f / l_tot, smem + wave * 4096, out + ((size_t)b * T + qw) * ld_out + head * 64, (size_t)ld_out, T - qw, lane);
+  const int q = qw + r31;
+  if (q < T && hh == 0 && lse != nullptr) lse[((size_t)b * H + head) * T + q] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
 }
 
 }  // namespace gvk
 
 namespace gvk {
-template <bool DROP>
-static int launch_attn_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale, AttnDrop dr, hipStream_t stream) {
-  // opt-in (GAVIKO_HIP_ATTN8=1): parity-green but no faster -- 32.8 vs 30.5 us isolated, 679 vs 684 volumes/s in the step (profiles/r02_pmc_attention.json:
-  // both forms spend ~0.3 of their wave cycles issuing VALU, ~0.2 in MFMA and the rest waiting; forcing the MFMA / VALU halves of the two waves
-  // of a SIMD apart by a barrier did not change that)
-  static const bool use8 = getenv("GAVIKO_HIP_ATTN8") != nullptr && getenv("GAVIKO_HIP_ATTN8")[0] == '1';
-  if (use8 && T > 128) {
-    const int lds8 = 3 * 2 * kTileBytes;
-    static bool attr8 = false;
-    if (!attr8) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd8_kernel<DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds8);
-      if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(attn_fwd8): %s", hipGetErrorString(e));
-      attr8 = true;
-    }
-    GVK_LAUNCH(attn_fwd8_kernel<DROP>, dim3(((T + kQB8 - 1) / kQB8) * H * B), dim3(512), lds8, stream, (const bf16*)qkv,
-                       (bf16*)out, lse, T, H, ld_qkv, ld_out, scale * 1.44269504088896340736f, dr);
-    return check_launch("attention_fwd8_bf16");
-  }
-  const int lds = 2 * 2 * kTileBytes;
-  static const bool rs = getenv("GAVIKO_HIP_ATTN_RS") != nullptr && getenv("GAVIKO_HIP_ATTN_RS")[0] == '1';   // opt-in: measured 32.3 vs 31.0 us (no gain)
+// diagnostics (tools/bench_attn.py): kernel variant forced by the environment; the library default is what launch_attn_fwd picks
+static int attn_var() { return getenv("GAVIKO_HIP_ATTN_VAR") ? atoi(getenv("GAVIKO_HIP_ATTN_VAR")) : -1; }   // read per launch: one process can A/B
+static int attn_kb() { return getenv("GAVIKO_HIP_ATTN_KB") ? atoi(getenv("GAVIKO_HIP_ATTN_KB")) : 0; }
+
+template <int KB, bool DROP, int VAR>
+static int launch_attn_fwd_t(const void* qkv, void* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale, AttnDrop dr, hipStream_t stream) {
+  constexpr int lds = 2 * 2 * KB * 128;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<DROP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<DROP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<KB, DROP, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(attn_fwd): %s", hipGetErrorString(e));
     attr = true;
   }
   const dim3 grid(((T + kQB - 1) / kQB) * H * B);
-  if (rs) GVK_LAUNCH((attn_fwd_kernel<DROP, true>), grid, dim3(256), lds, stream, (const bf16*)qkv, (bf16*)out, lse, T, H, ld_qkv, ld_out, scale * 1.44269504088896340736f, dr);
-  else GVK_LAUNCH((attn_fwd_kernel<DROP, false>), grid, dim3(256), lds, stream, (const bf16*)qkv, (bf16*)out, lse, T, H, ld_qkv, ld_out, scale * 1.44269504088896340736f, dr);
+  GVK_LAUNCH((attn_fwd_kernel<KB, DROP, VAR>), grid, dim3(256), lds, stream, (const bf16*)qkv, (bf16*)out, lse, T, H, ld_qkv, ld_out, dr);
   return check_launch("attention_fwd_bf16");
 }
+
+constexpr int kAttnVarDefault = 0;
+
+template <bool DROP>
+static int launch_attn_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale, AttnDrop dr, hipStream_t stream) {
+  // key tile: the size that pads the sequence less (T = 1033: 11 x 96 = 1056 against 9 x 128 = 1152); ties go to the larger tile
+  const int p96 = (T + 95) / 96 * 96, p128 = (T + 127) / 128 * 128;
+  int kb = p96 < p128 ? 96 : 128;
+  if (attn_kb() == 96 || attn_kb() == 128) kb = attn_kb();
+  if constexpr (DROP) {
+    if (kb == 96) return launch_attn_fwd_t<96, true, kAttnVarDefault>(qkv, out, lse, B, T, H, ld_qkv, ld_out, scale, dr, stream);
+    return launch_attn_fwd_t<128, true, kAttnVarDefault>(qkv, out, lse, B, T, H, ld_qkv, ld_out, scale, dr, stream);
+  } else {
+    const int var = attn_var() >= 0 ? attn_var() : kAttnVarDefault;
+#define GVK_ATTN_CASE(KB_, V_) if (kb == KB_ && var == V_) return launch_attn_fwd_t<KB_, false, V_>(qkv, out, lse, B, T, H, ld_qkv, ld_out, scale, dr, stream);
+    GVK_ATTN_CASE(96, 0) GVK_ATTN_CASE(96, 1) GVK_ATTN_CASE(96, 2) GVK_ATTN_CASE(96, 3)
+    GVK_ATTN_CASE(128, 0) GVK_ATTN_CASE(128, 1) GVK_ATTN_CASE(128, 2) GVK_ATTN_CASE(128, 3)
+#undef GVK_ATTN_CASE
+    return set_error(-2, "gvk_attention_fwd_bf16: no kernel variant %d for key tile %d", var, kb);
+  }
+}
 }  // namespace gvk
+
+namespace gvk {
+// x[m][n] *= s for n < cols (in place, fp32 multiply, one rounding): what gvk_gemm_desc.scale_cols does inside the qkv projection, for callers
+// that hold a raw q block.  8 elements per thread.
+__global__ __launch_bounds__(256) void qkv_prescale_kernel(bf16* __restrict__ x, int rows, int cols, int ld, float s) {
+  const int per = cols >> 3;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)rows * per) return;
+  const int m = (int)(i / per), c = (int)(i - (long long)m * per) << 3;
+  bf16x8 v = *(bf16x8*)(x + (size_t)m * ld + c);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] * s);
+  *(bf16x8*)(x + (size_t)m * ld + c) = v;
+}
+}  // namespace gvk
+
+extern "C" int gvk_qkv_prescale_bf16(void* qkv, int rows, int H, int ld_qkv, float scale, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(qkv && rows > 0 && H > 0 && ld_qkv >= 3 * H * 64 && ld_qkv % 8 == 0, "gvk_qkv_prescale_bf16: bad arguments");
+  const long long n = (long long)rows * (H * 8);
+  GVK_LAUNCH(qkv_prescale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (bf16*)qkv, rows, H * 64, ld_qkv,
+             scale * 1.44269504088896340736f);
+  return check_launch("qkv_prescale_bf16");
+}
 
 extern "C" int gvk_attention_fwd_bf16_dropout(const void* qkv, void* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale,
                                               float drop_p, uint64_t seed, const void* seed_ptr, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(qkv && out, "gvk_attention_fwd_bf16: null pointer");
   GVK_REQUIRE(B > 0 && T > 0 && H > 0, "gvk_attention_fwd_bf16: empty shape");
-  GVK_REQUIRE(ld_qkv >= 3 * H * 64 && ld_qkv % 8 == 0 && ld_out >= H * 64 && ld_out % 4 == 0,
-              "gvk_attention_fwd_bf16: head dim is fixed at 64; ld_qkv=%d ld_out=%d inconsistent with H=%d", ld_qkv, ld_out, H);
+  GVK_REQUIRE(ld_qkv >= 3 * H * 64 && ld_qkv % 8 == 0 && ld_out >= H * 64 && ld_out % 8 == 0,
+              "gvk_attention_fwd_bf16: head dim is fixed at 64; ld_qkv=%d ld_out=%d inconsistent with H=%d (16-byte rows)", ld_qkv, ld_out, H);
   GVK_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || seed_ptr != nullptr), "gvk_attention_fwd_bf16: drop_p in [0,1) and a seed word");
   GVK_REQUIRE(drop_p == 0.f || (int64_t)T * T < (int64_t)1 << 32, "gvk_attention_fwd_bf16: the dropout mask index (query*T + key) is 32-bit");
+  GVK_REQUIRE((int64_t)B * T * ld_qkv * 2 < (int64_t)1 << 31, "gvk_attention_fwd_bf16: the qkv tensor must stay below 2 GiB (32-bit buffer offsets)");
   const AttnDrop dr{seed, (const unsigned long long*)seed_ptr, drop_threshold_u32(drop_p), drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f};
   if (drop_p > 0.f) return launch_attn_fwd<true>(qkv, out, lse, B, T, H, ld_qkv, ld_out, scale, dr, (hipStream_t)stream);
   return launch_attn_fwd<false>(qkv, out, lse, B, T, H, ld_qkv, ld_out, scale, dr, (hipStream_t)stream);

@@ -321,6 +321,9 @@ extern "C" int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream) {
   GVK_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f && (d->drop_p == 0.f || d->seed_ptr != nullptr), "gvk_gemm_nt_bf16: drop_p in [0,1) and a seed word");
   a.seed = d->seed; a.seed_ptr = (const unsigned long long*)d->seed_ptr; a.drop_thresh = drop_threshold_u32(d->drop_p);
   a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
+  GVK_REQUIRE(d->scale_cols == 0 || (d->epilogue == GVK_EPI_STORE_BF16 && d->scale_cols > 0 && d->scale_cols % 8 == 0 && d->scale_cols <= d->N),
+              "gvk_gemm_nt_bf16: scale_cols=%d needs the STORE_BF16 epilogue, a multiple of 8 and <= N", d->scale_cols);
+  a.scale_cols = d->scale_cols; a.col_scale = d->col_scale;
   hipStream_t s = (hipStream_t)stream;
   switch (d->epilogue) {
     case GVK_EPI_STORE_BF16:

@@ -24,6 +24,8 @@ struct GemmArgs {
   int a_rows;                                            // rows the A buffer really has (M padded to 128): the 256-row tile clamps to it
   // DROP instantiations only (nn.Dropout behind a Linear of the unfrozen-backbone methods): mask index m * N + n
   unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;
+  // STORE_BF16 only: columns n < scale_cols leave as (acc + bias) * col_scale (the q block of a qkv projection, pre-scaled for the attention kernels)
+  int scale_cols; float col_scale;
 };
 
 // LDS swizzles (applied to the 16-byte chunk index of a 128-byte tile row; conflict-free for the ds_read_b128 lane groups)
@@ -107,6 +109,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
           for (int e = 0; e < 8; ++e) v[e] *= drop_scale(sd, (unsigned long long)m * p.N + n + e, p.drop_thresh, p.inv_keep);
         };
         if constexpr (EPI == GVK_EPI_STORE_BF16) {
+          if (n < p.scale_cols) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= p.col_scale;
+          }
           store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
         } else if constexpr (kRes) {
           if constexpr (DROP) drop8();                       // out = res + dropout(acc + bias): vision_transformer.py:34,54

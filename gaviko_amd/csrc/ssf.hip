@@ -49,6 +49,7 @@ struct ColGradArgs {
   const float* s; const float* t; float* ds; float* dt; float* scratch;
   int M, N, ld_dy, ld_y, dy_f32, y0_f32;
   int rows_in, rows_out, row_off;          // rows_in > 0: logical row m -> buffer row (m / rows_in) * rows_out + row_off + m % rows_in
+  int y0_cols; float y0_mul;               // y0 columns n < y0_cols are stored multiplied by 1 / y0_mul (the pre-scaled q block of a saved qkv)
 };
 constexpr int kCgSlabs = 64;
 
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256) void ssf_colgrad_partial_kernel(ColGradArgs p)
     }
     const float dy = ld_mixed(p.dy, row * p.ld_dy + n, p.dy_f32);
     float y = ld_mixed(p.y0, row * p.ld_y + n, p.y0_f32);
+    if (n < p.y0_cols) y *= p.y0_mul;
     if (p.y1 != nullptr) y -= p.y1[row * p.ld_y + n];
     if (p.pos != nullptr) y -= p.pos[(size_t)prow * p.N + n];
     a = __builtin_fmaf(dy, y, a);
@@ -154,7 +156,7 @@ extern "C" int gvk_ssf_colgrad(const gvk_ssf_colgrad_desc* d, void* stream) {
   GVK_REQUIRE(d->rows_in == 0 || (d->rows_in > 0 && d->rows_out >= d->rows_in + d->row_off), "gvk_ssf_colgrad: bad row mapping");
   GVK_REQUIRE(d->pos == nullptr || d->rows_in > 0, "gvk_ssf_colgrad: pos needs the row mapping");
   ColGradArgs a{d->dy, d->y0, d->y1, d->pos, d->s, d->t, d->ds, d->dt, d->scratch, d->M, d->N, d->ld_dy, d->ld_y, d->dy_f32, d->y0_f32,
-                d->rows_in, d->rows_out, d->row_off};
+                d->rows_in, d->rows_out, d->row_off, d->y0_cols, d->y0_mul};
   GVK_LAUNCH(ssf_colgrad_partial_kernel, dim3((d->N + 255) / 256, kCgSlabs), dim3(256), 0, (hipStream_t)stream, a);
   int rc = check_launch("ssf_colgrad/partial");
   if (rc) return rc;

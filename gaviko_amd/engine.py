@@ -140,6 +140,7 @@ class Engine:
         if prec not in ("bf16", "fp32", "float32"):
             raise L.GavikoHipError(f"precision={prec!r}: expected 'bf16' or 'fp32'")
         self.fp32 = prec != "bf16"
+        self.q_scale = 64 ** -0.5 * ops.LOG2E     # what the saved q block carries on the bf16 path (attention kernels' operand form)
         self.adt = torch.float32 if self.fp32 else torch.bfloat16
         if cfg.get("dim_head", 64) != 64:
             raise L.GavikoHipError("the attention kernels are built for dim_head = 64")
@@ -792,9 +793,12 @@ class Engine:
             ops.layernorm_fwd(gin, d(a + ".norm.weight"), d(a + ".norm.bias"), M, C, y16=ws["xn"], mean=st[0], rstd=st[1])
         if self._keep_inputs:
             ops.copy_(ws["sav"]["xn1"][si], ws["xn"])
-        self._gemm(ws["xn"], w[f"qkv{i}"], M, ws["qkv"][si], epilogue=ops.EPI_STORE_BF16, bias=self._eff.get(a + ".to_qkv.bias"))
+        # bf16 path: the q block leaves the projection as q * scale * log2(e) (one rounding, in the GEMM epilogue) -- the form the flash
+        # kernels take, forward and backward alike; the fp32 kernels take the raw block
+        qs = {} if self.fp32 else dict(scale_cols=self.heads * 64, col_scale=self.q_scale)
+        self._gemm(ws["xn"], w[f"qkv{i}"], M, ws["qkv"][si], epilogue=ops.EPI_STORE_BF16, bias=self._eff.get(a + ".to_qkv.bias"), **qs)
         ops.attention_fwd(ws["qkv"][si], ws["ctx"][si], ws["lse"][si], ws["B"], self.Ts[i], self.heads, 64 ** -0.5,
-                          drop_p=pdrop, seed=SEED_LAYER + 8 * i, seed_ptr=ws["seed"])
+                          drop_p=pdrop, seed=SEED_LAYER + 8 * i, seed_ptr=ws["seed"], q_prescaled=True)
         self._gemm(ws["ctx"][si], w[f"out{i}"], M, g1, epilogue=ops.EPI_BIAS_RES_F32, bias=d(a + ".to_out.0.bias"), res=gin,
                    drop_p=pdrop, seed=SEED_LAYER + 8 * i + 1, seed_ptr=ws["seed"])
 
@@ -808,7 +812,7 @@ class Engine:
             split = dict(y_split=ws["act"], col_split=self.mlp) if self._fuse_up else {}      # the plain latents ride fc2 (self._fuse_up)
             ops.layernorm_fwd_proj(g1, d(m + ".net.0.weight"), d(m + ".net.0.bias"), M, C, y16=ws["xn"], mean=st[2], rstd=st[3],
                                    w=d(pre + ".proj_down.0.weight"), bias=d(pre + ".proj_down.0.bias"), z=g["zx"], y=g["xl"], act=1, w_layout=0,
-                                   **split)
+                                   L_=self.Lat, **split)
         else:
             ops.layernorm_fwd(g1, d(m + ".net.0.weight"), d(m + ".net.0.bias"), M, C, y16=ws["xn"], mean=st[2], rstd=st[3])
 
@@ -1114,14 +1118,15 @@ class Engine:
             self._gemm(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
             self._mark(f"b{i}:outd")
             ops.attention_bwd(ws["qkv"][i], ws["ctx"][i], ws["dctx"], ws["lse"][i], ws["delta"], ws["dqkv"], B, T, self.heads, 64 ** -0.5,
-                              drop_p=pd_, seed=SEED_LAYER + 8 * i, seed_ptr=ws["seed"])
+                              drop_p=pd_, seed=SEED_LAYER + 8 * i, seed_ptr=ws["seed"], q_prescaled=True)
             self._mark(f"b{i}:attnb")
             if gaviko and shift:
                 self._mwsa_chain_bwd(ws, sv, gv, i, par, B, loc, self._ev_record(torch.cuda.current_stream()))
             if self.kind == "melo":
                 self._melo_bwd(ws, gv, i, M)
             if ssf:                                                          # to_qkv + ssf_1: dy = dqkv, y = saved qkv
-                self._ssf_linear_grad(ws, gv, a, 1, ws["dqkv"], ws["qkv"][i], M, 3 * C)
+                uq = {} if self.fp32 else dict(y0_cols=self.heads * 64, y0_mul=1.0 / self.q_scale)     # the saved q block is pre-scaled
+                self._ssf_linear_grad(ws, gv, a, 1, ws["dqkv"], ws["qkv"][i], M, 3 * C, **uq)
             if bb:                                                           # to_qkv (bias-free): dW = dqkv^T . LN1(G)
                 self._bb_linear_grads(ws, gv, bb, a + ".to_qkv", None, ws["dqkv"], ws["sav"]["xn1"][i] if sv["wgrad"] else None, M, 3 * C, C)
             self._gemm(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
@@ -1138,7 +1143,7 @@ class Engine:
                 if self._fuse_proj and i > 0:
                     pre_lo, _ = self._gpa_names(i - 1)
                     ops.layernorm_bwd_proj(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGnext, dres=dGin,
-                                           dx16=ws["dG16"], w=d(pre_lo + ".proj_up.weight"), y=ws["bw"]["dcomb"], w_layout=1)
+                                           dx16=ws["dG16"], w=d(pre_lo + ".proj_up.weight"), y=ws["bw"]["dcomb"], w_layout=1, L_=self.Lat)
                 else:
                     ops.layernorm_bwd(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGnext, dres=dGin,
                                       dx16=ws["dG16"])
@@ -1633,9 +1638,9 @@ class Engine:
                 ops.ssf_fold_weight(W2, s_, w[key], w[key + "_t"] if need_t else None)
                 ops.ssf_fold_vec(self.p[bname].detach() if bname in self.p else None, s_, t_, eff[bname])
 
-    def _ssf_linear_grad(self, ws, gv, prefix, idx, dy, y0, M, N, y1=None):
+    def _ssf_linear_grad(self, ws, gv, prefix, idx, dy, y0, M, N, y1=None, **kw):
         sn, tn = f"{prefix}.ssf_scale_{idx}", f"{prefix}.ssf_shift_{idx}"
-        ops.ssf_colgrad(dy, y0, self.p[sn].detach(), self.p[tn].detach(), gv[sn], gv[tn], ws["ssf_scratch"], M, N, y1=y1)
+        ops.ssf_colgrad(dy, y0, self.p[sn].detach(), self.p[tn].detach(), gv[sn], gv[tn], ws["ssf_scratch"], M, N, y1=y1, **kw)
 
     def _ssf_ln_grad(self, ws, gv, prefix, ln, dy, x, mean, rstd, M):
         C, tmp = self.C, ws["ssf_tmp"]

@@ -41,7 +41,7 @@ def _chk(t, dtype, what, min_elems=0):
 
 def gemm_nt(a, w, M, out0, *, epilogue, out1=None, bias=None, res=None, aux=None, pos=None,
             lda=None, ldo=None, ldres=None, ldaux=None, rows_in=0, rows_out=0, row_off=0, tile=0, N=None, K=None,
-            drop_p=0.0, seed=0, seed_ptr=None):
+            drop_p=0.0, seed=0, seed_ptr=None, scale_cols=0, col_scale=1.0):
     """Y[M,N] = A[M,K] . W[N,K]^T with a fused epilogue.  The operand dtype picks the kernel: bf16 -> gvk_gemm_nt_bf16 (MFMA
     bf16, fp32 accumulate), fp32 -> gvk_gemm_nt_f32 (every 16-bit slot of the epilogue table then carries fp32)."""
     adt = a.dtype
@@ -65,7 +65,7 @@ def gemm_nt(a, w, M, out0, *, epilogue, out1=None, bias=None, res=None, aux=None
     d = L.GemmDesc(L.ptr(a), L.ptr(w), L.ptr(out0), L.ptr(out1), L.ptr(bias), L.ptr(res), L.ptr(aux), L.ptr(pos),
                    L.ptr(seed_ptr) if (seed_ptr is not None and drop_p > 0) else None,
                    M, N, K, lda, ldw, ldo, (N if ldres is None else ldres), (N if ldaux is None else ldaux),
-                   epilogue, rows_in, rows_out, row_off, tile, float(drop_p), int(seed))
+                   epilogue, rows_in, rows_out, row_off, tile, float(drop_p), int(seed), int(scale_cols), float(col_scale))
     if adt == torch.float32:
         L.check(L.load().gvk_gemm_nt_f32(C.byref(d), L.stream_ptr()), "gvk_gemm_nt_f32")
     else:
@@ -328,8 +328,26 @@ def layernorm_bwd_affine(dy, x, mean, rstd, dgamma, dbeta, scratch, M, C_, accum
                                               L.ptr(scratch), M, C_, int(accumulate), L.stream_ptr()), "gvk_layernorm_bwd_affine")
 
 
-def attention_fwd(qkv, out, lse, B, T, H, scale, drop_p=0.0, seed=0, seed_ptr=None):
-    """qkv bf16 [pad(B*T), 3*H*64] -> out bf16 [pad(B*T), H*64], lse f32 [B,H,T].  drop_p > 0: dropout on the probabilities (bf16 path)."""
+LOG2E = 1.4426950408889634
+
+
+def qkv_prescale(qkv, rows, H, scale):
+    """In place: q block of a raw bf16 to_qkv output -> q * scale * log2(e), the form gvk_attention_*_bf16 take (the engine gets it from the
+    qkv projection's epilogue instead: gemm_nt(scale_cols=H*64, col_scale=scale*LOG2E))."""
+    _chk(qkv, torch.bfloat16, "qkv_prescale qkv", rows * 3 * H * 64)
+    L.check(L.load().gvk_qkv_prescale_bf16(L.ptr(qkv), rows, H, qkv.shape[-1], scale, L.stream_ptr()), "gvk_qkv_prescale_bf16")
+
+
+def _prescaled_copy(qkv, rows, H, scale):
+    c = qkv.clone()
+    qkv_prescale(c, rows, H, scale)
+    return c
+
+
+def attention_fwd(qkv, out, lse, B, T, H, scale, drop_p=0.0, seed=0, seed_ptr=None, q_prescaled=False):
+    """qkv bf16 [pad(B*T), 3*H*64] -> out bf16 [pad(B*T), H*64], lse f32 [B,H,T].  drop_p > 0: dropout on the probabilities (bf16 path).
+    bf16 path: the kernels take the q block pre-scaled by scale*log2(e) (include/gaviko_hip.h); q_prescaled=False (tests, tools) makes a
+    scaled copy of a raw qkv first -- an allocation and one more rounding of q, never on the engine's path."""
     inner = H * 64
     if qkv.dtype == torch.float32:
         _chk(qkv, torch.float32, "attn qkv", B * T * 3 * inner)
@@ -341,6 +359,8 @@ def attention_fwd(qkv, out, lse, B, T, H, scale, drop_p=0.0, seed=0, seed_ptr=No
     _chk(qkv, torch.bfloat16, "attn qkv", pad_rows(B * T) * 3 * inner)
     _chk(out, torch.bfloat16, "attn out", B * T * inner)
     _chk(lse, torch.float32, "attn lse", B * H * T)
+    if not q_prescaled:
+        qkv = _prescaled_copy(qkv, B * T, H, scale)
     if drop_p > 0:
         L.check(L.load().gvk_attention_fwd_bf16_dropout(L.ptr(qkv), L.ptr(out), L.ptr(lse), B, T, H, 3 * inner, inner, scale, float(drop_p),
                                                         int(seed), L.ptr(seed_ptr), L.stream_ptr()), "gvk_attention_fwd_bf16_dropout")
@@ -452,7 +472,7 @@ def head_bwd(**kw):
     L.check(L.load().gvk_head_bwd(C.byref(d), L.stream_ptr()), "gvk_head_bwd")
 
 
-def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, scale, drop_p=0.0, seed=0, seed_ptr=None):
+def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, scale, drop_p=0.0, seed=0, seed_ptr=None, q_prescaled=False):
     inner = H * 64
     if qkv.dtype == torch.float32:
         for t, n, k in ((qkv, "qkv", 3), (out, "out", 1), (dout, "dout", 1), (dqkv, "dqkv", 3)):
@@ -469,6 +489,8 @@ def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, scale, drop_p=0.0, 
     _chk(dqkv, torch.bfloat16, "attn_bwd dqkv", B * T * 3 * inner)
     _chk(lse, torch.float32, "attn_bwd lse", B * H * T)
     _chk(delta, torch.float32, "attn_bwd delta", B * H * T)
+    if not q_prescaled:                                      # see attention_fwd
+        qkv = _prescaled_copy(qkv, B * T, H, scale)
     if drop_p > 0:
         L.check(L.load().gvk_attention_bwd_bf16_dropout(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), B, T, H,
                                                         3 * inner, inner, scale, float(drop_p), int(seed), L.ptr(seed_ptr), L.stream_ptr()),
@@ -584,7 +606,8 @@ def ssf_fold_vec(a, s, t, out):
     L.check(L.load().gvk_ssf_fold_vec(L.ptr(a), L.ptr(s), L.ptr(t), L.ptr(out), n, L.stream_ptr()), "gvk_ssf_fold_vec")
 
 
-def ssf_colgrad(dy, y0, s, t, ds, dt, scratch, M, N, *, y1=None, pos=None, ld_dy=None, ld_y=None, rows_in=0, rows_out=0, row_off=0):
+def ssf_colgrad(dy, y0, s, t, ds, dt, scratch, M, N, *, y1=None, pos=None, ld_dy=None, ld_y=None, rows_in=0, rows_out=0, row_off=0,
+                y0_cols=0, y0_mul=1.0):
     for x, nm in ((s, "s"), (t, "t"), (ds, "ds"), (dt, "dt")):
         _chk(x, torch.float32, "ssf_colgrad " + nm, N)
     _chk(scratch, torch.float32, "ssf_colgrad scratch", 64 * 2 * N)
@@ -596,7 +619,7 @@ def ssf_colgrad(dy, y0, s, t, ds, dt, scratch, M, N, *, y1=None, pos=None, ld_dy
     d = L.SsfColgradDesc(dy=L.ptr(dy), y0=L.ptr(y0), y1=L.ptr(y1), pos=L.ptr(pos), s=L.ptr(s), t=L.ptr(t), ds=L.ptr(ds), dt=L.ptr(dt),
                          scratch=L.ptr(scratch), M=M, N=N, ld_dy=N if ld_dy is None else ld_dy, ld_y=N if ld_y is None else ld_y,
                          dy_f32=int(dy.dtype == torch.float32), y0_f32=int(y0.dtype == torch.float32), rows_in=rows_in, rows_out=rows_out,
-                         row_off=row_off)
+                         row_off=row_off, y0_cols=int(y0_cols), y0_mul=float(y0_mul))
     L.check(L.load().gvk_ssf_colgrad(C.byref(d), L.stream_ptr()), "gvk_ssf_colgrad")
 
 

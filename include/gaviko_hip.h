@@ -22,7 +22,7 @@ extern "C" {
 const char* gvk_last_error(void);
 /* returns 950 when the code object loaded on the current device is gfx950, else <0 */
 int gvk_device_check(void);
-int gvk_abi_version(void);   /* 6 */
+int gvk_abi_version(void);   /* 7 */
 
 /* ------------------------------------------------------------------ launch plans
  * The reference drives its step from the Python interpreter (train.py:296-319: one autograd node per op).  Here one
@@ -98,6 +98,9 @@ typedef struct gvk_gemm_desc {
   float drop_p;       /* nn.Dropout behind the Linear (vision_transformer.py:32-34,54), epilogues 1, 2 (on out1), 4: the value at
                          (m, n) is multiplied by mask(seed + *seed_ptr, m*N + n) / (1 - drop_p); 0 = off */
   uint64_t seed;
+  int32_t scale_cols; /* GVK_EPI_STORE_BF16 (bf16 entry point) only: columns n < scale_cols (a multiple of 8) are multiplied by col_scale in fp32 */
+  float col_scale;    /* before the ONE rounding to bf16 -- the q block of a qkv projection leaves the GEMM as q * scale * log2(e), the form
+                         the attention kernels take (gvk_attention_*_bf16); 0 columns = off */
 } gvk_gemm_desc;
 int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream);
 
@@ -189,14 +192,19 @@ int gvk_layernorm_bwd_up(const float* dy, const float* x, const float* mean, con
                          float* dx, void* dx_bf16, const float* lat, const float* w, int w_layout, int M, int C, int L, void* stream);
 
 /* ------------------------------------------------------------------ multi-head self-attention, head dim 64
- * qkv bf16 [B*T (padded)][ld_qkv]: columns [q | k | v], each (head, 64) -- the to_qkv output as is
- * (vision_transformer.py:62-63).  out bf16 [B*T][ld_out] in 'b n (h d)' order (vision_transformer.py:71), lse f32 [B][H][T]
+ * qkv bf16 [B*T (padded)][ld_qkv]: columns [q' | k | v], each (head, 64) -- the to_qkv output (vision_transformer.py:62-63) with the q
+ * block PRE-SCALED: q' = q * scale * log2(e), multiplied in fp32 before the one rounding to bf16.  gvk_gemm_nt_bf16 does it in the
+ * projection's epilogue (gvk_gemm_desc.scale_cols = H*64, col_scale = scale * log2(e)); gvk_qkv_prescale_bf16 converts a raw qkv buffer
+ * in place.  The forward and both backward passes then read bit-identical score operands (P of the backward is recomputed against the
+ * forward's lse) and no kernel spends a multiply per score.  out bf16 [B*T][ld_out] in 'b n (h d)' order (vision_transformer.py:71), lse f32 [B][H][T]
  * = log sum_j exp(scale * q.k_j) (natural log), saved for the backward.  scale = dim_head^-0.5 (vision_transformer.py:47,65). */
 int gvk_attention_fwd_bf16(const void* qkv, void* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale,
                            void* stream);
+/* q block of a raw to_qkv output -> q * scale * log2(e), in place (rows = B*T) */
+int gvk_qkv_prescale_bf16(void* qkv, int rows, int H, int ld_qkv, float scale, void* stream);
 
-/* backward: dqkv bf16 [B*T][ld_qkv] = [dq | dk | dv] in the qkv layout, from qkv, out (forward output, for
- * delta = rowsum(dout*out)), dout and lse.  delta f32 [B][H][T] is scratch.  Deterministic (no atomics). */
+/* backward: dqkv bf16 [B*T][ld_qkv] = [dq | dk | dv] in the qkv layout -- gradients of the UNSCALED q, k, v (what the to_qkv dgrad
+ * consumes) -- from qkv (q block pre-scaled as above), out (forward output, for delta = rowsum(dout*out)), dout and lse.  delta f32 [B][H][T] is scratch.  Deterministic (no atomics). */
 int gvk_attention_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                            int B, int T, int H, int ld_qkv, int ld_out, float scale, void* stream);
 /* the same with nn.Dropout(drop_p) on the attention probabilities (vision_transformer.py:52,68 -- live in training for the methods
@@ -397,6 +405,8 @@ typedef struct gvk_ssf_colgrad_desc {
   const void* dy; const void* y0; const float* y1; const float* pos;
   const float* s; const float* t; float* ds; float* dt; float* scratch;
   int32_t M, N, ld_dy, ld_y, dy_f32, y0_f32, rows_in, rows_out, row_off;
+  int32_t y0_cols;   /* columns n < y0_cols of y0 are multiplied by y0_mul when read: undoes the attention pre-scale of the q block of a saved */
+  float y0_mul;      /* qkv (gvk_gemm_desc.scale_cols), y0_mul = 1 / col_scale; 0 columns = off */
 } gvk_ssf_colgrad_desc;
 int gvk_ssf_fold_weight(const float* w, const float* s, void* out, void* out_t, int N, int K, int out_f32, void* stream);
 int gvk_ssf_fold_vec(const float* a, const float* s, const float* t, float* out, int n, void* stream);

@@ -77,6 +77,32 @@ def test_gemm_epilogues(dev):
     assert (act[:M].cpu().double() - want).abs().max().item() < 2 ** -6 * want.abs().max().item()
 
 
+@pytest.mark.parametrize("M,N,K,tile", [(1033, 768, 192, 0), (4132, 2304, 768, 0), (4132, 2304, 768, 128128), (300, 576, 192, 64064)])
+def test_gemm_store_bf16_column_scale(dev, M, N, K, tile):
+    """gvk_gemm_desc.scale_cols: the first N/3 columns (the q block of a qkv projection) leave the STORE_BF16 epilogue as
+    (acc + bias) * col_scale with ONE rounding -- bit for bit the bf16 of the fp32 product -- and the other columns are untouched.
+    Covers the eight-phase 256 x 256 kernel (the auto choice at M = 4132, N = 2304) and the four-wave tiles."""
+    from gaviko_amd import ops
+    a = _bf16_round(_rand((M, K), 15))
+    w = _bf16_round(_rand((N, K), 16, 2 / math.sqrt(K)))
+    bias = _rand((N,), 17, 0.2)
+    A = ops.act_zeros(M, K, torch.bfloat16, dev)
+    A[:M] = a.to(dev).bfloat16()
+    W = w.to(dev).bfloat16().contiguous()
+    cs = 0.125 * 1.4426950408889634
+    plain, scaled = ops.act_zeros(M, N, torch.bfloat16, dev), ops.act_zeros(M, N, torch.bfloat16, dev)
+    f32 = ops.act_zeros(M, N, torch.float32, dev)
+    ops.gemm_nt(A, W, M, plain, epilogue=ops.EPI_STORE_BF16, bias=bias.to(dev), tile=tile)
+    ops.gemm_nt(A, W, M, scaled, epilogue=ops.EPI_STORE_BF16, bias=bias.to(dev), tile=tile, scale_cols=N // 3, col_scale=cs)
+    ops.gemm_nt(A, W, M, f32, epilogue=ops.EPI_STORE_F32, bias=bias.to(dev), tile=tile)
+    assert torch.equal(scaled[:M, N // 3:], plain[:M, N // 3:])
+    want = (f32[:M, : N // 3] * cs).bfloat16()                # same fp32 accumulator, same fp32 multiply, one rounding
+    assert torch.equal(scaled[:M, : N // 3], want)
+    assert (scaled[M:] == 0).all()
+    with pytest.raises(Exception, match="scale_cols"):
+        ops.gemm_nt(A, W, M, f32, epilogue=ops.EPI_STORE_F32, scale_cols=N // 3, col_scale=cs)
+
+
 def test_patch_embed_path(dev):
     """patchify + GEMM(PATCH epilogue) == conv3d + flatten/transpose + pos, scattered into [P+1 .. ] rows."""
     from gaviko_amd import ops
@@ -178,46 +204,103 @@ def test_casts(dev):
     assert torch.equal(t.cpu(), x.t().contiguous().bfloat16())
 
 
+ATTN_C = 0.125 * 1.4426950408889634       # what the q block carries when it reaches the bf16 attention kernels: q * scale * log2(e)
+
+
 def _attn_ref(qkv, B, T, H):
     q, k, v = (t.reshape(B, T, H, 64).permute(0, 2, 1, 3) for t in qkv.double().chunk(3, dim=-1))
     s = q @ k.transpose(-1, -2) * 0.125
     return (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B, T, H * 64), torch.logsumexp(s, -1)
 
 
+def _attn_operands(qkv32, H):
+    """fp32 q | k | v -> (device operand bf16 [.., 3*H*64] with the q block pre-scaled by scale*log2(e) and rounded ONCE, as the qkv GEMM's
+    epilogue delivers it; the float64 q | k | v those operands represent exactly -- what the reference attends over)."""
+    inner = H * 64
+    dev_op = qkv32.clone()
+    dev_op[..., :inner] *= ATTN_C
+    dev_op = dev_op.bfloat16()
+    exact = dev_op.double()
+    exact[..., :inner] /= ATTN_C
+    return dev_op, exact
+
+
+@pytest.mark.parametrize("amp", [1.0, 2.5])
 @pytest.mark.parametrize("B,T,H", [(2, 1033, 3), (1, 1001, 12), (3, 65, 2), (1, 393, 3), (2, 128, 1)])
-def test_attention_fwd(dev, B, T, H):
+def test_attention_fwd(dev, B, T, H, amp):
+    """amp = standard deviation of the q / k / v entries (2.5: scores up to +-50, far hotter than any layer of the model).  The operand is
+    what the engine hands the kernel: the q block pre-scaled by scale*log2(e) with ONE rounding to bf16; the reference attends over
+    exactly the values those bf16 operands represent."""
     from gaviko_amd import ops
     inner = H * 64
-    qkv = _bf16_round(_rand((B, T, 3 * inner), 51, 2.5))
-    ref, lse_ref = _attn_ref(qkv, B, T, H)
+    op, exact = _attn_operands(_rand((B, T, 3 * inner), 51, amp), H)
+    ref, lse_ref = _attn_ref(exact, B, T, H)
     Q = ops.act_zeros(B * T, 3 * inner, torch.bfloat16, dev)
-    Q[: B * T] = qkv.reshape(B * T, -1).to(dev).bfloat16()
+    Q[: B * T] = op.reshape(B * T, -1).to(dev)
     O = ops.act_zeros(B * T, inner, torch.bfloat16, dev)
     lse = torch.zeros((B, H, T), device=dev)
+    ops.attention_fwd(Q, O, lse, B, T, H, 0.125, q_prescaled=True)
+    torch.cuda.synchronize()
+    got = O[: B * T].view(B, T, inner).cpu().double()
+    lse_err, o_err = (lse.cpu().double() - lse_ref).abs().max().item(), (got - ref).abs().max().item()
+    print(f"attention_fwd B={B} T={T} H={H} amp={amp}: lse err {lse_err:.2e}, O err {o_err:.2e} (|O| max {ref.abs().max().item():.2f})")
+    assert lse_err < 2e-3
+    assert o_err < 1.5e-2 * max(1.0, ref.abs().max().item())
+    # a raw qkv through the convenience path (ops makes the pre-scaled copy: one more rounding of q, hence the looser lse bound)
+    raw = _bf16_round(_rand((B, T, 3 * inner), 51, amp))
+    ref2, lse2 = _attn_ref(raw, B, T, H)
+    Q[: B * T] = raw.reshape(B * T, -1).to(dev).bfloat16()
     ops.attention_fwd(Q, O, lse, B, T, H, 0.125)
+    assert (lse.cpu().double() - lse2).abs().max().item() < (2e-3 if amp <= 1.0 else 1e-2)
+    assert (O[: B * T].view(B, T, inner).cpu().double() - ref2).abs().max().item() < 1.5e-2 * max(1.0, ref2.abs().max().item())
+
+
+@pytest.mark.parametrize("step", [3.0, 1.0, 0.25])
+def test_attention_fwd_forced_rescale(dev, step):
+    """Online-softmax rescale branch: one key per tile dominates, with the max growing tile after tile.  The kernel raises its running
+    maximum only when a tile exceeds it by more than 8 log2 units (attention_fwd.hip kThr): step 3.0 crosses that at every spike (the
+    slow path each time), step 1.0 every third spike (deferred in between: P up to 2^8 at the stale maximum), step 0.25 never after the
+    first (everything accumulated against a maximum that is up to ~2.6 log2 units stale)."""
+    from gaviko_amd import ops
+    B, T, H = 1, 300, 1
+    qkv = _bf16_round(_rand((B, T, 192), 52, 0.5))
+    for j, t in enumerate((10, 70, 110, 140, 200, 250, 299)):
+        qkv[0, t, 64:128] = qkv[0, 5, 0:64] * (4.0 + step * j)     # key t aligned with query 5, growing
+    op, exact = _attn_operands(qkv, H)
+    ref, lse_ref = _attn_ref(exact, B, T, H)
+    Q = ops.act_zeros(T, 192, torch.bfloat16, dev)
+    Q[:T] = op.reshape(T, -1).to(dev)
+    O = ops.act_zeros(T, 64, torch.bfloat16, dev)
+    lse = torch.zeros((1, 1, T), device=dev)
+    ops.attention_fwd(Q, O, lse, B, T, H, 0.125, q_prescaled=True)
+    got = O[:T].view(1, T, 64).cpu().double()
+    assert (got - ref).abs().max().item() < 1.5e-2 * max(1.0, ref.abs().max().item())
+    assert (lse.cpu().double() - lse_ref).abs().max().item() < 5e-3
+
+
+@pytest.mark.parametrize("var", [0, 1, 2, 3])
+@pytest.mark.parametrize("kb", [96, 128])
+@pytest.mark.parametrize("T", [1033, 1001, 97, 31])
+def test_attention_fwd_key_tiles(dev, monkeypatch, T, kb, var):
+    """Both key-tile sizes on every sequence length class (the launcher picks the one that pads less; GAVIKO_HIP_ATTN_KB forces one):
+    the last tile's key mask rides the augmented MFMA, rows past the sequence are staged from clamped addresses."""
+    from gaviko_amd import ops
+    monkeypatch.setenv("GAVIKO_HIP_ATTN_KB", str(kb))
+    monkeypatch.setenv("GAVIKO_HIP_ATTN_VAR", str(var))        # bit 0: row sums on the matrix pipe; bit 1: LDS-DMA spread over the S^T blocks
+    B, H = 2, 2
+    inner = H * 64
+    op, exact = _attn_operands(_rand((B, T, 3 * inner), 57 + T, 2.0), H)
+    ref, lse_ref = _attn_ref(exact, B, T, H)
+    Q = ops.act_zeros(B * T, 3 * inner, torch.bfloat16, dev)
+    Q[: B * T] = op.reshape(B * T, -1).to(dev)
+    O = ops.act_zeros(B * T, inner, torch.bfloat16, dev)
+    lse = torch.zeros((B, H, T), device=dev)
+    ops.attention_fwd(Q, O, lse, B, T, H, 0.125, q_prescaled=True)
     torch.cuda.synchronize()
     got = O[: B * T].view(B, T, inner).cpu().double()
     assert (lse.cpu().double() - lse_ref).abs().max().item() < 2e-3
     assert (got - ref).abs().max().item() < 1.5e-2 * max(1.0, ref.abs().max().item())
-
-
-def test_attention_fwd_forced_rescale(dev):
-    """Online-softmax rescale branch: one key per tile dominates, with the max growing tile after tile."""
-    from gaviko_amd import ops
-    B, T, H = 1, 300, 1
-    qkv = _bf16_round(_rand((B, T, 192), 52, 0.5))
-    for j, t in enumerate((10, 70, 140, 200, 299)):
-        qkv[0, t, 64:128] = qkv[0, 5, 0:64] * (4.0 + 3.0 * j)     # key t aligned with query 5, growing
-    qkv = _bf16_round(qkv)
-    ref, lse_ref = _attn_ref(qkv, B, T, H)
-    Q = ops.act_zeros(T, 192, torch.bfloat16, dev)
-    Q[:T] = qkv.reshape(T, -1).to(dev).bfloat16()
-    O = ops.act_zeros(T, 64, torch.bfloat16, dev)
-    lse = torch.zeros((1, 1, T), device=dev)
-    ops.attention_fwd(Q, O, lse, B, T, H, 0.125)
-    got = O[:T].view(1, T, 64).cpu().double()
-    assert (got - ref).abs().max().item() < 1.5e-2 * max(1.0, ref.abs().max().item())
-    assert (lse.cpu().double() - lse_ref).abs().max().item() < 5e-3
+    assert torch.isfinite(O.float()).all() and (O[B * T:] == 0).all()          # padding rows of the output stay untouched
 
 
 # ---- fp32 compute path (BASELINE cfg4: fp32, tolerance 1e-5) ------------------------------------------------------------

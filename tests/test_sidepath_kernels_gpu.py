@@ -26,30 +26,43 @@ def _close(got, want, rtol, name=""):
     assert err <= rtol * ref, f"{name}: max err {err:.3e} vs scale {ref:.3e} (tol {rtol})"
 
 
-@pytest.mark.parametrize("B,T,H", [(2, 1033, 3), (1, 1001, 2), (2, 65, 1), (1, 393, 3)])
-def test_attention_bwd(dev, B, T, H):
+@pytest.mark.parametrize("kb", [0, 96, 128])
+@pytest.mark.parametrize("B,T,H", [(2, 1033, 3), (1, 1001, 2), (2, 65, 1), (1, 393, 3), (1, 31, 2)])
+def test_attention_bwd(dev, monkeypatch, B, T, H, kb):
+    """kb: tile size of both passes (0 = the launcher's choice: whichever pads the sequence less)."""
     from gaviko_amd import ops
+    if kb:
+        monkeypatch.setenv("GAVIKO_HIP_ATTN_KB", str(kb))
     inner = H * 64
-    qkv = _bf(_rand((B, T, 3 * inner), 61, 2.0)).requires_grad_(True)
+    C_ = 0.125 * 1.4426950408889634
+    # device operand: q block pre-scaled by scale*log2(e), ONE rounding (what the qkv GEMM's epilogue writes); the reference differentiates
+    # attention over exactly the q, k, v those bf16 values represent, with respect to the UNSCALED q
+    raw = _rand((B, T, 3 * inner), 61, 2.0)
+    op = raw.clone(); op[..., :inner] *= C_
+    op = op.bfloat16()
+    exact = op.double(); exact[..., :inner] /= C_
+    qkv = exact.clone().requires_grad_(True)
     dO = _bf(_rand((B, T, inner), 62, 1.0))
     q, k, v = (t.reshape(B, T, H, 64).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=-1))
     s = q @ k.transpose(-1, -2) * 0.125
     o = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B, T, inner)
     o.backward(dO)
     Q = ops.act_zeros(B * T, 3 * inner, torch.bfloat16, dev)
-    Q[: B * T] = qkv.detach().reshape(B * T, -1).to(dev).bfloat16()
+    Q[: B * T] = op.reshape(B * T, -1).to(dev)
     O = ops.act_zeros(B * T, inner, torch.bfloat16, dev)
     lse = torch.zeros((B, H, T), device=dev)
-    ops.attention_fwd(Q, O, lse, B, T, H, 0.125)
+    ops.attention_fwd(Q, O, lse, B, T, H, 0.125, q_prescaled=True)
     DO = ops.act_zeros(B * T, inner, torch.bfloat16, dev)
     DO[: B * T] = dO.reshape(B * T, -1).to(dev).bfloat16()
     DQ = ops.act_zeros(B * T, 3 * inner, torch.bfloat16, dev)
     delta = torch.zeros((B, H, T), device=dev)
-    ops.attention_bwd(Q, O, DO, lse, delta, DQ, B, T, H, 0.125)
+    ops.attention_bwd(Q, O, DO, lse, delta, DQ, B, T, H, 0.125, q_prescaled=True)
     torch.cuda.synchronize()
     got = DQ[: B * T].view(B, T, 3 * inner).cpu().double()
     want = qkv.grad
     for name, sl in (("dq", slice(0, inner)), ("dk", slice(inner, 2 * inner)), ("dv", slice(2 * inner, 3 * inner))):
+        e = (got[..., sl] - want[..., sl]).abs().max().item() / want[..., sl].abs().max().item()
+        print(f"attention_bwd B={B} T={T} H={H} kb={kb} {name}: rel err {e:.2e}")
         _close(got[..., sl], want[..., sl], 2.5e-2, name)
 
 
