@@ -31,11 +31,14 @@
 namespace gvk {
 
 // tools/probe/probe_attn.hip compiles this file with GVK_STAMPS: shader-clock stamps of ONE steady-state key tile (kt == 4),
-// written through dr.seed_ptr (unused without dropout) as uint64 [workgroup][wave][8].  Compiled out of the library.
+// plus kernel entry / loop start / loop end / kernel end (slots 6..9), written through dr.seed_ptr (unused without dropout) as uint64
+// [workgroup][wave][12].  Compiled out of the library.
 #ifdef GVK_STAMPS
 #define GVK_ASTAMP(k) if (kt == 4) st_[k] = __builtin_amdgcn_s_memtime();
+#define GVK_KSTAMP(k) st_[k] = __builtin_amdgcn_s_memtime();
 #else
 #define GVK_ASTAMP(k)
+#define GVK_KSTAMP(k)
 #endif
 
 constexpr int kQB = 128;          // queries per workgroup
@@ -50,6 +53,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
   constexpr bool ONES = (VAR & 1) != 0 && !DROP;
   constexpr bool SPREAD = (VAR & 2) != 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K tile | V tile]
+#ifdef GVK_STAMPS
+  unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  GVK_KSTAMP(6)
   int bh, qb;
   xcd_group_block(blockIdx.x, (T + kQB - 1) / kQB, gridDim.x / ((T + kQB - 1) / kQB), bh, qb);   // all query blocks of a (batch, head) on one XCD
   const int b = bh / H, head = bh - b * H, q0 = qb * kQB;
@@ -109,12 +116,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
   [[maybe_unused]] const bf16 one_ = (bf16)1.0f;
   [[maybe_unused]] const bf16x8 ones = {one_, one_, one_, one_, one_, one_, one_, one_};
 
-#ifdef GVK_STAMPS
-  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
 #pragma unroll
   for (int r = 0; r < NKB; ++r) stage_piece(0, 0, r);
   __syncthreads();
+  GVK_KSTAMP(7)
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     GVK_ASTAMP(0)
@@ -254,13 +259,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
     __syncthreads();
     GVK_ASTAMP(5)
   }
-#ifdef GVK_STAMPS
-  if (dr.seed_ptr != nullptr && lane == 0) {
-    unsigned long long* o = (unsigned long long*)dr.seed_ptr + ((size_t)blockIdx.x * 4 + wave) * 8;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = st_[k];
-  }
-#endif
+  GVK_KSTAMP(8)
 
   // ---- epilogue: O[q][d] = O^T / l through a wave-private 4 KB LDS image (32 rows of 128 B, 16-B chunk c of row q at c ^ (q & 7)),
   //      then whole rows out: 8 lanes x 16 B per row, 8 rows per store instruction.  lse = ln(sum exp(s*scale))
@@ -272,6 +271,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
   store_rows_t(ot, 1.0f / l_tot, smem + wave * 4096, out + ((size_t)b * T + qw) * ld_out + head * 64, (size_t)ld_out, T - qw, lane);
   const int q = qw + r31;
   if (q < T && hh == 0 && lse != nullptr) lse[((size_t)b * H + head) * T + q] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.69314718055994530942f;
+#ifdef GVK_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);                     // stores retired
+  GVK_KSTAMP(9)
+  if (dr.seed_ptr != nullptr && lane == 0) {
+    unsigned long long* o = (unsigned long long*)dr.seed_ptr + ((size_t)blockIdx.x * 4 + wave) * 12;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) o[k] = st_[k];
+  }
+#endif
 }
 
 }  // namespace gvk
