@@ -65,20 +65,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16* __res
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)d_o, 0, nB * T * ld_o * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(wave < 2 ? lse : delta), 0, nB * H * T * 4, 0x00020000);
   const int rsub = lane >> 3, slot = lane & 7;
-  int voq[NSB], voq_last[NSB], vod[NSB], vod_last[NSB];
+  int voq[NSB], vod[NSB];
 #pragma unroll
   for (int r = 0; r < NSB; ++r) {
     const int row = r * 32 + wave * 8 + rsub;
     const int col = head * 64 + ((slot ^ attn_swz(row)) << 3);
-    const int over = max((nqt - 1) * QT + row - (T - 1), 0);      // rows past the end step back to row T-1 (finite; masked by the row flag)
     voq[r] = ((b * T + row) * ld_qkv + col) * 2;
-    voq_last[r] = ((b * T + row - over) * ld_qkv + col) * 2;
     vod[r] = ((b * T + row) * ld_o + col) * 2;
-    vod_last[r] = ((b * T + row - over) * ld_o + col) * 2;
   }
   const int lrow = (wave & 1) * 64 + lane;                         // row of the tile whose constant this lane fetches
   const int vol = ((b * H + head) * T + lrow) * 4;
-  const int vol_last = ((b * H + head) * T + lrow - max((nqt - 1) * QT + lrow - (T - 1), 0)) * 4;
   auto stage = [&](int buf, int qt) {
     char* sQ = smem + buf * kBuf;
     char* sD = sQ + kTileQ;
@@ -89,11 +85,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16* __res
     const int soq = qt * QT * ld_qkv * 2, sod = qt * QT * ld_o * 2, sol = qt * QT * 4;
 #pragma unroll
     for (int r = 0; r < NSB; ++r) {
-      const int vq = last ? voq_last[r] : voq[r], vd = last ? vod_last[r] : vod[r];
+      // only the last tile can reach past the sequence: its rows step back to row T-1 (finite; masked by the row flag), recomputed here
+      // rather than kept in registers
+      const int over = last ? max(qt * QT + r * 32 + wave * 8 + rsub - (T - 1), 0) : 0;
+      const int vq = voq[r] - over * ld_qkv * 2, vd = vod[r] - over * ld_o * 2;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (GVK_LDS void*)(sQ + (r * 32 + wave * 8) * 128), 16, vq, soq, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (GVK_LDS void*)(sD + (r * 32 + wave * 8) * 128), 16, vd, sod, 0, 0);
     }
-    const int vl = last ? vol_last : vol;
+    const int overl = last ? max(qt * QT + lrow - (T - 1), 0) : 0;
+    const int vl = vol - overl * 4;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (GVK_LDS void*)(sL + (wave >> 1) * 512 + (wave & 1) * 256), 4, vl, sol, 0, 0);
   };
 
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16* __res
 #pragma unroll
   for (int i = 0; i < 2; ++i) { dkt[i] = f32x16{}; dvt[i] = f32x16{}; }
   const bf16x8 sel_s = aug_sel_first(true, hh);      // [1, 1, 1, 1, 0...]: the query side carries -3e38 only in rows past the sequence
-  const bf16x8 sel_d = aug_sel_second(hh);           // [0, 0, 0, 0, 1, 1, 1, 0]
+  [[maybe_unused]] const bf16x8 sel_d = aug_sel_second(hh);           // [0, 0, 0, 0, 1, 1, 1, 0]
   const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
   stage(0, 0);
   __syncthreads();
@@ -112,10 +112,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16* __res
       const char* sQ0 = smem + buf * kBuf;
       const char* sD0 = sQ0 + kTileQ;
       const float* sL0 = (const float*)(sD0 + kTileQ);
-#pragma unroll
-      for (int sub = 0; sub < NSB; ++sub) {
+      // Three stages per 32-query sub-block, software-pipelined inside the wave so that the matrix pipe never waits for the VALU:
+      //   B(sub): S', dP' (10 MFMAs)   C(sub): exp2, multiply, bf16 conversion (VALU)   D(sub): dV^T, dK^T (8 MFMAs + transposed reads)
+      // issue order  B(0) | B(1) C(0) D(0) | B(2) C(1) D(1) | ... : C(sub) runs while B(sub+1) executes, B(sub+2) is issued behind D(sub).
+      auto scores = [&](int sub, f32x16& s, f32x16& dp) {
         const int qrow0 = qt * QT + sub * 32;
-        if (qrow0 >= T) break;                               // wave-uniform: sub-block entirely past the sequence
         const char* sQ = sQ0 + sub * 32 * 128;               // (32 rows = a multiple of the swizzle period 16)
         const char* sD = sD0 + sub * 32 * 128;
         // constant side of the augmented MFMAs: this lane's query row r31 -> [-lse*log2e pieces, row >= T ? -3e38 : 0, -delta pieces, 0]
@@ -123,8 +124,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16* __res
         const float dl = DROP ? 0.f : sL0[128 + sub * 32 + r31];   // with dropout delta is subtracted after the mask (dS = P.(M.dP - delta))
         const bf16x8 qaug = aug_const(l2, qrow0 + r31 >= T, dl, hh);
         // S'[q][key] = Q'.K^T - lse2 ;  dP'[q][key] = dO.V^T - delta
-        f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qaug, sel_s, f32x16{}, 0, 0, 0);
-        f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qaug, sel_d, f32x16{}, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qaug, sel_s, f32x16{}, 0, 0, 0);
+        if constexpr (DROP) dp = f32x16{};                   // (delta is subtracted behind the mask)
+        else dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qaug, sel_d, f32x16{}, 0, 0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const int chunk = 2 * ks + hh;
@@ -133,7 +135,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16* __res
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
         }
-        // P = exp2(S');  dS = P * dP'
+      };
+      // P = exp2(S');  dS = P * dP'  ->  bf16 B operands of the gradient products
+      auto soft = [&](int sub, f32x16& s, f32x16& dp) {
+        [[maybe_unused]] const int qrow0 = qt * QT + sub * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float pr = __builtin_amdgcn_exp2f(s[r]);
@@ -148,7 +153,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16* __res
             dp[r] = pr * dp[r];
           }
         }
-        // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]   (k = q, accumulator row order)
+      };
+      // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key]   (k = q, accumulator row order)
+      auto grads = [&](int sub, const f32x16& s, const f32x16& dp) {
+        const char* sQ = sQ0 + sub * 32 * 128;
+        const char* sD = sD0 + sub * 32 * 128;
 #pragma unroll
         for (int sk = 0; sk < 2; ++sk) {
           bf16x8 pf, dsf;
@@ -169,6 +178,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16* __res
             dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, dsf, dkt[db], 0, 0, 0);
           }
         }
+      };
+      constexpr bool PIPE = !DROP;                           // (the dropout variant's mask arithmetic leaves no registers for two score tiles)
+      f32x16 sc[PIPE ? 2 : 1], dpc[PIPE ? 2 : 1];
+      if constexpr (PIPE) scores(0, sc[0], dpc[0]);
+#pragma unroll
+      for (int sub = 0; sub < NSB; ++sub) {
+        const bool more = sub + 1 < NSB && qt * QT + (sub + 1) * 32 < T;     // wave-uniform: the next sub-block holds rows of the sequence
+        constexpr int kCurMask = PIPE ? 1 : 0;
+        const int cur = sub & kCurMask;
+        if constexpr (PIPE) {
+          if (more) scores(sub + 1, sc[(sub + 1) & kCurMask], dpc[(sub + 1) & kCurMask]);
+        } else {
+          scores(sub, sc[0], dpc[0]);
+        }
+        if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
+        soft(sub, sc[cur], dpc[cur]);
+        if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
+        grads(sub, sc[cur], dpc[cur]);
+        if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
+        if (!more) break;
       }
     }
     __syncthreads();
@@ -221,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
   // constant side of the augmented MFMAs (this lane's query): [-lse*log2e pieces, -3e38, -delta pieces, 0]
   const float l2 = lse[((size_t)b * H + head) * T + qc] * 1.44269504088896340736f;
   const bf16x8 qaug = aug_const(l2, true, DROP ? 0.f : del, hh);
-  const bf16x8 sel_d = aug_sel_second(hh);
+  [[maybe_unused]] const bf16x8 sel_d = aug_sel_second(hh);
 
   const int nkt = (T + KB - 1) / KB;
   const int nB = (int)gridDim.x / (((T + 127) / 128) * H);
@@ -259,12 +288,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
     if (active) {
       const char* sK = smem + buf * 2 * kTileBytes;
       const char* sV = sK + kTileBytes;
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
+      // the same three-stage pipeline as the dK/dV pass, over the 32-key blocks of the tile:
+      //   B(kb): S'^T, dP'^T (10 MFMAs)   C(kb): dS^T = exp2(S'^T) * dP'^T, bf16 (VALU)   D(kb): dQ^T += K^T.dS^T (4 MFMAs + transposed reads)
+      auto scores = [&](int kb, f32x16& st, f32x16& dpt) {
         const int row = kb * 32 + r31;
         const bf16x8 sel_s = aug_sel_first(kt * KB + row >= T, hh);        // [1, 1, 1, key >= T, 0...]
-        f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel_s, qaug, f32x16{}, 0, 0, 0);
-        f32x16 dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel_d, qaug, f32x16{}, 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel_s, qaug, f32x16{}, 0, 0, 0);
+        if constexpr (DROP) dpt = f32x16{};
+        else dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel_d, qaug, f32x16{}, 0, 0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const int chunk = 2 * ks + hh;
@@ -274,7 +305,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
           st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], st, 0, 0, 0);
           dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ks], dpt, 0, 0, 0);
         }
-        // dS^T = exp2(S'^T) * dP'^T
+      };
+      auto soft = [&](int kb, f32x16& st, f32x16& dpt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float dpv = dpt[r];
@@ -284,12 +316,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
           }
           st[r] = __builtin_amdgcn_exp2f(st[r]) * dpv;
         }
+      };
+      auto grads = [&](int kb, const f32x16& st) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s2 = 0; s2 < 2; ++s2) {
           bf16x8 dsf;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) dsf[j] = (bf16)st[8 * s + j];
-          const int key0 = kb * 32 + 16 * s + 4 * (g >> 1);
+          for (int j = 0; j < 8; ++j) dsf[j] = (bf16)st[8 * s2 + j];
+          const int key0 = kb * 32 + 16 * s2 + 4 * (g >> 1);
 #pragma unroll
           for (int db = 0; db < 2; ++db) {
             const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
@@ -300,6 +334,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
             dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt8, dsf, dqt[db], 0, 0, 0);
           }
         }
+      };
+      f32x16 sc[2], dpc[2];
+      scores(0, sc[0], dpc[0]);
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        if (kb + 1 < NKB) scores(kb + 1, sc[(kb + 1) & 1], dpc[(kb + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        soft(kb, sc[kb & 1], dpc[kb & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        grads(kb, sc[kb & 1]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
