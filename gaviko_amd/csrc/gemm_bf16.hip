@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs p) {
       const int row = (r * NW + wave) * RPI + rsub;
       const int chunk = slot ^ swz_chunk<BK>(row);
       int srow = row;
-      if constexpr (BM > 128) srow = min(row, p.a_rows - 1 - m0);     // activations are padded to 128 rows, not to the tile: re-read the last one
+      if constexpr (BM > 128 || 128 % BM != 0) srow = min(row, p.a_rows - 1 - m0);     // activations are padded to 128 rows, not to the tile: re-read the last one
       glds16(Ag + (size_t)srow * p.lda + k0 + chunk * 8, sA + (r * NW + wave) * 1024);
     }
 #pragma unroll
@@ -228,7 +228,9 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
 }
 
 static long wide_lo() {
-  static const long v = getenv("GAVIKO_HIP_GEMM_WIDE_LO") ? atol(getenv("GAVIKO_HIP_GEMM_WIDE_LO")) : 150;   // 153 tiles (the qkv shape at M = 4132) included: +0.7 % on the step
+  // 153 tiles (the qkv shape at M = 4132) included: +0.7 % on the ViT-B step; 144 tiles (fc1 / fc2 dgrad of ViT-L at M = 2066) included:
+  // 196.7 -> 200.0 volumes/s at cfg5, while 108 tiles (its qkv shape) lose on the big tile (198.0)
+  static const long v = getenv("GAVIKO_HIP_GEMM_WIDE_LO") ? atol(getenv("GAVIKO_HIP_GEMM_WIDE_LO")) : 140;
   return v;
 }
 
@@ -261,7 +263,23 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
       // single wave's latency chain is not what bounds the loop.  Opt-in.
       static const bool k2 = getenv("GAVIKO_HIP_GEMM_K2") != nullptr && getenv("GAVIKO_HIP_GEMM_K2")[0] == '1';
       static const bool k4 = getenv("GAVIKO_HIP_GEMM_K4") != nullptr && getenv("GAVIKO_HIP_GEMM_K4")[0] == '1';       // gemm_k4_bf16.hip, A/B switch
-      if (n768 == 3128) tile = t128 <= t64_hi ? 3064128 : (k4 && gemm_k4_supports(EPI) ? 4128128 : k2 && gemm_k2_supports(EPI) && a.K >= 192 ? 9128128 : 3128128);
+      if (n768 == 3128) {
+        // One workgroup per CU, three stages: the tile's life is bound by its own L2 -> LDS bytes, (BM + 128) per k-step, and a launch takes
+        // ceil(tiles / 256) such lives.  Row tile = the one of {128, 96, 64} with the smallest rounds x (BM + 128):
+        //   M = 4132, N = 768 : 198 / 264 / 390 tiles -> 128 (one round of 256);   M = 2066, N = 768 : 102 / 132 / 198 -> 64 (one round of 192)
+        //   M = 2066, N = 1024 (ViT-L, B = 2): 136 / 176 / 264 -> 96 (one round of 224; 64-row tiles would need two)
+        long best = -1; int best_bm = 128;
+        for (int cand : {128, 96, 64}) {
+          const long tiles = (long)((a.M + cand - 1) / cand) * (a.N / 128);
+          const long cost = ((tiles + 255) / 256) * (cand + 128);
+          if (best < 0 || cost < best) { best = cost; best_bm = cand; }
+        }
+        static const int force_bm = getenv("GAVIKO_HIP_GEMM_BM") ? atoi(getenv("GAVIKO_HIP_GEMM_BM")) : 0;      // A/B switch: 128 / 96 / 64
+        if (force_bm == 128 || force_bm == 96 || force_bm == 64) best_bm = force_bm;
+        else if (t128 <= t64_hi && best_bm == 128) best_bm = 64;                                           // (the round-2 rule, kept for the shapes it was tuned on)
+        tile = best_bm == 64 ? 3064128 : best_bm == 96 ? 3096128
+             : (k4 && gemm_k4_supports(EPI) ? 4128128 : k2 && gemm_k2_supports(EPI) && a.K >= 192 ? 9128128 : 3128128);
+      }
       else if (n768 == 128) tile = 128128;
       else if (n768 == 3064) tile = 3064128;
     }
@@ -286,6 +304,7 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     case 9128128: return launch_gemm_k2(a, EPI, stream);         // 128 x 128, eight waves splitting every k-tile, three LDS stages
     case 3128128: return launch_gemm<128, 128, EPI, false, 3>(a, stream);
     case 3064128: return launch_gemm<64, 128, EPI, false, 3>(a, stream);     // 64 x 128 with three stages (A/B switch GAVIKO_HIP_GEMM_N768=3064)
+    case 3096128: return launch_gemm<96, 128, EPI, false, 3>(a, stream);     // 96 x 128 with three stages (M = 2066, N = 1024: 176 tiles in one round)
     case 256256:
       if constexpr (EPI == GVK_EPI_STORE_BF16 || EPI == GVK_EPI_BIAS_GELU_BF16 || EPI == GVK_EPI_GELU_BWD_BF16) return launch_gemm<256, 256, EPI, false, 2, 8>(a, stream);
       else return set_error(-2, "gvk_gemm_nt_bf16: the 256x256 tile is built for STORE_BF16, BIAS_GELU_BF16 and GELU_BWD_BF16");

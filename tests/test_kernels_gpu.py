@@ -20,7 +20,10 @@ def _bf16_round(x):
 @pytest.mark.parametrize("M,N,K,tile", [(300, 192, 192, 0), (1033, 768, 768, 128128), (1033, 768, 768, 64064),
                                         (2066, 2304, 768, 0), (517, 576, 192, 128064), (517, 768, 3072, 64128),
                                         (517, 768, 3072, 3128128), (300, 256, 64, 3128128), (300, 256, 128, 3128128), (1033, 768, 192, 3128128),
-                                        (4132, 768, 768, 0), (4132, 768, 3072, 0)])
+                                        (4132, 768, 768, 0), (4132, 768, 3072, 0),
+                                        # 96-row three-stage tiles: M = 128 k (the last row tile reaches past the 128-row padding of A and clamps),
+                                        # the ViT-L B = 2 shapes that pick it (176 tiles in one round), a ragged M
+                                        (256, 256, 512, 3096128), (2066, 1024, 1024, 3096128), (2066, 1024, 4096, 0), (1001, 128, 576, 3096128)])
 def test_gemm_store_bf16_and_f32(dev, M, N, K, tile):
     from gaviko_amd import ops
     a = _bf16_round(_rand((M, K), 1))
