@@ -211,11 +211,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--launch-check", action="store_true", help="every rank reports its launcher environment and exits before any GPU call (tests)")
-    ap.add_argument("--allow-ablate", action="store_true", help="diagnostics only: run with GAVIKO_HIP_ABLATE set; the output line is marked INVALID")
+    ap.add_argument("--allow-diag", "--allow-ablate", dest="allow_diag", action="store_true",
+                    help="diagnostics only: run on the measurement build (GAVIKO_HIP_DIAG=1: A/B switches and timing ablations live there); the "
+                         "output line is marked INVALID")
     args = ap.parse_args()
-    if os.environ.get("GAVIKO_HIP_ABLATE") and not args.allow_ablate:
-        raise SystemExit("bench.py: GAVIKO_HIP_ABLATE is set -- the timing ablations compute WRONG results, so this is not a benchmark; unset it "
-                         "(or pass --allow-ablate: the line is then marked INVALID)")
+    if os.environ.get("GAVIKO_HIP_DIAG", "0") == "1" and not args.allow_diag:
+        raise SystemExit("bench.py: GAVIKO_HIP_DIAG=1 selects the measurement build (A/B switches, timing ablations that compute WRONG results): "
+                         "not a benchmark; unset it (or pass --allow-diag: the line is then marked INVALID)")
 
     if args.gpus > 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         raise SystemExit(spawn_ranks(args.gpus))              # bare `python bench.py --gpus N`: the ranks are started here, before any GPU call
@@ -309,8 +311,8 @@ def main():
                                   f"{'CrossEntropy' if args.loss == 'ce' else 'Focal(1.2)'} + bwd (frozen ViT; prompts+MWSA+GPA+head train), "
                                   f"attn_drop=proj_drop=0.2 live, grads all-reduced over {world} rank(s)",
                       "global_batch": world * B, "tokens": 1033, "parallelism": f"dp{world}"}}
-    if os.environ.get("GAVIKO_HIP_ABLATE"):
-        out["INVALID_timing_ablation"] = os.environ["GAVIKO_HIP_ABLATE"]
+    if os.environ.get("GAVIKO_HIP_DIAG", "0") == "1":
+        out["INVALID_measurement_build"] = {k: v for k, v in os.environ.items() if k.startswith("GAVIKO_HIP_")}
     gf = GF_PER_VOLUME.get(args.backbone)
     if gf:
         out["mfma_roofline_frac_whole_step"] = round(vps / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)

@@ -15,6 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libgaviko_hip.so")
+LIB_DIAG = os.path.join(HERE, "libgaviko_hip_diag.so")
+# experiment kernels (measured, not faster) and diagnostics: compiled into the diag library only (include/gaviko_hip_diag.h)
+DIAG_ONLY = {"gemm_k2_bf16.hip", "gemm_k4_bf16.hip", "patch_gemm.hip"}
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
@@ -40,20 +43,26 @@ def _newer(src_list, target) -> bool:
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(HERE, "..", "include", "gaviko_hip.h")]
-    os.makedirs(OBJ, exist_ok=True)
+def build(force: bool = False, verbose: bool = True, diag: bool = False) -> str:
+    """diag=False: the product library (no A/B switches, no experiment kernels).  diag=True: libgaviko_hip_diag.so = every source with
+    -DGVK_DIAG, for tools/ (GAVIKO_HIP_DIAG=1)."""
+    srcs = sorted(s for s in glob.glob(os.path.join(CSRC, "*.hip")) if diag or os.path.basename(s) not in DIAG_ONLY)
+    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(HERE, "..", "include", "gaviko_hip.h"),
+                                                              os.path.join(HERE, "..", "include", "gaviko_hip_diag.h")]
+    obj_dir = OBJ + ("_diag" if diag else "")
+    lib_path = LIB_DIAG if diag else LIB
+    extra = ["-DGVK_DIAG=1"] if diag else []
+    os.makedirs(obj_dir, exist_ok=True)
     cc = hipcc()
     jobs = []
     for s in srcs:
-        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
+        o = os.path.join(obj_dir, os.path.basename(s)[:-4] + ".o")
         if force or _newer([s] + hdrs + [os.path.abspath(__file__)], o):
             jobs.append((s, o))
 
     def compile_one(job):
         s, o = job
-        cmd = [cc, *FLAGS, *FILE_FLAGS.get(os.path.basename(s), []), "-c", s, "-o", o]
+        cmd = [cc, *FLAGS, *extra, *FILE_FLAGS.get(os.path.basename(s), []), "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return s, r.returncode, r.stdout + r.stderr
 
@@ -66,21 +75,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
                     print(out, file=sys.stderr)
                 if rc:
                     raise RuntimeError(f"hipcc failed on {s}")
-    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs]
-    if force or jobs or _newer(objs, LIB):
-        cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    objs = [os.path.join(obj_dir, os.path.basename(s)[:-4] + ".o") for s in srcs]
+    if force or jobs or _newer(objs, lib_path):
+        cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib_path, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             print(r.stdout + r.stderr, file=sys.stderr)
-            raise RuntimeError("link of libgaviko_hip.so failed")
+            raise RuntimeError(f"link of {os.path.basename(lib_path)} failed")
         # a kernel template whose host stub was silently dropped by the compiler shows up only as an undefined symbol at load time:
         # resolve every symbol now (fresh interpreter, RTLD_NOW) so that such a build fails HERE and not on the GPU box
-        r = subprocess.run([sys.executable, "-c", f"import ctypes, os; ctypes.CDLL({LIB!r}, mode=os.RTLD_NOW)"], capture_output=True, text=True)
+        r = subprocess.run([sys.executable, "-c", f"import ctypes, os; ctypes.CDLL({lib_path!r}, mode=os.RTLD_NOW)"], capture_output=True, text=True)
         if r.returncode:
             print(r.stdout + r.stderr, file=sys.stderr)
-            raise RuntimeError("libgaviko_hip.so does not load (undefined symbol?)")
-    return LIB
+            raise RuntimeError(f"{os.path.basename(lib_path)} does not load (undefined symbol?)")
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, diag="--diag" in sys.argv))

@@ -20,7 +20,7 @@
 //   * the running maximum is only raised when a tile exceeds it by more than kThr (log2 units): the O / l rescale and the
 //     rebuild of B_aug sit in a wave-uniform slow path that a few tiles per workgroup take (P <= 2^kThr stays harmless: bf16
 //     keeps fp32's exponent range and the accumulators are fp32);
-//   * row sums either as v_add_f32 (VAR bit 0 clear) or as a third "d block" of the PV product with an all-ones A operand;
+//   * row sums as a third "d block" of the PV product with an all-ones A operand (VAR bit 0; the v_add_f32 form is kept in the diag build);
 //   * 96-key tiles when they pad the sequence less than 128-key tiles do (T = 1033: 11 x 96 = 1056 keys instead of 1152);
 //   * O leaves through LDS as whole 128-byte rows (16 B per lane) instead of 8-byte pieces at a 1.5 KB row stride.
 // LDS tile rows are 64 bf16 = 128 B; 16-B chunk c of row r sits at chunk c ^ attn_swz(r), attn_swz(r) = bit1(r)<<2 | bits3:2(r)
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
 
 namespace gvk {
 // diagnostics (tools/bench_attn.py): kernel variant forced by the environment; the library default is what launch_attn_fwd picks
-static int attn_var() { return getenv("GAVIKO_HIP_ATTN_VAR") ? atoi(getenv("GAVIKO_HIP_ATTN_VAR")) : -1; }   // read per launch: one process can A/B
+static int attn_var() { return diag_env("GAVIKO_HIP_ATTN_VAR") ? atoi(diag_env("GAVIKO_HIP_ATTN_VAR")) : -1; }   // read per launch: one process can A/B
 static int attn_kb() { return getenv("GAVIKO_HIP_ATTN_KB") ? atoi(getenv("GAVIKO_HIP_ATTN_KB")) : 0; }
 
 template <int KB, bool DROP, int VAR>
@@ -303,7 +303,9 @@ static int launch_attn_fwd_t(const void* qkv, void* out, float* lse, int B, int 
   return check_launch("attention_fwd_bf16");
 }
 
-constexpr int kAttnVarDefault = 0;
+// row sums on the matrix pipe (VAR bit 0): 724.1 / 725.7 / 725.5 against 719.9 / 718.7 / 719.9 volumes/s with v_add sums, same box, interleaved;
+// the spread LDS-DMA (bit 1) is neutral in the step (719.4 / 719.6 / 720.1) although 3 % faster in isolation
+constexpr int kAttnVarDefault = 1;
 
 template <bool DROP>
 static int launch_attn_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale, AttnDrop dr, hipStream_t stream) {
@@ -317,8 +319,10 @@ static int launch_attn_fwd(const void* qkv, void* out, float* lse, int B, int T,
   } else {
     const int var = attn_var() >= 0 ? attn_var() : kAttnVarDefault;
 #define GVK_ATTN_CASE(KB_, V_) if (kb == KB_ && var == V_) return launch_attn_fwd_t<KB_, false, V_>(qkv, out, lse, B, T, H, ld_qkv, ld_out, scale, dr, stream);
-    GVK_ATTN_CASE(96, 0) GVK_ATTN_CASE(96, 1) GVK_ATTN_CASE(96, 2) GVK_ATTN_CASE(96, 3)
-    GVK_ATTN_CASE(128, 0) GVK_ATTN_CASE(128, 1) GVK_ATTN_CASE(128, 2) GVK_ATTN_CASE(128, 3)
+    GVK_ATTN_CASE(96, kAttnVarDefault) GVK_ATTN_CASE(128, kAttnVarDefault)
+#ifdef GVK_DIAG                                          // the other variants (row sums on the matrix pipe, spread LDS-DMA): measurement build only
+    GVK_ATTN_CASE(96, 0) GVK_ATTN_CASE(96, 2) GVK_ATTN_CASE(96, 3) GVK_ATTN_CASE(128, 0) GVK_ATTN_CASE(128, 2) GVK_ATTN_CASE(128, 3)
+#endif
 #undef GVK_ATTN_CASE
     return set_error(-2, "gvk_attention_fwd_bf16: no kernel variant %d for key tile %d", var, kb);
   }

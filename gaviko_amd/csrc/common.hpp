@@ -109,6 +109,18 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
 
 }  // namespace gvk
 
+// A/B switches of the measurement builds.  The product library is compiled WITHOUT GVK_DIAG: every such switch folds to its measured-best
+// constant there and the environment is never consulted.  `python -m gaviko_amd.build --diag` builds libgaviko_hip_diag.so with GVK_DIAG
+// (plus the experiment kernels of gemm_k2 / gemm_k4 / patch_gemm and the diagnostics of include/gaviko_hip_diag.h) for tools/.
+#include <stdlib.h>
+namespace gvk {
+#ifdef GVK_DIAG
+inline const char* diag_env(const char* name) { return getenv(name); }
+#else
+inline const char* diag_env(const char*) { return nullptr; }
+#endif
+}  // namespace gvk
+
 // host-side error plumbing shared by every C-ABI entry point
 extern "C" const char* gvk_last_error(void);
 namespace gvk {
@@ -121,15 +133,10 @@ int set_error(int code, const char* fmt, ...);
 // serialises three forked branches on this runtime (tools/probe/probe_streams.hip) -- exact stream/event semantics.
 bool plan_recording();
 void plan_push(std::function<void()>&& node);
-void plan_push_launch(hipStream_t stream, std::function<void()>&& node);   // same; GAVIKO_HIP_ABLATE=sidenop swaps side-stream kernels for empty ones
-
-// LDS exclusion (runtime.hip): extra dynamic LDS for launches on a registered stream, so that its workgroups cannot share a CU with
-// the backbone kernels' (0 for every other stream)
-unsigned stream_lds_pad(hipStream_t stream, const void* kernel, unsigned lds);
+void plan_push_launch(hipStream_t stream, std::function<void()>&& node);   // same (the diag library can swap a stream's kernels for empty ones)
 
 template <typename... KArgs, typename... Args>
 inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned lds, hipStream_t stream, Args... args) {
-  lds += stream_lds_pad(stream, (const void*)kernel, lds);
   if (plan_recording())
     plan_push_launch(stream, [=]() { hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...); });
   hipLaunchKernelGGL(kernel, grid, block, lds, stream, static_cast<KArgs>(args)...);

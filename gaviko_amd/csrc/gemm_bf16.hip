@@ -230,7 +230,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
 static long wide_lo() {
   // 153 tiles (the qkv shape at M = 4132) included: +0.7 % on the ViT-B step; 144 tiles (fc1 / fc2 dgrad of ViT-L at M = 2066) included:
   // 196.7 -> 200.0 volumes/s at cfg5, while 108 tiles (its qkv shape) lose on the big tile (198.0)
-  static const long v = getenv("GAVIKO_HIP_GEMM_WIDE_LO") ? atol(getenv("GAVIKO_HIP_GEMM_WIDE_LO")) : 140;
+  static const long v = diag_env("GAVIKO_HIP_GEMM_WIDE_LO") ? atol(diag_env("GAVIKO_HIP_GEMM_WIDE_LO")) : 140;
   return v;
 }
 
@@ -242,27 +242,27 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     const long t128 = (long)((a.M + 127) / 128) * (a.N / bn);
     // A/B switch GAVIKO_HIP_GEMM_N768: 64 = 64x128 tiles (two workgroups on most CUs), 128 = 128x128 two-stage, default = 128x128
     // with three stages at one workgroup per CU
-    static const int n768 = getenv("GAVIKO_HIP_GEMM_N768") ? atoi(getenv("GAVIKO_HIP_GEMM_N768")) : 3128;
+    static const int n768 = diag_env("GAVIKO_HIP_GEMM_N768") ? atoi(diag_env("GAVIKO_HIP_GEMM_N768")) : 3128;
     const int bm = (t128 >= 384) ? 128 : 64;
     tile = bm * 1000 + bn;
     if constexpr (EPI == GVK_EPI_STORE_BF16 || EPI == GVK_EPI_BIAS_GELU_BF16 || EPI == GVK_EPI_GELU_BWD_BF16) {
       // wide shapes whose 256 x 256 tiles give (just under) one workgroup per CU: eight waves share one staging of twice the rows
-      static const int wide = getenv("GAVIKO_HIP_GEMM_WIDE") ? atoi(getenv("GAVIKO_HIP_GEMM_WIDE")) : 8;   // A/B switch: 0 = off, 256 = the one-barrier 256x256 kernel, 8 = gemm8p
+      static const int wide = diag_env("GAVIKO_HIP_GEMM_WIDE") ? atoi(diag_env("GAVIKO_HIP_GEMM_WIDE")) : 8;   // A/B switch: 0 = off, 256 = the one-barrier 256x256 kernel, 8 = gemm8p
       const long t256 = (long)((a.M + 255) / 256) * (a.N / 256);
-      static const bool wide_bwd = getenv("GAVIKO_HIP_GEMM_WIDE_BWD") == nullptr || getenv("GAVIKO_HIP_GEMM_WIDE_BWD")[0] != '0';
+      static const bool wide_bwd = diag_env("GAVIKO_HIP_GEMM_WIDE_BWD") == nullptr || diag_env("GAVIKO_HIP_GEMM_WIDE_BWD")[0] != '0';
       if (wide != 0 && a.N % 256 == 0 && a.drop_thresh == 0u && t256 >= wide_lo() && t256 <= 256 && (EPI != GVK_EPI_GELU_BWD_BF16 || wide_bwd))
         tile = (wide == 256 || a.K < 128) ? 256256 : 8256256;
     }
     // N = 768-type shapes (64 x 128 by the fill rule above) with K >= 512 run THREE LDS stages: as 128 x 128 tiles at one workgroup per CU
     // when those fill at least half the chip (M = 4132: 198 tiles), as 64 x 128 tiles below that (M = 2066: 102 tiles of 128 rows would leave
     // 60 % of the CUs idle; 198 tiles of 64: 465 -> 488 volumes/s at B = 2, while at B = 4 the small tile costs 6 %)
-    static const long t64_hi = getenv("GAVIKO_HIP_GEMM_T64HI") ? atol(getenv("GAVIKO_HIP_GEMM_T64HI")) : 130;
+    static const long t64_hi = diag_env("GAVIKO_HIP_GEMM_T64HI") ? atol(diag_env("GAVIKO_HIP_GEMM_T64HI")) : 130;
     if (bm == 64 && bn == 128 && t128 <= 256 && a.K >= 512 && a.drop_thresh == 0u) {
       // GAVIKO_HIP_GEMM_K2=1: the same tile on EIGHT waves that split every k-tile (gemm_k2_bf16.hip) -- two waves per SIMD instead of one.
       // Measured: isolated 32.7 vs 35.9 us (fc2), 23.6 vs 25.2 (qkv dgrad), equal elsewhere; 709-715 vs 713 volumes/s on the step: the
       // single wave's latency chain is not what bounds the loop.  Opt-in.
-      static const bool k2 = getenv("GAVIKO_HIP_GEMM_K2") != nullptr && getenv("GAVIKO_HIP_GEMM_K2")[0] == '1';
-      static const bool k4 = getenv("GAVIKO_HIP_GEMM_K4") != nullptr && getenv("GAVIKO_HIP_GEMM_K4")[0] == '1';       // gemm_k4_bf16.hip, A/B switch
+      static const bool k2 = diag_env("GAVIKO_HIP_GEMM_K2") != nullptr && diag_env("GAVIKO_HIP_GEMM_K2")[0] == '1';
+      static const bool k4 = diag_env("GAVIKO_HIP_GEMM_K4") != nullptr && diag_env("GAVIKO_HIP_GEMM_K4")[0] == '1';       // gemm_k4_bf16.hip, A/B switch
       if (n768 == 3128) {
         // One workgroup per CU, three stages: the tile's life is bound by its own L2 -> LDS bytes, (BM + 128) per k-step, and a launch takes
         // ceil(tiles / 256) such lives.  Row tile = the one of {128, 96, 64} with the smallest rounds x (BM + 128):
@@ -274,11 +274,16 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
           const long cost = ((tiles + 255) / 256) * (cand + 128);
           if (best < 0 || cost < best) { best = cost; best_bm = cand; }
         }
-        static const int force_bm = getenv("GAVIKO_HIP_GEMM_BM") ? atoi(getenv("GAVIKO_HIP_GEMM_BM")) : 0;      // A/B switch: 128 / 96 / 64
+        static const int force_bm = diag_env("GAVIKO_HIP_GEMM_BM") ? atoi(diag_env("GAVIKO_HIP_GEMM_BM")) : 0;      // A/B switch: 128 / 96 / 64
         if (force_bm == 128 || force_bm == 96 || force_bm == 64) best_bm = force_bm;
         else if (t128 <= t64_hi && best_bm == 128) best_bm = 64;                                           // (the round-2 rule, kept for the shapes it was tuned on)
+#ifdef GVK_DIAG
         tile = best_bm == 64 ? 3064128 : best_bm == 96 ? 3096128
              : (k4 && gemm_k4_supports(EPI) ? 4128128 : k2 && gemm_k2_supports(EPI) && a.K >= 192 ? 9128128 : 3128128);
+#else
+        (void)k2; (void)k4;
+        tile = best_bm == 64 ? 3064128 : best_bm == 96 ? 3096128 : 3128128;
+#endif
       }
       else if (n768 == 128) tile = 128128;
       else if (n768 == 3064) tile = 3064128;
@@ -300,8 +305,10 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
   switch (tile) {
     case 8256256: return launch_gemm8p(a, EPI, 0, stream);      // eight-phase kernel, LDS-DMA issued in the load sections (default)
     case 7256256: return launch_gemm8p(a, EPI, 1, stream);      // ... issued inside the MFMA clusters (2546 vs 2426 cycles per k-tile)
+#ifdef GVK_DIAG                                                   // experiment kernels (measured, not faster): the diag library only
     case 4128128: return launch_gemm_k4(a, EPI, stream);         // 128 x 128, eight waves = 2 column halves x 4 k quarters (128 x 64 per wave)
     case 9128128: return launch_gemm_k2(a, EPI, stream);         // 128 x 128, eight waves splitting every k-tile, three LDS stages
+#endif
     case 3128128: return launch_gemm<128, 128, EPI, false, 3>(a, stream);
     case 3064128: return launch_gemm<64, 128, EPI, false, 3>(a, stream);     // 64 x 128 with three stages (A/B switch GAVIKO_HIP_GEMM_N768=3064)
     case 3096128: return launch_gemm<96, 128, EPI, false, 3>(a, stream);     // 96 x 128 with three stages (M = 2066, N = 1024: 176 tiles in one round)

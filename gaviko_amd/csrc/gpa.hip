@@ -485,7 +485,7 @@ extern "C" int gvk_gpa_bwd(const gvk_gpa_desc* d, void* stream) {
   GpaArgs a{};
   fill_gpa(a, d);
   hipStream_t s = (hipStream_t)stream;
-  static const bool two_waves = getenv("GAVIKO_HIP_GPA_BWD_WAVES") != nullptr && getenv("GAVIKO_HIP_GPA_BWD_WAVES")[0] == '2';   // A/B switch
+  static const bool two_waves = diag_env("GAVIKO_HIP_GPA_BWD_WAVES") != nullptr && diag_env("GAVIKO_HIP_GPA_BWD_WAVES")[0] == '2';   // A/B switch
   if (two_waves) { GVK_GPA_LAUNCH(gpa_cross_bwd_p2_kernel, dim3(d->P, d->B), dim3(128), 0); }
   else { GVK_GPA_LAUNCH(gpa_cross_bwd_p_kernel, dim3(d->P, d->B), dim3(512), 0); }
   rc = check_launch("gpa_cross_bwd_p");

@@ -42,33 +42,9 @@ static bool g_plan_timing = false;      // gvk_plan_set_timing: events of plans 
 bool plan_recording() { return g_rec != nullptr; }
 void plan_push(std::function<void()>&& node) { g_rec->nodes.push_back(std::move(node)); }
 
-// ---- LDS exclusion ------------------------------------------------------------------------------------------------------------
-// A workgroup that asks for `pad` bytes of (unused) dynamic LDS only fits on a CU with that much LDS free: with the pad above
-// 160 KiB - (a backbone workgroup's LDS) the side kernels of a registered stream never share a CU with a GEMM / attention
-// workgroup -- they take idle CUs or wait a tile -- instead of slowing the slowest tile of every backbone kernel.
-struct PadStream { hipStream_t s; unsigned pad; };
-static std::vector<PadStream> g_pad_streams;
-static std::mutex g_pad_mu;
-static std::vector<const void*> g_pad_kernels;    // kernels whose dynamic-LDS limit has been raised
-unsigned stream_lds_pad(hipStream_t stream, const void* kernel, unsigned lds) {
-  if (g_pad_streams.empty()) return 0;
-  for (const PadStream& ps : g_pad_streams)
-    if (ps.s == stream) {
-      std::lock_guard<std::mutex> lk(g_pad_mu);
-      bool known = false;
-      for (const void* k : g_pad_kernels) known |= k == kernel;
-      if (!known) {
-        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + ps.pad));
-        if (e != hipSuccess) fprintf(stderr, "gaviko_hip: hipFuncSetAttribute(%u B dynamic LDS): %s\n", lds + ps.pad, hipGetErrorString(e));
-        g_pad_kernels.push_back(kernel);
-      }
-      return ps.pad;
-    }
-  return 0;
-}
-
+#ifdef GVK_DIAG
 __global__ void nop_kernel() {}
-// Diagnostics (GAVIKO_HIP_ABLATE=sidenop|locnop|gpanop, refused by bench.py without --allow-ablate): every launch on a stream the
+// Diagnostics, diag library only (include/gaviko_hip_diag.h; GAVIKO_HIP_ABLATE=sidenop|locnop|gpanop): every launch on a stream the
 // engine registered with gvk_plan_nop_stream keeps its place, stream and events but runs an empty kernel -- separates what the side
 // streams cost the main one in dispatch and synchronisation from what they cost in CUs and bandwidth.  Results are garbage.
 static std::vector<hipStream_t> g_nop_streams;
@@ -80,6 +56,9 @@ void plan_push_launch(hipStream_t stream, std::function<void()>&& node) {
     }
   g_rec->nodes.push_back(std::move(node));
 }
+#else
+void plan_push_launch(hipStream_t, std::function<void()>&& node) { g_rec->nodes.push_back(std::move(node)); }
+#endif
 
 __global__ void seed_advance_kernel(unsigned long long* seed, unsigned long long inc) { seed[0] += inc; }
 // zero / copy as ordinary kernels: hipMemsetAsync issued inside a torch stream capture was executed immediately instead of
@@ -101,20 +80,16 @@ __global__ void scale_kernel(float* x, float alpha, long n) {
 }
 }  // namespace gvk
 
-extern "C" int gvk_stream_set_lds_pad(void* stream, int bytes) {
-  using namespace gvk;
-  GVK_REQUIRE(bytes >= 0 && bytes <= 128 * 1024, "gvk_stream_set_lds_pad: %d bytes out of range", bytes);
-  std::lock_guard<std::mutex> lk(g_pad_mu);
-  for (PadStream& ps : g_pad_streams)
-    if (ps.s == (hipStream_t)stream) { ps.pad = (unsigned)bytes; return 0; }
-  g_pad_streams.push_back({(hipStream_t)stream, (unsigned)bytes});
-  return 0;
-}
-
+#ifdef GVK_DIAG
 extern "C" int gvk_plan_nop_stream(void* stream) {
   gvk::g_nop_streams.push_back((hipStream_t)stream);
   return 0;
 }
+extern "C" int gvk_plan_nop_clear(void) {
+  gvk::g_nop_streams.clear();
+  return 0;
+}
+#endif
 
 extern "C" int gvk_plan_begin(void) {
   using namespace gvk;
@@ -196,7 +171,7 @@ static int plan_event_record_impl(void* stream, bool force_sys_fence) {
   // Plan events only order streams of ONE device: kernel boundaries already carry the device-scope release/acquire, so the
   // system-scope fence (an L2 writeback + invalidate per record, and refetches for whatever runs next) is switched off.
   // GAVIKO_HIP_EVENT_FENCE=1 restores the default events.
-  static const bool sys_fence = getenv("GAVIKO_HIP_EVENT_FENCE") != nullptr;
+  static const bool sys_fence = diag_env("GAVIKO_HIP_EVENT_FENCE") != nullptr;
   const unsigned flags = ((env_timing || g_plan_timing) ? hipEventDefault : hipEventDisableTiming) | ((sys_fence || force_sys_fence) ? 0u : hipEventDisableSystemFence);
   hipError_t e = hipEventCreateWithFlags(&ev, flags);
   if (e != hipSuccess) return set_error(-1, "hipEventCreate: %s", hipGetErrorString(e));

@@ -654,12 +654,12 @@ __global__ __launch_bounds__(64 * kSW, NPW <= 3 ? 4 : 2) void side_up_kernel(UpA
 // diagnostics (GAVIKO_HIP_SIDE_CHUNKS = k): a launch is issued as k back-to-back launches over row ranges -- the same work at 1/k of the
 // concurrency, to see whether the backbone kernels suffer from the side kernels' bandwidth BURST or from their total work
 static int side_chunks() {
-  static const int k = getenv("GAVIKO_HIP_SIDE_CHUNKS") ? max(1, atoi(getenv("GAVIKO_HIP_SIDE_CHUNKS"))) : 1;
+  static const int k = diag_env("GAVIKO_HIP_SIDE_CHUNKS") ? max(1, atoi(diag_env("GAVIKO_HIP_SIDE_CHUNKS"))) : 1;
   return k;
 }
 
 static bool side_enabled() {
-  static const bool on = getenv("GAVIKO_HIP_SIDE") == nullptr || getenv("GAVIKO_HIP_SIDE")[0] != '0';   // A/B switch: 0 = the row-per-wave kernels
+  static const bool on = diag_env("GAVIKO_HIP_SIDE") == nullptr || diag_env("GAVIKO_HIP_SIDE")[0] != '0';   // A/B switch: 0 = the row-per-wave kernels
   return on;
 }
 
@@ -674,7 +674,7 @@ int launch_side_down(const DownArgs& a, int L, hipStream_t s) {
   if (!side_enabled() || L != kSL || ngw == 0 || a.mode < 0 || a.mode > 2 || (a.w2 != nullptr && a.L2 > 64)) return 1;
   if (a.mode != 0 && (a.w2 != nullptr || a.drop_thresh != 0u)) return 1;
   // A/B switch, see DESIGN.md section 7b: '1' = both LayerNorm modes on the tile kernels, 'f' = the forward one (MODE 1), 'b' = the backward one
-  static const char ln_sel = getenv("GAVIKO_HIP_SIDE_LN") != nullptr ? getenv("GAVIKO_HIP_SIDE_LN")[0] : 'f';
+  static const char ln_sel = diag_env("GAVIKO_HIP_SIDE_LN") != nullptr ? diag_env("GAVIKO_HIP_SIDE_LN")[0] : 'f';
   if (a.mode == 1 && !(ln_sel == '1' || ln_sel == 'f')) return 1;
   if (a.mode == 2 && !(ln_sel == '1' || ln_sel == 'b')) return 1;
   const int tiles = (a.M + 15) / 16, chunks = side_chunks(), per = (tiles + chunks - 1) / chunks;

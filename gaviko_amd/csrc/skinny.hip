@@ -669,7 +669,7 @@ extern "C" int gvk_skinny_down(const gvk_skinny_down_desc* d, void* stream) {
   a.eps = d->eps > 0.f ? d->eps : 1e-5f;
   a.seed = d->seed; a.seed_ptr = (const unsigned long long*)d->seed_ptr; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
   hipStream_t s = (hipStream_t)stream;
-  static const bool mfma_only = getenv("GAVIKO_HIP_SKINNY_MFMA") != nullptr;     // A/B switch: force the MFMA-tile kernels
+  static const bool mfma_only = diag_env("GAVIKO_HIP_SKINNY_MFMA") != nullptr;     // A/B switch: force the MFMA-tile kernels
   if (d->act_in != 0) {
     GVK_REQUIRE(d->act_in == 1 && d->ln_gamma == nullptr && d->drop_p <= 0.f, "gvk_skinny_down: act_in=1 (QuickGELU on the input) takes no LN / dropout");
     a.mode = 3;
@@ -732,7 +732,7 @@ extern "C" int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream) {
   a.ln_x = d->ln_x; a.ln_mean = d->ln_mean; a.ln_rstd = d->ln_rstd; a.ln_g = d->ln_gamma; a.out16 = (bf16*)d->out_bf16;
   a.seed = d->seed; a.seed_ptr = (const unsigned long long*)d->seed_ptr; a.drop_thresh = drop_threshold(d->drop_p); a.inv_keep = d->drop_p > 0.f ? 1.f / (1.f - d->drop_p) : 1.f;
   hipStream_t s = (hipStream_t)stream;
-  static const bool mfma_only = getenv("GAVIKO_HIP_SKINNY_MFMA") != nullptr;
+  static const bool mfma_only = diag_env("GAVIKO_HIP_SKINNY_MFMA") != nullptr;
   a.alpha_ptr = d->alpha_ptr; a.gg_x = d->gg_x;
   GVK_REQUIRE(d->w2 == nullptr || ((d->z2 || d->y2) && d->L2 > 0), "gvk_skinny_up: the second projection needs z2 or y2 and L2");
   if (d->lat_b != nullptr) {                            // the layer-boundary form: 16-row-tile kernel only

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64 * kSplit) void win_mfma_bwd_kv_kernel(WinArgs p)
 }
 
 bool mfma_enabled() {
-  static const bool on = [] { const char* e = getenv("GAVIKO_HIP_WIN_MFMA"); return !(e && e[0] == '0'); }();   // A/B switch
+  static const bool on = [] { const char* e = diag_env("GAVIKO_HIP_WIN_MFMA"); return !(e && e[0] == '0'); }();   // A/B switch
   return on;
 }
 

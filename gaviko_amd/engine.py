@@ -27,102 +27,17 @@ from . import ops
 
 import os
 
-# How a step is issued after the GRAPH_WARMUP eager passes (env GAVIKO_HIP_GRAPHS):
-#   "plan"  (default, also "1") -- the library's launch plan: recorded once, replayed from one C loop on the real streams
-#   "graph"                     -- one captured hipGraph per pass (kept for comparison: its executor serialises three forked
-#                                  branches on this runtime, tools/probe/probe_streams.hip: 7.6 ms vs 3.9 ms eager)
-#   "0" / "eager"               -- every launch from Python
-_MODE = os.environ.get("GAVIKO_HIP_GRAPHS", "plan")
-STEP_MODE = {"1": "plan", "0": "eager"}.get(_MODE, _MODE)
-USE_GRAPHS = STEP_MODE != "eager"
-GRAPH_WARMUP = 2
-PLAN_TIMING = os.environ.get("GAVIKO_HIP_PLAN_TIMING") is not None
-# Timing ablations (tools/ablate_streams.py) -- the RESULTS ARE WRONG with either switch; they only answer "where does the step go":
-#   nowait: the main stream skips its waits on the side chains;  noside: the MWSA / GPA chains are not launched at all.
-_ABLATE = set(filter(None, os.environ.get("GAVIKO_HIP_ABLATE", "").split(",")))
-
-
-def _on(tag: str) -> bool:
-    """False when the timing ablation `tag` is switched on (GAVIKO_HIP_ABLATE, diagnostics only: bench.py refuses it without --allow-ablate)."""
-    return tag not in _ABLATE
-# Site seeds of the backbone's own nn.Dropout modules (added to the device epoch word): embedding, VPT prompts of layer i, and per layer
-# {+0 attention probabilities, +1 to_out, +2 after GELU, +3 after fc2}.  The MWSA sites use 2*i and 2*i + 1.
-SEED_EMB, SEED_PROMPT, SEED_LAYER = 900, 950, 1000
+from .engine_common import (SEED_EMB, SEED_LAYER, SEED_PROMPT, GRAPH_WARMUP, Names, PLAN_TIMING, SIDE_STREAM_PRIORITY, STEP_MODE, USE_GRAPHS, _ABLATE, _EPI_NAMES, _FIX_IN_LN, _LOC_SHIFT, _MODE, _PATCH_IMPLICIT, _SIDE_STREAMS, _on, evp_highpass_operator)  # noqa: F401
+from .engine_gaviko import GavikoPaths
+from .engine_peft import PeftPaths
 
 # bench.py instrumentation: when a dict, every GEMM launch is bracketed by HIP events recorded on the launch stream
 # bench.py instrumentation: when set to a dict, plans recorded from then on bracket every GEMM launch (and the patch-embed
 # stage) with timestamped plan events, so the kernels are timed inside the real three-stream schedule of a replayed step.
 GEMM_MARKS = None
-# Dispatch priority of the side-chain streams (negative = higher).  Measured: -1 drops the step rate from 448 to 274 volumes/s
-# (priority queues serialise against the captured graph's main queue on this runtime), so the default stays 0.
-SIDE_STREAM_PRIORITY = int(os.environ.get("GAVIKO_HIP_SIDE_PRIORITY", "0"))
-# Patch embedding as one implicit GEMM (csrc/patch_gemm.hip) instead of the im2col kernel + GEMM: correct and bit-identical, but 74-79 us
-# against 54 us for the pair (DESIGN.md section 7b.5) -- opt-in
-_PATCH_IMPLICIT = os.environ.get("GAVIKO_HIP_PATCH_IMPLICIT", "0") == "1"
-# GPA prompt fix inside the next layer's first LayerNorm (gvk_layernorm_fwd_fix) instead of its own 128-row launch: measured 709-711 vs
-# 719-721 volumes/s -- the 128 prompt rows' waves become the tail of a 4132-row kernel; opt-in
-_FIX_IN_LN = os.environ.get("GAVIKO_HIP_FIX_IN_LN", "0") == "1"
-_SIDE_STREAMS = {}                       # (device index, kind) -> the process-wide side stream of that kind
-# MWSA backward chain held behind the layer's attention backward: measured 669 vs 688 volumes/s -- the chain then slows the dgrad GEMMs
-# of the next layer by as much as it slowed the attention kernels before (start->fc1d 82 -> 98 us); opt-in only
-_LOC_SHIFT = os.environ.get("GAVIKO_HIP_LOC_SHIFT", "0") == "1"
-_EPI_NAMES = {0: "store_bf16", 1: "bias_res_f32", 2: "bias_gelu_bf16", 3: "patch_f32", 4: "gelu_bwd_bf16", 5: "store_f32", 6: "bias_res_f32_bf16",
-              7: "bias_relu_bf16", 8: "relu_bwd_bf16"}
 
 
-def evp_highpass_operator(D: int, H: int, W: int, rate: float):
-    """The linear operator behind PromptGenerator.fft (evp.py:126-147) as it executes on a [B, C, D, H, W] volume.
-    fft2 / ifft2 run over (H, W); fftshift / ifftshift run over EVERY axis; the mask `mask[:, :, w//2-line:w//2+line, h//2-line:h//2+line]`
-    (w, h = the last two sizes) is indexed on axes 2 and 3 = (D, H).  Net effect: on the depth slices whose shifted index falls in the
-    first range, the H-frequencies whose shifted index falls in the second range are zeroed for every W-frequency; all other slices pass.
-    Returns (Hp [H][H] float32 with Hp = I - Re(F^-1 diag(band) F), depth mask int32 [D]): out[b, d] = |Hp . x[b, d]| or |x[b, d]|."""
-    import numpy as np
-    w_, h_ = H, W                                            # the reference's names for x.shape[-2:]
-    line = int((w_ * h_ * rate) ** 0.5 // 2)
-    dlo, dhi = max(0, w_ // 2 - line), min(D, w_ // 2 + line)              # slice of axis 2 (depth), clipped like Python slicing
-    hlo, hhi = max(0, h_ // 2 - line), min(H, h_ // 2 + line)              # slice of axis 3 (H)
-    d_shift = (np.arange(D) + D // 2) % D                    # fftshift: original index d sits at shifted index (d + D//2) % D
-    dmask = ((d_shift >= dlo) & (d_shift < dhi)).astype(np.int32)
-    k_shift = (np.arange(H) + H // 2) % H
-    band = ((k_shift >= hlo) & (k_shift < hhi)).astype(np.float64)
-    idx = np.arange(H)
-    ph = np.exp(2j * np.pi * np.outer(idx, idx) / H)          # ph[i][k] = e^{2 pi i k i / H}
-    A = (ph * band[None, :]) @ ph.conj().T / H                # A[i][j] = 1/H sum_k band[k] e^{2 pi i k (i - j) / H}
-    return (np.eye(H) - A.real).astype(np.float32), dmask
-
-
-class Names:
-    """Maps logical backbone tensors to the state_dict names of each reference class."""
-
-    def __init__(self, kind: str):
-        self.kind = kind
-        self.root = {"vpt": "vision_transformer.", "melo": "lora_vit."}.get(kind, "")
-
-    def attn(self, i):
-        if self.kind == "gaviko":
-            return f"transformer.attns.{i}"
-        if self.kind == "dvpt":
-            return f"transformer.layers.{i}.0.attn"
-        return f"{self.root}transformer.layers.{i}.0"
-
-    def mlp(self, i):
-        if self.kind == "gaviko":
-            return f"transformer.mlps.{i}"
-        if self.kind == "dvpt":
-            return f"transformer.layers.{i}.0.mlp"
-        return f"{self.root}transformer.layers.{i}." + ("2" if self.kind == "adaptformer" else "1")
-
-    def conv(self):
-        return "conv_proj.proj" if self.kind == "evp" else f"{self.root}conv_proj.0"      # evp.py:292: a PatchEmbed, not a Sequential
-
-    def qkv_weight(self, i):
-        return self.attn(i) + (".to_qkv.qkv.weight" if self.kind == "melo" else ".to_qkv.weight")
-
-    def head(self):
-        return "mlp_head.head" if self.kind == "gaviko" else f"{self.root}mlp_head"
-
-
-class Engine:
+class Engine(GavikoPaths, PeftPaths):
     def __init__(self, kind: str, cfg: dict, params: Dict[str, torch.nn.Parameter], depth, heads, dim, mlp_dim):
         self.kind, self.cfg, self.p = kind, cfg, params
         self.depth, self.heads, self.C, self.mlp = depth, heads, dim, mlp_dim
@@ -209,16 +124,16 @@ class Engine:
         self._eff: Dict[str, torch.Tensor] = {}
         # GPA projections of backbone rows ride along in the backbone's LayerNorm kernels (gvk_layernorm_*_proj)
         self._fuse_proj = (kind == "gaviko" and not self.fp32 and ops.rowproj_supported(self.Lat, dim)
-                           and os.environ.get("GAVIKO_HIP_FUSE_PROJ", "1") != "0")
+                           and L.diag_env("GAVIKO_HIP_FUSE_PROJ", "1") != "0")
         self._fuse_local = kind == "gaviko" and ops.side_tile_supported(self.Lat, dim)
-        self._fuse_bnd = self._fuse_local and os.environ.get("GAVIKO_HIP_FUSE_BOUNDARY", "1") != "0"
-        self._fuse_next = self._fuse_local and os.environ.get("GAVIKO_HIP_FUSE_NEXT", "1") != "0"
+        self._fuse_bnd = self._fuse_local and L.diag_env("GAVIKO_HIP_FUSE_BOUNDARY", "1") != "0"
+        self._fuse_next = self._fuse_local and L.diag_env("GAVIKO_HIP_FUSE_NEXT", "1") != "0"
         self._mwsa_pending = None
         # GPA up-projection as K-concatenation of the MLP's second Linear: 64 spare K columns carry the rank-L product in split-bf16 form,
         # A' = [act | lat_hi | lat_lo | lat_hi | 1 | 1], W' = [W_fc2 | Wup_hi | Wup_hi | Wup_lo | b_hi | b_lo] (fp32-grade: the dropped
         # lo.lo term is 2^-16 relative), so x + ff(x) + proj_up(.) (gaviko.py:187 after vision_transformer.py:34) is ONE GEMM and the
         # main stream loses a full read-modify-write pass over the token stream per layer
-        self._fuse_up = (kind == "gaviko" and not self.fp32 and 3 * self.Lat + 2 <= 64 and os.environ.get("GAVIKO_HIP_FUSE_UP", "1") != "0")
+        self._fuse_up = (kind == "gaviko" and not self.fp32 and 3 * self.Lat + 2 <= 64 and L.diag_env("GAVIKO_HIP_FUSE_UP", "1") != "0")
         self.ldx = self.mlp + 64 if self._fuse_up else self.mlp      # row stride of the MLP hidden buffers
         self._marks = []
         self.plan_marks = {}                # plan id -> [(name, event id)]
@@ -460,11 +375,8 @@ class Engine:
                 return st
             # (confining the side streams to a CU subset with hipExtStreamCreateWithCUMask was measured: 676 -> 170-260 volumes/s for
             #  every mask shape tried -- masked queues are far slower to dispatch on this runtime)
-            prio = int(os.environ.get(f"GAVIKO_HIP_{name.upper()}_PRIORITY", SIDE_STREAM_PRIORITY))     # per-stream A/B switch
+            prio = int(L.diag_env(f"GAVIKO_HIP_{name.upper()}_PRIORITY", SIDE_STREAM_PRIORITY))     # per-stream A/B switch (diag)
             st = self._streams[name] = _SIDE_STREAMS[key] = torch.cuda.Stream(priority=prio)
-            pad = int(os.environ.get(f"GAVIKO_HIP_LDS_PAD_{name.upper()}", os.environ.get("GAVIKO_HIP_LDS_PAD", "0")))
-            if pad:
-                L.check(L.load().gvk_stream_set_lds_pad(st.cuda_stream, pad), "gvk_stream_set_lds_pad")
             if "sidenop" in _ABLATE or f"{name}nop" in _ABLATE:
                 L.load().gvk_plan_nop_stream(st.cuda_stream)
         return st
@@ -831,79 +743,6 @@ class Engine:
                    alg_k=self.mlp + self.Lat if up_in_fc2 else None,
                    drop_p=pdrop, seed=SEED_LAYER + 8 * i + 3, seed_ptr=ws["seed"])
 
-    # ---- GAViKO side paths --------------------------------------------------------------------------------------
-    def _mwsa_fwd(self, ws, sv, i, si, lin, lout, gpa_local=False):
-        """MWSA of layer i on the local stream (gaviko.py:229-244).  With self._fuse_next the up-projection kernel of layer i also runs layer
-        i+1's entry (LayerNorm + proj_down + qkv of the rows it writes), so only layer 0 launches the entry kernel itself."""
-        if not _on("noside"):
-            return
-        pre = f"transformer.local_attns.{i // self.share}"
-        d, C, Lt, B = self._d, self.C, self.Lat, ws["B"]
-        BN = B * self.N
-        m = ws["mw"][si]
-        chained = self._fuse_next and gpa_local and _on("loc_noupdown")
-        if _on("loc_noupdown") and not (chained and i > 0):
-            ops.skinny_down(x=lin, w=d(pre + ".proj_down.weight"), bias=d(pre + ".proj_down.bias"), ln_gamma=d(pre + ".norm.weight"),
-                            ln_beta=d(pre + ".norm.bias"), mean=m["mean"], rstd=m["rstd"], y=m["lat"], w2=d(pre + ".qkv.weight"), y2=m["qkv"],
-                            M=BN, C=C, L=Lt, L2=3 * Lt, act=0, w_layout=0, eps=1e-5)
-        if _on("nowin"):
-            ops.window_attn_fwd(qkv=m["qkv"], ctx=m["ctx"], lse=m["lse"], B=B, D=self.grid[0], H=self.grid[1], W=self.grid[2],
-                                kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt, scale=C ** -0.5, drop_p=sv["attn_drop"],
-                                seed=2 * i, seed_ptr=ws["seed"])
-        second = {}
-        if gpa_local:                                       # ll = QuickGELU(proj_down(L')) (gaviko.py:156) of the rows this launch produces
-            gpre, _ = self._gpa_names(i)
-            g = ws["gp"][si]
-            second = dict(w2=d(gpre + ".proj_down.0.weight"), bias2=d(gpre + ".proj_down.0.bias"), z2=g["zl"], y2=g["ll"], L2=Lt, act2=1)
-        if chained and i + 1 < self.depth:                  # layer i+1's norm + proj_down + qkv of the same rows
-            nx = f"transformer.local_attns.{(i + 1) // self.share}"
-            mn = ws["mw"][si + 1 if sv["train"] else 0]
-            second.update(nx_w=d(nx + ".proj_down.weight"), nx_bias=d(nx + ".proj_down.bias"), nx_ln_gamma=d(nx + ".norm.weight"),
-                          nx_ln_beta=d(nx + ".norm.bias"), nx_mean=mn["mean"], nx_rstd=mn["rstd"], nx_lat=mn["lat"], nx_w2=d(nx + ".qkv.weight"),
-                          nx_y2=mn["qkv"], nx_L2=3 * Lt, nx_eps=1e-5)
-        if _on("loc_noupdown"):
-            ops.skinny_up(lat=m["ctx"], w=d(pre + ".proj_up.weight"), bias=d(pre + ".proj_up.bias"), res=lin, out=lout, M=BN, C=C, L=Lt,
-                          w_layout=0, drop_p=sv["proj_drop"], seed=2 * i + 1, seed_ptr=ws["seed"], **second)
-
-    def _gpa_names(self, i):
-        s = i // self.share
-        pre = f"transformer.prompt_projs.{s}"
-        ca, gl = pre + ".cls_analyzer.cls_analyzer_", pre + ".gl_balancer.gl_balancer_"
-        return pre, dict(ca0_g=ca + ".0.weight", ca0_b=ca + ".0.bias", ca1_w=ca + ".1.weight", ca1_b=ca + ".1.bias", ca3_w=ca + ".3.weight",
-                         ca3_b=ca + ".3.bias", gl0_g=gl + ".0.weight", gl0_b=gl + ".0.bias", gl1_w=gl + ".1.weight", gl1_b=gl + ".1.bias",
-                         wgq=pre + ".global_attention.query_proj.weight", bgq=pre + ".global_attention.query_proj.bias",
-                         wlq=pre + ".local_attention.query_proj.weight", blq=pre + ".local_attention.query_proj.bias")
-
-    def _gpa_down_local(self, ws, i, si, lnew, B):
-        """ll = QuickGELU(proj_down(L')) (gaviko.py:156): depends on the MWSA chain only, so it runs at its tail."""
-        if "noside" in _ABLATE:
-            return
-        pre, _ = self._gpa_names(i)
-        d, g = self._d, ws["gp"][si]
-        ops.skinny_down(x=lnew, w=d(pre + ".proj_down.0.weight"), bias=d(pre + ".proj_down.0.bias"), z=g["zl"], y=g["ll"], M=B * self.N,
-                        C=self.C, L=self.Lat, act=1, w_layout=0)
-
-    def _gpa_fwd_latents(self, ws, i, si, g1, lnew, M, B, project, enh16=None):
-        if "noside" in _ABLATE:
-            return
-        pre, names = self._gpa_names(i)
-        d, C, Lt = self._d, self.C, self.Lat
-        g = ws["gp"][si]
-        if project:
-            ops.skinny_down(x=g1, w=d(pre + ".proj_down.0.weight"), bias=d(pre + ".proj_down.0.bias"), z=g["zx"], y=g["xl"], M=M, C=C, L=Lt,
-                            act=1, w_layout=0)
-            self._gpa_down_local(ws, i, si, lnew, B)
-        slot = {} if enh16 is None else dict(enh16=enh16, ld16=enh16.shape[-1], col16=self.mlp)
-        ops.gpa_fwd(xl=g["xl"], ll=g["ll"], B=B, T=self.T, N=self.N, P=self.P, L=Lt, scale=Lt ** -0.5,
-                    imp=g["imp"], gw=g["gw"], enh=g["enh"], prm=g["prm"], qg=g["qg"], ql=g["ql"], cg=g["cg"], cl=g["cl"],
-                    lse_g=g["lse_g"], lse_l=g["lse_l"], **slot, **{k: d(v) for k, v in names.items()})
-
-    def _gpa_fwd_up(self, ws, i, si, gout, M):
-        pre, _ = self._gpa_names(i)
-        d, g = self._d, ws["gp"][si]
-        ops.skinny_up(lat=g["xl"], w=d(pre + ".proj_up.weight"), bias=d(pre + ".proj_up.bias"), out=gout, lat_override=g["enh"],
-                      M=M, C=self.C, L=self.Lat, T=self.T, P=self.P, w_layout=0, accumulate=1)
-
     # ------------------------------------------------------------------ backward
     def trainable_names(self) -> List[str]:
         return [k for k, p in self.p.items() if p.requires_grad]
@@ -1080,7 +919,7 @@ class Engine:
                 self._ssf_ln_grad(ws, gv, m, ".net.0", ws["dx32"], ws["G1"][i], st[2], st[3], M)
             adapter = self.kind == "adaptformer"
             fuse_scatter = (gaviko and self._fuse_local and not self.fp32 and "noside" not in _ABLATE
-                            and os.environ.get("GAVIKO_HIP_FUSE_SCATTER", "0") == "1")     # measured: 651 vs 676 volumes/s -- off
+                            and L.diag_env("GAVIKO_HIP_FUSE_SCATTER", "0") == "1")     # measured: 651 vs 676 volumes/s -- off
             if fuse_scatter:
                 # dG1 = dGout + LN'(dx32) + dzx . W_d (+ the bf16 operand of the out-proj dgrad) in ONE pass: the GPA core of this layer
                 # (started at the top of the layer on its own stream) has long finished when the two MLP dgrad GEMMs are through
@@ -1221,473 +1060,3 @@ class Engine:
 
     def _needs_backbone_backward(self) -> bool:
         return any(not n.startswith(self.names.head()) for n in self.trainable_names())
-
-    def _acc(self, i) -> int:
-        """0 when layer i is the first (highest) layer of the sweep that touches its shared side-path module, else 1."""
-        s = i // self.share
-        top = min(self.depth - 1, s * self.share + self.share - 1)
-        return 0 if i == top else 1
-
-    def _gpa_bwd_core(self, ws, sv, gv, i, dGout, M, B, par, project=True):
-        """Critical part of the GPA backward: dcomb = dGout . Wup and the latent-space backward -> dzx / dzl
-        (what the main stream's dG1 update and the MWSA chain wait for)."""
-        if "noside" in _ABLATE:
-            return
-        pre, names = self._gpa_names(i)
-        d, C, Lt, P, T, N = self._d, self.C, self.Lat, self.P, self.T, self.N
-        g, bw = ws["gp"][i], ws["bw"]
-        if project:
-            ops.skinny_down(x=dGout, w=d(pre + ".proj_up.weight"), y=bw["dcomb"], M=M, C=C, L=Lt, act=0, w_layout=1)
-        ops.gpa_bwd(xl=g["xl"], ll=g["ll"], B=B, T=T, N=N, P=P, L=Lt, scale=Lt ** -0.5, imp=g["imp"], gw=g["gw"], enh=g["enh"], prm=g["prm"],
-                    qg=g["qg"], ql=g["ql"], cg=g["cg"], cl=g["cl"], lse_g=g["lse_g"], lse_l=g["lse_l"], dcomb=bw["dcomb"], zx=g["zx"], zl=g["zl"],
-                    dimp=bw["dimp"], dgw_part=bw["dgw_part"], dqg=bw["dqg"], dql=bw["dql"], dcg=bw["dcg"], dcl=bw["dcl"],
-                    delta_g=bw["delta_g"], delta_l=bw["delta_l"], dprm=bw["dprm"], dcls=bw["dcls"], gate_partials=bw["gate_partials"],
-                    dzx=bw["dzx"], dzl=bw["dzl"][par], **{k: d(v) for k, v in names.items()})
-
-    def _gpa_bwd_params(self, ws, sv, gv, i, dGout, M, B, par):
-        """Off the critical path: every parameter gradient of the GPA module (reads dGout, dzx, dzl, saved activations)."""
-        if "noside" in _ABLATE or "noparams" in _ABLATE:
-            return
-        pre, names = self._gpa_names(i)
-        d, C, Lt, P, T, N = self._d, self.C, self.Lat, self.P, self.T, self.N
-        g, bw, sc = ws["gp"][i], ws["bw"], ws["scratch"]
-        acc = self._acc(i)
-        ops.outer_reduce(narrow=g["xl"], wide=dGout, lat_override=g["enh"], scratch=sc, out=gv[pre + ".proj_up.weight"],
-                         colsum=gv[pre + ".proj_up.bias"], M=M, C=C, L=Lt, T=T, P=P, transposed=1, accumulate=acc)
-        # gate parameters: one contiguous slice of the flat gradient buffer, in the kernel's order
-        ng = ops.gpa_gate_param_count(Lt, P)
-        first = gv[names["ca0_g"]]
-        gate_flat = self._flat_grad["buf"][self._offset_of(names["ca0_g"]): self._offset_of(names["ca0_g"]) + ng]
-        assert gate_flat.data_ptr() == first.data_ptr()
-        gwd, gbd = gv[pre + ".proj_down.0.weight"], gv[pre + ".proj_down.0.bias"]
-        BP = B * P
-        dqg, dql, prm = bw["dqg"].view(BP, Lt), bw["dql"].view(BP, Lt), g["prm"].view(BP, Lt)
-        ops.reduce_batch([(bw["gate_partials"], None, gate_flat, acc),
-                          (dqg, prm, gv[names["wgq"]], acc), (dqg, None, gv[names["bgq"]], acc),
-                          (dql, prm, gv[names["wlq"]], acc), (dql, None, gv[names["blq"]], acc),
-                          (bw["dzx"], None, gbd, acc, bw["dzl"][par])], ws["rscratch"])      # proj_down bias: both token streams
-        # proj_down (shared by both streams): dWd = dzx^T.G1 + dzl^T.Lnew
-        if M + B * N <= ops.OUTER_MAX_ROWS:                                   # both token streams in one pass
-            ops.outer_reduce(narrow=bw["dzx"], wide=ws["G1"][i], narrow2=bw["dzl"][par], wide2=ws["Lc"][i + 1], scratch=sc, out=gwd, M=M, M2=B * N,
-                             C=C, L=Lt, transposed=0, accumulate=acc)
-        else:
-            ops.outer_reduce(narrow=bw["dzx"], wide=ws["G1"][i], scratch=sc, out=gwd, M=M, C=C, L=Lt, transposed=0, accumulate=acc)
-            ops.outer_reduce(narrow=bw["dzl"][par], wide=ws["Lc"][i + 1], scratch=sc, out=gwd, M=B * N, C=C, L=Lt, transposed=0, accumulate=1)
-
-    def _gpa_bwd_scatter_g(self, ws, i, dG1, M):
-        """main stream: dG1 += dzx . Wd, with the bf16 copy for the out-proj dgrad."""
-        pre, _ = self._gpa_names(i)
-        ops.skinny_up(lat=ws["bw"]["dzx"], w=self._d(pre + ".proj_down.0.weight"), out=dG1, out_bf16=None if self.fp32 else ws["dG16"],
-                      M=M, C=self.C, L=self.Lat, w_layout=1, accumulate=1)
-        if self.fp32:
-            ops.copy_(ws["dG16"], dG1)
-
-    def _mwsa_chain_bwd(self, ws, sv, gv, i, par, B, loc, after):
-        """Local stream: dL += dzl . Wd (GPA's share), then the MWSA backward of layer i; starts once event `after` is reached.
-        The last step of a layer's MWSA backward (dL_in = dL_out + LN'(dlat . Wd)) is deferred to the start of the next-lower layer's
-        chain, where ONE kernel does it together with that layer's scatter and its first down-projection (self._fuse_bnd)."""
-        self._ev_wait(loc, after)
-        with torch.cuda.stream(loc):
-            pend, fused = self._mwsa_pending, False
-            if pend is not None and self._fuse_bnd and "noside" not in _ABLATE and "loc_noupdown" not in _ABLATE:
-                self._mwsa_boundary(ws, sv, pend, i, par, B)
-                fused = True
-            else:
-                if pend is not None:
-                    self._mwsa_final(ws, pend, B)
-                self._gpa_bwd_scatter_l(ws, i, ws["dL"][par], B, par)        # dL[par] was written on this stream
-            self._scl_done = self._ev_record(loc)
-            self._mwsa_bwd(ws, sv, gv, i, ws["dL"][par], ws["dL"][par ^ 1], B, have_dctx=fused, defer_final=True)
-            self._mwsa_pending = i
-            self._bucket_mark("loc", i)
-
-    def _mwsa_flush(self, ws, B, loc):
-        """End of a backward plan: the deferred last step of the lowest layer of the sweep."""
-        if self._mwsa_pending is not None:
-            with torch.cuda.stream(loc):
-                self._mwsa_final(ws, self._mwsa_pending, B)
-            self._mwsa_pending = None
-
-    def _mwsa_final(self, ws, j, B):
-        """dL_in = dL_out + LN'(dlat . Wd) of layer j (gaviko.py:231): the rank-L product never touches HBM."""
-        if "noside" in _ABLATE or "loc_noupdown" in _ABLATE:
-            return
-        pre = f"transformer.local_attns.{j // self.share}"
-        d, m, par = self._d, ws["mw"][j], (self.depth - 1 - j) & 1
-        ops.skinny_up(lat=ws["bw"]["dlat"], w=d(pre + ".proj_down.weight"), res=ws["dL"][par], out=ws["dL"][par ^ 1], ln_x=ws["Lc"][j],
-                      ln_mean=m["mean"], ln_rstd=m["rstd"], ln_gamma=d(pre + ".norm.weight"), M=B * self.N, C=self.C, L=self.Lat, w_layout=1)
-
-    def _mwsa_boundary(self, ws, sv, j, i, par, B):
-        """Layer j = i + 1's last step, layer i's GPA scatter and layer i's dctx = proj_drop'(dL) . Wup in one pass over the local-stream
-        gradient (gvk_skinny_up with lat_b): dL[par] = dL[par ^ 1] + LN'(dlat_j . Wd_j) + dzl_i . Wd_gpa_i;  dctx_i = (dL[par] o mask_i) . Wup_i."""
-        pj, pi_ = f"transformer.local_attns.{j // self.share}", f"transformer.local_attns.{i // self.share}"
-        gpre, _ = self._gpa_names(i)
-        d, m, bw = self._d, ws["mw"][j], ws["bw"]
-        ops.skinny_up(lat=bw["dlat"], w=d(pj + ".proj_down.weight"), res=ws["dL"][par ^ 1], out=ws["dL"][par], ln_x=ws["Lc"][j],
-                      ln_mean=m["mean"], ln_rstd=m["rstd"], ln_gamma=d(pj + ".norm.weight"), M=B * self.N, C=self.C, L=self.Lat, w_layout=1,
-                      lat_b=bw["dzl"][par], w_b=d(gpre + ".proj_down.0.weight"),
-                      w2=d(pi_ + ".proj_up.weight"), z2=bw["dctx"], L2=self.Lat, act2=0, w2_layout=1,
-                      drop2_p=sv["proj_drop"], seed2=2 * i + 1, seed_ptr=ws["seed"])
-
-    def _gpa_bwd_scatter_l(self, ws, i, dLnew, B, par):
-        """MWSA chain: dL += dzl . Wd."""
-        if "noside" in _ABLATE:
-            return
-        pre, _ = self._gpa_names(i)
-        if _on("loc_noupdown"):
-            ops.skinny_up(lat=ws["bw"]["dzl"][par], w=self._d(pre + ".proj_down.0.weight"), out=dLnew, M=B * self.N, C=self.C, L=self.Lat,
-                          w_layout=1, accumulate=1)
-
-    # ---- AdaptFormer (adaptformer.py:58-78, 93-97): r = up(ReLU(down(LN_a(x)))), x_out = ff(x) + x + r -----------------------
-    def _adapter_prefix(self, i):
-        return f"transformer.layers.{i}.1"
-
-    def _adapter_shadows(self, train):
-        """bf16 MFMA operands of the TRAINABLE adapter weights, refreshed in place every step (inside the captured graph)."""
-        w = self._w16
-        for i in range(self.depth):
-            p = self._adapter_prefix(i)
-            wd, wu = self._d(p + ".down_adapter_proj.weight"), self._d(p + ".up_adapter_proj.weight")
-            w[f"ad_d{i}"] = ops.to_operand(wd, None if self.fp32 else w.get(f"ad_d{i}"), self.adt)
-            w[f"ad_u{i}"] = ops.to_operand(wu, None if self.fp32 else w.get(f"ad_u{i}"), self.adt)
-            if train:
-                w[f"ad_dT{i}"] = ops.transpose_operand(wd, w.get(f"ad_dT{i}"), self.adt)
-                w[f"ad_uT{i}"] = ops.transpose_operand(wu, w.get(f"ad_uT{i}"), self.adt)
-
-    def _adapter_fwd_down(self, ws, i, si, g1, M):
-        p, d, ad = self._adapter_prefix(i), self._d, ws["ad"][si]
-        ops.layernorm_fwd(g1, d(p + ".adapter_layer_norm_before.weight"), d(p + ".adapter_layer_norm_before.bias"), M, self.C, y16=ws["xa"],
-                          mean=ad["mean"], rstd=ad["rstd"])
-        self._gemm(ws["xa"], self._w16[f"ad_d{i}"], M, ad["h16"], epilogue=ops.EPI_BIAS_RELU_BF16, bias=d(p + ".down_adapter_proj.bias"))
-
-    def _adapter_fwd_up(self, ws, i, si, gout, M):
-        p = self._adapter_prefix(i)
-        self._gemm(ws["ad"][si]["h16"], self._w16[f"ad_u{i}"], M, gout, epilogue=ops.EPI_BIAS_RES_F32, bias=self._d(p + ".up_adapter_proj.bias"),
-                   res=gout)
-
-    def _adapter_bwd(self, ws, gv, i, dGout, dG1, M):
-        p, d, C, A = self._adapter_prefix(i), self._d, self.C, self.adim
-        ad, w, sc = ws["ad"][i], self._w16, ws["scratch"]
-        g, b = d(p + ".adapter_layer_norm_before.weight"), d(p + ".adapter_layer_norm_before.bias")
-        # up-projection: dh = (dGout . Wu) * [h > 0]; dWu = dGout^T . h; dbu = colsum(dGout)
-        self._gemm(ws["dG16"], w[f"ad_uT{i}"], M, ws["dh16"], epilogue=ops.EPI_RELU_BWD_BF16, aux=ad["h16"])
-        ops.cast_bf16_f32_strided(ad["h16"], ws["h32"], M, A, A)
-        ops.cast_bf16_f32_strided(ws["dh16"], ws["dh32"], M, A, A)
-        ops.outer_reduce(narrow=ws["h32"], wide=dGout, scratch=sc, out=gv[p + ".up_adapter_proj.weight"], colsum=gv[p + ".up_adapter_proj.bias"],
-                         M=M, C=C, L=A, transposed=1, accumulate=0)
-        # down-projection: dxa = dh . Wd; dWd = dh^T . LN_a(G1); dbd = colsum(dh)
-        self._gemm(ws["dh16"], w[f"ad_dT{i}"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
-        ops.outer_reduce(narrow=ws["dh32"], wide=ws["G1"][i], mean=ad["mean"], rstd=ad["rstd"], ln_gamma=g, ln_beta=b, scratch=sc,
-                         out=gv[p + ".down_adapter_proj.weight"], M=M, C=C, L=A, transposed=0, accumulate=0)
-        ops.colsum(ws["dh32"], gv[p + ".down_adapter_proj.bias"], sc, M, A)
-        # trainable LayerNorm in front of the adapter: input gradient accumulates into dG1, affine gradients
-        ops.layernorm_bwd(ws["dx32"], ws["G1"][i], ad["mean"], ad["rstd"], g, M, C, dx=dG1, dres=dG1, dx16=ws["dG16"])
-        ops.layernorm_bwd_affine(ws["dx32"], ws["G1"][i], ad["mean"], ad["rstd"], gv[p + ".adapter_layer_norm_before.weight"],
-                                 gv[p + ".adapter_layer_norm_before.bias"], sc, M, C)
-
-    # ---- MeLO / LoRA (melo.py:41-47): qkv = W x + s B_q A_q x (q columns) + s B_v A_v x (v columns) -------------------------
-    def _lora_names(self, i):
-        q = self.names.attn(i) + ".to_qkv"
-        return q + ".linear_a_q.weight", q + ".linear_b_q.weight", q + ".linear_a_v.weight", q + ".linear_b_v.weight"
-
-    def _melo_merge(self, ws, train):
-        """Fold the rank-r update into the bf16 QKV operand (and its transpose) every step: the forward is then the plain GEMM."""
-        w, C = self._w16, self.C
-        for i in range(self.depth):
-            aq, bq, av, bv = (self._d(n) for n in self._lora_names(i))
-            ops.lora_merge(self._d(self.names.qkv_weight(i)), aq, bq, av, bv, ws["merge32"], C, self.r, self.lora_s)
-            if self.fp32 and not isinstance(w.get(f"qkv{i}_own"), torch.Tensor):
-                w[f"qkv{i}_own"] = torch.empty_like(ws["merge32"])     # the merged weight needs its own buffer per layer
-            w[f"qkv{i}"] = ops.to_operand(ws["merge32"], w[f"qkv{i}_own"] if self.fp32 else w.get(f"qkv{i}"), self.adt)
-            if train:
-                w[f"qkv{i}_t"] = ops.transpose_operand(ws["merge32"], w.get(f"qkv{i}_t"), self.adt)
-
-    def _melo_bwd(self, ws, gv, i, M):
-        """dB = s dq^T u, dA = s (dq B)^T LN(x), u = LN(x) A^T -- all rank-r fp32 kernels over the bf16 dq / dv blocks."""
-        C, r, d, sc = self.C, self.r, self._d, ws["scratch"]
-        na_q, nb_q, na_v, nb_v = self._lora_names(i)
-        a = self.names.attn(i)
-        g1, b1, st, x = d(a + ".norm.weight"), d(a + ".norm.bias"), ws["stat"][i], ws["G"][i]
-        lu = ws["lu"]
-        ops.cast_bf16_f32_strided(ws["dqkv"], ws["dq32"], M, C, 3 * C, col0=0)
-        ops.cast_bf16_f32_strided(ws["dqkv"], ws["dv32"], M, C, 3 * C, col0=2 * C)
-        for na, nb, dblk, u, du in ((na_q, nb_q, ws["dq32"], lu["uq"], lu["duq"]), (na_v, nb_v, ws["dv32"], lu["uv"], lu["duv"])):
-            ops.skinny_down(x=x, w=d(na), ln_gamma=g1, ln_beta=b1, y=u, M=M, C=C, L=r, act=0, w_layout=0, eps=1e-5)
-            ops.outer_reduce(narrow=u, wide=dblk, scratch=sc, out=gv[nb], M=M, C=C, L=r, transposed=1, accumulate=0)
-            ops.skinny_down(x=dblk, w=d(nb), y=du, M=M, C=C, L=r, act=0, w_layout=1)
-            ops.outer_reduce(narrow=du, wide=x, mean=st[0], rstd=st[1], ln_gamma=g1, ln_beta=b1, scratch=sc, out=gv[na], M=M, C=C, L=r,
-                             transposed=0, accumulate=0)
-            if self.lora_s != 1:
-                ops.scale_(gv[na], float(self.lora_s))
-                ops.scale_(gv[nb], float(self.lora_s))
-
-    # ---- unfrozen ViT tensors (`bitfit` / `fft`, train.py:123-137): biases and LayerNorm affines from column sums, weights from
-    #      wgrad GEMMs dW = dY^T . X run as NT GEMMs over the transposed operands (contraction over the padded token count) -------
-    def _bb_buffers(self, ws, B, device, wgrad):
-        if "bbw" not in ws:
-            C, M = self.C, B * self.T
-            n = max(self.mlp, 3 * C, self.Kp)
-            ws["bbw"] = dict(ones=torch.ones(n, device=device), zeros=torch.zeros(n, device=device), junk=torch.zeros(2 * n, device=device),
-                             scratch=torch.zeros(64 * 2 * n, device=device), stat=[torch.zeros(M, device=device), torch.zeros(M, device=device)])
-            ws["dyd"] = ops.act_zeros(M, C, torch.float32, device)           # dropout-masked copy of a layer gradient (bias / weight-gradient operand)
-        if wgrad and "sav" not in ws:
-            C, M, Mp = self.C, B * self.T, ops.pad_rows(B * self.T)
-            z = lambda r, c: ops.act_zeros(r, c, self.adt, device)
-            ws["sav"] = dict(xn1=[z(M, C) for _ in range(self.depth)], xn2=[z(M, C) for _ in range(self.depth)],
-                             act=[z(M, self.mlp) for _ in range(self.depth)])
-            ws["tA"] = z(max(self.mlp, 3 * C), Mp)
-            ws["tB"] = z(max(self.mlp, self.Kp), Mp)
-            ws["pg16"] = z(B * self.N, C)
-            ws["pg32"] = ops.act_zeros(B * self.N, C, torch.float32, device)
-
-    def _bb_wgrad(self, ws, dy_op, x_op, out, M, N, K):
-        """out [N][K] (fp32) = dy_op[0:M, 0:N]^T . x_op[0:M, 0:K]; rows >= M of both operand buffers are zero by construction."""
-        Mp = ops.pad_rows(M)
-        tA, tB = ws["tA"].view(-1)[: ops.pad_rows(N) * Mp].view(-1, Mp), ws["tB"].view(-1)[: ops.pad_rows(K) * Mp].view(-1, Mp)
-        ops.transpose_any(dy_op, tA, Mp, N)
-        ops.transpose_any(x_op, tB, Mp, K)
-        self._gemm(tA, tB[:K], N, out.view(N, K), epilogue=ops.EPI_STORE_F32)
-
-    def _bb_linear_grads(self, ws, gv, bb, prefix, dy32, dy_op, x_op, M, N, K):
-        """db = colsum(dy), dW = dy^T . x for one Linear of the backbone, for whichever of the two trains."""
-        bw = ws["bbw"]
-        if prefix + ".bias" in bb:
-            src = dy32 if dy32 is not None else dy_op
-            ops.colsum_any(src, gv[prefix + ".bias"], bw["ones"][:N], bw["zeros"][:N], bw["junk"][:N], bw["scratch"], M, N)
-        if prefix + ".weight" in bb:
-            self._bb_wgrad(ws, dy_op, x_op, gv[prefix + ".weight"], M, N, K)
-
-    def _bb_ln_grads(self, ws, gv, bb, prefix, dy, x, mean, rstd, M):
-        wn, bn = prefix + ".weight", prefix + ".bias"
-        if wn in bb or bn in bb:
-            C, junk = self.C, ws["bbw"]["junk"]
-            ops.layernorm_bwd_affine(dy, x, mean, rstd, gv[wn] if wn in bb else junk[:C], gv[bn] if bn in bb else junk[C: 2 * C], ws["scratch"], M, C)
-
-    def _bb_embed_grads(self, ws, gv, bb, dG0, B):
-        """pos_embedding / cls_token (batch sums of the input gradient), conv_proj bias and weight (the patch rows)."""
-        C, T, N, bw = self.C, self.T, self.N, ws["bbw"]
-        nm = self.names
-        if "pos_embedding" in bb:
-            ops.rows_batch_sum(dG0, gv["pos_embedding"].view(T, C), None, B, T, 0, T, C)
-        if "cls_token" in bb:
-            ops.rows_batch_sum(dG0, gv["cls_token"].view(1, C), None, B, T, 0, 1, C)
-        cw, cb = nm.conv() + ".weight", nm.conv() + ".bias"
-        if cb in bb:
-            ops.colsum_any(dG0, gv[cb], bw["ones"][:C], bw["zeros"][:C], bw["junk"][:C], bw["scratch"], B * N, C, rows_in=N, rows_out=T, row_off=1)
-        if cw in bb:
-            ops.rows_gather(dG0, ws["pg32"], B, T, N, C, 1)
-            ops.to_operand(ws["pg32"], ws["pg16"], self.adt)
-            self._bb_wgrad(ws, ws["pg16"], ws["cols"], gv[cw].view(C, self.Kp), B * N, C, self.Kp)
-
-    # ---- EVP (evp.py): prompts from a high-pass copy of the volume + the patch embeddings, added in front of every layer --------
-    def _evp_state(self, device):
-        """Static per-engine buffers: the high-pass operator, zero-padded copies of the trainable prompt-generator weights and of
-        their gradients (the latents have rank r = dim/32 = 6 / 24 / 32; the rank-L kernels run at the padded width Lp)."""
-        st = self.__dict__.get("_evp")
-        if st is not None:
-            return st
-        C, Lp, Kp = self.C, self.Lp, self.Kp
-        mk = lambda *s_: torch.zeros(s_, device=device)
-        D, H, W = (g * p_ for g, p_ in zip(self.grid, self.patch))
-        hp, dm = evp_highpass_operator(D, H, W, self.freq)
-        st = dict(hp=torch.from_numpy(hp).to(device), dmask=torch.from_numpy(dm).to(device),
-                  Wp=mk(64, Kp), bp=mk(64), We=mk(Lp, C), be=mk(Lp), Ws=mk(C, Lp),
-                  Wi=[mk(Lp, Lp) for _ in range(self.depth)], WiT=[mk(Lp, Lp) for _ in range(self.depth)], bi=[mk(Lp) for _ in range(self.depth)],
-                  dWs=mk(C, Lp), dWe=mk(Lp, C), dWp=mk(Lp, Kp), dvec=mk(Lp), dWi=mk(Lp, Lp))
-        self.__dict__["_evp"] = st
-        return st
-
-    def _evp_latents(self, ws, B):
-        """s = proj(highpass(img)) + embedding_generator(conv(img))  (evp.py:76-84, 347-349), at the padded width."""
-        st, ev, d = self._evp_state(ws["img"].device), ws["ev"], self._d
-        r, Lp, C, Kp, BN = self.r, self.Lp, self.C, self.Kp, B * self.N
-        pg = "prompt_generator."
-        ops.pad2d(d(pg + "prompt_generator.proj.weight").reshape(r, Kp), r, Kp, st["Wp"], 64, Kp)
-        ops.pad2d(d(pg + "prompt_generator.proj.bias"), 1, r, st["bp"], 1, 64)
-        ops.pad2d(d(pg + "embedding_generator.weight"), r, C, st["We"], Lp, C)
-        ops.pad2d(d(pg + "embedding_generator.bias"), 1, r, st["be"], 1, Lp)
-        ops.pad2d(d(pg + "shared_mlp.weight"), C, r, st["Ws"], C, Lp)
-        for i in range(self.depth):
-            wi = d(pg + f"lightweight_mlp_{i}.0.weight")
-            ops.pad2d(wi, r, r, st["Wi"][i], Lp, Lp)
-            ops.pad2d(wi, r, r, st["WiT"][i], Lp, Lp, transpose=True)
-            ops.pad2d(d(pg + f"lightweight_mlp_{i}.0.bias"), 1, r, st["bi"][i], 1, Lp)
-        ops.skinny_down(x=ws["xc"], w=st["We"], bias=st["be"], y=ev["e"], M=BN, C=C, L=Lp, act=0, w_layout=0)
-        ops.evp_highpass(ws["img"], st["hp"], st["dmask"], ws["hp"])
-        ops.patchify(ws["hp"], ws["hcols"], self.patch)
-        ops.gemm_nt(ws["hcols"], st["Wp"], BN, ws["hc"], epilogue=ops.EPI_STORE_F32, bias=st["bp"])      # fp32 GEMM in both precisions (1.6 GF)
-        ops.add2d(ws["hc"], 64, ev["e"], Lp, ev["s"], Lp, BN, Lp)
-
-    def _evp_add_prompt(self, ws, i, si, g, B):
-        """prompt_i = shared_mlp(GELU(lightweight_mlp_i(s)))  (evp.py:86-95), added to the patch rows of the layer input."""
-        st, ev, d = self._evp_state(g.device), ws["ev"], self._d
-        Lp, C, BN = self.Lp, self.C, B * self.N
-        ops.small_linear_fwd(ev["s"], st["Wi"][i], st["bi"][i], ev["pre"][si], BN, Lp, Lp)
-        ops.gelu_fwd(ev["pre"][si], ev["u"][si])
-        ops.skinny_up(lat=ev["u"][si], w=st["Ws"], bias=d("prompt_generator.shared_mlp.bias"), out=ev["tmp"], M=BN, C=C, L=Lp, w_layout=0)
-        ops.rows_patch(g, ev["tmp"], None, B, self.T, self.N, C, 1, True)
-
-    def _evp_bwd_layer(self, ws, gv, i, dG, B):
-        """d prompt_i = the patch rows of the gradient of layer i's input; accumulates d shared_mlp over the layers and d s."""
-        st, ev, bw = self._evp_state(dG.device), ws["ev"], ws["evb"]
-        Lp, C, BN, r = self.Lp, self.C, B * self.N, self.r
-        pg = "prompt_generator."
-        top = i == self.depth - 1
-        ops.rows_gather(dG, ev["tmp"], B, self.T, self.N, C, 1)
-        ops.outer_reduce(narrow=ev["u"][i], wide=ev["tmp"], scratch=ws["scratch"], out=st["dWs"], colsum=gv[pg + "shared_mlp.bias"], M=BN, C=C, L=Lp,
-                         transposed=1, accumulate=0 if top else 1)
-        ops.skinny_down(x=ev["tmp"], w=st["Ws"], y=bw["du"], M=BN, C=C, L=Lp, act=0, w_layout=1)
-        ops.gelu_bwd(bw["du"], ev["pre"][i], bw["dpre"])
-        ops.reduce_batch([(bw["dpre"], ev["s"], st["dWi"], 0), (bw["dpre"], None, st["dvec"], 0)], ws["rscratch"])
-        ops.pad2d(st["dWi"], r, r, gv[pg + f"lightweight_mlp_{i}.0.weight"], r, r, ld_src=Lp)
-        ops.pad2d(st["dvec"], 1, r, gv[pg + f"lightweight_mlp_{i}.0.bias"], 1, r, ld_src=Lp)
-        ops.small_linear_fwd(bw["dpre"], st["WiT"][i], None, bw["ds"] if top else bw["ds_tmp"], BN, Lp, Lp)       # d s = dpre . W_i
-        if not top:
-            ops.add2d(bw["ds"], Lp, bw["ds_tmp"], Lp, bw["ds"], Lp, BN, Lp)
-
-    def _evp_bwd_finish(self, ws, gv, B):
-        st, ev, bw = self._evp_state(ws["img"].device), ws["ev"], ws["evb"]
-        Lp, C, BN, r, Kp = self.Lp, self.C, B * self.N, self.r, self.Kp
-        pg = "prompt_generator."
-        ops.pad2d(st["dWs"], C, r, gv[pg + "shared_mlp.weight"], C, r, ld_src=Lp)
-        ops.outer_reduce(narrow=bw["ds"], wide=ws["xc"], scratch=ws["scratch"], out=st["dWe"], M=BN, C=C, L=Lp, transposed=0, accumulate=0)
-        ops.pad2d(st["dWe"], r, C, gv[pg + "embedding_generator.weight"], r, C)
-        ops.reduce_batch([(bw["ds"], None, st["dvec"], 0)], ws["rscratch"])
-        ops.pad2d(st["dvec"], 1, r, gv[pg + "embedding_generator.bias"], 1, r, ld_src=Lp)
-        ops.pad2d(st["dvec"], 1, r, gv[pg + "prompt_generator.proj.bias"], 1, r, ld_src=Lp)
-        ops.outer_reduce(narrow=bw["ds"], wide=ws["hcols"], scratch=ws["scratch"], out=st["dWp"], M=BN, C=Kp, L=Lp, transposed=0, accumulate=0)
-        ops.pad2d(st["dWp"], r, Kp, gv[pg + "prompt_generator.proj.weight"].view(r, Kp), r, Kp)
-
-    # ---- DVPT (dvpt.py:24-63): share_MLP beside the MLP block ------------------------------------------------------------------
-    def _dvpt_names(self, i):
-        p = f"transformer.layers.{i}.0.prompt_proj"
-        return p + ".prompt_key_proj_d", p + ".prompt_key_proj_u", p + ".prompt_gate"
-
-    def _dvpt_fwd_latents(self, ws, i, si, g1, M, B):
-        pd, pu, pg = self._dvpt_names(i)
-        d, v = self._d, ws["dv"][si]
-        ops.skinny_down(x=g1, w=d(pd + ".weight"), bias=d(pd + ".bias"), y=v["z"], M=M, C=self.C, L=self.Lat, act=0, w_layout=0, act_in=1)
-        ops.dvpt_fwd(z=v["z"], enh=v["enh"], lse=v["lse"], B=B, T=self.T, P=self.P, L=self.Lat, C=self.C, scale=self.C ** -0.5)
-
-    def _dvpt_fwd_up(self, ws, i, si, gout, M):
-        pd, pu, pg = self._dvpt_names(i)
-        d, v = self._d, ws["dv"][si]
-        ops.skinny_up(lat=v["z"], lat_override=v["enh"], w=d(pu + ".weight"), bias=d(pu + ".bias"), alpha_ptr=d(pg), out=gout, M=M, C=self.C,
-                      L=self.Lat, T=self.T, P=self.P, w_layout=0, accumulate=1)
-
-    def _dvpt_bwd_latents(self, ws, gv, i, dGout, M, B):
-        """dcomb = dGout . W_u;  dW_u, db_u (gate applied afterwards), dgate;  latent backward -> dz;  db_d, dW_d."""
-        pd, pu, pg = self._dvpt_names(i)
-        d, v, bw, C, Lt = self._d, ws["dv"][i], ws["dvb"], self.C, self.Lat
-        ops.skinny_down(x=dGout, w=d(pu + ".weight"), y=bw["dcomb"], M=M, C=C, L=Lt, act=0, w_layout=1)
-        ops.outer_reduce(narrow=v["z"], lat_override=v["enh"], wide=dGout, scratch=ws["scratch"], out=gv[pu + ".weight"], colsum=gv[pu + ".bias"],
-                         M=M, C=C, L=Lt, T=self.T, P=self.P, transposed=1, accumulate=0)
-        ops.dvpt_bwd(z=v["z"], enh=v["enh"], lse=v["lse"], dcomb=bw["dcomb"], gate=d(pg), bu=d(pu + ".bias"), colsum_dy=gv[pu + ".bias"],
-                     delta=bw["delta"], dz=bw["dz"], dgate=gv[pg], B=B, T=self.T, P=self.P, L=Lt, C=C, scale=C ** -0.5)
-        ops.scale_dev_(gv[pu + ".weight"], d(pg))
-        ops.scale_dev_(gv[pu + ".bias"], d(pg))
-        ops.reduce_batch([(bw["dz"], None, gv[pd + ".bias"], 0)], ws["rscratch"])
-        ops.outer_reduce(narrow=bw["dz"], wide=ws["G1"][i], scratch=ws["scratch"], out=gv[pd + ".weight"], M=M, C=C, L=Lt, transposed=0,
-                         accumulate=0, wide_act=1)
-
-    def _dvpt_bwd_scatter(self, ws, i, dG1, M):
-        pd, pu, pg = self._dvpt_names(i)
-        ops.skinny_up(lat=ws["dvb"]["dz"], w=self._d(pd + ".weight"), out=dG1, out_bf16=None if self.fp32 else ws["dG16"], gg_x=ws["G1"][i],
-                      M=M, C=self.C, L=self.Lat, w_layout=1, accumulate=1)
-        if self.fp32:
-            ops.copy_(ws["dG16"], dG1)
-
-    # ---- SSF (ssf.py): effective parameters per step, scale / shift gradients per site -----------------------------------------
-    def _ssf_sites(self):
-        """(scale name, shift name, kind, target) for every ssf_ada of the model, in forward order."""
-        nm = self.names
-        sites = [("ssf_scale_1", "ssf_shift_1", "linear", ("conv", "conv_proj.0.weight", "conv_proj.0.bias"))]
-        for i in range(self.depth):
-            a, m = nm.attn(i), nm.mlp(i)
-            sites += [(a + ".ssf_scale_0", a + ".ssf_shift_0", "ln", (a + ".norm.weight", a + ".norm.bias")),
-                      (a + ".ssf_scale_1", a + ".ssf_shift_1", "linear", (f"qkv{i}", a + ".to_qkv.weight", a + ".to_qkv.bias")),
-                      (a + ".ssf_scale_2", a + ".ssf_shift_2", "linear", (f"out{i}", a + ".to_out.0.weight", a + ".to_out.0.bias")),
-                      (m + ".ssf_scale_0", m + ".ssf_shift_0", "ln", (m + ".net.0.weight", m + ".net.0.bias")),
-                      (m + ".ssf_scale_1", m + ".ssf_shift_1", "linear", (f"fc1{i}", m + ".net.1.weight", m + ".net.1.bias")),
-                      (m + ".ssf_scale_2", m + ".ssf_shift_2", "linear", (f"fc2{i}", m + ".net.4.weight", m + ".net.4.bias"))]
-        sites.append(("transformer.ssf_scale_1", "transformer.ssf_shift_1", "ln", ("transformer.norm.weight", "transformer.norm.bias")))
-        return sites
-
-    def _ssf_fold(self, train):
-        """gamma' = gamma*s, beta' = beta*s + t;  W' = s[:,None]*W (operand dtype, + transpose for the dgrad), b' = b*s + t.
-        Runs inside the recorded step: the scales and shifts are what the optimiser updates."""
-        w, eff, raw = self._w16, self._eff, (lambda n: self.p[n].detach())
-        for sn, tn, kind, tgt in self._ssf_sites():
-            s_, t_ = raw(sn), raw(tn)
-            if kind == "ln":
-                gname, bname = tgt
-                if gname not in eff:
-                    eff[gname], eff[bname] = torch.empty_like(s_), torch.empty_like(s_)
-                ops.ssf_fold_vec(raw(gname), s_, None, eff[gname])
-                ops.ssf_fold_vec(raw(bname), s_, t_, eff[bname])
-            else:
-                key, wname, bname = tgt
-                W = raw(wname)
-                W2 = W.reshape(W.shape[0], -1)
-                if key not in w:
-                    w[key] = torch.empty(W2.shape, dtype=self.adt, device=W.device)
-                    eff[bname] = torch.empty_like(s_)
-                need_t = train and key != "conv"
-                if need_t and key + "_t" not in w:
-                    w[key + "_t"] = torch.empty((W2.shape[1], W2.shape[0]), dtype=self.adt, device=W.device)
-                ops.ssf_fold_weight(W2, s_, w[key], w[key + "_t"] if need_t else None)
-                ops.ssf_fold_vec(self.p[bname].detach() if bname in self.p else None, s_, t_, eff[bname])
-
-    def _ssf_linear_grad(self, ws, gv, prefix, idx, dy, y0, M, N, y1=None, **kw):
-        sn, tn = f"{prefix}.ssf_scale_{idx}", f"{prefix}.ssf_shift_{idx}"
-        ops.ssf_colgrad(dy, y0, self.p[sn].detach(), self.p[tn].detach(), gv[sn], gv[tn], ws["ssf_scratch"], M, N, y1=y1, **kw)
-
-    def _ssf_ln_grad(self, ws, gv, prefix, ln, dy, x, mean, rstd, M):
-        C, tmp = self.C, ws["ssf_tmp"]
-        ops.layernorm_bwd_affine(dy, x, mean, rstd, tmp[:C], tmp[C:], ws["scratch"], M, C)
-        ops.ssf_ln_grad(tmp[:C], tmp[C:], self.p[prefix + ln + ".weight"].detach(), self.p[prefix + ln + ".bias"].detach(),
-                        gv[prefix + ".ssf_scale_0"], gv[prefix + ".ssf_shift_0"])
-
-    def _offset_of(self, name) -> int:
-        return (self._flat_grad["views"][name].data_ptr() - self._flat_grad["buf"].data_ptr()) // 4
-
-    def _mwsa_bwd(self, ws, sv, gv, i, dLout, dLin, B, have_dctx=False, defer_final=False):
-        """MWSA backward of layer i on the local stream.  have_dctx: the layer-boundary kernel already produced dctx (_mwsa_boundary);
-        defer_final: the last step (dL_in) is left to the next-lower layer's boundary kernel (_mwsa_chain_bwd).  The `_on(...)` guards are
-        the timing ablations of DESIGN.md section 7b.3."""
-        if not _on("noside"):
-            return
-        pre = f"transformer.local_attns.{i // self.share}"
-        d, C, Lt = self._d, self.C, self.Lat
-        BN = B * self.N
-        m, bw, sc = ws["mw"][i], ws["bw"], ws["scratch_l"]
-        lin = ws["Lc"][i]
-        acc = self._acc(i)
-        pd, seed_p, seed_a, sp = sv["proj_drop"], 2 * i + 1, 2 * i, ws["seed"]
-        if _on("loc_noupdown") and not have_dctx:
-            ops.skinny_down(x=dLout, w=d(pre + ".proj_up.weight"), y=bw["dctx"], M=BN, C=C, L=Lt, act=0, w_layout=1, drop_p=pd, seed=seed_p,
-                            seed_ptr=sp)
-        if _on("loc_noouter"):
-            ops.outer_reduce(narrow=m["ctx"], wide=dLout, scratch=sc, out=gv[pre + ".proj_up.weight"], colsum=gv[pre + ".proj_up.bias"],
-                             M=BN, C=C, L=Lt, transposed=1, accumulate=acc, drop_p=pd, seed=seed_p, seed_ptr=sp)
-        if _on("nowin"):
-            ops.window_attn_bwd(qkv=m["qkv"], ctx=m["ctx"], lse=m["lse"], dctx=bw["dctx"], delta=bw["wdelta"], dqkv=bw["dqkv"], B=B,
-                                D=self.grid[0], H=self.grid[1], W=self.grid[2], kd=self.win[0], kh=self.win[1], kw=self.win[2], L=Lt,
-                                scale=C ** -0.5, drop_p=sv["attn_drop"], seed=seed_a, seed_ptr=sp)
-        if _on("loc_nosmall"):
-            ops.skinny_down(x=bw["dqkv"], w=d(pre + ".qkv.weight"), y=bw["dlat"], M=BN, C=3 * Lt, L=Lt, act=0, w_layout=1)
-        wd = d(pre + ".proj_down.weight")
-        g_, b_ = d(pre + ".norm.weight"), d(pre + ".norm.bias")
-        if _on("loc_noouter"):
-            # Q[l][c] = sum_m dlat[m][l] xhat[m][c], S[l] = sum_m dlat[m][l]  ->  dWd, dbd, dgamma, dbeta in one tiny kernel
-            ops.outer_reduce(narrow=bw["dlat"], wide=lin, mean=m["mean"], rstd=m["rstd"], scratch=sc, out=bw["Q"], M=BN, C=C, L=Lt,
-                             transposed=0, accumulate=0)
-        if _on("loc_nosmall"):
-            # qkv weight gradient (dqkv^T . lat) and S[l] = sum_m dlat[m][l] in one two-stage reduction
-            ops.reduce_batch([(bw["dqkv"], m["lat"], gv[pre + ".qkv.weight"], acc), (bw["dlat"], None, bw["S"], 0)], ws["rscratch_l"])
-            ops.ln_lowrank_affine(bw["Q"], bw["S"], wd, g_, b_, gv[pre + ".proj_down.weight"], gv[pre + ".norm.weight"],
-                                  gv[pre + ".norm.bias"], gv[pre + ".proj_down.bias"], Lt, C, accumulate=bool(acc))
-        if _on("loc_noupdown") and not defer_final:
-            # dL_in = dL_out + LN'(dlat . Wd): the rank-L product never touches HBM
-            ops.skinny_up(lat=bw["dlat"], w=wd, res=dLout, out=dLin, ln_x=lin, ln_mean=m["mean"], ln_rstd=m["rstd"], ln_gamma=g_, M=BN, C=C,
-                          L=Lt, w_layout=1)

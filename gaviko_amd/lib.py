@@ -14,10 +14,28 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The step runs on three streams (+ the collective's and RCCL's own
 # in data-parallel runs); two of them landing on one queue serialises them: 5.9 -> 6.9-7.7 ms per step when a second model instance's
 # side streams wrapped around onto the main stream's queue (tools/bench_reducer.py).  Must be set before the first HIP call.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if os.environ.get("GPU_MAX_HW_QUEUES") is None:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    try:                                          # the variable is read when the HIP runtime starts: too late if torch has already started it
+        import sys as _sys
+        _t = _sys.modules.get("torch")
+        if _t is not None and _t.cuda.is_initialized():
+            import warnings as _w
+            _w.warn("gaviko_amd: HIP was initialised before gaviko_amd was imported, so GPU_MAX_HW_QUEUES=8 cannot take effect; the three "
+                    "streams of a step may share hardware queues (slower, not wrong).  Import gaviko_amd first or export the variable.")
+    except Exception:
+        pass
 
 ABI_VERSION = 7                                   # gvk_abi_version() of the library these declarations describe
-LIB_PATH = os.environ.get("GAVIKO_HIP_LIB") or os.path.join(_HERE, "libgaviko_hip.so")     # override: A/B runs of two builds
+# GAVIKO_HIP_DIAG=1 (tools/ only): load the measurement build libgaviko_hip_diag.so (`python -m gaviko_amd.build --diag`) -- the product
+# library ignores every A/B switch of the kernel sources and exports no diagnostics (include/gaviko_hip_diag.h)
+DIAG = os.environ.get("GAVIKO_HIP_DIAG", "0") == "1"
+LIB_PATH = os.environ.get("GAVIKO_HIP_LIB") or os.path.join(_HERE, "libgaviko_hip_diag.so" if DIAG else "libgaviko_hip.so")
+
+
+def diag_env(name: str, default=None):
+    """An A/B switch of the measurement build: read from the environment only when GAVIKO_HIP_DIAG=1, else its measured-best default."""
+    return os.environ.get(name, default) if DIAG else default
 
 
 class GemmDesc(C.Structure):
@@ -88,7 +106,6 @@ SIGNATURES = {
     "gvk_cast_f32_bf16": [_P, _P, _L, _P],
     "gvk_transpose_cast_f32_bf16": [_P, _P, _I, _I, _P],
     "gvk_pack_split_bf16": [_P, _I, _P, _P, _I, _I, _I, _I, _P],
-    "gvk_patch_embed_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "gvk_prompt_up_fix": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gvk_layernorm_fwd_fix": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _I, _I, _I, _P],
     "gvk_patchify_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -159,11 +176,15 @@ NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, [
              "gvk_plan_begin": (C.c_int, []), "gvk_plan_end": (C.c_int, []), "gvk_plan_abort": (C.c_int, []),
              "gvk_plan_size": (C.c_int, [C.c_int]), "gvk_plan_replay": (C.c_int, [C.c_int]), "gvk_plan_free": (C.c_int, [C.c_int]),
              "gvk_plan_event_record": (C.c_int, [_P]), "gvk_plan_event_wait": (C.c_int, [_P, C.c_int]),
-             "gvk_plan_event_record_fenced": (C.c_int, [_P]), "gvk_plan_nop_stream": (C.c_int, [_P]), "gvk_stream_set_lds_pad": (C.c_int, [_P, C.c_int]), "gvk_plan_event_stream_wait": (C.c_int, [C.c_int, C.c_int, _P]),
+             "gvk_plan_event_record_fenced": (C.c_int, [_P]), "gvk_plan_event_stream_wait": (C.c_int, [C.c_int, C.c_int, _P]),
              "gvk_plan_set_timing": (C.c_int, [C.c_int]),
              "gvk_plan_event_elapsed": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)])}
 STRUCTS = {"gvk_gemm_desc": GemmDesc, "gvk_skinny_down_desc": SkinnyDownDesc, "gvk_skinny_up_desc": SkinnyUpDesc,
            "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob, "gvk_rowproj_desc": RowProjDesc, "gvk_adam_desc": AdamDesc, "gvk_loss_desc": LossDesc, "gvk_dropout_desc": DropoutDesc, "gvk_ssf_colgrad_desc": SsfColgradDesc, "gvk_dvpt_desc": DvptDesc}
+
+# diag library only (include/gaviko_hip_diag.h): bound when GAVIKO_HIP_DIAG=1 selects libgaviko_hip_diag.so
+DIAG_SIGNATURES = {"gvk_patch_embed_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]}
+DIAG_NO_STREAM = {"gvk_plan_nop_stream": (C.c_int, [_P]), "gvk_plan_nop_clear": (C.c_int, [])}
 
 _lib = None
 
@@ -188,6 +209,13 @@ def load() -> C.CDLL:
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = C.c_int, args
+    if DIAG:
+        for name, (res, args) in DIAG_NO_STREAM.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        for name, args in DIAG_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = C.c_int, args
     if lib.gvk_abi_version() != ABI_VERSION:
         raise GavikoHipError(f"{LIB_PATH} has ABI version {lib.gvk_abi_version()}, these bindings describe {ABI_VERSION}: rebuild with "
                              "`python -m gaviko_amd.build`")

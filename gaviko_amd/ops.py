@@ -92,7 +92,9 @@ def pack_split_bf16(a, dst, col0, rows, b=None, weight_side=False):
 
 def patch_embed(img, w, bias, pos, out0, out1, patch, C_, rows_out, row_off):
     """Conv3d(kernel = stride = patch) + bias + position rows, scattered into the token rows of out0 (and densely into out1): one implicit
-    GEMM over the fp32 volume (gaviko_hip.h: gvk_patch_embed_bf16)."""
+    GEMM over the fp32 volume.  Experiment kernel (slower than the two-kernel form): diag library only (gaviko_hip_diag.h: gvk_patch_embed_bf16)."""
+    if not L.DIAG:
+        raise L.GavikoHipError("patch_embed (implicit GEMM) is an experiment kernel of the diag library: GAVIKO_HIP_DIAG=1 + `python -m gaviko_amd.build --diag`")
     B, _, D, H, W = img.shape
     pd, ph, pw = patch
     n = (D // pd) * (H // ph) * (W // pw)
@@ -241,8 +243,7 @@ def side_tile_supported(L_: int, C_: int) -> bool:
     gvk_skinny_up (w2 / z2 / y2) and the chained layer-boundary forms.  Mirrors the C side exactly (sidepass.hip: kSL = 20,
     groups_per_wave(C) != 0 only for C in {192, 768, 1024}); any other latent width or channel count runs the generic
     row-per-wave / MFMA-tile kernels of rowwise.hip / skinny.hip without the fusions."""
-    import os
-    return os.environ.get("GAVIKO_HIP_SIDE", "1")[:1] != "0" and L_ == 20 and C_ in (192, 768, 1024)
+    return str(L.diag_env("GAVIKO_HIP_SIDE", "1"))[:1] != "0" and L_ == 20 and C_ in (192, 768, 1024)
 
 
 def rowproj_supported(L_: int, C_: int) -> bool:

@@ -42,11 +42,6 @@ int gvk_plan_event_record(void* stream);           /* -> event id within the pla
 int gvk_plan_event_wait(void* stream, int event);
 /* gvk_plan_event_record with the system-scope fence kept (events that peer devices' reads are ordered behind: all-reduce buckets) */
 int gvk_plan_event_record_fenced(void* stream);
-/* LDS exclusion: every later launch of this library on `stream` asks for `bytes` of extra (unused) dynamic LDS, so its workgroups only
-   fit on CUs with that much LDS free -- keeps side-stream kernels off the CUs the backbone GEMM / attention workgroups occupy */
-int gvk_stream_set_lds_pad(void* stream, int bytes);
-/* diagnostics only: launches recorded on `stream` from now on are replaced by an empty kernel (contention studies; results are garbage) */
-int gvk_plan_nop_stream(void* stream);
 /* issued immediately (not recorded): `stream` waits for event `event` of plan `plan` as recorded by its most recent replay */
 int gvk_plan_event_stream_wait(int plan, int event, void* stream);
 /* measurement: milliseconds between two events of a replayed plan.  Events carry timestamps only in plans recorded after
@@ -91,7 +86,7 @@ typedef struct gvk_gemm_desc {
   int32_t lda, ldw, ldo, ldres, ldaux;
   int32_t epilogue;
   int32_t rows_in, rows_out, row_off; /* GVK_EPI_PATCH_F32 only */
-  int32_t tile;       /* 0 = auto, else BM*1000+BN (128128, 128064, 64064, 64128); 3128128 / 3064128 = 128x128 / 64x128 with three LDS stages; 9128128 / 4128128 = 128x128 on eight waves that split every k-tile two / four ways (STORE_BF16, BIAS_RES_F32, STORE_F32; measured, not faster);
+  int32_t tile;       /* 0 = auto, else BM*1000+BN (128128, 128064, 64064, 64128); 3128128 / 3064128 = 128x128 / 64x128 with three LDS stages; 3096128 = 96x128 with three stages; (9128128 / 4128128, eight waves splitting every k-tile: diag library only, include/gaviko_hip_diag.h);
                          256256 = eight waves on a 256x256 tile (STORE_BF16, BIAS_GELU_BF16, GELU_BWD_BF16 only);
                          8256256 / 7256256 = the eight-phase 256x256 kernel (gemm8p_bf16.hip: two wave groups one barrier apart, counted
                          vmcnt), LDS-DMA issued in the load sections / inside the MFMA clusters; epilogues 0, 1, 2, 4, 5, N % 256 == 0, K >= 128 */
@@ -142,12 +137,7 @@ int gvk_pack_split_bf16(const float* a, int ca, const float* b, void* dst, int l
 /* im2col of non-overlapping 3-D patches, fp32 volume -> bf16 rows [B*n_patches][pd*ph*pw]
  * (K order (kd,kh,kw) == Conv3d weight.flatten(1); vision_transformer.py:126-128,150-151). */
 int gvk_patchify_bf16(const float* img, void* out, int B, int D, int H, int W, int pd, int ph, int pw, void* stream);
-/* The same Conv3d (kernel = stride = patch; vision_transformer.py:126-128,150-157) as ONE implicit GEMM: the A operand is gathered from the
- * fp32 volume inside the kernel (no im2col matrix), w bf16 [C][pd*ph*pw] = Conv3d.weight.flatten(1), epilogue = GVK_EPI_PATCH_F32:
- * out0 f32 [B*rows_out][C] rows b*rows_out + row_off + t = patch(b, t) . w^T + bias + pos[t] (pos f32 [n_tokens][C]); out1 (optional)
- * f32 [B*n_tokens][C] receives the same rows densely (GAViKO's local stream, gaviko.py:532-548).  pw = 16, ph*pw % 64 == 0, C % 128 == 0. */
-int gvk_patch_embed_bf16(const float* img, const void* w, const float* bias, const float* pos, float* out0, float* out1, int B, int D, int H,
-                         int W, int pd, int ph, int pw, int C, int rows_out, int row_off, void* stream);
+
 
 /* ------------------------------------------------------------------ LayerNorm (eps 1e-5; vision_transformer.py:30,49,77)
  * fwd: x f32 [M][C] -> y bf16 [M][C] (MFMA operand) and/or y32 f32; saves mean/rstd f32 [M] (either may be NULL). */

@@ -2,6 +2,7 @@
 Runs one fixture's forward under the kernel's tile-size / row-sum variants (all of them exact to rounding) and prints the logits error
 against the golden fixture for each -- the spread is the realisation noise of that figure."""
 import sys, os
+os.environ.setdefault("GAVIKO_HIP_DIAG", "1")      # kernel variants / A/B switches live in the measurement build (python -m gaviko_amd.build --diag)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
