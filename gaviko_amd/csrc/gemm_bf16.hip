@@ -47,10 +47,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs p) {
     const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  // Grouped rasterisation inside the XCD's run: GROUP_M row panels x all column tiles, m fastest.  The L2 (4 MiB / XCD) then holds
+  // Grouped rasterisation inside the XCD's run: group_m row panels x all column tiles, m fastest.  The L2 (4 MiB / XCD) then holds
   // the group's A panels while each weight column tile is streamed once per group instead of once per row panel
   // (rocprofv3 FETCH_SIZE of the fc2-dgrad GEMM: 110 MB with the plain n-fastest order vs 36 MB algorithmic).
-  constexpr int GROUP_M = 8;
+  // group_m is chosen by the launcher so that ONE group is about one XCD's run of tiles (all of which are resident together): every column
+  // tile of a row panel then runs on the same XCD at the same time and the activation panel is fetched from HBM / MALL once, not once per
+  // XCD that holds a piece of the group (round 2, fixed groups of 8 panels: the fc2-forward activation panel was fetched about twice).
+  const int GROUP_M = p.group_m;
   const int gsz = GROUP_M * p.nbn;
   const int grp = wg / gsz, first_m = grp * GROUP_M;
   const int gm = min(p.nbm - first_m, GROUP_M);
@@ -223,6 +226,14 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   p.nbm = (a.M + BM - 1) / BM;
   p.nbn = a.N / BN;
   p.a_rows = (a.M + 127) / 128 * 128;
+  {
+    // row panels per group ~ (tiles per XCD) / (column tiles), within 1..8: N = 768 at M = 4132 -> 198 tiles, 24.75 per XCD, 6 columns -> 4
+    const int per_xcd = (p.nbm * p.nbn) >> 3;
+    int g = (per_xcd + p.nbn / 2) / p.nbn;
+    g = g < 1 ? 1 : g > 8 ? 8 : g;
+    static const int force = diag_env("GAVIKO_HIP_GEMM_GROUP_M") ? atoi(diag_env("GAVIKO_HIP_GEMM_GROUP_M")) : 0;     // A/B switch (8 = the round-2 mapping)
+    p.group_m = force > 0 ? force : g;
+  }
   GVK_LAUNCH((gemm_nt_kernel<BM, BN, EPI, BK, DROP, NS, NW>), dim3(p.nbm * p.nbn), dim3(64 * NW), lds, stream, p);
   return check_launch("gemm_nt_bf16");
 }
