@@ -336,6 +336,8 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
 
 }  // namespace gvk
 
+extern "C" int gvk_gemm_stat_parts(int N) { return N / 64; }
+
 extern "C" int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(d != nullptr, "gvk_gemm_nt_bf16: null descriptor");
@@ -361,6 +363,12 @@ extern "C" int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream) {
   GVK_REQUIRE(d->scale_cols == 0 || (d->epilogue == GVK_EPI_STORE_BF16 && d->scale_cols > 0 && d->scale_cols % 8 == 0 && d->scale_cols <= d->N),
               "gvk_gemm_nt_bf16: scale_cols=%d needs the STORE_BF16 epilogue, a multiple of 8 and <= N", d->scale_cols);
   a.scale_cols = d->scale_cols; a.col_scale = d->col_scale;
+  GVK_REQUIRE(d->ln_mean == nullptr || (d->epilogue == GVK_EPI_STORE_BF16 && d->ln_rstd && d->ln_c1 && d->bias),
+              "gvk_gemm_nt_bf16: the LayerNorm fold needs the STORE_BF16 epilogue, ln_rstd, ln_c1 and bias (= sum_c beta[c] W[n][c])");
+  a.ln_mean = d->ln_mean; a.ln_rstd = d->ln_rstd; a.ln_c1 = d->ln_c1;
+  GVK_REQUIRE(d->stat_part == nullptr || (d->epilogue == GVK_EPI_BIAS_RES_F32_BF16 && d->N % 128 == 0 && (d->tile == 0 || d->tile % 1000 == 128)),
+              "gvk_gemm_nt_bf16: stat_part needs the BIAS_RES_F32_BF16 epilogue on 128-column tiles (64-column groups)");
+  a.stat_part = d->stat_part;
   hipStream_t s = (hipStream_t)stream;
   switch (d->epilogue) {
     case GVK_EPI_STORE_BF16:

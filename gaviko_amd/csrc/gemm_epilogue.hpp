@@ -27,6 +27,12 @@ struct GemmArgs {
   unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;
   // STORE_BF16 only: columns n < scale_cols leave as (acc + bias) * col_scale (the q block of a qkv projection, pre-scaled for the attention kernels)
   int scale_cols; float col_scale;
+  // LayerNorm folded into the consumer GEMM (STORE_BF16): A holds the RAW rows x (bf16), W the rows gamma o W; the epilogue applies
+  //   y = rstd[m] * (acc - mean[m] * c1[n]) + bias[n]      c1[n] = sum_c (gamma o W)[n][c] (of the bf16 operand), bias[n] = sum_c beta[c] W[n][c]
+  const float* ln_mean; const float* ln_rstd; const float* ln_c1;
+  // BIAS_RES_F32_BF16: per-row partial (sum, sum of squares) of the fp32 output over this wave's columns, written to
+  // stat_part[(column group)][m] (float2; group = column / (16 * NT)); a later kernel turns the groups of a row into mean / rstd
+  float* stat_part;
 };
 
 // LDS swizzles (applied to the 16-byte chunk index of a 128-byte tile row; conflict-free for the ds_read_b128 lane groups)
@@ -46,20 +52,33 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
   constexpr bool kRes = EPI == GVK_EPI_BIAS_RES_F32 || EPI == GVK_EPI_BIAS_RES_F32_BF16;
   constexpr bool kAux = EPI == GVK_EPI_GELU_BWD_BF16 || EPI == GVK_EPI_RELU_BWD_BF16;
   constexpr bool kPos = EPI == GVK_EPI_PATCH_F32;
+  constexpr bool kFold = EPI == GVK_EPI_STORE_BF16;          // optional LayerNorm fold (p.ln_mean != nullptr)
+  constexpr bool kStat = EPI == GVK_EPI_BIAS_RES_F32_BF16;   // optional row-statistic partials (p.stat_part != nullptr)
   f32x4 bv[NP][2];
+  [[maybe_unused]] f32x4 c1v[NP][2];
 #pragma unroll
   for (int jp = 0; jp < NP; ++jp) {
     bv[jp][0] = bv[jp][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int n = nbase + 32 * jp + 8 * lq;
     if (p.bias != nullptr) {
-      const int n = nbase + 32 * jp + 8 * lq;
       bv[jp][0] = *(const f32x4*)(p.bias + n);
       bv[jp][1] = *(const f32x4*)(p.bias + n + 4);
     }
+    if constexpr (kFold) {
+      c1v[jp][0] = c1v[jp][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.ln_mean != nullptr) {
+        c1v[jp][0] = *(const f32x4*)(p.ln_c1 + n);
+        c1v[jp][1] = *(const f32x4*)(p.ln_c1 + n + 4);
+      }
+    }
   }
-  struct Side { f32x4 r0[NP], r1[NP]; bf16x8 a8[NP]; };
+  struct Side { f32x4 r0[NP], r1[NP]; bf16x8 a8[NP]; float mu, rs; };
   auto fetch = [&](const int i, Side& sd) {
     const int m = mbase + i * 16 + l15;
     if (m >= p.M) return;
+    if constexpr (kFold) {
+      if (p.ln_mean != nullptr) { sd.mu = p.ln_mean[m]; sd.rs = p.ln_rstd[m]; }
+    }
 #pragma unroll
     for (int jp = 0; jp < NP; ++jp) {
       const int n = nbase + 32 * jp + 8 * lq;
@@ -82,6 +101,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
   for (int i = 0; i < MT; ++i) {
     if (i + 1 < MT) fetch(i + 1, nxt);
     const int m = mbase + i * 16 + l15;
+    [[maybe_unused]] float ps1 = 0.f, ps2 = 0.f;             // kStat: this lane's share of the row's (sum, sum of squares)
     if (m < p.M) {
       size_t orow = (size_t)m;
       if constexpr (kPos) {
@@ -94,6 +114,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
         float v[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jp][e] + bv[jp][0][e]; v[4 + e] = acc[i][2 * jp + 1][e] + bv[jp][1][e]; }
+        if constexpr (kFold) {
+          if (p.ln_mean != nullptr) {                        // y = rstd * (acc - mean * c1) + bias
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = __builtin_fmaf(__builtin_fmaf(-cur.mu, c1v[jp][0][e], acc[i][2 * jp][e]), cur.rs, bv[jp][0][e]);
+              v[4 + e] = __builtin_fmaf(__builtin_fmaf(-cur.mu, c1v[jp][1][e], acc[i][2 * jp + 1][e]), cur.rs, bv[jp][1][e]);
+            }
+          }
+        }
         auto store_f32 = [&](float* dst) {
           *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
           *(f32x4*)(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
@@ -120,7 +149,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[e] += cur.r0[jp][e]; v[4 + e] += cur.r1[jp][e]; }
           store_f32((float*)p.out0 + (size_t)m * p.ldo + n);
-          if constexpr (EPI == GVK_EPI_BIAS_RES_F32_BF16) store_bf16((bf16*)p.out1 + (size_t)m * p.ldo + n);
+          if constexpr (EPI == GVK_EPI_BIAS_RES_F32_BF16) {
+            store_bf16((bf16*)p.out1 + (size_t)m * p.ldo + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ps1 += v[e]; ps2 = __builtin_fmaf(v[e], v[e], ps2); }
+          }
         } else if constexpr (EPI == GVK_EPI_BIAS_GELU_BF16) {
           if (p.out0 != nullptr) store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
 #pragma unroll
@@ -148,6 +181,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
           for (int e = 0; e < 8; ++e) v[e] = (float)cur.a8[jp][e] > 0.f ? v[e] : 0.f;
           store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
         }
+      }
+    }
+    if constexpr (kStat) {
+      if (p.stat_part != nullptr) {                          // wave-uniform: the four lanes lq = 0..3 of a row hold its column quarters
+        ps1 += __shfl_xor(ps1, 16, 64); ps2 += __shfl_xor(ps2, 16, 64);
+        ps1 += __shfl_xor(ps1, 32, 64); ps2 += __shfl_xor(ps2, 32, 64);
+        if (lq == 0 && m < p.M) *(f32x2*)(p.stat_part + ((size_t)(nbase / (16 * NT)) * p.M + m) * 2) = f32x2{ps1, ps2};
       }
     }
     cur = nxt;

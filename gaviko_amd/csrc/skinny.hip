@@ -712,6 +712,79 @@ __global__ __launch_bounds__(256) void prompt_up_fix_kernel(const float* __restr
 }
 }  // namespace gvk
 
+namespace gvk {
+// gvk_prompt_up_fix for a layer whose first LayerNorm is folded into the qkv projection (gvk_gemm_desc.ln_mean): the fc2 GEMM in front of
+// this kernel has left the fp32 rows, their bf16 copy and per-row (sum, sum of squares) partials over 64-column groups.
+//   blocks [0, P*B):      fix one prompt row (as prompt_up_fix_kernel), rewrite its bf16 copy and compute its mean / rstd from the row itself
+//   blocks [P*B, ...):    one thread per remaining row: mean / rstd from the GEMM's partials (prompt rows are left to the blocks above)
+__global__ __launch_bounds__(256) void prompt_fix_stats_kernel(const float* __restrict__ enh, const float* __restrict__ lat, const float* __restrict__ w,
+                                                               float* __restrict__ out, bf16* __restrict__ out16, const float* __restrict__ part,
+                                                               int nparts, float* __restrict__ mean, float* __restrict__ rstd, int B, int T, int P,
+                                                               int C, int L, float eps) {
+  const int M = B * T;
+  if ((int)blockIdx.x >= P * B) {
+    const int m = ((int)blockIdx.x - P * B) * 256 + threadIdx.x;
+    if (m >= M || (m % T) < P) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int g = 0; g < nparts; ++g) {                          // fixed order: deterministic
+      const f32x2 v = *(const f32x2*)(part + ((size_t)g * M + m) * 2);
+      s1 += v[0]; s2 += v[1];
+    }
+    const float mu = s1 / (float)C;
+    const float var = fmaxf(s2 / (float)C - mu * mu, 0.f);
+    mean[m] = mu;
+    rstd[m] = 1.0f / sqrtf(var + eps);
+    return;
+  }
+  __shared__ float dl[64];
+  __shared__ float red[8];
+  const int b = blockIdx.x / P, pi = blockIdx.x - b * P;
+  const size_t row = (size_t)b * T + pi;
+  if ((int)threadIdx.x < L) dl[threadIdx.x] = enh[((size_t)b * P + pi) * L + threadIdx.x] - lat[row * L + threadIdx.x];
+  __syncthreads();
+  float x[4] = {0.f, 0.f, 0.f, 0.f};                            // C <= 1024: up to four columns per thread
+  float s1 = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = threadIdx.x + 256 * u;
+    if (c < C) {
+      float a = 0.f;
+      for (int l = 0; l < L; ++l) a = __builtin_fmaf(dl[l], w[(size_t)c * L + l], a);
+      x[u] = out[row * C + c] + a;
+      out[row * C + c] = x[u];
+      out16[row * C + c] = (bf16)x[u];
+      s1 += x[u];
+    }
+  }
+  // two-pass statistics of the row (as the LayerNorm kernel takes them): block sum -> mean -> block sum of squared deviations
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  const float mu = block_sum(s1) / (float)C;
+  float s2 = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if ((int)threadIdx.x + 256 * u < C) s2 = __builtin_fmaf(x[u] - mu, x[u] - mu, s2);
+  const float var = block_sum(s2) / (float)C;
+  if (threadIdx.x == 0) { mean[row] = mu; rstd[row] = 1.0f / sqrtf(var + eps); }
+}
+}  // namespace gvk
+
+extern "C" int gvk_prompt_up_fix_stats(const float* enh, const float* lat, const float* w, float* out, void* out16, const float* part, int nparts,
+                                       float* mean, float* rstd, int B, int T, int P, int C, int L, float eps, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(enh && lat && w && out && out16 && part && mean && rstd, "gvk_prompt_up_fix_stats: null pointer");
+  GVK_REQUIRE(B > 0 && P > 0 && P <= T && C > 0 && C <= 1024 && L > 0 && L <= 64 && nparts > 0, "gvk_prompt_up_fix_stats: bad arguments");
+  const int nblk = P * B + (B * T + 255) / 256;
+  GVK_LAUNCH(prompt_fix_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, enh, lat, w, out, (bf16*)out16, part, nparts, mean, rstd, B, T, P,
+             C, L, eps > 0.f ? eps : 1e-5f);
+  return check_launch("prompt_up_fix_stats");
+}
+
 extern "C" int gvk_prompt_up_fix(const float* enh, const float* lat, const float* w, float* out, int B, int T, int P, int C, int L, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(enh && lat && w && out && B > 0 && P > 0 && P <= T && C > 0 && L > 0 && L <= 64, "gvk_prompt_up_fix: bad arguments");

@@ -41,7 +41,8 @@ class Engine(GavikoPaths, PeftPaths):
     def __init__(self, kind: str, cfg: dict, params: Dict[str, torch.nn.Parameter], depth, heads, dim, mlp_dim):
         self.kind, self.cfg, self.p = kind, cfg, params
         self.depth, self.heads, self.C, self.mlp = depth, heads, dim, mlp_dim
-        self.names = Names(kind)
+        self.lora_layers = frozenset(cfg.get("lora_layer") or range(depth)) if kind == "melo" else frozenset()
+        self.names = Names(kind, self.lora_layers if kind == "melo" else None)
         fp, ip = cfg["frame_patch_size"], cfg["image_patch_size"]
         self.patch = (fp, ip, ip)
         self.grid = (cfg["frames"] // fp, cfg["image_size"] // ip, cfg["image_size"] // ip)
@@ -135,6 +136,12 @@ class Engine(GavikoPaths, PeftPaths):
         # main stream loses a full read-modify-write pass over the token stream per layer
         self._fuse_up = (kind == "gaviko" and not self.fp32 and 3 * self.Lat + 2 <= 64 and L.diag_env("GAVIKO_HIP_FUSE_UP", "1") != "0")
         self.ldx = self.mlp + 64 if self._fuse_up else self.mlp      # row stride of the MLP hidden buffers
+        # First LayerNorm of layers 1.. folded into their qkv projection (vision_transformer.py:49,61-62): the fc2 GEMM of the layer below
+        # leaves the bf16 copy of its output rows and per-row (sum, sum of squares) partials, the prompt-fix kernel turns them into mean /
+        # rstd, and the qkv GEMM runs on the RAW rows against gamma o W with  rstd * (acc - mean * c1) + c2  in its epilogue -- one launch
+        # (and its dependency gap) less per layer on the main stream.  128-column tiles only (C % 128 == 0: ViT-B / ViT-L).
+        self._fold_ln1 = (self._fuse_up and self._fuse_proj and dim % 128 == 0 and L.diag_env("GAVIKO_HIP_FOLD_LN1", "1") != "0")
+        self._fold: Dict[str, torch.Tensor] = {}
         self._marks = []
         self.plan_marks = {}                # plan id -> [(name, event id)]
         self._bucket_marks = {}             # (stream kind, layer) -> event of the pass being issued / recorded: gradients of that layer final
@@ -220,6 +227,14 @@ class Engine(GavikoPaths, PeftPaths):
                     w[f"{tag}{i}"] = ops.to_operand(src, None if self.fp32 else w.get(f"{tag}{i}"), self.adt)   # fp32: the parameter itself
                 if need_dgrad and (stale or not self._have_dgrad):
                     w[f"{tag}{i}_t"] = ops.transpose_operand(src, w.get(f"{tag}{i}_t"), self.adt)
+        if self._fold_ln1 and (stale or not self._fold):
+            for i in range(1, self.depth):
+                a = self.names.attn(i)
+                Wq, g, b = self._d(self.names.qkv_weight(i)), self._d(a + ".norm.weight"), self._d(a + ".norm.bias")
+                w16 = ops.to_operand((Wq * g[None, :]).contiguous(), self._fold.get(f"w{i}"), self.adt)
+                self._fold[f"w{i}"] = w16
+                self._fold[f"c1_{i}"] = w16.float().sum(1).contiguous()          # row sums of the bf16 operand the MFMAs actually multiply
+                self._fold[f"c2_{i}"] = (Wq * b[None, :]).sum(1).contiguous()      # beta . W^T
         self._have_dgrad = self._have_dgrad and not stale or need_dgrad
         self._w16_version = version
 
@@ -273,6 +288,9 @@ class Engine(GavikoPaths, PeftPaths):
             ws["act"][:, self.mlp + 3 * self.Lat: self.mlp + 3 * self.Lat + 2] = 1.0     # the two bias columns (b_hi, b_lo); the rest of the slot stays 0
         ws["stat"] = [[torch.zeros(M, device=device) for _ in range(4)] for _ in range(nsave)]   # mean1, rstd1, mean2, rstd2
         ws["pooled"] = torch.zeros((B, C), device=device)
+        if self._fold_ln1:
+            ws["xg16"] = z(M, C, bf16)                                          # bf16 copy of the global stream entering a folded layer
+            ws["spart"] = torch.zeros((C // 64) * M * 2, device=device)         # per-row (sum, sum of squares) over 64-column groups
         if self.kind == "gaviko":
             Lt, P, BN = self.Lat, self.P, B * N
             ws["Lc"] = [torch.zeros((BN, C), device=device) for _ in range((self.depth + 1) if train else 2)]
@@ -591,6 +609,7 @@ class Engine(GavikoPaths, PeftPaths):
                         pre, _ = self._gpa_names(i)
                         ops.pack_split_bf16(d(pre + ".proj_up.weight"), self._w16[f"fc2{i}"], self.mlp, C, b=d(pre + ".proj_up.bias"), weight_side=True)
         pending_fix = None
+        folded_in = False                                            # this layer's first LayerNorm rides its qkv GEMM (self._fold_ln1)
         for i in range(self.depth):
             si = i if train else 0
             gi, go = (i, i + 1) if train else (i & 1, (i + 1) & 1)
@@ -611,7 +630,8 @@ class Engine(GavikoPaths, PeftPaths):
                 self._evp_add_prompt(ws, i, si, ws["G"][gi], B)               # x[:, 1:] += prompt_i (evp.py:235-238)
             if gaviko and pending_fix is not None:
                 self._wait(None, "gpa")                              # the previous layer's enh
-            self._attn_block_fwd(ws, i, si, ws["G"][gi], ws["G1"][si], Mi, sv["bdrop"], fix=pending_fix if gaviko and _on("noside") else None)
+            self._attn_block_fwd(ws, i, si, ws["G"][gi], ws["G1"][si], Mi, sv["bdrop"], fix=pending_fix if gaviko and _on("noside") else None,
+                                 folded=folded_in)
             pending_fix = None
             self._mark(f"f{i}:attn")
             fused = gaviko and self._fuse_proj
@@ -631,10 +651,11 @@ class Engine(GavikoPaths, PeftPaths):
                 with torch.cuda.stream(gpa):
                     self._gpa_fwd_latents(ws, i, si, ws["G1"][si], ws["Lc"][go], M, B, False)
             up_in_fc2 = gaviko and fused and fuse_up
+            fold_next = bool(up_in_fc2 and self._fold_ln1 and i + 1 < self.depth and _on("noside") and not _FIX_IN_LN and not self._keep_inputs)
             # fc2 carries proj_up of the PLAIN latents of every row (ready right behind the LayerNorm); the GPA has the two GEMMs' time
             # to finish, and only the P prompt rows it replaces are fixed up afterwards
             self._mlp_block_fwd(ws, i, si, ws["G1"][si], gout, Mi, train, sv["bdrop"],
-                                up_in_fc2=up_in_fc2)
+                                up_in_fc2=up_in_fc2, stats_out=fold_next)
             if self.kind == "adaptformer":
                 self._adapter_fwd_up(ws, i, si, gout, Mi)
             if self.kind == "dvpt":
@@ -646,11 +667,18 @@ class Engine(GavikoPaths, PeftPaths):
                 pre, _ = self._gpa_names(i)
                 g = ws["gp"][si]
                 pending_fix = dict(enh=g["enh"], lat=g["xl"], wup=d(pre + ".proj_up.weight"))
-                if i + 1 == self.depth or not _FIX_IN_LN:
+                if fold_next:
+                    self._wait(None, "gpa")                          # enh ready
+                    sn = ws["stat"][si + 1 if train else 0]
+                    ops.prompt_up_fix_stats(pending_fix["enh"], pending_fix["lat"], pending_fix["wup"], ws["G"][go], ws["xg16"], ws["spart"],
+                                            sn[0], sn[1], B, self.T, self.P, C, self.Lat)
+                    pending_fix = None
+                elif i + 1 == self.depth or not _FIX_IN_LN:
                     self._wait(None, "gpa")                          # enh ready
                     if _on("noside"):
                         ops.prompt_up_fix(pending_fix["enh"], pending_fix["lat"], pending_fix["wup"], ws["G"][go], B, self.T, self.P, C, self.Lat)
                     pending_fix = None
+                folded_in = fold_next
             elif gaviko:
                 self._wait(None, "gpa")                              # enh ready
                 self._gpa_fwd_up(ws, i, si, ws["G"][go], M)
@@ -694,10 +722,21 @@ class Engine(GavikoPaths, PeftPaths):
         if sv["pdrop"] > 0:
             ops.dropout_rows(g, sv["pdrop"], SEED_PROMPT + i, ws["seed"], out32=g, M=sv["B"] * self.P, N=self.C, rows_in=self.P, rows_out=T, row_off=1)
 
-    def _attn_block_fwd(self, ws, i, si, gin, g1, M, pdrop=0.0, fix=None):
+    def _attn_block_fwd(self, ws, i, si, gin, g1, M, pdrop=0.0, fix=None, folded=False):
         nm, w, d, C = self.names, self._w16, self._d, self.C
         a = nm.attn(i)
         st = ws["stat"][si]
+        if folded:
+            # LayerNorm folded into the projection: A = the raw rows (bf16 copy left by the fc2 GEMM below + the prompt fix), W = gamma o W,
+            # mean / rstd of the rows already in st[0], st[1] (gvk_prompt_up_fix_stats)
+            fo = self._fold
+            self._gemm(ws["xg16"], fo[f"w{i}"], M, ws["qkv"][si], epilogue=ops.EPI_STORE_BF16, bias=fo[f"c2_{i}"], ln_mean=st[0], ln_rstd=st[1],
+                       ln_c1=fo[f"c1_{i}"], scale_cols=self.heads * 64, col_scale=self.q_scale)
+            ops.attention_fwd(ws["qkv"][si], ws["ctx"][si], ws["lse"][si], ws["B"], self.Ts[i], self.heads, 64 ** -0.5,
+                              drop_p=pdrop, seed=SEED_LAYER + 8 * i, seed_ptr=ws["seed"], q_prescaled=True)
+            self._gemm(ws["ctx"][si], w[f"out{i}"], M, g1, epilogue=ops.EPI_BIAS_RES_F32, bias=d(a + ".to_out.0.bias"), res=gin,
+                       drop_p=pdrop, seed=SEED_LAYER + 8 * i + 1, seed_ptr=ws["seed"])
+            return
         if fix is not None:                                  # + the previous layer's GPA prompt fix, applied to gin in place
             ops.layernorm_fwd_fix(gin, d(a + ".norm.weight"), d(a + ".norm.bias"), M, C, y16=ws["xn"], mean=st[0], rstd=st[1], T=self.T, P=self.P,
                                   L_=self.Lat, **fix)
@@ -728,7 +767,7 @@ class Engine(GavikoPaths, PeftPaths):
         else:
             ops.layernorm_fwd(g1, d(m + ".net.0.weight"), d(m + ".net.0.bias"), M, C, y16=ws["xn"], mean=st[2], rstd=st[3])
 
-    def _mlp_block_fwd(self, ws, i, si, g1, gout, M, train, pdrop=0.0, up_in_fc2=False):
+    def _mlp_block_fwd(self, ws, i, si, g1, gout, M, train, pdrop=0.0, up_in_fc2=False, stats_out=False):
         nm, w, d, C = self.names, self._w16, self._d, self.C
         m = nm.mlp(i)
         if self._keep_inputs:
@@ -738,10 +777,11 @@ class Engine(GavikoPaths, PeftPaths):
                     ldo=self.ldx, drop_p=pdrop, seed=SEED_LAYER + 8 * i + 2, seed_ptr=ws["seed"])
         if self._keep_inputs:
             ops.copy_(ws["sav"]["act"][si], ws["act"])
-        self._gemm(ws["act"], w[f"fc2{i}"], M, gout, epilogue=ops.EPI_BIAS_RES_F32, bias=d(m + ".net.4.bias"), res=g1,
+        so = dict(epilogue=ops.EPI_BIAS_RES_F32_BF16, out1=ws["xg16"], stat_part=ws["spart"]) if stats_out else dict(epilogue=ops.EPI_BIAS_RES_F32)
+        self._gemm(ws["act"], w[f"fc2{i}"], M, gout, bias=d(m + ".net.4.bias"), res=g1,
                    K=self.ldx if up_in_fc2 else self.mlp,      # the GPA latents ride this GEMM as 64 extra K columns (self._fuse_up)
                    alg_k=self.mlp + self.Lat if up_in_fc2 else None,
-                   drop_p=pdrop, seed=SEED_LAYER + 8 * i + 3, seed_ptr=ws["seed"])
+                   drop_p=pdrop, seed=SEED_LAYER + 8 * i + 3, seed_ptr=ws["seed"], **so)
 
     # ------------------------------------------------------------------ backward
     def trainable_names(self) -> List[str]:
@@ -961,7 +1001,7 @@ class Engine(GavikoPaths, PeftPaths):
             self._mark(f"b{i}:attnb")
             if gaviko and shift:
                 self._mwsa_chain_bwd(ws, sv, gv, i, par, B, loc, self._ev_record(torch.cuda.current_stream()))
-            if self.kind == "melo":
+            if self.kind == "melo" and i in self.lora_layers:
                 self._melo_bwd(ws, gv, i, M)
             if ssf:                                                          # to_qkv + ssf_1: dy = dqkv, y = saved qkv
                 uq = {} if self.fp32 else dict(y0_cols=self.heads * 64, y0_mul=1.0 / self.q_scale)     # the saved q block is pre-scaled

@@ -71,8 +71,9 @@ def evp_highpass_operator(D: int, H: int, W: int, rate: float):
 class Names:
     """Maps logical backbone tensors to the state_dict names of each reference class."""
 
-    def __init__(self, kind: str):
+    def __init__(self, kind: str, lora_layers=None):
         self.kind = kind
+        self.lora_layers = None if lora_layers is None else frozenset(lora_layers)     # MeLO: layers whose to_qkv is wrapped (melo.py:53-68)
         self.root = {"vpt": "vision_transformer.", "melo": "lora_vit."}.get(kind, "")
 
     def attn(self, i):
@@ -93,7 +94,8 @@ class Names:
         return "conv_proj.proj" if self.kind == "evp" else f"{self.root}conv_proj.0"      # evp.py:292: a PatchEmbed, not a Sequential
 
     def qkv_weight(self, i):
-        return self.attn(i) + (".to_qkv.qkv.weight" if self.kind == "melo" else ".to_qkv.weight")
+        wrapped = self.kind == "melo" and (self.lora_layers is None or i in self.lora_layers)
+        return self.attn(i) + (".to_qkv.qkv.weight" if wrapped else ".to_qkv.weight")
 
     def head(self):
         return "mlp_head.head" if self.kind == "gaviko" else f"{self.root}mlp_head"

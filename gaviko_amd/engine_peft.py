@@ -70,6 +70,8 @@ class PeftPaths:
         """Fold the rank-r update into the bf16 QKV operand (and its transpose) every step: the forward is then the plain GEMM."""
         w, C = self._w16, self.C
         for i in range(self.depth):
+            if i not in self.lora_layers:                   # a layer outside lora_layer (melo.py:67-68) keeps the plain frozen shadows
+                continue                                    # refresh_weights() built for it
             aq, bq, av, bv = (self._d(n) for n in self._lora_names(i))
             ops.lora_merge(self._d(self.names.qkv_weight(i)), aq, bq, av, bv, ws["merge32"], C, self.r, self.lora_s)
             if self.fp32 and not isinstance(w.get(f"qkv{i}_own"), torch.Tensor):

@@ -47,6 +47,7 @@ class GemmDesc(C.Structure):
         ("epilogue", C.c_int32), ("rows_in", C.c_int32), ("rows_out", C.c_int32), ("row_off", C.c_int32),
         ("tile", C.c_int32), ("drop_p", C.c_float), ("seed", C.c_uint64),
         ("scale_cols", C.c_int32), ("col_scale", C.c_float),
+        ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p), ("ln_c1", C.c_void_p), ("stat_part", C.c_void_p),
     ]
 
 
@@ -114,6 +115,7 @@ SIGNATURES = {
     "gvk_layernorm_bwd_affine": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gvk_attention_fwd_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "gvk_qkv_prescale_bf16": [_P, _I, _I, _I, _F, _P],
+    "gvk_prompt_up_fix_stats": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "gvk_attention_bwd_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "gvk_attention_fwd_f32_dropout": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P, _P],
     "gvk_attention_bwd_f32_dropout": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P, _P],
@@ -172,7 +174,7 @@ SIGNATURES = {
     "gvk_head_bwd": [C.POINTER(HeadDesc), _P],
 }
 NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, []), "gvk_abi_version": (C.c_int, []),
-             "gvk_gpa_gate_param_count": (C.c_int, [C.c_int, C.c_int]), "gvk_minmax_partials": (C.c_int, []),
+             "gvk_gpa_gate_param_count": (C.c_int, [C.c_int, C.c_int]), "gvk_gemm_stat_parts": (C.c_int, [C.c_int]), "gvk_minmax_partials": (C.c_int, []),
              "gvk_plan_begin": (C.c_int, []), "gvk_plan_end": (C.c_int, []), "gvk_plan_abort": (C.c_int, []),
              "gvk_plan_size": (C.c_int, [C.c_int]), "gvk_plan_replay": (C.c_int, [C.c_int]), "gvk_plan_free": (C.c_int, [C.c_int]),
              "gvk_plan_event_record": (C.c_int, [_P]), "gvk_plan_event_wait": (C.c_int, [_P, C.c_int]),

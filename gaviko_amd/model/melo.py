@@ -29,13 +29,13 @@ class MeLO(HotPathModule):
         assert r > 0
         assert alpha > 0
         layers = vit.transformer.layers
-        self.lora_layer = lora_layer if lora_layer else list(range(len(layers)))
-        if sorted(self.lora_layer) != list(range(len(layers))):
-            raise NotImplementedError("LoRA on a subset of layers is not built (the reference default wraps every layer)")
+        self.lora_layer = list(lora_layer) if lora_layer else list(range(len(layers)))       # melo.py:53-56
         self.w_As, self.w_Bs = [], []
         for p in vit.parameters():                       # melo.py:63-65
             p.requires_grad = False
         for i, (attn, mlp) in enumerate(layers):
+            if i not in self.lora_layer:                 # melo.py:67-68: that layer keeps its plain (frozen) to_qkv Linear
+                continue
             base = attn.to_qkv
             self.dim = base.in_features
             aq, bq = nn.Linear(self.dim, r, bias=False), nn.Linear(r, self.dim, bias=False)
@@ -51,7 +51,7 @@ class MeLO(HotPathModule):
         if num_classes > 0:
             self.lora_vit.mlp_head = nn.Linear(self.dim, num_classes)
         self.__dict__["_kw_precision"] = kwargs.get("precision")      # "bf16" (default) | "fp32": see HotPathModule.set_precision
-        self._cfg = dict(vit._cfg, r=r, alpha=alpha)
+        self._cfg = dict(vit._cfg, r=r, alpha=alpha, lora_layer=sorted(self.lora_layer))
 
     def _drop_config(self):
         # no train() override (melo.py:56-110): the wrapped ViT's nn.Dropout modules follow module.training

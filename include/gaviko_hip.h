@@ -96,8 +96,17 @@ typedef struct gvk_gemm_desc {
   int32_t scale_cols; /* GVK_EPI_STORE_BF16 (bf16 entry point) only: columns n < scale_cols (a multiple of 8) are multiplied by col_scale in fp32 */
   float col_scale;    /* before the ONE rounding to bf16 -- the q block of a qkv projection leaves the GEMM as q * scale * log2(e), the form
                          the attention kernels take (gvk_attention_*_bf16); 0 columns = off */
+  /* LayerNorm folded into its consumer (GVK_EPI_STORE_BF16, bf16 entry point): a = the RAW rows x as bf16, w = gamma o W; with ln_mean /
+     ln_rstd f32 [M] and ln_c1 f32 [N] = row sums of w (of its bf16 values) the epilogue stores rstd[m]*(acc - mean[m]*c1[n]) + bias[n],
+     bias[n] = sum_c beta[c] W[n][c] -- LayerNorm(x) . W^T (vision_transformer.py:49,61-62) without the LayerNorm launch.  NULL = off */
+  const float* ln_mean; const float* ln_rstd; const float* ln_c1;
+  /* GVK_EPI_BIAS_RES_F32_BF16: also write per-row partial (sum, sum of squares) of the fp32 output, f32 [N / 64][M][2] (64-column groups
+     of the 128-wide tiles); gvk_prompt_up_fix_stats turns them into the mean / rstd the folded consumer reads.  NULL = off */
+  float* stat_part;
 } gvk_gemm_desc;
 int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream);
+/* number of 64-column groups gvk_gemm_desc.stat_part is indexed by for an N-column output */
+int gvk_gemm_stat_parts(int N);
 
 /* ------------------------------------------------------------------ fp32 compute path
  * BASELINE cfg4 (adaptformer / melo) runs the reference in fp32 with a 1e-5 tolerance, which bf16 MFMA operands cannot
@@ -262,6 +271,11 @@ int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream);
 /* out f32 [B*T][C] rows b*T + p (p < P) += (enh[b][p] - lat[b*T + p]) . w^T, w f32 [C][L]: the prompt rows of the GPA up-projection
  * (gaviko.py:183-187) when the plain-latent part rides the MLP GEMM as K-concatenation (gvk_pack_split_bf16) */
 int gvk_prompt_up_fix(const float* enh, const float* lat, const float* w, float* out, int B, int T, int P, int C, int L, void* stream);
+/* The same for a layer whose FIRST LayerNorm is folded into its qkv projection (gvk_gemm_desc.ln_mean): besides fixing the P prompt rows of
+ * out (and of its bf16 copy out16, the folded GEMM's A operand) it finishes the row statistics -- mean / rstd f32 [B*T] of every row, from
+ * the per-row partials part f32 [nparts][B*T][2] the fc2 GEMM left (gvk_gemm_desc.stat_part), of the prompt rows from the rows themselves. */
+int gvk_prompt_up_fix_stats(const float* enh, const float* lat, const float* w, float* out, void* out16, const float* part, int nparts,
+                            float* mean, float* rstd, int B, int T, int P, int C, int L, float eps, void* stream);
 
 /* outer: out[l][c] (transposed=0) or out[c][l] (transposed=1) (+)= sum_m narrow[m][l] * wide'[m][c];
  *        colsum[c] (+)= sum_m wide'[m][c] (optional).  wide' = LN(wide) when mean/rstd(/gamma/beta) are given, times the

@@ -133,15 +133,16 @@ def adaptformer_trainable(name: str) -> bool:
 def melo_forward(sd: SD, img: Tensor, cfg: dict, taps: Optional[dict] = None) -> Tensor:
     """MeLO.forward (melo.py:100-101) == the wrapped VisionTransformer with _LoRA_qkv_timm (41-47)
     in every attention; integer scale alpha // r."""
-    return vit_forward(sd, img, cfg, taps, prefix="lora_vit.", lora={"r": cfg["r"], "alpha": cfg["alpha"]})
+    return vit_forward(sd, img, cfg, taps, prefix="lora_vit.", lora={"r": cfg["r"], "alpha": cfg["alpha"], "layers": cfg.get("lora_layer") or None})
 
 
 def melo_param_shapes(cfg: dict) -> Dict[str, tuple]:
     depth, heads, dim, mlp = mapping_vit(cfg["backbone"])
     base = vit_param_shapes(cfg, "lora_vit.")
     s = {}
+    wrapped = cfg.get("lora_layer") or list(range(depth))          # melo.py:53-56,67-68
     for k, v in base.items():
-        if k.endswith(".to_qkv.weight"):
+        if k.endswith(".to_qkv.weight") and int(k.split(".layers.")[1].split(".")[0]) in wrapped:
             p = k[: -len(".weight")]
             s[p + ".qkv.weight"] = v
             s[p + ".linear_a_q.weight"] = (cfg["r"], dim)

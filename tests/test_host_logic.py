@@ -71,6 +71,23 @@ def test_linear_and_bitfit_freeze_rules():
     assert set(m.state_dict()) == set(oracle.vit_param_shapes(dict(BASE, method="linear")))
 
 
+@pytest.mark.parametrize("lora_layer", [None, [0, 5, 11]])
+def test_melo_schema_and_lora_layer_subset(lora_layer):
+    """melo.py:53-68: `lora_layer` wraps only the listed layers' to_qkv (keys `...to_qkv.{qkv,linear_a_q,...}.weight`); every other layer keeps
+    its plain `...to_qkv.weight`.  The parameter schema equals the oracle's (which is checked against the reference's own state_dict)."""
+    cfg = dict(BASE, method="melo", r=4, alpha=8, lora_layer=lora_layer)
+    m = build_model(cfg)
+    named = dict(m.named_parameters())
+    want = oracle.SHAPES["melo"](cfg)
+    assert set(named) == set(want) and all(tuple(named[k].shape) == tuple(want[k]) for k in named)
+    wrapped = lora_layer or list(range(12))
+    for i in range(12):
+        assert (f"lora_vit.transformer.layers.{i}.0.to_qkv.qkv.weight" in named) == (i in wrapped)
+        assert (f"lora_vit.transformer.layers.{i}.0.to_qkv.weight" in named) == (i not in wrapped)
+    tr = {k for k, p in named.items() if p.requires_grad}
+    assert tr == {k for k in named if oracle.trainable("melo", k)} and len(tr) == 4 * len(wrapped) + 2
+
+
 def test_mwsa_mask_property_equals_oracle():
     m = build_model(dict(BASE, method="gaviko", **GAVIKO))
     mask = m.transformer.local_attns[0].mask

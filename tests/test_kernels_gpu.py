@@ -106,6 +106,62 @@ def test_gemm_store_bf16_column_scale(dev, M, N, K, tile):
         ops.gemm_nt(A, W, M, f32, epilogue=ops.EPI_STORE_F32, scale_cols=N // 3, col_scale=cs)
 
 
+@pytest.mark.parametrize("M,C_,N", [(4132, 768, 2304), (2066, 1024, 3072), (300, 128, 384)])
+def test_layernorm_folded_into_gemm(dev, M, C_, N):
+    """The first LayerNorm of a layer folded into its qkv projection (vision_transformer.py:49,61-62): the producer GEMM (BIAS_RES_F32_BF16)
+    leaves the fp32 rows, their bf16 copy and per-row (sum, sum of squares) partials; gvk_prompt_up_fix_stats fixes P prompt rows and turns
+    the partials into mean / rstd; the consumer GEMM runs on the RAW bf16 rows against gamma o W with rstd*(acc - mean*c1) + beta.W^T in its
+    epilogue.  Against float64 LayerNorm + Linear of the fp32 rows (a row mean of ~2 standard deviations is included on purpose)."""
+    from gaviko_amd import ops
+    B, P, Lt, K0 = 2, 8, 20, 256
+    T = M // B
+    M = B * T
+    a0 = _bf16_round(_rand((M, K0), 21))
+    w0 = _bf16_round(_rand((C_, K0), 22, 2.0 / math.sqrt(K0)))
+    bias0 = _rand((C_,), 23, 0.3) + 1.5                         # a common offset: row mean ~ 1.5 against a row std ~ 2
+    res = _rand((M, C_), 24, 1.0)
+    x_ref = a0.double() @ w0.double().T + bias0.double() + res.double()
+    enh, lat, wup = _rand((B, P, Lt), 25), _rand((M, Lt), 26), _rand((C_, Lt), 27, 0.3)
+    for b in range(B):
+        x_ref[b * T: b * T + P] += (enh[b].double() - lat[b * T: b * T + P].double()) @ wup.double().T
+    A = ops.act_zeros(M, K0, torch.bfloat16, dev); A[:M] = a0.to(dev).bfloat16()
+    G = ops.act_zeros(M, C_, torch.float32, dev)
+    R = ops.act_zeros(M, C_, torch.float32, dev); R[:M] = res.to(dev)
+    G16 = ops.act_zeros(M, C_, torch.bfloat16, dev)
+    part = torch.zeros((C_ // 64) * M * 2, device=dev)
+    ops.gemm_nt(A, w0.to(dev).bfloat16().contiguous(), M, G, epilogue=ops.EPI_BIAS_RES_F32_BF16, out1=G16, bias=bias0.to(dev), res=R, stat_part=part)
+    mean, rstd = torch.zeros(M, device=dev), torch.zeros(M, device=dev)
+    ops.prompt_up_fix_stats(enh.to(dev).contiguous(), lat.to(dev).contiguous(), wup.to(dev).contiguous(), G, G16, part, mean, rstd, B, T, P, C_, Lt)
+    torch.cuda.synchronize()
+    assert (G[:M].cpu().double() - x_ref).abs().max().item() < 2e-4 * x_ref.abs().max().item()
+    assert torch.equal(G16[:M], G[:M].bfloat16())               # the bf16 copy is the rounding of the stored fp32 rows, prompt rows included
+    mu_ref, var_ref = x_ref.mean(1), x_ref.var(1, unbiased=False)
+    assert (mean.cpu().double() - mu_ref).abs().max().item() < 1e-5 * max(1.0, mu_ref.abs().max().item())
+    assert ((rstd.cpu().double() - (var_ref + 1e-5).rsqrt()) / (var_ref + 1e-5).rsqrt()).abs().max().item() < 1e-5
+    # consumer: y = LN(x) . W^T with the LayerNorm in the epilogue (+ the q-block pre-scale of the real call site)
+    gamma, beta = 1 + _rand((C_,), 28, 0.2), _rand((C_,), 29, 0.1)
+    W = _rand((N, C_), 30, 1.0 / math.sqrt(C_))
+    Wf = (W * gamma[None, :]).to(dev).bfloat16().contiguous()
+    c1 = Wf.float().sum(1).contiguous()
+    c2 = (W * beta[None, :]).sum(1).to(dev).contiguous()
+    Y = ops.act_zeros(M, N, torch.bfloat16, dev)
+    cs = 0.125 * 1.4426950408889634
+    ops.gemm_nt(G16, Wf, M, Y, epilogue=ops.EPI_STORE_BF16, bias=c2, ln_mean=mean, ln_rstd=rstd, ln_c1=c1, scale_cols=N // 3, col_scale=cs)
+    xg = G[:M].cpu().double()
+    y_ref = torch.nn.functional.layer_norm(xg, (C_,), gamma.double(), beta.double(), 1e-5) @ W.double().T
+    y_ref[:, : N // 3] *= cs
+    got = Y[:M].cpu().double()
+    err = (got - y_ref).abs().max().item() / y_ref.abs().max().item()
+    # the unfolded path for scale: LayerNorm kernel (bf16 out) + plain GEMM
+    xn = ops.act_zeros(M, C_, torch.bfloat16, dev)
+    ops.layernorm_fwd(G, gamma.to(dev), beta.to(dev), M, C_, y16=xn)
+    Y2 = ops.act_zeros(M, N, torch.bfloat16, dev)
+    ops.gemm_nt(xn, W.to(dev).bfloat16().contiguous(), M, Y2, epilogue=ops.EPI_STORE_BF16, scale_cols=N // 3, col_scale=cs)
+    err2 = (Y2[:M].cpu().double() - y_ref).abs().max().item() / y_ref.abs().max().item()
+    print(f"LN fold M={M} C={C_} N={N}: folded rel err {err:.2e}, LayerNorm kernel + GEMM {err2:.2e}")
+    assert err < 1.2e-2 and err < 2.5 * err2 + 2e-3
+
+
 def test_patch_embed_path(dev):
     """patchify + GEMM(PATCH epilogue) == conv3d + flatten/transpose + pos, scattered into [P+1 .. ] rows."""
     from gaviko_amd import ops

@@ -189,6 +189,7 @@ PEFT_CASES = [("deep_vpt_t16_b2", "deep_vpt", "vit-t16", 2, dict(num_prompts=8, 
               ("shallow_vpt_t16_b2", "shallow_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True)),
               ("adaptformer_t16_b2", "adaptformer", "vit-t16", 2, dict(freeze_vit=True)),
               ("melo_t16_b2", "melo", "vit-t16", 2, dict(r=4, alpha=4)),
+              ("melo_t16_b2_layers", "melo", "vit-t16", 2, dict(r=4, alpha=8, lora_layer=[0, 5, 11])),   # melo.py:53-68: only these layers are wrapped
               ("cfg4_adaptformer_b16_b8", "adaptformer", "vit-b16", 8, dict(freeze_vit=True)),
               ("cfg4_melo_b16_b8", "melo", "vit-b16", 8, dict(r=4, alpha=4)),
               ("ssf_t16_b2", "ssf", "vit-t16", 2, dict(freeze_vit=True)),
@@ -334,6 +335,7 @@ def test_bucketed_backward_segments_match_single_graph(dev):
 FP32_CASES = [("cfg1_linear_t16_b1", "linear", "vit-t16", 1, dict()),
               ("adaptformer_t16_b2", "adaptformer", "vit-t16", 2, dict(freeze_vit=True)),
               ("melo_t16_b2", "melo", "vit-t16", 2, dict(r=4, alpha=4)),
+              ("melo_t16_b2_layers", "melo", "vit-t16", 2, dict(r=4, alpha=8, lora_layer=[0, 5, 11])),   # melo.py:53-68: only these layers are wrapped
               ("deep_vpt_t16_b2", "deep_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True)),
               ("gaviko_t16_b2", "gaviko", "vit-t16", 2, dict(GAVIKO)),
               ("cfg4_adaptformer_b16_b8", "adaptformer", "vit-b16", 8, dict(freeze_vit=True)),

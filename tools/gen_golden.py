@@ -48,6 +48,7 @@ CASES = {
     "cfg3_deep_vpt_b16_8x4": ("deep_vpt", "vit-b16", 4, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True, deep_prompt=True, shards=8)),
     "adaptformer_t16_b2": ("adaptformer", "vit-t16", 2, dict(freeze_vit=True)),
     "melo_t16_b2": ("melo", "vit-t16", 2, dict(r=4, alpha=4)),
+    "melo_t16_b2_layers": ("melo", "vit-t16", 2, dict(r=4, alpha=8, lora_layer=[0, 5, 11])),      # LoRA on a subset of layers, integer scale alpha // r = 2
     "cfg4_adaptformer_b16_b8": ("adaptformer", "vit-b16", 8, dict(freeze_vit=True)),
     "cfg4_melo_b16_b8": ("melo", "vit-b16", 8, dict(r=4, alpha=4)),
     "cfg5_gaviko_l16_b2": ("gaviko", "vit-l16", 2, dict(GAVIKO)),

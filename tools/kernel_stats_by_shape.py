@@ -44,7 +44,7 @@ def gemm_labels(M, C, mlp, ldx):
         (r"gemm8p_kernel<0,", r".*", f"qkv fwd        M={M} N={3 * C} K={C}"),
         (r"gemm_nt_kernel<\d+, \d+, 1,", r"attn_fwd", f"out-proj fwd   M={M} N={C} K={C}"),
         (r"gemm8p_kernel<2,", r".*", f"fc1 fwd        M={M} N={mlp} K={C}"),
-        (r"gemm_nt_kernel<\d+, \d+, 1,", r"gemm8p_kernel<2,", f"fc2 fwd (+GPA up-projection)  M={M} N={C} K={ldx} (algorithmic K {mlp}+20)"),
+        (r"gemm_nt_kernel<\d+, \d+, [16],", r"gemm8p_kernel<2,", f"fc2 fwd (+GPA up-projection)  M={M} N={C} K={ldx} (algorithmic K {mlp}+20)"),
         (r"gemm8p_kernel<4,", r".*", f"fc2 dgrad      M={M} N={mlp} K={C}"),
         (r"gemm_nt_kernel<\d+, \d+, 5,", r"gemm8p_kernel<4,", f"fc1 dgrad      M={M} N={C} K={mlp}"),
         (r"gemm_nt_kernel<\d+, \d+, 0,", r".*", f"out-proj dgrad M={M} N={C} K={C}"),
