@@ -20,7 +20,8 @@
 //   * the running maximum is only raised when a tile exceeds it by more than kThr (log2 units): the O / l rescale and the
 //     rebuild of B_aug sit in a wave-uniform slow path that a few tiles per workgroup take (P <= 2^kThr stays harmless: bf16
 //     keeps fp32's exponent range and the accumulators are fp32);
-//   * row sums as a third "d block" of the PV product with an all-ones A operand (VAR bit 0; the v_add_f32 form is kept in the diag build);
+//   * row sums in fp32 from the unrounded probabilities (the matrix-pipe form -- a third "d block" of the PV product with an all-ones A
+//     operand, VAR bit 0 -- is 0.8 % faster in the step but sums ROUNDED probabilities; it is kept in the diag build, see kAttnVarDefault);
 //   * 96-key tiles when they pad the sequence less than 128-key tiles do (T = 1033: 11 x 96 = 1056 keys instead of 1152);
 //   * O leaves through LDS as whole 128-byte rows (16 B per lane) instead of 8-byte pieces at a 1.5 KB row stride.
 // LDS tile rows are 64 bf16 = 128 B; 16-B chunk c of row r sits at chunk c ^ attn_swz(r), attn_swz(r) = bit1(r)<<2 | bits3:2(r)
@@ -303,9 +304,13 @@ static int launch_attn_fwd_t(const void* qkv, void* out, float* lse, int B, int 
   return check_launch("attention_fwd_bf16");
 }
 
-// row sums on the matrix pipe (VAR bit 0): 724.1 / 725.7 / 725.5 against 719.9 / 718.7 / 719.9 volumes/s with v_add sums, same box, interleaved;
-// the spread LDS-DMA (bit 1) is neutral in the step (719.4 / 719.6 / 720.1) although 3 % faster in isolation
-constexpr int kAttnVarDefault = 1;
+// Shipped: VAR 0, row sums added in fp32 from the UNROUNDED probabilities -- lse then agrees with float64 to 1.3e-6.  Row sums on the matrix
+// pipe (VAR bit 0) are 0.8 % faster in the step (724.1 / 725.7 / 725.5 against 719.9 / 718.7 / 719.9 volumes/s, same box, interleaved) but
+// add up the bf16-ROUNDED probabilities: on a peaked row lse then carries the 2^-9 rounding of the dominating term (measured 2.2e-3 at
+// amp 2.5, 2-6e-4 at amp 1; tests/test_kernels_gpu.py::test_attention_fwd), which the backward's P = exp2(s - lse) turns into a per-row
+// scale error of the same size.  Parity first: that variant stays in the diag build.  The spread LDS-DMA (bit 1) is neutral in the step
+// (719.4 / 719.6 / 720.1) although 3 % faster in isolation.
+constexpr int kAttnVarDefault = 0;
 
 template <bool DROP>
 static int launch_attn_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, int ld_qkv, int ld_out, float scale, AttnDrop dr, hipStream_t stream) {
@@ -321,7 +326,8 @@ static int launch_attn_fwd(const void* qkv, void* out, float* lse, int B, int T,
 #define GVK_ATTN_CASE(KB_, V_) if (kb == KB_ && var == V_) return launch_attn_fwd_t<KB_, false, V_>(qkv, out, lse, B, T, H, ld_qkv, ld_out, scale, dr, stream);
     GVK_ATTN_CASE(96, kAttnVarDefault) GVK_ATTN_CASE(128, kAttnVarDefault)
 #ifdef GVK_DIAG                                          // the other variants (row sums on the matrix pipe, spread LDS-DMA): measurement build only
-    GVK_ATTN_CASE(96, 0) GVK_ATTN_CASE(96, 2) GVK_ATTN_CASE(96, 3) GVK_ATTN_CASE(128, 0) GVK_ATTN_CASE(128, 2) GVK_ATTN_CASE(128, 3)
+    GVK_ATTN_CASE(96, 0) GVK_ATTN_CASE(96, 1) GVK_ATTN_CASE(96, 2) GVK_ATTN_CASE(96, 3)
+    GVK_ATTN_CASE(128, 0) GVK_ATTN_CASE(128, 1) GVK_ATTN_CASE(128, 2) GVK_ATTN_CASE(128, 3)
 #endif
 #undef GVK_ATTN_CASE
     return set_error(-2, "gvk_attention_fwd_bf16: no kernel variant %d for key tile %d", var, kb);

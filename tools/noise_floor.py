@@ -24,8 +24,7 @@ BASE = dict(image_size=160, image_patch_size=16, frames=120, frame_patch_size=12
 GAVIKO = dict(num_prompts=32, prompt_latent_dim=20, local_dim=20, local_k=(6, 6, 6), DHW=(10, 10, 10), attn_drop=0.0, proj_drop=0.0, freeze_vit=True,
               share_factor=1)
 VPT = dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True, deep_prompt=True)
-CASES = {"cfg3_deep_vpt_b16_shard4": ("deep_vpt", "vit-b16", 4, VPT, 16), "cfg3_deep_vpt_b16_shard0": ("deep_vpt", "vit-b16", 4, VPT, 0),
-         "cfg3_deep_vpt_b16_shard2": ("deep_vpt", "vit-b16", 4, VPT, 8), "cfg2_gaviko_b16_b4": ("gaviko", "vit-b16", 4, GAVIKO, 0),
+CASES = {**{f"cfg3_deep_vpt_b16_shard{s}": ("deep_vpt", "vit-b16", 4, VPT, 4 * s) for s in range(8)}, "cfg2_gaviko_b16_b4": ("gaviko", "vit-b16", 4, GAVIKO, 0),
          "cfg4_adaptformer_b16_b8": ("adaptformer", "vit-b16", 8, dict(freeze_vit=True), 0), "cfg4_melo_b16_b8": ("melo", "vit-b16", 8, dict(r=4, alpha=4), 0),
          "gaviko_t16_b2": ("gaviko", "vit-t16", 2, GAVIKO, 0), "melo_t16_b2": ("melo", "vit-t16", 2, dict(r=4, alpha=4), 0)}
 
