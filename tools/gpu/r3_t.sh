@@ -1,0 +1,9 @@
+#!/bin/bash
+set -e
+export GAVIKO_HIP_DIAG=1
+for i in 1 2 3; do
+  for v in 0 1; do
+    echo -n "EARLY_FIXWAIT=$v: "; GAVIKO_HIP_EARLY_FIXWAIT=$v python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-roofline --allow-diag 2>/dev/null | grep -o '"value": [0-9.]*'
+  done
+done
+for v in 0 1; do echo "== marks EARLY_FIXWAIT=$v"; GAVIKO_HIP_EARLY_FIXWAIT=$v timeout -k 10 200 python tools/plan_marks.py 4 vit-b16 2>/dev/null | grep -A5 "fwd"; done

@@ -27,7 +27,7 @@ def short(name: str) -> str:
     mm = re.match(r"_ZN3gvk(\d+)", name)
     if mm:
         name = name[mm.end(): mm.end() + int(mm.group(1))]
-    name = re.sub(r"^void ", "", name).replace("gvk::", "")
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "").replace("gvk::", "")
     depth, out = 0, []
     for ch in name:                                   # drop the argument list, keep the template arguments
         if ch == "(" and depth == 0:

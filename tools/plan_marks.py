@@ -12,7 +12,7 @@ from gaviko_amd.utils import synth
 
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-model = bench.build("vit-b16", dev)
+model = bench.build(sys.argv[2] if len(sys.argv) > 2 else "vit-b16", dev)      # plan_marks.py [B [backbone]]
 x = torch.from_numpy(synth.volumes(0, B)).to(dev); y = torch.from_numpy(synth.labels(0, B)).to(dev)
 def step():
     for p in model.parameters(): p.grad = None
