@@ -285,17 +285,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    prio = os.environ.get("GAVIKO_BENCH_MAIN_PRIORITY")          # experiment: run the backbone stream at a higher HIP priority than the side chains
-    main_stream = torch.cuda.Stream(device=dev, priority=int(prio)) if prio is not None else torch.cuda.current_stream(dev)
-    with torch.cuda.stream(main_stream):
-        for _ in range(args.warmup):
-            step()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        dt = time.perf_counter() - t0
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

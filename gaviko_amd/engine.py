@@ -450,57 +450,46 @@ class Engine(GavikoPaths, PeftPaths):
 
     # ------------------------------------------------------------------ graphs
     def _run(self, tag, key, fn):
-        """Run `fn` eagerly the first GRAPH_WARMUP times, then capture it into a HIP graph and replay that.
+        """Run `fn` eagerly the first GRAPH_WARMUP times, then record it into a launch plan (csrc/runtime.hip) and replay that.
         Everything `fn` launches reads/writes workspace buffers only, so a replay is exactly one more step."""
         k = (tag,) + key + (torch.cuda.current_stream().cuda_stream,)
         g = self._graphs.get(k)
         self._last_run = ("eager", None)
         if g is not None:
-            if isinstance(g, int):
-                L.check(L.load().gvk_plan_replay(g), "gvk_plan_replay")
-                self._last_run = ("replayed", g)
-            else:
-                g.replay()
-                self._last_run = ("graph", None)
+            L.check(L.load().gvk_plan_replay(g), "gvk_plan_replay")
+            self._last_run = ("replayed", g)
             return
         n = self._calls.get(k, 0)
         self._calls[k] = n + 1
         if not USE_GRAPHS or n < GRAPH_WARMUP:
             fn()
             return
-        if STEP_MODE == "plan":
-            # this pass both executes and records; every launch inside fn goes through the library (no torch kernels)
-            lib = L.load()
-            L.check(lib.gvk_plan_begin(), "gvk_plan_begin")
-            self._recording = True
-            self._marks, self._gemm_marks = [], []
-            self._bucket_marks = {}
-            try:
-                if GEMM_MARKS is not None:               # calibration: an empty event pair on the launch stream
-                    cur = torch.cuda.current_stream()
-                    self._gemm_marks.append(("__empty__", 0.0, None, None, self._ev_record(cur), self._ev_record(cur)))
-                fn()
-            except BaseException:
-                lib.gvk_plan_abort()
-                raise
-            finally:
-                self._recording = False
-            pid = lib.gvk_plan_end()
-            if pid < 0:
-                L.check(pid, "gvk_plan_end")
-            self._graphs[k] = pid
-            self.plan_marks[pid] = (tag, self._marks)
-            self.plan_bucket_marks[pid] = dict(self._bucket_marks)
-            self._last_run = ("recorded", pid)
-            if self._gemm_marks:
-                self.plan_gemm_marks[pid] = self._gemm_marks
-            return
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # this pass both executes and records; every launch inside fn goes through the library (no torch kernels)
+        lib = L.load()
+        L.check(lib.gvk_plan_begin(), "gvk_plan_begin")
+        self._recording = True
+        self._marks, self._gemm_marks = [], []
+        self._bucket_marks = {}
+        try:
+            if GEMM_MARKS is not None:               # calibration: an empty event pair on the launch stream
+                cur = torch.cuda.current_stream()
+                self._gemm_marks.append(("__empty__", 0.0, None, None, self._ev_record(cur), self._ev_record(cur)))
             fn()
-        self._graphs[k] = g
-        g.replay()
+        except BaseException:
+            lib.gvk_plan_abort()
+            raise
+        finally:
+            self._recording = False
+        pid = lib.gvk_plan_end()
+        if pid < 0:
+            L.check(pid, "gvk_plan_end")
+        self._graphs[k] = pid
+        self.plan_marks[pid] = (tag, self._marks)
+        self.plan_bucket_marks[pid] = dict(self._bucket_marks)
+        self._last_run = ("recorded", pid)
+        if self._gemm_marks:
+            self.plan_gemm_marks[pid] = self._gemm_marks
+        return
 
     # ------------------------------------------------------------------ forward
     def forward(self, img: torch.Tensor, train: bool, drop: Optional[dict] = None) -> torch.Tensor:
@@ -546,6 +535,7 @@ class Engine(GavikoPaths, PeftPaths):
         B, C, T, N, train = sv["B"], self.C, self.T, self.N, sv["train"]
         M = B * T
         nm, w, d = self.names, self._w16, self._d
+        self._mark("f:begin")
         ops.seed_advance(ws["seed"], 7919)                  # device-side dropout epoch (replay safe)
         if self.kind == "ssf":
             self._ssf_fold(train)
@@ -694,6 +684,7 @@ class Engine(GavikoPaths, PeftPaths):
         ops.head_fwd(g=gfin, ln_gamma=d(nm.root + "transformer.norm.weight"), ln_beta=d(nm.root + "transformer.norm.bias"),
                      wh=d(nm.head() + ".weight"), bh=d(nm.head() + ".bias"), logits=ws["logits"], pooled=ws["pooled"],
                      B=B, T=self.Ts[-1], C=C, K=self.K, r0=r0, R=R)
+        self._mark("f:head")
 
     def _final_stream(self, ws, train):
         if self.kind == "vpt" and self.deep:
@@ -828,7 +819,7 @@ class Engine(GavikoPaths, PeftPaths):
             if reducer is not None:
                 reducer.finish(flat)
             return gv
-        if reducer is not None and getattr(reducer, "mode", "segments") == "events" and STEP_MODE != "graph":
+        if reducer is not None and getattr(reducer, "mode", "segments") == "events":
             # ONE plan; every bucket is reduced behind the event recorded on the stream that finalises it (no cut, no join)
             self._want_bucket_marks = True
             self._bucket_marks = {}
@@ -902,6 +893,7 @@ class Engine(GavikoPaths, PeftPaths):
         B, C, T, M = sv["B"], self.C, self.T, sv["B"] * self.T
         gaviko = self.kind == "gaviko"
         if first:
+            self._mark("b:begin")
             self._backward_head(ws, sv, gv, True)
         dGout, dGin = ws["dG"][0], ws["dG"][1]
         if gaviko and ((self.depth - 1 - hi) & 1):
@@ -1078,6 +1070,7 @@ class Engine(GavikoPaths, PeftPaths):
                                self.P, C)
         if last:
             self._bucket_mark("main", -1)                                    # everything else (prompts, head, unindexed tensors): end of the sweep
+        self._mark("b:tail")                                                 # side streams joined, embedding-side gradients issued
 
     def _grad_supported(self, name: str) -> bool:
         if name.startswith(self.names.head()) or self.kind == "vit":       # plain ViT: every tensor (`linear` / `bitfit` / `fft`)

@@ -8,11 +8,13 @@ from . import lib as L
 
 # How a step is issued after the GRAPH_WARMUP eager passes (env GAVIKO_HIP_GRAPHS):
 #   "plan"  (default, also "1") -- the library's launch plan: recorded once, replayed from one C loop on the real streams
-#   "graph"                     -- one captured hipGraph per pass (kept for comparison: its executor serialises three forked
-#                                  branches on this runtime, tools/probe/probe_streams.hip: 7.6 ms vs 3.9 ms eager)
 #   "0" / "eager"               -- every launch from Python
+# (a captured hipGraph per pass was the round-1 form; its executor serialises three forked branches on this runtime,
+#  tools/probe/probe_streams.hip: 7.6 ms vs 3.9 ms eager -- removed in round 3)
 _MODE = os.environ.get("GAVIKO_HIP_GRAPHS", "plan")
 STEP_MODE = {"1": "plan", "0": "eager"}.get(_MODE, _MODE)
+if STEP_MODE not in ("plan", "eager"):
+    raise L.GavikoHipError(f"GAVIKO_HIP_GRAPHS={_MODE!r}: expected 'plan' (default) or 'eager'")
 USE_GRAPHS = STEP_MODE != "eager"
 GRAPH_WARMUP = 2
 PLAN_TIMING = os.environ.get("GAVIKO_HIP_PLAN_TIMING") is not None
