@@ -9,6 +9,7 @@
 // Replaces: gaviko.py:231 (norm + proj_down), :232 (qkv), :242 (proj_up), :155-156 (GPA proj_down + QuickGELU),
 //           :187 (GPA proj_up) and the autograd wgrad/dgrad of each.
 #include "common.hpp"
+#include <algorithm>
 #include <cstdlib>
 #include "skinny_args.hpp"
 #include "../../include/gaviko_hip.h"
@@ -517,48 +518,51 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 }
 
 // ---- batched small reductions: several independent column sums / (J x L) weight-gradient products in TWO launches.
-// Deterministic: stage 1 = (job, 64-output chunk, row slab) workgroups whose 1024 threads are (output, row slice) pairs
-// combined through LDS in a fixed order; stage 2 sums the kRedSlabs partials of every output of every job.
+// Deterministic: stage 1 = (job, 64-output chunk, row slab) workgroups whose 256 threads are (output, row slice) pairs combined through
+// LDS in a fixed order; stage 2 sums every output's partials.  The number of row slabs is PER JOB (one per 128 rows, at most kRedSlabs):
+// the GPA's gate-parameter job sums 4 rows into 3525 outputs and used to launch 56 x 32 workgroups of 1024 threads for it, 28 of every 32
+// empty -- 2336 workgroups (2.4 M threads, 15-17 us on the GPA stream beside the dgrad GEMMs) for 110 workgroups of work.
 constexpr int kMaxJobs = 8;
 constexpr int kRedSlabs = 32;
-struct ReduceJob { const float* a; const float* b; float* out; int M, J, L, accumulate, wg0, o_base; const float* a2; int M1; };   // a2: rows M1.. of a column sum
+struct ReduceJob { const float* a; const float* b; float* out; int M, J, L, accumulate, wg0, o_base; const float* a2; int M1; int nslab; };   // a2: rows M1.. of a column sum
 struct ReduceBatch { ReduceJob job[kMaxJobs]; int njobs; float* scratch; int total_out; };
 
-__global__ __launch_bounds__(1024) void reduce_batch_partial_kernel(ReduceBatch bt) {
-  __shared__ float red[1024];
+__global__ __launch_bounds__(256) void reduce_batch_partial_kernel(ReduceBatch bt) {
+  __shared__ float red[256];
   int ji = 0;
 #pragma unroll
   for (int k = 1; k < kMaxJobs; ++k)
     if (k < bt.njobs && (int)blockIdx.x >= bt.job[k].wg0) ji = k;
   const ReduceJob jb = bt.job[ji];
-  const int slab = blockIdx.y;
+  const int local = (int)blockIdx.x - jb.wg0;
+  const int slab = local % jb.nslab;
   const int nout = jb.b ? jb.J * jb.L : jb.J;
-  const int o0 = ((int)blockIdx.x - jb.wg0) * 64;
+  const int o0 = (local / jb.nslab) * 64;
   const int no = min(64, nout - o0);
-  const int rows_per = (jb.M + kRedSlabs - 1) / kRedSlabs;
+  const int rows_per = (jb.M + jb.nslab - 1) / jb.nslab;
   const int r0 = slab * rows_per, r1 = min(jb.M, r0 + rows_per);
-  const int oi = threadIdx.x & 63, sl = threadIdx.x >> 6;     // 16 row slices
+  const int oi = threadIdx.x & 63, sl = threadIdx.x >> 6;     // 4 row slices
   float acc = 0.f;
   if (oi < no) {
     const int o = o0 + oi;
     if (jb.b != nullptr) {
       const int j = o / jb.L, l = o - j * jb.L;
-      for (int m = r0 + sl; m < r1; m += 64) {
+      for (int m = r0 + sl; m < r1; m += 16) {
         float av[4], bv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int mm = m + u * 16;
+          const int mm = m + u * 4;
           av[u] = mm < r1 ? jb.a[(size_t)mm * jb.J + j] : 0.f;
           bv[u] = mm < r1 ? jb.b[(size_t)mm * jb.L + l] : 0.f;
         }
         acc += (av[0] * bv[0] + av[1] * bv[1]) + (av[2] * bv[2] + av[3] * bv[3]);
       }
     } else {
-      for (int m = r0 + sl; m < r1; m += 64) {
+      for (int m = r0 + sl; m < r1; m += 16) {
         float av[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int mm = m + u * 16;
+          const int mm = m + u * 4;
           av[u] = mm < r1 ? (mm < jb.M1 ? jb.a[(size_t)mm * jb.J + o] : jb.a2[(size_t)(mm - jb.M1) * jb.J + o]) : 0.f;
         }
         acc += (av[0] + av[1]) + (av[2] + av[3]);
@@ -567,12 +571,8 @@ __global__ __launch_bounds__(1024) void reduce_batch_partial_kernel(ReduceBatch 
   }
   red[threadIdx.x] = acc;
   __syncthreads();
-  if (sl == 0 && oi < no) {
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k * 64 + oi];
-    bt.scratch[(size_t)slab * bt.total_out + jb.o_base + o0 + oi] = t;
-  }
+  if (sl == 0 && oi < no)
+    bt.scratch[(size_t)slab * bt.total_out + jb.o_base + o0 + oi] = (red[oi] + red[64 + oi]) + (red[128 + oi] + red[192 + oi]);
 }
 
 __global__ __launch_bounds__(256) void reduce_batch_final_kernel(ReduceBatch bt) {
@@ -582,11 +582,12 @@ __global__ __launch_bounds__(256) void reduce_batch_final_kernel(ReduceBatch bt)
 #pragma unroll
   for (int k = 1; k < kMaxJobs; ++k)
     if (k < bt.njobs && g >= bt.job[k].o_base) ji = k;
+  const int ns = bt.job[ji].nslab;
   float a4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < kRedSlabs; s += 4) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) a4[u] += bt.scratch[(size_t)(s + u) * bt.total_out + g];
+    for (int u = 0; u < 4; ++u) a4[u] += (s + u < ns) ? bt.scratch[(size_t)(s + u) * bt.total_out + g] : 0.f;
   }
   const float t = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   float* dst = bt.job[ji].out + (g - bt.job[ji].o_base);
@@ -604,13 +605,24 @@ __global__ __launch_bounds__(256) void ln_lowrank_affine_kernel(const float* __r
   if (c < C) {
     const float gc = g[c], bc = b[c];
     float dg = 0.f, db = 0.f;
-    for (int l = 0; l < L; ++l) {
-      const float q = Q[(size_t)l * C + c], sl = S[l], w = W[(size_t)l * C + c];
-      const float v = gc * q + bc * sl;
-      float* o = dW + (size_t)l * C + c;
-      *o = accumulate ? *o + v : v;
-      dg += w * q;
-      db += w * sl;
+    for (int l0 = 0; l0 < L; l0 += 8) {                     // eight rows' loads in flight per round trip (one thread per column: the
+      float q[8], w[8], o0[8];                              // row-by-row form was a 20-deep latency chain, 15 us on the MWSA stream)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool ok = l0 + u < L;
+        q[u] = ok ? Q[(size_t)(l0 + u) * C + c] : 0.f;
+        w[u] = ok ? W[(size_t)(l0 + u) * C + c] : 0.f;
+        o0[u] = (ok && accumulate) ? dW[(size_t)(l0 + u) * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (l0 + u < L) {
+          const float sl = S[l0 + u];
+          dW[(size_t)(l0 + u) * C + c] = o0[u] + (gc * q[u] + bc * sl);
+          dg += w[u] * q[u];
+          db += w[u] * sl;
+        }
+      }
     }
     dgamma[c] = accumulate ? dgamma[c] + dg : dg;
     dbeta[c] = accumulate ? dbeta[c] + db : db;
@@ -920,13 +932,15 @@ extern "C" int gvk_reduce_batch(const gvk_reduce_job* jobs, int njobs, float* sc
     GVK_REQUIRE(j.a && j.out && j.M > 0 && j.J > 0 && (j.b == nullptr || j.L > 0), "gvk_reduce_batch: job %d malformed", k);
     GVK_REQUIRE(j.a2 == nullptr || (j.b == nullptr && j.M2 > 0), "gvk_reduce_batch: job %d: a second source (a2, M2) goes with a column sum only", k);
     const int nout = j.b ? j.J * j.L : j.J;
-    bt.job[k] = ReduceJob{j.a, j.b, j.out, j.M + (j.a2 ? j.M2 : 0), j.J, j.L, j.accumulate, wg, ob, j.a2, j.a2 ? j.M : 0x7fffffff};
-    wg += (nout + 63) / 64;
+    const int rows = j.M + (j.a2 ? j.M2 : 0);
+    const int nslab = std::min(kRedSlabs, std::max(1, (rows + 127) / 128));
+    bt.job[k] = ReduceJob{j.a, j.b, j.out, rows, j.J, j.L, j.accumulate, wg, ob, j.a2, j.a2 ? j.M : 0x7fffffff, nslab};
+    wg += ((nout + 63) / 64) * nslab;
     ob += nout;
   }
   bt.total_out = ob;
   hipStream_t s = (hipStream_t)stream;
-  GVK_LAUNCH(reduce_batch_partial_kernel, dim3(wg, kRedSlabs), dim3(1024), 0, s, bt);
+  GVK_LAUNCH(reduce_batch_partial_kernel, dim3(wg), dim3(256), 0, s, bt);
   int rc = check_launch("reduce_batch/partial");
   if (rc) return rc;
   GVK_LAUNCH(reduce_batch_final_kernel, dim3((ob + 255) / 256), dim3(256), 0, s, bt);

@@ -431,6 +431,31 @@ def test_reduce_batch_column_sum_over_two_sources(dev):
     assert (w.double() - a.double().t() @ b.double()).abs().max().item() < 1e-2
 
 
+def test_reduce_batch_mixed_row_counts(dev):
+    """One launch pair, jobs of very different heights (the GPA's call: 4 rows into 3525 gate-parameter sums, 128-row 20 x 20 products, an
+    8132-row column sum): every job gets its own number of row slabs; accumulate and overwrite both honoured; bitwise repeatable."""
+    from gaviko_amd import ops
+    gen = torch.Generator().manual_seed(6)
+    r = lambda *s: torch.randn(*s, generator=gen).to(dev)
+    gp, dq, prm, dz, dz2 = r(4, 3525), r(128, 20), r(128, 20), r(4132, 20), r(4000, 20)
+    tall_a, tall_b = r(4000, 60), r(4000, 20)
+    total = 3525 + 400 + 20 + 20 + 1200
+    sc = torch.zeros(32 * total, device=dev)
+    outs = []
+    for _ in range(2):
+        o_g, o_w, o_b, o_c, o_t = torch.ones(3525, device=dev), torch.zeros(20, 20, device=dev), torch.zeros(20, device=dev), torch.zeros(20, device=dev), torch.zeros(60, 20, device=dev)
+        ops.reduce_batch([(gp, None, o_g, 1), (dq, prm, o_w, 0), (dq, None, o_b, 0), (dz, None, o_c, 0, dz2), (tall_a, tall_b, o_t, 0)], sc)
+        outs.append((o_g, o_w, o_b, o_c, o_t))
+    o_g, o_w, o_b, o_c, o_t = outs[0]
+    assert (o_g.double() - (1.0 + gp.double().sum(0))).abs().max().item() < 1e-5
+    assert (o_w.double() - dq.double().t() @ prm.double()).abs().max().item() < 1e-4
+    assert (o_b.double() - dq.double().sum(0)).abs().max().item() < 1e-4
+    assert (o_c.double() - (dz.double().sum(0) + dz2.double().sum(0))).abs().max().item() < 1e-3
+    assert (o_t.double() - tall_a.double().t() @ tall_b.double()).abs().max().item() < 1e-2
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+
+
 @pytest.mark.parametrize("M,C", [(4132, 768), (2002, 192), (2066, 1024), (37, 768)])
 def test_layernorm_bwd_up_matches_two_kernels(dev, M, C):
     """gvk_layernorm_bwd_up (sidepass.hip, LayerNorm' + rank-20 update in one pass) against gvk_layernorm_bwd followed by the accumulating
