@@ -340,20 +340,29 @@ __global__ __launch_bounds__(256) void outer_partial_kernel(OuterArgs p) {
   const int rows_per = (p.M + kOuterSlabs - 1) / kOuterSlabs;
   const int r0 = slab * rows_per, r1 = min(p.M, r0 + rows_per);
   const int nr = max(0, r1 - r0);
-  for (int i = threadIdx.x; i < nr * NT * 16; i += 256) {
-    const int r = i / (NT * 16), l = i - r * (NT * 16), m = r0 + r;
-    float v = 0.f;
-    if (l < L) {
-      const float* src = (p.narrow2 != nullptr && m >= p.M1) ? p.narrow2 + (size_t)(m - p.M1) * L : p.narrow + (size_t)m * L;
-      if (p.lat_override != nullptr) {
-        const int s = m / p.T, t = m - s * p.T;
-        if (t < p.P) src = p.lat_override + ((size_t)s * p.P + t) * L;
+  // the slab's narrow rows -> LDS, four elements per thread requested before the first is stored (one element per pass was a chain of
+  // nr / 8 dependent round trips in front of everything else the workgroup does)
+  for (int i0 = threadIdx.x; i0 < nr * NT * 16; i0 += 4 * 256) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256;
+      const int r = i / (NT * 16), l = i - r * (NT * 16), m = r0 + r;
+      v[u] = (l == L) ? 1.f : 0.f;
+      if (i < nr * NT * 16 && l < L) {
+        const float* src = (p.narrow2 != nullptr && m >= p.M1) ? p.narrow2 + (size_t)(m - p.M1) * L : p.narrow + (size_t)m * L;
+        if (p.lat_override != nullptr) {
+          const int s = m / p.T, t = m - s * p.T;
+          if (t < p.P) src = p.lat_override + ((size_t)s * p.P + t) * L;
+        }
+        v[u] = src[l];
       }
-      v = src[l];
-    } else if (l == L) {
-      v = 1.f;
     }
-    nar[r][l] = v;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256;
+      if (i < nr * NT * 16) nar[i / (NT * 16)][i % (NT * 16)] = v[u];
+    }
   }
   if (p.mean != nullptr && (int)threadIdx.x < nr) {
     st[threadIdx.x][0] = p.mean[r0 + threadIdx.x];
