@@ -505,14 +505,19 @@ class Engine(GavikoPaths, PeftPaths):
         # nn.Dropout of the backbone itself (vision_transformer.py:33-34,52-54,157; vpt.py:129,148): live for the classes without a
         # train() override (linear / bitfit / fft, melo) and for VPT's prompt_dropout.  bf16 path only.
         sv["bdrop"], sv["edrop"], sv["pdrop"] = (float(drop.get(k, 0.0)) for k in ("dropout", "emb_dropout", "prompt_dropout"))
-        if (sv["bdrop"] > 0 or sv["edrop"] > 0 or sv["pdrop"] > 0) and self.kind not in ("vit", "melo", "vpt"):
-            raise L.GavikoHipError(f"backbone dropout > 0 in training mode is built for the vit / melo / vpt classes, not kind={self.kind!r}")
+        if (sv["bdrop"] > 0 or sv["edrop"] > 0 or sv["pdrop"] > 0) and self.kind not in ("vit", "melo", "vpt", "adaptformer"):
+            raise L.GavikoHipError(f"backbone dropout > 0 in training mode is built for the vit / melo / vpt / adaptformer classes, not kind={self.kind!r}")
         self.refresh_weights(need_dgrad=train)
         ws = self.workspace(B, img.device, train)
         if img.data_ptr() != ws["img"].data_ptr():           # a caller that fills input_buffer() itself skips the copy-in launch
             ws["img"].copy_(img.detach())                   # static input buffer (the only per-step host-visible copy-in)
         # unfrozen backbone tensors (`fft` / `bitfit`, train.py:123-137): which ones train, and whether GEMM inputs must be kept
-        bb = frozenset(n for n in self.trainable_names() if not n.startswith(self.names.head())) if (train and self.kind == "vit") else frozenset()
+        # (`fft` / `bitfit` of the plain ViT; AdaptFormer(freeze_vit=False): adapters keep their own kernels, everything else is backbone)
+        bb = frozenset()
+        if train and self.kind == "vit":
+            bb = frozenset(n for n in self.trainable_names() if not n.startswith(self.names.head()))
+        elif train and self.kind == "adaptformer":
+            bb = frozenset(n for n in self.trainable_names() if not n.startswith(self.names.head()) and "adapter" not in n)
         sv["bb"] = bb
         sv["wgrad"] = any(self.p[n].dim() >= 2 and n.endswith("weight") for n in bb)
         if bb:
@@ -965,7 +970,7 @@ class Engine(GavikoPaths, PeftPaths):
             if dvpt:
                 self._dvpt_bwd_scatter(ws, i, dGin, M)                       # dG1 += (dz . Wd) * QuickGELU'(G1)  (+ operand copy)
             if adapter:
-                self._adapter_bwd(ws, gv, i, dGout, dGin, M)                 # adds LN_a'(...) into dG1 and refreshes dG16
+                self._adapter_bwd(ws, gv, i, dGout, dGin, M, refresh_operand=pd_ > 0)   # adds LN_a'(...) into dG1 and refreshes dG16
             self._mark(f"b{i}:ln2")
             if gaviko:
                 if not fuse_scatter:
@@ -1080,7 +1085,7 @@ class Engine(GavikoPaths, PeftPaths):
         if self.kind == "vpt":
             return name in ("prompt_proj.weight", "prompt_proj.bias", "deep_prompt_embeddings", "prompt_embeddings")
         if self.kind == "adaptformer":
-            return "adapter" in name
+            return True                                                     # adapters + (freeze_vit=False) the whole backbone
         if self.kind == "melo":
             return ".linear_a_" in name or ".linear_b_" in name
         if self.kind == "ssf":

@@ -41,10 +41,14 @@ class PeftPaths:
         self._gemm(ws["ad"][si]["h16"], self._w16[f"ad_u{i}"], M, gout, epilogue=ops.EPI_BIAS_RES_F32, bias=self._d(p + ".up_adapter_proj.bias"),
                    res=gout)
 
-    def _adapter_bwd(self, ws, gv, i, dGout, dG1, M):
+    def _adapter_bwd(self, ws, gv, i, dGout, dG1, M, refresh_operand=False):
         p, d, C, A = self._adapter_prefix(i), self._d, self.C, self.adim
         ad, w, sc = ws["ad"][i], self._w16, ws["scratch"]
         g, b = d(p + ".adapter_layer_norm_before.weight"), d(p + ".adapter_layer_norm_before.bias")
+        if refresh_operand:
+            # backbone dropout live (freeze_vit=False): the operand buffer holds dGout * mask(fc2's dropout) for the FFN branch; the adapter
+            # branch joins the stream unmasked (adaptformer.py:96-98: x = ff(x) + x + adapter(x)), so it needs the plain gradient again
+            ops.to_operand(dGout, ws["dG16"], self.adt)
         # up-projection: dh = (dGout . Wu) * [h > 0]; dWu = dGout^T . h; dbu = colsum(dGout)
         self._gemm(ws["dG16"], w[f"ad_uT{i}"], M, ws["dh16"], epilogue=ops.EPI_RELU_BWD_BF16, aux=ad["h16"])
         ops.cast_bf16_f32_strided(ad["h16"], ws["h32"], M, A, A)

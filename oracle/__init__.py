@@ -25,7 +25,12 @@ SHAPES = {
 }
 
 
-def trainable(method: str, name: str) -> bool:
+def trainable(method: str, name: str, cfg: dict = None) -> bool:
+    """requires_grad of parameter `name` as the reference's constructors leave it.  `cfg` matters only for freeze_vit=False on the classes
+    that freeze by default: the freeze loops (adaptformer.py:163-168 and its copies) are skipped and every parameter keeps nn.Parameter's
+    default requires_grad=True."""
+    if cfg is not None and cfg.get("freeze_vit") is False and method in ("adaptformer",):
+        return True
     if method == "gaviko":
         return gaviko_trainable(name)
     if method == "linear":       # train.py:117-121

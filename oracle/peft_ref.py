@@ -92,12 +92,15 @@ def adaptformer_forward(sd: SD, img: Tensor, cfg: dict, taps: Optional[dict] = N
     x = attn(x)+x ; r = adapter(x) ; x = ff(x)+x+r."""
     depth, heads, dim, mlp = mapping_vit(cfg["backbone"])
     patch = (cfg["frame_patch_size"], cfg["image_patch_size"], cfg["image_patch_size"])
+    masks = cfg.get("_masks")                       # explicit dropout masks (tests; live only with freeze_vit=False: adaptformer.py:175-191)
     x = embed_tokens(sd, img, patch)
+    if masks is not None and ("emb", 0) in masks:
+        x = x * masks[("emb", 0)]                   # self.dropout, adaptformer.py:203
     for i in range(depth):
         p = f"transformer.layers.{i}"
-        x = attention(sd, p + ".0", x, heads) + x
-        r = adapter(sd, p + ".1", x)
-        f = feed_forward(sd, p + ".2", x)
+        x = attention(sd, p + ".0", x, heads, masks=masks, layer=i) + x
+        r = adapter(sd, p + ".1", x)                # Adapter(dim): its own dropout p = 0.0 (adaptformer.py:23-27,67)
+        f = feed_forward(sd, p + ".2", x, masks=masks, layer=i)
         x = f + x + r
         if taps is not None:
             taps[f"layer{i}.ff_out"] = f

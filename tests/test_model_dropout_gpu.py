@@ -50,6 +50,7 @@ CASES = [("fft", dict(dropout=P, emb_dropout=P), (P, P, 0.0)),
          ("bitfit", dict(dropout=P, emb_dropout=P), (P, P, 0.0)),
          ("linear", dict(dropout=P, emb_dropout=P), (P, P, 0.0)),
          ("melo", dict(dropout=P, emb_dropout=P, r=4, alpha=4), (P, P, 0.0)),
+         ("adaptformer", dict(dropout=P, emb_dropout=P, freeze_vit=False), (P, P, 0.0)),     # unfrozen: the backbone's dropouts follow .training (adaptformer.py:175-191)
          ("deep_vpt", dict(dropout=P, emb_dropout=P, num_prompts=8, prompt_dim=64, prompt_dropout=P, freeze_vit=True, deep_prompt=True), (0.0, 0.0, P)),
          ("shallow_vpt", dict(dropout=P, emb_dropout=P, num_prompts=8, prompt_dim=64, prompt_dropout=P, freeze_vit=True, deep_prompt=False), (0.0, 0.0, P))]
 
@@ -72,7 +73,7 @@ def test_training_step_with_live_dropout_matches_oracle_with_the_same_masks(dev,
     for k, v in masks.items():
         keep = (v > 0).float().mean().item()
         assert abs(keep - (1 - P)) < 0.02, (k, keep)
-    osd = {k: v.detach().cpu().clone().requires_grad_(oracle.trainable(method, k)) for k, v in m.state_dict().items()}
+    osd = {k: v.detach().cpu().clone().requires_grad_(oracle.trainable(method, k, cfg)) for k, v in m.state_dict().items()}
     ologits = oracle.FORWARD[method](osd, x, dict(cfg, _masks=masks), None)
     oloss = torch.nn.functional.cross_entropy(ologits, y)
     oloss.backward()
@@ -90,7 +91,7 @@ def test_training_step_with_live_dropout_matches_oracle_with_the_same_masks(dev,
     #  a dropped element contributes exactly nothing to them)
     if "vpt" not in method:
         assert (plain - ologits.detach()).abs().max().item() > 5 * (lg - ologits.detach()).abs().max().item()
-    errs = []
+    errs, cosines = [], []
     for k, p in m.named_parameters():
         if not p.requires_grad:
             continue
@@ -101,8 +102,21 @@ def test_training_step_with_live_dropout_matches_oracle_with_the_same_masks(dev,
         wn = want.norm().item()
         errs.append((abs(p.grad.norm().item() - wn) / max(wn, 1e-12), k))
         if wn > 1e-6 and want.numel() <= 200000:
-            e = (p.grad.cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
-            assert e < 6e-2, (k, e)
+            got = p.grad.cpu()
+            if method == "adaptformer":
+                # AdaptFormer's ReLU mask comes from bf16 pre-activations: a unit within rounding of zero flips, and with it one whole row of
+                # its adapter's dW (4.7e-1 of the largest element on layers.3.1.down_adapter_proj.weight; the reference's own arithmetic
+                # with bf16 operands moves single elements by 3.3e-1, tests/golden/bf16_noise_floor.json).  Direction and norm are the
+                # robust statements: cosine to the oracle's gradient, the norm bounds below, and the fp32 run of this case (next test),
+                # which is exact to 5e-4 on every element.
+                cos = torch.nn.functional.cosine_similarity(got.flatten().double(), want.flatten().double(), dim=0).item()
+                cosines.append((cos, k))
+            else:
+                e = (got - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
+                assert e < 6e-2, (k, e)
+    if cosines:
+        print("lowest cosines:", sorted(cosines)[:5])
+        assert min(c for c, _ in cosines) > 0.97, sorted(cosines)[:5]
     e = np.array([v[0] for v in errs])
     assert len(e) > 0 and np.median(e) < 1.5e-2 and e.max() < 0.15, sorted(errs, reverse=True)[:5]
 

@@ -47,6 +47,7 @@ CASES = {
     "shallow_vpt_t16_b2": ("shallow_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True, deep_prompt=False)),
     "cfg3_deep_vpt_b16_8x4": ("deep_vpt", "vit-b16", 4, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True, deep_prompt=True, shards=8)),
     "adaptformer_t16_b2": ("adaptformer", "vit-t16", 2, dict(freeze_vit=True)),
+    "adaptformer_t16_b2_unfrozen": ("adaptformer", "vit-t16", 2, dict(freeze_vit=False)),       # every tensor trains (adaptformer.py:163: the freeze loop is skipped)
     "melo_t16_b2": ("melo", "vit-t16", 2, dict(r=4, alpha=4)),
     "melo_t16_b2_layers": ("melo", "vit-t16", 2, dict(r=4, alpha=8, lora_layer=[0, 5, 11])),      # LoRA on a subset of layers, integer scale alpha // r = 2
     "cfg4_adaptformer_b16_b8": ("adaptformer", "vit-b16", 8, dict(freeze_vit=True)),
@@ -238,7 +239,7 @@ def run_case(mods, name, outdir):
             for k, v in taps.items():
                 out["tap/" + k] = v
             # ---- oracle cross-check on the same weights/inputs (shard 0) ----
-            osd = {k: v.detach().clone().requires_grad_(oracle.trainable(method, k)) for k, v in model.state_dict().items()}
+            osd = {k: v.detach().clone().requires_grad_(oracle.trainable(method, k, cfg)) for k, v in model.state_dict().items()}
             otaps = {}
             ologits = oracle.FORWARD[method](osd, x, cfg, otaps)
             oloss = torch.nn.functional.cross_entropy(ologits, y)
