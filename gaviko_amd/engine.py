@@ -37,6 +37,10 @@ from .engine_peft import PeftPaths
 GEMM_MARKS = None
 
 
+# classes whose backbone tensors can train (engine_peft.py `_bb_*`): the plain ViT (`fft` / `bitfit`), AdaptFormer and Gaviko with freeze_vit=False
+_BB_KINDS = ("vit", "adaptformer", "gaviko")
+
+
 class Engine(GavikoPaths, PeftPaths):
     def __init__(self, kind: str, cfg: dict, params: Dict[str, torch.nn.Parameter], depth, heads, dim, mlp_dim):
         self.kind, self.cfg, self.p = kind, cfg, params
@@ -227,7 +231,7 @@ class Engine(GavikoPaths, PeftPaths):
                     w[f"{tag}{i}"] = ops.to_operand(src, None if self.fp32 else w.get(f"{tag}{i}"), self.adt)   # fp32: the parameter itself
                 if need_dgrad and (stale or not self._have_dgrad):
                     w[f"{tag}{i}_t"] = ops.transpose_operand(src, w.get(f"{tag}{i}_t"), self.adt)
-        if self._fold_ln1 and (stale or not self._fold):
+        if self._fold_ln1 and (stale or not self._fold) and not self.p[self.names.qkv_weight(0)].requires_grad:      # (unused when the backbone trains)
             for i in range(1, self.depth):
                 a = self.names.attn(i)
                 Wq, g, b = self._d(self.names.qkv_weight(i)), self._d(a + ".norm.weight"), self._d(a + ".norm.bias")
@@ -513,11 +517,10 @@ class Engine(GavikoPaths, PeftPaths):
             ws["img"].copy_(img.detach())                   # static input buffer (the only per-step host-visible copy-in)
         # unfrozen backbone tensors (`fft` / `bitfit`, train.py:123-137): which ones train, and whether GEMM inputs must be kept
         # (`fft` / `bitfit` of the plain ViT; AdaptFormer(freeze_vit=False): adapters keep their own kernels, everything else is backbone)
+        # Gaviko(freeze_vit=False): prompts / MWSA / GPA keep their own kernels, everything else is backbone)
         bb = frozenset()
-        if train and self.kind == "vit":
-            bb = frozenset(n for n in self.trainable_names() if not n.startswith(self.names.head()))
-        elif train and self.kind == "adaptformer":
-            bb = frozenset(n for n in self.trainable_names() if not n.startswith(self.names.head()) and "adapter" not in n)
+        if train and self.kind in _BB_KINDS:
+            bb = frozenset(n for n in self.trainable_names() if not n.startswith(self.names.head()) and not self._own_grad_kernels(n))
         sv["bb"] = bb
         sv["wgrad"] = any(self.p[n].dim() >= 2 and n.endswith("weight") for n in bb)
         if bb:
@@ -934,7 +937,8 @@ class Engine(GavikoPaths, PeftPaths):
             if pd_ > 0:                                                      # gradient of dropout(fc2(.)): the forward's mask on dGout
                 dy_ff = self._masked_grad(ws, dGout, pd_, SEED_LAYER + 8 * i + 3, bool(bb), M)
             if bb:                                                           # fc2: db = colsum(dGout), dW = dGout^T . act
-                self._bb_linear_grads(ws, gv, bb, m + ".net.4", dy_ff, ws["dG16"], ws["sav"]["act"][i] if sv["wgrad"] else None, M, C, self.mlp)
+                self._bb_linear_grads(ws, gv, bb, m + ".net.4", dy_ff, ws["dG16"], ws["sav"]["act"][i] if sv["wgrad"] else None, M, C, self.mlp,
+                                      ldx=self.ldx if self.ldx != self.mlp else None)
             dvpt = self.kind == "dvpt"
             if dvpt:
                 self._dvpt_bwd_latents(ws, gv, i, dGout, M, B)
@@ -1057,7 +1061,7 @@ class Engine(GavikoPaths, PeftPaths):
         if last and sv.get("bb"):
             if sv.get("edrop", 0.0) > 0:                                     # through emb_dropout
                 ops.dropout_rows(dGout, sv["edrop"], SEED_EMB, ws["seed"], out32=dGout, M=B * self.T, N=C)
-            self._bb_embed_grads(ws, gv, sv["bb"], dGout, B)
+            self._bb_embed_grads(ws, gv, sv["bb"], dGout, B, dlocal=ws["dL"][(self.depth - 1 - lo + 1) & 1] if gaviko else None)
         if last and self.kind == "evp":
             self._evp_bwd_finish(ws, gv, B)
         if last and self.kind == "ssf":
@@ -1078,14 +1082,20 @@ class Engine(GavikoPaths, PeftPaths):
         self._mark("b:tail")                                                 # side streams joined, embedding-side gradients issued
 
     def _grad_supported(self, name: str) -> bool:
-        if name.startswith(self.names.head()) or self.kind == "vit":       # plain ViT: every tensor (`linear` / `bitfit` / `fft`)
-            return True
+        # head: always; backbone tensors: the classes of _BB_KINDS (plain ViT `linear` / `bitfit` / `fft`, AdaptFormer and Gaviko with
+        # freeze_vit=False); everything else: the method's own tensors
+        return name.startswith(self.names.head()) or self.kind in _BB_KINDS or self._own_grad_kernels(name)
+
+    def _own_grad_kernels(self, name: str) -> bool:
+        """The method's OWN trainable tensors (prompts, adapters, LoRA factors, ...): gradients from the method-specific kernels."""
+        if self.kind == "vit":
+            return False
         if self.kind == "gaviko":
             return ("local_attns" in name or "prompt_projs" in name or name in ("prompt_embeddings", "prompt_positional_embedding"))
         if self.kind == "vpt":
             return name in ("prompt_proj.weight", "prompt_proj.bias", "deep_prompt_embeddings", "prompt_embeddings")
         if self.kind == "adaptformer":
-            return True                                                     # adapters + (freeze_vit=False) the whole backbone
+            return "adapter" in name
         if self.kind == "melo":
             return ".linear_a_" in name or ".linear_b_" in name
         if self.kind == "ssf":

@@ -112,32 +112,34 @@ class PeftPaths:
             ws["bbw"] = dict(ones=torch.ones(n, device=device), zeros=torch.zeros(n, device=device), junk=torch.zeros(2 * n, device=device),
                              scratch=torch.zeros(64 * 2 * n, device=device), stat=[torch.zeros(M, device=device), torch.zeros(M, device=device)])
             ws["dyd"] = ops.act_zeros(M, C, torch.float32, device)           # dropout-masked copy of a layer gradient (bias / weight-gradient operand)
+            ws["pg32"] = ops.act_zeros(B * self.N, C, torch.float32, device)  # patch rows of the input gradient (+ GAViKO's local-stream share)
         if wgrad and "sav" not in ws:
             C, M, Mp = self.C, B * self.T, ops.pad_rows(B * self.T)
             z = lambda r, c: ops.act_zeros(r, c, self.adt, device)
             ws["sav"] = dict(xn1=[z(M, C) for _ in range(self.depth)], xn2=[z(M, C) for _ in range(self.depth)],
-                             act=[z(M, self.mlp) for _ in range(self.depth)])
+                             act=[z(M, self.ldx) for _ in range(self.depth)])     # (row stride of the hidden buffers: mlp, + 64 with the GPA columns)
             ws["tA"] = z(max(self.mlp, 3 * C), Mp)
-            ws["tB"] = z(max(self.mlp, self.Kp), Mp)
+            ws["tB"] = z(max(self.ldx, self.Kp), Mp)
             ws["pg16"] = z(B * self.N, C)
-            ws["pg32"] = ops.act_zeros(B * self.N, C, torch.float32, device)
 
-    def _bb_wgrad(self, ws, dy_op, x_op, out, M, N, K):
-        """out [N][K] (fp32) = dy_op[0:M, 0:N]^T . x_op[0:M, 0:K]; rows >= M of both operand buffers are zero by construction."""
+    def _bb_wgrad(self, ws, dy_op, x_op, out, M, N, K, ldx=None):
+        """out [N][K] (fp32) = dy_op[0:M, 0:N]^T . x_op[0:M, 0:K]; rows >= M of both operand buffers are zero by construction.
+        ldx: row stride of x_op when it carries more than K columns (the MLP hidden buffer with the GPA columns behind it)."""
         Mp = ops.pad_rows(M)
-        tA, tB = ws["tA"].view(-1)[: ops.pad_rows(N) * Mp].view(-1, Mp), ws["tB"].view(-1)[: ops.pad_rows(K) * Mp].view(-1, Mp)
+        Kx = K if ldx is None else ldx
+        tA, tB = ws["tA"].view(-1)[: ops.pad_rows(N) * Mp].view(-1, Mp), ws["tB"].view(-1)[: ops.pad_rows(Kx) * Mp].view(-1, Mp)
         ops.transpose_any(dy_op, tA, Mp, N)
-        ops.transpose_any(x_op, tB, Mp, K)
+        ops.transpose_any(x_op, tB, Mp, Kx)
         self._gemm(tA, tB[:K], N, out.view(N, K), epilogue=ops.EPI_STORE_F32)
 
-    def _bb_linear_grads(self, ws, gv, bb, prefix, dy32, dy_op, x_op, M, N, K):
+    def _bb_linear_grads(self, ws, gv, bb, prefix, dy32, dy_op, x_op, M, N, K, ldx=None):
         """db = colsum(dy), dW = dy^T . x for one Linear of the backbone, for whichever of the two trains."""
         bw = ws["bbw"]
         if prefix + ".bias" in bb:
             src = dy32 if dy32 is not None else dy_op
             ops.colsum_any(src, gv[prefix + ".bias"], bw["ones"][:N], bw["zeros"][:N], bw["junk"][:N], bw["scratch"], M, N)
         if prefix + ".weight" in bb:
-            self._bb_wgrad(ws, dy_op, x_op, gv[prefix + ".weight"], M, N, K)
+            self._bb_wgrad(ws, dy_op, x_op, gv[prefix + ".weight"], M, N, K, ldx=ldx)
 
     def _bb_ln_grads(self, ws, gv, bb, prefix, dy, x, mean, rstd, M):
         wn, bn = prefix + ".weight", prefix + ".bias"
@@ -145,19 +147,35 @@ class PeftPaths:
             C, junk = self.C, ws["bbw"]["junk"]
             ops.layernorm_bwd_affine(dy, x, mean, rstd, gv[wn] if wn in bb else junk[:C], gv[bn] if bn in bb else junk[C: 2 * C], ws["scratch"], M, C)
 
-    def _bb_embed_grads(self, ws, gv, bb, dG0, B):
-        """pos_embedding / cls_token (batch sums of the input gradient), conv_proj bias and weight (the patch rows)."""
+    def _bb_embed_grads(self, ws, gv, bb, dG0, B, dlocal=None):
+        """pos_embedding / cls_token (batch sums of the input gradient), conv_proj bias and weight (the patch rows).  Rows: [cls | patches]
+        for the plain layout, [P prompts | cls | patches] for GAViKO (gaviko.py:536-548), whose local stream = conv(img) + pos[1:]
+        (gaviko.py:545-546) hands the patch rows a second gradient, `dlocal` [B*N][C] (the MWSA chain's input gradient)."""
         C, T, N, bw = self.C, self.T, self.N, ws["bbw"]
         nm = self.names
-        if "pos_embedding" in bb:
-            ops.rows_batch_sum(dG0, gv["pos_embedding"].view(T, C), None, B, T, 0, T, C)
-        if "cls_token" in bb:
-            ops.rows_batch_sum(dG0, gv["cls_token"].view(1, C), None, B, T, 0, 1, C)
+        r_cls = self.row_off - 1                                # row of the cls token; the patch rows start at self.row_off
         cw, cb = nm.conv() + ".weight", nm.conv() + ".bias"
+        need_rows = dlocal is not None and ("pos_embedding" in bb or cb in bb or cw in bb)
+        if need_rows or cw in bb:
+            ops.rows_gather(dG0, ws["pg32"], B, T, N, C, self.row_off)          # the patch rows of the input gradient, [B*N][C]
+            if dlocal is not None:
+                ops.add2d(ws["pg32"], C, dlocal, C, ws["pg32"], C, B * N, C)
+        if "pos_embedding" in bb:
+            pos = gv["pos_embedding"].view(N + 1, C)
+            if dlocal is None:
+                ops.rows_batch_sum(dG0, pos, None, B, T, r_cls, N + 1, C)
+            else:
+                ops.rows_batch_sum(dG0, pos[:1], None, B, T, r_cls, 1, C)
+                ops.rows_batch_sum(ws["pg32"], pos[1:], None, B, N, 0, N, C)
+        if "cls_token" in bb:
+            ops.rows_batch_sum(dG0, gv["cls_token"].view(1, C), None, B, T, r_cls, 1, C)
         if cb in bb:
-            ops.colsum_any(dG0, gv[cb], bw["ones"][:C], bw["zeros"][:C], bw["junk"][:C], bw["scratch"], B * N, C, rows_in=N, rows_out=T, row_off=1)
+            if dlocal is None:
+                ops.colsum_any(dG0, gv[cb], bw["ones"][:C], bw["zeros"][:C], bw["junk"][:C], bw["scratch"], B * N, C, rows_in=N, rows_out=T,
+                               row_off=self.row_off)
+            else:
+                ops.colsum_any(ws["pg32"], gv[cb], bw["ones"][:C], bw["zeros"][:C], bw["junk"][:C], bw["scratch"], B * N, C)
         if cw in bb:
-            ops.rows_gather(dG0, ws["pg32"], B, T, N, C, 1)
             ops.to_operand(ws["pg32"], ws["pg16"], self.adt)
             self._bb_wgrad(ws, ws["pg16"], ws["cols"], gv[cw].view(C, self.Kp), B * N, C, self.Kp)
 

@@ -82,6 +82,7 @@ def _parity_report():
 
 
 GAVIKO_CASES = [("gaviko_t16_b2", "vit-t16", 2, dict(GAVIKO)),
+                ("gaviko_t16_b2_unfrozen", "vit-t16", 2, dict(GAVIKO, freeze_vit=False)),   # gaviko.py:428-434 skipped: all 442 tensors train
                 ("gaviko_t16_b2_k366_p8", "vit-t16", 2, dict(GAVIKO, local_k=(3, 6, 6), num_prompts=8)),
                 ("gaviko_t16_b1_share2", "vit-t16", 1, dict(GAVIKO, share_factor=2)),
                 # latent width 16: outside the L = 20 tile kernels (sidepass.hip / window_mfma.hip), so the engine must take the
@@ -357,6 +358,7 @@ FP32_CASES = [("cfg1_linear_t16_b1", "linear", "vit-t16", 1, dict()),
               ("melo_t16_b2_layers", "melo", "vit-t16", 2, dict(r=4, alpha=8, lora_layer=[0, 5, 11])),   # melo.py:53-68: only these layers are wrapped
               ("deep_vpt_t16_b2", "deep_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True)),
               ("gaviko_t16_b2", "gaviko", "vit-t16", 2, dict(GAVIKO)),
+              ("gaviko_t16_b2_unfrozen", "gaviko", "vit-t16", 2, dict(GAVIKO, freeze_vit=False)),
               ("cfg4_adaptformer_b16_b8", "adaptformer", "vit-b16", 8, dict(freeze_vit=True)),
               ("cfg4_melo_b16_b8", "melo", "vit-b16", 8, dict(r=4, alpha=4)),
               ("ssf_t16_b2", "ssf", "vit-t16", 2, dict(freeze_vit=True)),

@@ -41,6 +41,7 @@ CASES = {
     "gaviko_t16_b2": ("gaviko", "vit-t16", 2, dict(GAVIKO)),
     "gaviko_t16_b2_k366_p8": ("gaviko", "vit-t16", 2, dict(GAVIKO, local_k=(3, 6, 6), num_prompts=8)),
     "gaviko_t16_b1_share2": ("gaviko", "vit-t16", 1, dict(GAVIKO, share_factor=2)),
+    "gaviko_t16_b2_unfrozen": ("gaviko", "vit-t16", 2, dict(GAVIKO, freeze_vit=False)),       # gaviko.py:428-434 skipped: the whole backbone trains too
     "gaviko_t16_b2_lat16": ("gaviko", "vit-t16", 2, dict(GAVIKO, prompt_latent_dim=16, local_dim=16)),   # a latent width the L = 20 tile kernels do not cover
     "cfg2_gaviko_b16_b4": ("gaviko", "vit-b16", 4, dict(GAVIKO)),
     "deep_vpt_t16_b2": ("deep_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True, deep_prompt=True)),
