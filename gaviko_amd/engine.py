@@ -509,8 +509,8 @@ class Engine(GavikoPaths, PeftPaths):
         # nn.Dropout of the backbone itself (vision_transformer.py:33-34,52-54,157; vpt.py:129,148): live for the classes without a
         # train() override (linear / bitfit / fft, melo) and for VPT's prompt_dropout.  bf16 path only.
         sv["bdrop"], sv["edrop"], sv["pdrop"] = (float(drop.get(k, 0.0)) for k in ("dropout", "emb_dropout", "prompt_dropout"))
-        if (sv["bdrop"] > 0 or sv["edrop"] > 0 or sv["pdrop"] > 0) and self.kind not in ("vit", "melo", "vpt", "adaptformer"):
-            raise L.GavikoHipError(f"backbone dropout > 0 in training mode is built for the vit / melo / vpt / adaptformer classes, not kind={self.kind!r}")
+        if (sv["bdrop"] > 0 or sv["edrop"] > 0 or sv["pdrop"] > 0) and self.kind not in ("vit", "melo", "vpt", "adaptformer", "gaviko"):
+            raise L.GavikoHipError(f"backbone dropout > 0 in training mode is built for the vit / melo / vpt / adaptformer / gaviko classes, not kind={self.kind!r}")
         self.refresh_weights(need_dgrad=train)
         ws = self.workspace(B, img.device, train)
         if img.data_ptr() != ws["img"].data_ptr():           # a caller that fills input_buffer() itself skips the copy-in launch
@@ -585,6 +585,8 @@ class Engine(GavikoPaths, PeftPaths):
             ops.rows_broadcast(G0, cls, pos[0:1], B, T, 0, 1, C)
         if sv["edrop"] > 0:                                   # x = dropout(x + pos) over [cls | patches] (vision_transformer.py:157)
             ops.dropout_rows(G0, sv["edrop"], SEED_EMB, ws["seed"], out32=G0, M=B * T, N=C)
+            if self.kind == "gaviko":                         # ... and, with its own draw, over the local tokens (gaviko.py:544,548)
+                ops.dropout_rows(ws["Lc"][0], sv["edrop"], SEED_EMB + 1, ws["seed"], out32=ws["Lc"][0], M=B * N, N=C)
         if self.kind == "vpt":                                # prompt_proj on every layer's prompts at once (vpt.py:56,127-153)
             emb = d("deep_prompt_embeddings" if self.deep else "prompt_embeddings").reshape(-1, self.pd)
             ops.small_linear_fwd(emb, d("prompt_proj.weight"), d("prompt_proj.bias"), ws["vproj"], emb.shape[0], self.pd, C)
@@ -1061,7 +1063,10 @@ class Engine(GavikoPaths, PeftPaths):
         if last and sv.get("bb"):
             if sv.get("edrop", 0.0) > 0:                                     # through emb_dropout
                 ops.dropout_rows(dGout, sv["edrop"], SEED_EMB, ws["seed"], out32=dGout, M=B * self.T, N=C)
-            self._bb_embed_grads(ws, gv, sv["bb"], dGout, B, dlocal=ws["dL"][(self.depth - 1 - lo + 1) & 1] if gaviko else None)
+            dlocal = ws["dL"][(self.depth - 1 - lo + 1) & 1] if gaviko else None      # what _mwsa_final of the lowest layer wrote
+            if gaviko and sv.get("edrop", 0.0) > 0:
+                ops.dropout_rows(dlocal, sv["edrop"], SEED_EMB + 1, ws["seed"], out32=dlocal, M=B * self.N, N=C)
+            self._bb_embed_grads(ws, gv, sv["bb"], dGout, B, dlocal=dlocal)
         if last and self.kind == "evp":
             self._evp_bwd_finish(ws, gv, B)
         if last and self.kind == "ssf":

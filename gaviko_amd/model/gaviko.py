@@ -235,11 +235,10 @@ class Gaviko(HotPathModule):
     def _drop_config(self):
         la = self.transformer.local_attns
         live = len(la) > 0 and la[0].training
-        return {"attn_drop": self._cfg["attn_drop"] if live else 0.0, "proj_drop": self._cfg["proj_drop"] if live else 0.0}
+        # the backbone's own nn.Dropout modules: in eval under freeze_vit=True (train() above), following .training otherwise (gaviko.py:513-528)
+        return {"attn_drop": self._cfg["attn_drop"] if live else 0.0, "proj_drop": self._cfg["proj_drop"] if live else 0.0,
+                "dropout": self._cfg["dropout"] if self.transformer.attns[0].dropout.training else 0.0,
+                "emb_dropout": self._cfg["emb_dropout"] if self.dropout.training else 0.0}
 
     def forward(self, img):
-        backbone_drop = (self.dropout.training and self._cfg["emb_dropout"] > 0) or \
-                        (self.transformer.attns[0].dropout.training and self._cfg["dropout"] > 0)
-        if backbone_drop:
-            raise NotImplementedError("backbone / embedding dropout is live only with freeze_vit=False; that training mode is not built")
         return self._run(img)

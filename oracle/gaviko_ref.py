@@ -112,6 +112,11 @@ def gaviko_forward(sd: SD, img: Tensor, cfg: dict, taps: Optional[dict] = None) 
     g = torch.cat([sd["prompt_embeddings"].expand(b, -1, -1), sd["cls_token"].expand(b, -1, -1), x], dim=1)
     g = g + torch.cat([sd["prompt_positional_embedding"], sd["pos_embedding"]], dim=1)   # 540-543
     loc = x + sd["pos_embedding"][:, 1:, :]                    # 546-547
+    emasks = cfg.get("_masks") or {}                           # explicit dropout masks (tests).  self.dropout is applied TWICE, with independent
+    if ("emb", 0) in emasks:                                   # draws: to the global tokens (544) and to the local tokens (548); live only
+        g = g * emasks[("emb", 0)]                             # with freeze_vit=False (gaviko.py:513-528)
+    if ("emb_local", 0) in emasks:
+        loc = loc * emasks[("emb_local", 0)]
     mask = None
     if cfg.get("DHW") is not None:
         mask = window_mask(tuple(cfg["DHW"]), tuple(cfg["local_k"]), dtype=x.dtype)
@@ -123,12 +128,12 @@ def gaviko_forward(sd: SD, img: Tensor, cfg: dict, taps: Optional[dict] = None) 
         masks = cfg.get("_masks") or {}
         loc = local_self_attention(sd, f"transformer.local_attns.{s}", loc, mask, taps, masks.get(("mwsa_attn", i)),
                                    masks.get(("mwsa_proj", i))) + loc                                # 301
-        g = attention(sd, f"transformer.attns.{i}", g, heads, None) + g                              # 302
+        g = attention(sd, f"transformer.attns.{i}", g, heads, None, masks=masks, layer=i) + g        # 302
         if taps is not None:
             taps[f"layer{i}.local"] = loc
             taps[f"layer{i}.post_attn"] = g
         prompt = awakening_prompt(sd, f"transformer.prompt_projs.{s}", g, loc, P, None)              # 303
-        g = feed_forward(sd, f"transformer.mlps.{i}", g) + g + prompt                                # 304
+        g = feed_forward(sd, f"transformer.mlps.{i}", g, masks=masks, layer=i) + g + prompt          # 304
         if taps is not None:
             taps[f"layer{i}.gpa"] = prompt
             taps[f"layer{i}.post_mlp"] = g

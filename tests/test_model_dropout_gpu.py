@@ -33,6 +33,8 @@ def masks_for(eng, word, B, backbone_p, emb_p, prompt_p):
     C, H, mlp = eng.C, eng.heads, eng.mlp
     if emb_p > 0:
         masks[("emb", 0)] = t(dropmask.rows_mask(E.SEED_EMB + word, B * eng.T, C, emb_p)).view(B, eng.T, C)
+        if eng.kind == "gaviko":                    # self.dropout is applied a second time, to the local tokens (gaviko.py:548)
+            masks[("emb_local", 0)] = t(dropmask.rows_mask(E.SEED_EMB + 1 + word, B * eng.N, C, emb_p)).view(B, eng.N, C)
     for i in range(eng.depth):
         T = eng.Ts[i]
         if backbone_p > 0:
@@ -51,6 +53,9 @@ CASES = [("fft", dict(dropout=P, emb_dropout=P), (P, P, 0.0)),
          ("linear", dict(dropout=P, emb_dropout=P), (P, P, 0.0)),
          ("melo", dict(dropout=P, emb_dropout=P, r=4, alpha=4), (P, P, 0.0)),
          ("adaptformer", dict(dropout=P, emb_dropout=P, freeze_vit=False), (P, P, 0.0)),     # unfrozen: the backbone's dropouts follow .training (adaptformer.py:175-191)
+         # Gaviko(freeze_vit=False) with the shipped dropout = emb_dropout = 0.1 (gaviko.py:513-528); the MWSA dropouts have their own test below
+         ("gaviko", dict(dropout=P, emb_dropout=P, freeze_vit=False, num_prompts=8, prompt_latent_dim=20, local_dim=20, local_k=(3, 6, 6),
+                         DHW=(10, 10, 10), attn_drop=0.0, proj_drop=0.0, share_factor=1), (P, P, 0.0)),
          ("deep_vpt", dict(dropout=P, emb_dropout=P, num_prompts=8, prompt_dim=64, prompt_dropout=P, freeze_vit=True, deep_prompt=True), (0.0, 0.0, P)),
          ("shallow_vpt", dict(dropout=P, emb_dropout=P, num_prompts=8, prompt_dim=64, prompt_dropout=P, freeze_vit=True, deep_prompt=False), (0.0, 0.0, P))]
 
@@ -113,7 +118,9 @@ def test_training_step_with_live_dropout_matches_oracle_with_the_same_masks(dev,
                 cosines.append((cos, k))
             else:
                 e = (got - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
-                assert e < 6e-2, (k, e)
+                # GAViKO's gl_balancer scalars (norms 1e-4, 100x below every other tensor) are cancellation-dominated: 1.4e-1 here, 1.1e-1 in
+                # the reference's own bf16-operand arithmetic (tests/golden/bf16_noise_floor.json); exact on the fp32 path (next test)
+                assert e < (0.2 if "gl_balancer" in k else 6e-2), (k, e)
     if cosines:
         print("lowest cosines:", sorted(cosines)[:5])
         assert min(c for c, _ in cosines) > 0.97, sorted(cosines)[:5]
@@ -134,7 +141,7 @@ def test_dropout_draws_fresh_masks_every_step_and_eval_is_deterministic(dev):
     assert torch.equal(c, d)
 
 
-@pytest.mark.parametrize("method,extra,live", [CASES[0], CASES[3], CASES[4]])
+@pytest.mark.parametrize("method,extra,live", [c for c in CASES if c[0] in ("fft", "melo", "deep_vpt", "adaptformer", "gaviko")])
 def test_fp32_path_with_live_dropout_is_exact_against_the_oracle(dev, method, extra, live):
     """The same masks through exact fp32 arithmetic: logits to 2e-5, every gradient to 2e-4 -- the mask logic itself, free of bf16 noise."""
     from gaviko_amd.utils import synth
@@ -147,8 +154,8 @@ def test_fp32_path_with_live_dropout_is_exact_against_the_oracle(dev, method, ex
     torch.cuda.synchronize()
     eng = m._engine()
     masks = masks_for(eng, int(eng._ws["seed"].item()), B, *live)
-    osd = {k: v.detach().cpu().clone().requires_grad_(oracle.trainable(method, k)) for k, v in m.state_dict().items()}
     ocfg = {k: v for k, v in cfg.items() if k != "precision"}
+    osd = {k: v.detach().cpu().clone().requires_grad_(oracle.trainable(method, k, ocfg)) for k, v in m.state_dict().items()}
     ologits = oracle.FORWARD[method](osd, x, dict(ocfg, _masks=masks), None)
     torch.nn.functional.cross_entropy(ologits, y).backward()
     assert (logits.detach().cpu() - ologits.detach()).abs().max().item() < 2e-5 * max(1.0, ologits.abs().max().item())
