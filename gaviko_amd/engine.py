@@ -37,8 +37,8 @@ from .engine_peft import PeftPaths
 GEMM_MARKS = None
 
 
-# classes whose backbone tensors can train (engine_peft.py `_bb_*`): the plain ViT (`fft` / `bitfit`), AdaptFormer and Gaviko with freeze_vit=False
-_BB_KINDS = ("vit", "adaptformer", "gaviko")
+# classes whose backbone tensors can train (engine_peft.py `_bb_*`): the plain ViT (`fft` / `bitfit`); AdaptFormer, Gaviko and DVPT with freeze_vit=False
+_BB_KINDS = ("vit", "adaptformer", "gaviko", "dvpt")
 
 
 class Engine(GavikoPaths, PeftPaths):
@@ -509,8 +509,8 @@ class Engine(GavikoPaths, PeftPaths):
         # nn.Dropout of the backbone itself (vision_transformer.py:33-34,52-54,157; vpt.py:129,148): live for the classes without a
         # train() override (linear / bitfit / fft, melo) and for VPT's prompt_dropout.  bf16 path only.
         sv["bdrop"], sv["edrop"], sv["pdrop"] = (float(drop.get(k, 0.0)) for k in ("dropout", "emb_dropout", "prompt_dropout"))
-        if (sv["bdrop"] > 0 or sv["edrop"] > 0 or sv["pdrop"] > 0) and self.kind not in ("vit", "melo", "vpt", "adaptformer", "gaviko"):
-            raise L.GavikoHipError(f"backbone dropout > 0 in training mode is built for the vit / melo / vpt / adaptformer / gaviko classes, not kind={self.kind!r}")
+        if (sv["bdrop"] > 0 or sv["edrop"] > 0 or sv["pdrop"] > 0) and self.kind not in ("vit", "melo", "vpt", "adaptformer", "gaviko", "dvpt"):
+            raise L.GavikoHipError(f"backbone dropout > 0 in training mode is built for the vit / melo / vpt / adaptformer / gaviko / dvpt classes, not kind={self.kind!r}")
         self.refresh_weights(need_dgrad=train)
         ws = self.workspace(B, img.device, train)
         if img.data_ptr() != ws["img"].data_ptr():           # a caller that fills input_buffer() itself skips the copy-in launch

@@ -36,11 +36,14 @@ def dvpt_forward(sd: SD, img: Tensor, cfg: dict, taps: Optional[dict] = None) ->
     x = torch.cat((sd["cls_token"].expand(b, -1, -1), x), dim=1)
     x = torch.cat([sd["prompt_embeddings"].expand(b, -1, -1), x], dim=1)
     x = x + torch.cat([sd["prompt_positional_embedding"], sd["pos_embedding"]], dim=1)
+    masks = cfg.get("_masks")                       # explicit dropout masks (tests; live only with freeze_vit=False: dvpt.py:168-184)
+    if masks is not None and ("emb", 0) in masks:
+        x = x * masks[("emb", 0)]                   # self.dropout, dvpt.py:200
     for i in range(depth):
         p = f"transformer.layers.{i}.0"
-        x = attention(sd, p + ".attn", x, heads) + x
+        x = attention(sd, p + ".attn", x, heads, masks=masks, layer=i) + x
         prompt = share_mlp(sd, p + ".prompt_proj", x, num)
-        f = feed_forward(sd, p + ".mlp", x)
+        f = feed_forward(sd, p + ".mlp", x, masks=masks, layer=i)
         x = f + x + prompt
         if taps is not None:
             taps[f"layer{i}.ff_out"] = f

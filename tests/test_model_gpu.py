@@ -198,6 +198,7 @@ PEFT_CASES = [("deep_vpt_t16_b2", "deep_vpt", "vit-t16", 2, dict(num_prompts=8, 
               ("ssf_b16_b4", "ssf", "vit-b16", 4, dict(freeze_vit=True)),
               ("dvpt_t16_b2", "dvpt", "vit-t16", 2, dict(num_prompts=50, freeze_vit=True)),
               ("dvpt_t16_b2_mean_p8", "dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=True, pool="mean")),
+              ("dvpt_t16_b2_unfrozen", "dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=False)),
               ("dvpt_b16_b4", "dvpt", "vit-b16", 4, dict(num_prompts=50, freeze_vit=True)),
               ("evp_t16_b2", "evp", "vit-t16", 2, dict(freeze_vit=True)),
               ("evp_b16_b2", "evp", "vit-b16", 2, dict(freeze_vit=True)),
@@ -365,6 +366,7 @@ FP32_CASES = [("cfg1_linear_t16_b1", "linear", "vit-t16", 1, dict()),
               ("ssf_b16_b4", "ssf", "vit-b16", 4, dict(freeze_vit=True)),
               ("dvpt_t16_b2", "dvpt", "vit-t16", 2, dict(num_prompts=50, freeze_vit=True)),
               ("dvpt_t16_b2_mean_p8", "dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=True, pool="mean")),
+              ("dvpt_t16_b2_unfrozen", "dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=False)),
               ("dvpt_b16_b4", "dvpt", "vit-b16", 4, dict(num_prompts=50, freeze_vit=True)),
               ("evp_t16_b2", "evp", "vit-t16", 2, dict(freeze_vit=True)),
               ("evp_b16_b2", "evp", "vit-b16", 2, dict(freeze_vit=True)),

@@ -57,6 +57,7 @@ CASES = {
     "ssf_t16_b2": ("ssf", "vit-t16", 2, dict(freeze_vit=True)),
     "ssf_b16_b4": ("ssf", "vit-b16", 4, dict(freeze_vit=True)),
     "dvpt_t16_b2": ("dvpt", "vit-t16", 2, dict(num_prompts=50, freeze_vit=True)),
+    "dvpt_t16_b2_unfrozen": ("dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=False)),      # dvpt.py:156 skipped: the backbone trains too
     "dvpt_t16_b2_mean_p8": ("dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=True, pool="mean")),
     "dvpt_b16_b4": ("dvpt", "vit-b16", 4, dict(num_prompts=50, freeze_vit=True)),
     "bitfit_t16_b2": ("bitfit", "vit-t16", 2, {}),
