@@ -37,8 +37,8 @@ from .engine_peft import PeftPaths
 GEMM_MARKS = None
 
 
-# classes whose backbone tensors can train (engine_peft.py `_bb_*`): the plain ViT (`fft` / `bitfit`); AdaptFormer, Gaviko and DVPT with freeze_vit=False
-_BB_KINDS = ("vit", "adaptformer", "gaviko", "dvpt")
+# classes whose backbone tensors can train (engine_peft.py `_bb_*`): the plain ViT (`fft` / `bitfit`); AdaptFormer, Gaviko, DVPT and EVP with freeze_vit=False
+_BB_KINDS = ("vit", "adaptformer", "gaviko", "dvpt", "evp")
 
 
 class Engine(GavikoPaths, PeftPaths):
@@ -509,8 +509,8 @@ class Engine(GavikoPaths, PeftPaths):
         # nn.Dropout of the backbone itself (vision_transformer.py:33-34,52-54,157; vpt.py:129,148): live for the classes without a
         # train() override (linear / bitfit / fft, melo) and for VPT's prompt_dropout.  bf16 path only.
         sv["bdrop"], sv["edrop"], sv["pdrop"] = (float(drop.get(k, 0.0)) for k in ("dropout", "emb_dropout", "prompt_dropout"))
-        if (sv["bdrop"] > 0 or sv["edrop"] > 0 or sv["pdrop"] > 0) and self.kind not in ("vit", "melo", "vpt", "adaptformer", "gaviko", "dvpt"):
-            raise L.GavikoHipError(f"backbone dropout > 0 in training mode is built for the vit / melo / vpt / adaptformer / gaviko / dvpt classes, not kind={self.kind!r}")
+        if (sv["bdrop"] > 0 or sv["edrop"] > 0 or sv["pdrop"] > 0) and self.kind not in ("vit", "melo", "vpt", "adaptformer", "gaviko", "dvpt", "evp"):
+            raise L.GavikoHipError(f"backbone dropout > 0 in training mode is built for every class but ssf (kind={self.kind!r})")
         self.refresh_weights(need_dgrad=train)
         ws = self.workspace(B, img.device, train)
         if img.data_ptr() != ws["img"].data_ptr():           # a caller that fills input_buffer() itself skips the copy-in launch
@@ -1066,7 +1066,12 @@ class Engine(GavikoPaths, PeftPaths):
             dlocal = ws["dL"][(self.depth - 1 - lo + 1) & 1] if gaviko else None      # what _mwsa_final of the lowest layer wrote
             if gaviko and sv.get("edrop", 0.0) > 0:
                 ops.dropout_rows(dlocal, sv["edrop"], SEED_EMB + 1, ws["seed"], out32=dlocal, M=B * self.N, N=C)
-            self._bb_embed_grads(ws, gv, sv["bb"], dGout, B, dlocal=dlocal)
+            if self.kind == "evp":
+                # the raw conv output also feeds embedding_generator (evp.py:347-348): d xc += d s . W_e  (d s is complete once layer 0 is through)
+                dlocal = ws["ev"]["tmp"]
+                ops.skinny_up(lat=ws["evb"]["ds"], w=self._evp_state(dGout.device)["We"], out=dlocal, M=B * self.N, C=C, L=self.Lp, w_layout=1,
+                              accumulate=0)
+            self._bb_embed_grads(ws, gv, sv["bb"], dGout, B, dlocal=dlocal, dlocal_to_pos=gaviko)
         if last and self.kind == "evp":
             self._evp_bwd_finish(ws, gv, B)
         if last and self.kind == "ssf":

@@ -147,10 +147,11 @@ class PeftPaths:
             C, junk = self.C, ws["bbw"]["junk"]
             ops.layernorm_bwd_affine(dy, x, mean, rstd, gv[wn] if wn in bb else junk[:C], gv[bn] if bn in bb else junk[C: 2 * C], ws["scratch"], M, C)
 
-    def _bb_embed_grads(self, ws, gv, bb, dG0, B, dlocal=None):
+    def _bb_embed_grads(self, ws, gv, bb, dG0, B, dlocal=None, dlocal_to_pos=True):
         """pos_embedding / cls_token (batch sums of the input gradient), conv_proj bias and weight (the patch rows).  Rows: [cls | patches]
         for the plain layout, [P prompts | cls | patches] for GAViKO (gaviko.py:536-548), whose local stream = conv(img) + pos[1:]
-        (gaviko.py:545-546) hands the patch rows a second gradient, `dlocal` [B*N][C] (the MWSA chain's input gradient)."""
+        (gaviko.py:545-546) hands the patch rows a second gradient, `dlocal` [B*N][C] (the MWSA chain's input gradient).  EVP's `dlocal` is
+        the embedding_generator's share of the RAW conv output (evp.py:347-348): it reaches the conv tensors but not pos_embedding."""
         C, T, N, bw = self.C, self.T, self.N, ws["bbw"]
         nm = self.names
         r_cls = self.row_off - 1                                # row of the cls token; the patch rows start at self.row_off
@@ -162,7 +163,7 @@ class PeftPaths:
                 ops.add2d(ws["pg32"], C, dlocal, C, ws["pg32"], C, B * N, C)
         if "pos_embedding" in bb:
             pos = gv["pos_embedding"].view(N + 1, C)
-            if dlocal is None:
+            if dlocal is None or not dlocal_to_pos:
                 ops.rows_batch_sum(dG0, pos, None, B, T, r_cls, N + 1, C)
             else:
                 ops.rows_batch_sum(dG0, pos[:1], None, B, T, r_cls, 1, C)

@@ -100,8 +100,10 @@ class ExplicitVisualPrompting(HotPathModule):
             for module in self.children():
                 module.eval()
 
+    def _drop_config(self):
+        # freeze_vit=True keeps transformer / conv_proj / dropout in eval (train() above); otherwise every nn.Dropout follows .training
+        return {"dropout": self._cfg["dropout"] if self.transformer.layers[0][0].dropout.training else 0.0,
+                "emb_dropout": self._cfg["emb_dropout"] if self.dropout.training else 0.0}
+
     def forward(self, img):
-        if (self.dropout.training and self._cfg["emb_dropout"] > 0) or \
-                (self.transformer.layers[0][0].dropout.training and self._cfg["dropout"] > 0):
-            raise NotImplementedError("backbone dropout is live only with freeze_vit=False; that training mode is not built")
         return self._run(img)

@@ -42,13 +42,16 @@ def evp_forward(sd: SD, img: Tensor, cfg: dict, taps: Optional[dict] = None) -> 
     hc = hc.view(b, hc.shape[1], -1).permute(0, 2, 1)
     s = hc + emb
     x = torch.cat((sd["cls_token"].expand(b, -1, -1), tok), dim=1) + sd["pos_embedding"][:, : tok.shape[1] + 1]
+    masks = cfg.get("_masks")                       # explicit dropout masks (tests; live only with freeze_vit=False: evp.py:333-344)
+    if masks is not None and ("emb", 0) in masks:
+        x = x * masks[("emb", 0)]                   # self.dropout, evp.py:365
     for i in range(depth):
         u = F.gelu(F.linear(s, sd[pg + f"lightweight_mlp_{i}.0.weight"], sd[pg + f"lightweight_mlp_{i}.0.bias"]))
         prompt = F.linear(u, sd[pg + "shared_mlp.weight"], sd[pg + "shared_mlp.bias"])
         x = torch.cat((x[:, :1], prompt + x[:, 1:]), dim=1)
         p = f"transformer.layers.{i}"
-        x = attention(sd, p + ".0", x, heads) + x
-        f = feed_forward(sd, p + ".1", x)
+        x = attention(sd, p + ".0", x, heads, masks=masks, layer=i) + x
+        f = feed_forward(sd, p + ".1", x, masks=masks, layer=i)
         x = f + x
         if taps is not None:
             taps[f"layer{i}.ff_out"] = f

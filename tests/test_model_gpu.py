@@ -201,6 +201,7 @@ PEFT_CASES = [("deep_vpt_t16_b2", "deep_vpt", "vit-t16", 2, dict(num_prompts=8, 
               ("dvpt_t16_b2_unfrozen", "dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=False)),
               ("dvpt_b16_b4", "dvpt", "vit-b16", 4, dict(num_prompts=50, freeze_vit=True)),
               ("evp_t16_b2", "evp", "vit-t16", 2, dict(freeze_vit=True)),
+              ("evp_t16_b2_unfrozen", "evp", "vit-t16", 2, dict(freeze_vit=False)),
               ("evp_b16_b2", "evp", "vit-b16", 2, dict(freeze_vit=True)),
               ("bitfit_t16_b2", "bitfit", "vit-t16", 2, dict()),
               ("fft_t16_b2", "fft", "vit-t16", 2, dict()),
@@ -369,6 +370,7 @@ FP32_CASES = [("cfg1_linear_t16_b1", "linear", "vit-t16", 1, dict()),
               ("dvpt_t16_b2_unfrozen", "dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=False)),
               ("dvpt_b16_b4", "dvpt", "vit-b16", 4, dict(num_prompts=50, freeze_vit=True)),
               ("evp_t16_b2", "evp", "vit-t16", 2, dict(freeze_vit=True)),
+              ("evp_t16_b2_unfrozen", "evp", "vit-t16", 2, dict(freeze_vit=False)),
               ("evp_b16_b2", "evp", "vit-b16", 2, dict(freeze_vit=True)),
               ("bitfit_t16_b2", "bitfit", "vit-t16", 2, dict()),
               ("fft_t16_b2", "fft", "vit-t16", 2, dict()),

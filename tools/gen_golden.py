@@ -64,6 +64,7 @@ CASES = {
     "fft_t16_b2": ("fft", "vit-t16", 2, {}),
     "fft_b16_b2": ("fft", "vit-b16", 2, {}),
     "evp_t16_b2": ("evp", "vit-t16", 2, dict(freeze_vit=True)),
+    "evp_t16_b2_unfrozen": ("evp", "vit-t16", 2, dict(freeze_vit=False)),        # evp.py:322 skipped: the backbone trains too
     "evp_b16_b2": ("evp", "vit-b16", 2, dict(freeze_vit=True)),
 }
 
