@@ -37,8 +37,8 @@ from .engine_peft import PeftPaths
 GEMM_MARKS = None
 
 
-# classes whose backbone tensors can train (engine_peft.py `_bb_*`): the plain ViT (`fft` / `bitfit`); AdaptFormer, Gaviko, DVPT and EVP with freeze_vit=False
-_BB_KINDS = ("vit", "adaptformer", "gaviko", "dvpt", "evp")
+# classes whose backbone tensors can train (engine_peft.py `_bb_*`): the plain ViT (`fft` / `bitfit`); AdaptFormer, Gaviko, DVPT, EVP and VPT with freeze_vit=False
+_BB_KINDS = ("vit", "adaptformer", "gaviko", "dvpt", "evp", "vpt")
 
 
 class Engine(GavikoPaths, PeftPaths):
@@ -873,12 +873,12 @@ class Engine(GavikoPaths, PeftPaths):
                      dlogits=ws["dlogits"], dg=dG, dwh=gv[nm.head() + ".weight"], dbh=gv[nm.head() + ".bias"], B=B, T=self.Ts[-1], C=C,
                      K=self.K, r0=r0, R=R, accumulate=0)
         bb = sv.get("bb") or ()
-        if backbone_bwd and ("transformer.norm.weight" in bb or "transformer.norm.bias" in bb):
-            g, bw = self._final_stream(ws, True), ws["bbw"]
-            ops.layernorm_fwd(g, d("transformer.norm.weight"), d("transformer.norm.bias"), B * T, C, y16=ws["xn"], mean=bw["stat"][0], rstd=bw["stat"][1])
+        nw, nb = nm.root + "transformer.norm.weight", nm.root + "transformer.norm.bias"
+        if backbone_bwd and (nw in bb or nb in bb):
+            g, bw, Tl = self._final_stream(ws, True), ws["bbw"], self.Ts[-1]
+            ops.layernorm_fwd(g, d(nw), d(nb), B * Tl, C, y16=ws["xn"], mean=bw["stat"][0], rstd=bw["stat"][1])
             ops.ssf_head_grad(g, bw["stat"][0], bw["stat"][1], d(nm.head() + ".weight"), ws["dlogits"], bw["ones"][:C], bw["zeros"][:C],
-                              gv["transformer.norm.weight"] if "transformer.norm.weight" in bb else bw["junk"][:C],
-                              gv["transformer.norm.bias"] if "transformer.norm.bias" in bb else bw["junk"][C: 2 * C], B, T, C, self.K, r0, R)
+                              gv[nw] if nw in bb else bw["junk"][:C], gv[nb] if nb in bb else bw["junk"][C: 2 * C], B, Tl, C, self.K, r0, R)
         if self.kind == "ssf" and backbone_bwd:
             # final norm + ssf (ssf.py:138): statistics of the final stream, then the pooled rows' scale / shift gradients
             g = self._final_stream(ws, True)

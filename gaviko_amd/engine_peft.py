@@ -128,6 +128,11 @@ class PeftPaths:
         Mp = ops.pad_rows(M)
         Kx = K if ldx is None else ldx
         tA, tB = ws["tA"].view(-1)[: ops.pad_rows(N) * Mp].view(-1, Mp), ws["tB"].view(-1)[: ops.pad_rows(Kx) * Mp].view(-1, Mp)
+        if self.kind == "vpt" and self.deep and Mp > M:
+            # deep VPT's sequence shrinks layer by layer (vpt.py:147-153) while the operand buffers are shared: rows M.. of this layer's
+            # operands still hold a longer layer's values, and the contraction runs over the padded row count
+            ops.memset_zero(dy_op.view(-1)[M * N: Mp * N])
+            ops.memset_zero(x_op.view(-1)[M * Kx: Mp * Kx])
         ops.transpose_any(dy_op, tA, Mp, N)
         ops.transpose_any(x_op, tB, Mp, Kx)
         self._gemm(tA, tB[:K], N, out.view(N, K), epilogue=ops.EPI_STORE_F32)
@@ -154,22 +159,24 @@ class PeftPaths:
         the embedding_generator's share of the RAW conv output (evp.py:347-348): it reaches the conv tensors but not pos_embedding."""
         C, T, N, bw = self.C, self.T, self.N, ws["bbw"]
         nm = self.names
-        r_cls = self.row_off - 1                                # row of the cls token; the patch rows start at self.row_off
+        # row of the cls token (VPT: [cls | prompts | patches], vpt.py:127-131); the patch rows start at self.row_off
+        r_cls = 0 if self.kind == "vpt" else self.row_off - 1
+        pe, ct = nm.root + "pos_embedding", nm.root + "cls_token"
         cw, cb = nm.conv() + ".weight", nm.conv() + ".bias"
-        need_rows = dlocal is not None and ("pos_embedding" in bb or cb in bb or cw in bb)
+        need_rows = dlocal is not None and (pe in bb or cb in bb or cw in bb)
         if need_rows or cw in bb:
             ops.rows_gather(dG0, ws["pg32"], B, T, N, C, self.row_off)          # the patch rows of the input gradient, [B*N][C]
             if dlocal is not None:
                 ops.add2d(ws["pg32"], C, dlocal, C, ws["pg32"], C, B * N, C)
-        if "pos_embedding" in bb:
-            pos = gv["pos_embedding"].view(N + 1, C)
+        if pe in bb:
+            pos = gv[pe].view(N + 1, C)
+            ops.rows_batch_sum(dG0, pos[:1], None, B, T, r_cls, 1, C)
             if dlocal is None or not dlocal_to_pos:
-                ops.rows_batch_sum(dG0, pos, None, B, T, r_cls, N + 1, C)
+                ops.rows_batch_sum(dG0, pos[1:], None, B, T, self.row_off, N, C)
             else:
-                ops.rows_batch_sum(dG0, pos[:1], None, B, T, r_cls, 1, C)
                 ops.rows_batch_sum(ws["pg32"], pos[1:], None, B, N, 0, N, C)
-        if "cls_token" in bb:
-            ops.rows_batch_sum(dG0, gv["cls_token"].view(1, C), None, B, T, r_cls, 1, C)
+        if ct in bb:
+            ops.rows_batch_sum(dG0, gv[ct].view(1, C), None, B, T, r_cls, 1, C)
         if cb in bb:
             if dlocal is None:
                 ops.colsum_any(dG0, gv[cb], bw["ones"][:C], bw["zeros"][:C], bw["junk"][:C], bw["scratch"], B * N, C, rows_in=N, rows_out=T,

@@ -67,10 +67,11 @@ class PromptedVisionTransformer(HotPathModule):
 
     def _drop_config(self):
         # vpt.py:106-119 leaves prompt_dropout in training mode while the frozen backbone (and its dropouts) go to eval
-        return {"prompt_dropout": self._cfg["prompt_dropout"] if self.prompt_dropout.training else 0.0}
+        # ... and with freeze_vit=False the backbone's own dropouts follow .training as well
+        vt = self.vision_transformer
+        return {"prompt_dropout": self._cfg["prompt_dropout"] if self.prompt_dropout.training else 0.0,
+                "dropout": self._cfg["dropout"] if vt.transformer.layers[0][0].dropout.training else 0.0,
+                "emb_dropout": self._cfg["emb_dropout"] if vt.dropout.training else 0.0}
 
     def forward(self, x):
-        vt = self.vision_transformer
-        if (vt.dropout.training and self._cfg["emb_dropout"] > 0) or (vt.transformer.layers[0][0].dropout.training and self._cfg["dropout"] > 0):
-            raise NotImplementedError("backbone dropout is live only with freeze_vit=False; that VPT training mode is not built")
         return self._run(x)

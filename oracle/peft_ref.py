@@ -29,7 +29,9 @@ def vpt_forward(sd: SD, img: Tensor, cfg: dict, taps: Optional[dict] = None) -> 
     deep = cfg.get("deep_prompt", True)
     P = cfg.get("num_prompts", 8)
 
-    masks = cfg.get("_masks")                       # explicit prompt_dropout masks (tests): {('prompt', layer): [b, P, dim]}
+    masks = cfg.get("_masks")                       # explicit dropout masks (tests): {('prompt', layer): [b, P, dim]}; with freeze_vit=False
+    if masks is not None and ("emb", 0) in masks:   # also the backbone's own: ('emb', 0) over [cls | patches] (vpt.py:171, before the prompts
+        x = x * masks[("emb", 0)]                   # go in) and the per-layer attention / MLP sites of vit_ref
 
     def proj(e, i):
         y = F.linear(e, sd["prompt_proj.weight"], sd["prompt_proj.bias"]).expand(b, -1, -1)
@@ -44,8 +46,8 @@ def vpt_forward(sd: SD, img: Tensor, cfg: dict, taps: Optional[dict] = None) -> 
             keep = x[:, 1:] if i == 0 else x[:, 1 + sd["deep_prompt_embeddings"].shape[2]:]
             x = torch.cat((x[:, :1], proj(sd["deep_prompt_embeddings"][i], i), keep), dim=1)
         p = f"{pre}transformer.layers.{i}"
-        x = attention(sd, p + ".0", x, heads) + x
-        f = feed_forward(sd, p + ".1", x)
+        x = attention(sd, p + ".0", x, heads, masks=masks, layer=i) + x
+        f = feed_forward(sd, p + ".1", x, masks=masks, layer=i)
         x = f + x
         if taps is not None:
             taps[f"layer{i}.ff_out"] = f

@@ -33,6 +33,9 @@ def masks_for(eng, word, B, backbone_p, emb_p, prompt_p):
     C, H, mlp = eng.C, eng.heads, eng.mlp
     if emb_p > 0:
         masks[("emb", 0)] = t(dropmask.rows_mask(E.SEED_EMB + word, B * eng.T, C, emb_p)).view(B, eng.T, C)
+        if eng.kind == "vpt":                       # drawn over the [cls | prompt slots | patches] rows of the buffer; the reference drops
+            m_ = masks[("emb", 0)]                  # [cls | patches] before the prompts go in (vpt.py:171): the slots' draws are unused
+            masks[("emb", 0)] = torch.cat((m_[:, :1], m_[:, 1 + eng.P:]), dim=1)
         if eng.kind == "gaviko":                    # self.dropout is applied a second time, to the local tokens (gaviko.py:548)
             masks[("emb_local", 0)] = t(dropmask.rows_mask(E.SEED_EMB + 1 + word, B * eng.N, C, emb_p)).view(B, eng.N, C)
     for i in range(eng.depth):
@@ -53,6 +56,8 @@ CASES = [("fft", dict(dropout=P, emb_dropout=P), (P, P, 0.0)),
          ("linear", dict(dropout=P, emb_dropout=P), (P, P, 0.0)),
          ("melo", dict(dropout=P, emb_dropout=P, r=4, alpha=4), (P, P, 0.0)),
          ("adaptformer", dict(dropout=P, emb_dropout=P, freeze_vit=False), (P, P, 0.0)),     # unfrozen: the backbone's dropouts follow .training (adaptformer.py:175-191)
+         ("deep_vpt", dict(dropout=P, emb_dropout=P, num_prompts=8, prompt_dim=64, prompt_dropout=P, freeze_vit=False, deep_prompt=True), (P, P, P)),
+         ("shallow_vpt", dict(dropout=P, emb_dropout=P, num_prompts=8, prompt_dim=64, prompt_dropout=P, freeze_vit=False, deep_prompt=False), (P, P, P)),
          ("dvpt", dict(dropout=P, emb_dropout=P, freeze_vit=False, num_prompts=8), (P, P, 0.0)),
          ("evp", dict(dropout=P, emb_dropout=P, freeze_vit=False), (P, P, 0.0)),
          # Gaviko(freeze_vit=False) with the shipped dropout = emb_dropout = 0.1 (gaviko.py:513-528); the MWSA dropouts have their own test below

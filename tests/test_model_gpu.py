@@ -188,6 +188,8 @@ def test_product_path_fails_loudly_on_cpu():
 
 PEFT_CASES = [("deep_vpt_t16_b2", "deep_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True)),
               ("shallow_vpt_t16_b2", "shallow_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True)),
+              ("deep_vpt_t16_b2_unfrozen", "deep_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=False)),
+              ("shallow_vpt_t16_b2_unfrozen", "shallow_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=False)),
               ("adaptformer_t16_b2", "adaptformer", "vit-t16", 2, dict(freeze_vit=True)),
               ("adaptformer_t16_b2_unfrozen", "adaptformer", "vit-t16", 2, dict(freeze_vit=False)),   # adaptformer.py:163: no freeze loop, all 212 tensors train
               ("melo_t16_b2", "melo", "vit-t16", 2, dict(r=4, alpha=4)),
@@ -359,6 +361,8 @@ FP32_CASES = [("cfg1_linear_t16_b1", "linear", "vit-t16", 1, dict()),
               ("melo_t16_b2", "melo", "vit-t16", 2, dict(r=4, alpha=4)),
               ("melo_t16_b2_layers", "melo", "vit-t16", 2, dict(r=4, alpha=8, lora_layer=[0, 5, 11])),   # melo.py:53-68: only these layers are wrapped
               ("deep_vpt_t16_b2", "deep_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True)),
+              ("deep_vpt_t16_b2_unfrozen", "deep_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=False)),
+              ("shallow_vpt_t16_b2_unfrozen", "shallow_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=False)),
               ("gaviko_t16_b2", "gaviko", "vit-t16", 2, dict(GAVIKO)),
               ("gaviko_t16_b2_unfrozen", "gaviko", "vit-t16", 2, dict(GAVIKO, freeze_vit=False)),
               ("cfg4_adaptformer_b16_b8", "adaptformer", "vit-b16", 8, dict(freeze_vit=True)),

@@ -45,6 +45,8 @@ CASES = {
     "gaviko_t16_b2_lat16": ("gaviko", "vit-t16", 2, dict(GAVIKO, prompt_latent_dim=16, local_dim=16)),   # a latent width the L = 20 tile kernels do not cover
     "cfg2_gaviko_b16_b4": ("gaviko", "vit-b16", 4, dict(GAVIKO)),
     "deep_vpt_t16_b2": ("deep_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True, deep_prompt=True)),
+    "deep_vpt_t16_b2_unfrozen": ("deep_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=False, deep_prompt=True)),
+    "shallow_vpt_t16_b2_unfrozen": ("shallow_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=False, deep_prompt=False)),
     "shallow_vpt_t16_b2": ("shallow_vpt", "vit-t16", 2, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True, deep_prompt=False)),
     "cfg3_deep_vpt_b16_8x4": ("deep_vpt", "vit-b16", 4, dict(num_prompts=8, prompt_dim=64, prompt_dropout=0.0, freeze_vit=True, deep_prompt=True, shards=8)),
     "adaptformer_t16_b2": ("adaptformer", "vit-t16", 2, dict(freeze_vit=True)),
