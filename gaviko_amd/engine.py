@@ -37,8 +37,8 @@ from .engine_peft import PeftPaths
 GEMM_MARKS = None
 
 
-# classes whose backbone tensors can train (engine_peft.py `_bb_*`): the plain ViT (`fft` / `bitfit`); AdaptFormer, Gaviko, DVPT, EVP and VPT with freeze_vit=False
-_BB_KINDS = ("vit", "adaptformer", "gaviko", "dvpt", "evp", "vpt")
+# classes whose backbone tensors can train (engine_peft.py `_bb_*`): the plain ViT (`fft` / `bitfit`); every class that freezes by default, with freeze_vit=False
+_BB_KINDS = ("vit", "adaptformer", "gaviko", "dvpt", "evp", "vpt", "ssf")
 
 
 class Engine(GavikoPaths, PeftPaths):
@@ -888,6 +888,7 @@ class Engine(GavikoPaths, PeftPaths):
             ops.ssf_head_grad(g, st[0], st[1], d(nm.head() + ".weight"), ws["dlogits"], self.p["transformer.norm.weight"].detach(),
                               self.p["transformer.norm.bias"].detach(), gv["transformer.ssf_scale_1"], gv["transformer.ssf_shift_1"],
                               B, T, C, self.K, r0, R)
+            self._ssf_unfold(gv, bb, self._ssf_sites()[-1:])                           # the final norm's affine
         if backbone_bwd:
             ops.to_operand(dG, ws["dG16"], self.adt)
             if self.kind == "gaviko":
@@ -1042,6 +1043,8 @@ class Engine(GavikoPaths, PeftPaths):
                 self._wait("gpa", None)                                      # the next layer's GPA backward needs this dG[i]
             if self.kind == "evp":
                 self._evp_bwd_layer(ws, gv, i, dGout, B)
+            if ssf and bb:
+                self._ssf_unfold(gv, bb, self._ssf_sites()[1 + 6 * i: 7 + 6 * i])     # this layer's six sites, before its bucket is final
             self._mark(f"b{i}:end")
             if not gaviko:
                 self._bucket_mark("main", i)                                 # transformer.layers.{i}.* gradients (adapters, LoRA, ...) are final
@@ -1079,6 +1082,7 @@ class Engine(GavikoPaths, PeftPaths):
             pos = self.p["pos_embedding"].detach()[0]
             ops.ssf_colgrad(dGout, ws["G"][0], self.p["ssf_scale_1"].detach(), self.p["ssf_shift_1"].detach(), gv["ssf_scale_1"], gv["ssf_shift_1"],
                             ws["ssf_scratch"], B * self.N, C, pos=pos[1:], rows_in=self.N, rows_out=T, row_off=1)
+            self._ssf_unfold(gv, sv.get("bb") or (), self._ssf_sites()[:1])            # the patch embedding's conv tensors
         if last and self.kind == "vpt":
             emb_name = "deep_prompt_embeddings" if self.deep else "prompt_embeddings"
             emb = d(emb_name).reshape(-1, self.pd)

@@ -346,6 +346,25 @@ class PeftPaths:
                 ops.ssf_fold_weight(W2, s_, w[key], w[key + "_t"] if need_t else None)
                 ops.ssf_fold_vec(self.p[bname].detach() if bname in self.p else None, s_, t_, eff[bname])
 
+    def _ssf_unfold(self, gv, bb, sites):
+        """ScalingShiftingFeatures(freeze_vit=False): the backbone-gradient hooks see the EFFECTIVE tensors (W' = s o W, b' = b o s + t,
+        gamma' = gamma o s, beta' = beta o s + t), so what they left in gv is dW', db', dgamma', dbeta'; the chain rule to the raw
+        tensors is one multiplication by the site's scale (in place)."""
+        if not bb:
+            return
+        for sn, tn, kind, tgt in sites:
+            s_ = self.p[sn].detach()
+            if kind == "ln":
+                for n in tgt:
+                    if n in bb:
+                        ops.ssf_fold_vec(gv[n], s_, None, gv[n])
+            else:
+                _, wname, bname = tgt
+                if wname in bb:
+                    ops.ssf_fold_weight(gv[wname], s_, gv[wname], None)
+                if bname in bb:
+                    ops.ssf_fold_vec(gv[bname], s_, None, gv[bname])
+
     def _ssf_linear_grad(self, ws, gv, prefix, idx, dy, y0, M, N, y1=None, **kw):
         sn, tn = f"{prefix}.ssf_scale_{idx}", f"{prefix}.ssf_shift_{idx}"
         ops.ssf_colgrad(dy, y0, self.p[sn].detach(), self.p[tn].detach(), gv[sn], gv[tn], ws["ssf_scratch"], M, N, y1=y1, **kw)

@@ -115,5 +115,6 @@ class ScalingShiftingFeatures(HotPathModule):
     def forward(self, img):
         if (self.dropout.training and self._cfg["emb_dropout"] > 0) or \
                 (self.transformer.layers[0][0].dropout.training and self._cfg["dropout"] > 0):
-            raise NotImplementedError("backbone dropout is live only with freeze_vit=False; that training mode is not built")
+            raise NotImplementedError("ScalingShiftingFeatures(freeze_vit=False) trains on this path with dropout = emb_dropout = 0 only: the "
+                                      "scale gradients are taken from saved outputs, which a dropout behind the site would have masked")
         return self._run(img)

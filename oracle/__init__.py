@@ -29,7 +29,7 @@ def trainable(method: str, name: str, cfg: dict = None) -> bool:
     """requires_grad of parameter `name` as the reference's constructors leave it.  `cfg` matters only for freeze_vit=False on the classes
     that freeze by default: the freeze loops (adaptformer.py:163-168 and its copies) are skipped and every parameter keeps nn.Parameter's
     default requires_grad=True."""
-    if cfg is not None and cfg.get("freeze_vit") is False and method in ("adaptformer", "gaviko", "dvpt", "evp", "deep_vpt", "shallow_vpt"):
+    if cfg is not None and cfg.get("freeze_vit") is False and method in ("adaptformer", "gaviko", "dvpt", "evp", "deep_vpt", "shallow_vpt", "ssf"):
         return True
     if method == "gaviko":
         return gaviko_trainable(name)

@@ -197,6 +197,7 @@ PEFT_CASES = [("deep_vpt_t16_b2", "deep_vpt", "vit-t16", 2, dict(num_prompts=8, 
               ("cfg4_adaptformer_b16_b8", "adaptformer", "vit-b16", 8, dict(freeze_vit=True)),
               ("cfg4_melo_b16_b8", "melo", "vit-b16", 8, dict(r=4, alpha=4)),
               ("ssf_t16_b2", "ssf", "vit-t16", 2, dict(freeze_vit=True)),
+              ("ssf_t16_b2_unfrozen", "ssf", "vit-t16", 2, dict(freeze_vit=False)),
               ("ssf_b16_b4", "ssf", "vit-b16", 4, dict(freeze_vit=True)),
               ("dvpt_t16_b2", "dvpt", "vit-t16", 2, dict(num_prompts=50, freeze_vit=True)),
               ("dvpt_t16_b2_mean_p8", "dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=True, pool="mean")),
@@ -368,6 +369,7 @@ FP32_CASES = [("cfg1_linear_t16_b1", "linear", "vit-t16", 1, dict()),
               ("cfg4_adaptformer_b16_b8", "adaptformer", "vit-b16", 8, dict(freeze_vit=True)),
               ("cfg4_melo_b16_b8", "melo", "vit-b16", 8, dict(r=4, alpha=4)),
               ("ssf_t16_b2", "ssf", "vit-t16", 2, dict(freeze_vit=True)),
+              ("ssf_t16_b2_unfrozen", "ssf", "vit-t16", 2, dict(freeze_vit=False)),
               ("ssf_b16_b4", "ssf", "vit-b16", 4, dict(freeze_vit=True)),
               ("dvpt_t16_b2", "dvpt", "vit-t16", 2, dict(num_prompts=50, freeze_vit=True)),
               ("dvpt_t16_b2_mean_p8", "dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=True, pool="mean")),

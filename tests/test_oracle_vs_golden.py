@@ -11,7 +11,7 @@ from conftest import golden
 from gaviko_amd.utils import synth
 
 FAST = ["cfg1_linear_t16_b1", "gaviko_t16_b2", "gaviko_t16_b2_unfrozen", "gaviko_t16_b2_k366_p8", "gaviko_t16_b1_share2", "gaviko_t16_b2_lat16", "deep_vpt_t16_b2", "shallow_vpt_t16_b2", "deep_vpt_t16_b2_unfrozen", "shallow_vpt_t16_b2_unfrozen",
-        "adaptformer_t16_b2", "adaptformer_t16_b2_unfrozen", "melo_t16_b2", "melo_t16_b2_layers", "ssf_t16_b2", "dvpt_t16_b2", "dvpt_t16_b2_unfrozen", "dvpt_t16_b2_mean_p8", "evp_t16_b2", "evp_t16_b2_unfrozen", "bitfit_t16_b2", "fft_t16_b2"]
+        "adaptformer_t16_b2", "adaptformer_t16_b2_unfrozen", "melo_t16_b2", "melo_t16_b2_layers", "ssf_t16_b2", "ssf_t16_b2_unfrozen", "dvpt_t16_b2", "dvpt_t16_b2_unfrozen", "dvpt_t16_b2_mean_p8", "evp_t16_b2", "evp_t16_b2_unfrozen", "bitfit_t16_b2", "fft_t16_b2"]
 
 
 def _cfg(g):

@@ -57,6 +57,7 @@ CASES = {
     "cfg4_melo_b16_b8": ("melo", "vit-b16", 8, dict(r=4, alpha=4)),
     "cfg5_gaviko_l16_b2": ("gaviko", "vit-l16", 2, dict(GAVIKO)),
     "ssf_t16_b2": ("ssf", "vit-t16", 2, dict(freeze_vit=True)),
+    "ssf_t16_b2_unfrozen": ("ssf", "vit-t16", 2, dict(freeze_vit=False)),        # ssf.py:192 skipped: the backbone trains beside the scales / shifts
     "ssf_b16_b4": ("ssf", "vit-b16", 4, dict(freeze_vit=True)),
     "dvpt_t16_b2": ("dvpt", "vit-t16", 2, dict(num_prompts=50, freeze_vit=True)),
     "dvpt_t16_b2_unfrozen": ("dvpt", "vit-t16", 2, dict(num_prompts=8, freeze_vit=False)),      # dvpt.py:156 skipped: the backbone trains too
