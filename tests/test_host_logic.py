@@ -55,10 +55,19 @@ def test_gaviko_train_override_semantics():
     assert m.train() is None                                   # gaviko.py:513-528 returns None
     assert not m.transformer.training and not m.conv_proj.training and not m.dropout.training
     assert m.transformer.local_attns.training and m.transformer.prompt_projs.training and m.mlp_head.training
-    assert m._drop_config() == {"attn_drop": 0.2, "proj_drop": 0.2}
+    # frozen: the MWSA dropouts are live, the backbone's own nn.Dropout modules sit in eval whatever the config says
+    assert m._drop_config() == {"attn_drop": 0.2, "proj_drop": 0.2, "dropout": 0.0, "emb_dropout": 0.0}
     assert m.eval() is None
     assert not m.transformer.local_attns.training
-    assert m._drop_config() == {"attn_drop": 0.0, "proj_drop": 0.0}
+    assert m._drop_config() == {"attn_drop": 0.0, "proj_drop": 0.0, "dropout": 0.0, "emb_dropout": 0.0}
+    # freeze_vit=False (gaviko.py:428-434 skipped, 513-528: plain nn.Module.train): everything trains, every dropout follows .training
+    u = build_model(dict(BASE, method="gaviko", **dict(GAVIKO, freeze_vit=False, dropout=0.1, emb_dropout=0.1)))
+    assert all(p.requires_grad for p in u.parameters())
+    u.train()
+    assert u.transformer.training and u.conv_proj.training and u.dropout.training
+    assert u._drop_config() == {"attn_drop": 0.2, "proj_drop": 0.2, "dropout": 0.1, "emb_dropout": 0.1}
+    u.eval()
+    assert u._drop_config() == {"attn_drop": 0.0, "proj_drop": 0.0, "dropout": 0.0, "emb_dropout": 0.0}
 
 
 def test_linear_and_bitfit_freeze_rules():
