@@ -50,6 +50,7 @@ struct ColGradArgs {
   int M, N, ld_dy, ld_y, dy_f32, y0_f32;
   int rows_in, rows_out, row_off;          // rows_in > 0: logical row m -> buffer row (m / rows_in) * rows_out + row_off + m % rows_in
   int y0_cols; float y0_mul;               // y0 columns n < y0_cols are stored multiplied by 1 / y0_mul (the pre-scaled q block of a saved qkv)
+  float y_mul;                             // y = y_mul * (y0 - y1) - pos (a site stored behind nn.Dropout: kept / (1 - p) -> kept)
 };
 constexpr int kCgSlabs = 64;
 
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(256) void ssf_colgrad_partial_kernel(ColGradArgs p)
     float y = ld_mixed(p.y0, row * p.ld_y + n, p.y0_f32);
     if (n < p.y0_cols) y *= p.y0_mul;
     if (p.y1 != nullptr) y -= p.y1[row * p.ld_y + n];
+    y *= p.y_mul;
     if (p.pos != nullptr) y -= p.pos[(size_t)prow * p.N + n];
     a = __builtin_fmaf(dy, y, a);
     d += dy;
@@ -156,7 +158,7 @@ extern "C" int gvk_ssf_colgrad(const gvk_ssf_colgrad_desc* d, void* stream) {
   GVK_REQUIRE(d->rows_in == 0 || (d->rows_in > 0 && d->rows_out >= d->rows_in + d->row_off), "gvk_ssf_colgrad: bad row mapping");
   GVK_REQUIRE(d->pos == nullptr || d->rows_in > 0, "gvk_ssf_colgrad: pos needs the row mapping");
   ColGradArgs a{d->dy, d->y0, d->y1, d->pos, d->s, d->t, d->ds, d->dt, d->scratch, d->M, d->N, d->ld_dy, d->ld_y, d->dy_f32, d->y0_f32,
-                d->rows_in, d->rows_out, d->row_off, d->y0_cols, d->y0_mul};
+                d->rows_in, d->rows_out, d->row_off, d->y0_cols, d->y0_mul, d->y_mul == 0.f ? 1.f : d->y_mul};
   GVK_LAUNCH(ssf_colgrad_partial_kernel, dim3((d->N + 255) / 256, kCgSlabs), dim3(256), 0, (hipStream_t)stream, a);
   int rc = check_launch("ssf_colgrad/partial");
   if (rc) return rc;

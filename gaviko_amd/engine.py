@@ -509,8 +509,8 @@ class Engine(GavikoPaths, PeftPaths):
         # nn.Dropout of the backbone itself (vision_transformer.py:33-34,52-54,157; vpt.py:129,148): live for the classes without a
         # train() override (linear / bitfit / fft, melo) and for VPT's prompt_dropout.  bf16 path only.
         sv["bdrop"], sv["edrop"], sv["pdrop"] = (float(drop.get(k, 0.0)) for k in ("dropout", "emb_dropout", "prompt_dropout"))
-        if (sv["bdrop"] > 0 or sv["edrop"] > 0 or sv["pdrop"] > 0) and self.kind not in ("vit", "melo", "vpt", "adaptformer", "gaviko", "dvpt", "evp"):
-            raise L.GavikoHipError(f"backbone dropout > 0 in training mode is built for every class but ssf (kind={self.kind!r})")
+        if (sv["bdrop"] > 0 or sv["edrop"] > 0 or sv["pdrop"] > 0) and self.kind not in ("vit", "melo", "vpt", "adaptformer", "gaviko", "dvpt", "evp", "ssf"):
+            raise L.GavikoHipError(f"backbone dropout > 0 in training mode: unknown kind {self.kind!r}")
         self.refresh_weights(need_dgrad=train)
         ws = self.workspace(B, img.device, train)
         if img.data_ptr() != ws["img"].data_ptr():           # a caller that fills input_buffer() itself skips the copy-in launch
@@ -938,7 +938,7 @@ class Engine(GavikoPaths, PeftPaths):
             pd_ = sv.get("bdrop", 0.0)
             dy_ff = dGout
             if pd_ > 0:                                                      # gradient of dropout(fc2(.)): the forward's mask on dGout
-                dy_ff = self._masked_grad(ws, dGout, pd_, SEED_LAYER + 8 * i + 3, bool(bb), M)
+                dy_ff = self._masked_grad(ws, dGout, pd_, SEED_LAYER + 8 * i + 3, bool(bb) or self.kind == "ssf", M)
             if bb:                                                           # fc2: db = colsum(dGout), dW = dGout^T . act
                 self._bb_linear_grads(ws, gv, bb, m + ".net.4", dy_ff, ws["dG16"], ws["sav"]["act"][i] if sv["wgrad"] else None, M, C, self.mlp,
                                       ldx=self.ldx if self.ldx != self.mlp else None)
@@ -947,7 +947,8 @@ class Engine(GavikoPaths, PeftPaths):
                 self._dvpt_bwd_latents(ws, gv, i, dGout, M, B)
             ssf = self.kind == "ssf"
             if ssf:                                                          # fc2 + ssf_2: dy = dGout, y = G[i+1] - G1[i]
-                self._ssf_linear_grad(ws, gv, m, 2, dGout, ws["G"][i + 1], M, C, y1=ws["G1"][i])
+                # (behind a live dropout the stored difference is kept / (1 - p): masked gradient, y_mul = 1 - p)
+                self._ssf_linear_grad(ws, gv, m, 2, dy_ff, ws["G"][i + 1], M, C, y1=ws["G1"][i], y_mul=1.0 - pd_)
             self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i], ldaux=self.ldx,
                        drop_p=pd_, seed=SEED_LAYER + 8 * i + 2, seed_ptr=ws["seed"])
             if ssf:                                                          # fc1 + ssf_1: dy = d(pre-activation), y = saved pre-activation
@@ -991,11 +992,11 @@ class Engine(GavikoPaths, PeftPaths):
                 if not shift:
                     self._mwsa_chain_bwd(ws, sv, gv, i, par, B, loc, dz_ready)
             # main stream, attention block: dG0 = dG1 + LN'(qkv^T(attn'(out^T(dG1))))
-            if ssf:                                                          # to_out + ssf_2: dy = dG1, y = G1[i] - G[i]
-                self._ssf_linear_grad(ws, gv, a, 2, dGin, ws["G1"][i], M, C, y1=ws["G"][i])
             dy_at = dGin
             if pd_ > 0:                                                      # gradient of dropout(to_out(.))
-                dy_at = self._masked_grad(ws, dGin, pd_, SEED_LAYER + 8 * i + 1, bool(bb), M)
+                dy_at = self._masked_grad(ws, dGin, pd_, SEED_LAYER + 8 * i + 1, bool(bb) or ssf, M)
+            if ssf:                                                          # to_out + ssf_2: dy = dG1, y = G1[i] - G[i]
+                self._ssf_linear_grad(ws, gv, a, 2, dy_at, ws["G1"][i], M, C, y1=ws["G"][i], y_mul=1.0 - pd_)
             if bb:                                                           # to_out: db = colsum(dG1), dW = dG1^T . ctx
                 self._bb_linear_grads(ws, gv, bb, a + ".to_out.0", dy_at, ws["dG16"], ws["ctx"][i], M, C, C)
             self._gemm(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
@@ -1081,7 +1082,8 @@ class Engine(GavikoPaths, PeftPaths):
             # patch embedding + ssf (ssf.py:229-232): dy = the patch rows of the input gradient, y = G[0] patch rows - pos[1:]
             pos = self.p["pos_embedding"].detach()[0]
             ops.ssf_colgrad(dGout, ws["G"][0], self.p["ssf_scale_1"].detach(), self.p["ssf_shift_1"].detach(), gv["ssf_scale_1"], gv["ssf_shift_1"],
-                            ws["ssf_scratch"], B * self.N, C, pos=pos[1:], rows_in=self.N, rows_out=T, row_off=1)
+                            ws["ssf_scratch"], B * self.N, C, pos=pos[1:], rows_in=self.N, rows_out=T, row_off=1,
+                            y_mul=1.0 - sv.get("edrop", 0.0))              # (dGout is already masked by emb_dropout when that is live)
             self._ssf_unfold(gv, sv.get("bb") or (), self._ssf_sites()[:1])            # the patch embedding's conv tensors
         if last and self.kind == "vpt":
             emb_name = "deep_prompt_embeddings" if self.deep else "prompt_embeddings"

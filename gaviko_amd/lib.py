@@ -26,7 +26,7 @@ if os.environ.get("GPU_MAX_HW_QUEUES") is None:
     except Exception:
         pass
 
-ABI_VERSION = 7                                   # gvk_abi_version() of the library these declarations describe
+ABI_VERSION = 8                                   # gvk_abi_version() of the library these declarations describe
 # GAVIKO_HIP_DIAG=1 (tools/ only): load the measurement build libgaviko_hip_diag.so (`python -m gaviko_amd.build --diag`) -- the product
 # library ignores every A/B switch of the kernel sources and exports no diagnostics (include/gaviko_hip_diag.h)
 DIAG = os.environ.get("GAVIKO_HIP_DIAG", "0") == "1"
@@ -78,7 +78,7 @@ GpaDesc = _struct("GpaDesc",
                    "dcls", "gate_partials", "dzx", "dzl", "enh16"],
                   ["B", "T", "N", "P", "L", "ld16", "col16"], ["scale"])
 SsfColgradDesc = _struct("SsfColgradDesc", ["dy", "y0", "y1", "pos", "s", "t", "ds", "dt", "scratch"],
-                         ["M", "N", "ld_dy", "ld_y", "dy_f32", "y0_f32", "rows_in", "rows_out", "row_off", "y0_cols"], ["y0_mul"])
+                         ["M", "N", "ld_dy", "ld_y", "dy_f32", "y0_f32", "rows_in", "rows_out", "row_off", "y0_cols"], ["y0_mul", "y_mul"])
 DvptDesc = _struct("DvptDesc", ["z", "enh", "lse", "dcomb", "gate", "bu", "colsum_dy", "delta", "dz", "dgate"], ["B", "T", "P", "L", "C"], ["scale"])
 AdamDesc = _struct("AdamDesc", ["ptr_tab", "blk_tab", "grad", "m", "v", "norm_sq"], ["nblocks"],
                    ["lr", "beta1", "beta2", "eps", "bias_c1", "bias_c2", "max_norm"])

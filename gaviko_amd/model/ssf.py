@@ -112,9 +112,10 @@ class ScalingShiftingFeatures(HotPathModule):
             for module in self.children():
                 module.eval()
 
+    def _drop_config(self):
+        # freeze_vit=True keeps transformer / conv_proj / dropout in eval (train() above); otherwise every nn.Dropout follows .training
+        return {"dropout": self._cfg["dropout"] if self.transformer.layers[0][0].dropout.training else 0.0,
+                "emb_dropout": self._cfg["emb_dropout"] if self.dropout.training else 0.0}
+
     def forward(self, img):
-        if (self.dropout.training and self._cfg["emb_dropout"] > 0) or \
-                (self.transformer.layers[0][0].dropout.training and self._cfg["dropout"] > 0):
-            raise NotImplementedError("ScalingShiftingFeatures(freeze_vit=False) trains on this path with dropout = emb_dropout = 0 only: the "
-                                      "scale gradients are taken from saved outputs, which a dropout behind the site would have masked")
         return self._run(img)

@@ -629,7 +629,7 @@ def ssf_fold_vec(a, s, t, out):
 
 
 def ssf_colgrad(dy, y0, s, t, ds, dt, scratch, M, N, *, y1=None, pos=None, ld_dy=None, ld_y=None, rows_in=0, rows_out=0, row_off=0,
-                y0_cols=0, y0_mul=1.0):
+                y0_cols=0, y0_mul=1.0, y_mul=1.0):
     for x, nm in ((s, "s"), (t, "t"), (ds, "ds"), (dt, "dt")):
         _chk(x, torch.float32, "ssf_colgrad " + nm, N)
     _chk(scratch, torch.float32, "ssf_colgrad scratch", 64 * 2 * N)
@@ -641,7 +641,7 @@ def ssf_colgrad(dy, y0, s, t, ds, dt, scratch, M, N, *, y1=None, pos=None, ld_dy
     d = L.SsfColgradDesc(dy=L.ptr(dy), y0=L.ptr(y0), y1=L.ptr(y1), pos=L.ptr(pos), s=L.ptr(s), t=L.ptr(t), ds=L.ptr(ds), dt=L.ptr(dt),
                          scratch=L.ptr(scratch), M=M, N=N, ld_dy=N if ld_dy is None else ld_dy, ld_y=N if ld_y is None else ld_y,
                          dy_f32=int(dy.dtype == torch.float32), y0_f32=int(y0.dtype == torch.float32), rows_in=rows_in, rows_out=rows_out,
-                         row_off=row_off, y0_cols=int(y0_cols), y0_mul=float(y0_mul))
+                         row_off=row_off, y0_cols=int(y0_cols), y0_mul=float(y0_mul), y_mul=float(y_mul))
     L.check(L.load().gvk_ssf_colgrad(C.byref(d), L.stream_ptr()), "gvk_ssf_colgrad")
 
 

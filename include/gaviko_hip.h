@@ -22,7 +22,7 @@ extern "C" {
 const char* gvk_last_error(void);
 /* returns 950 when the code object loaded on the current device is gfx950, else <0 */
 int gvk_device_check(void);
-int gvk_abi_version(void);   /* 7 */
+int gvk_abi_version(void);   /* 8 */
 
 /* ------------------------------------------------------------------ launch plans
  * The reference drives its step from the Python interpreter (train.py:296-319: one autograd node per op).  Here one
@@ -411,6 +411,9 @@ typedef struct gvk_ssf_colgrad_desc {
   int32_t M, N, ld_dy, ld_y, dy_f32, y0_f32, rows_in, rows_out, row_off;
   int32_t y0_cols;   /* columns n < y0_cols of y0 are multiplied by y0_mul when read: undoes the attention pre-scale of the q block of a saved */
   float y0_mul;      /* qkv (gvk_gemm_desc.scale_cols), y0_mul = 1 / col_scale; 0 columns = off */
+  float y_mul;       /* y = y_mul * (y0 - y1) - pos: a site whose output went through nn.Dropout before it was stored (to_out / fc2 + ssf_2 of an
+                        unfrozen backbone, the patch embedding under emb_dropout) is read back as kept / (1 - p), so y_mul = 1 - p with dy = the
+                        MASKED gradient (dropped elements then contribute nothing); 0 is taken as 1 */
 } gvk_ssf_colgrad_desc;
 int gvk_ssf_fold_weight(const float* w, const float* s, void* out, void* out_t, int N, int K, int out_f32, void* stream);
 int gvk_ssf_fold_vec(const float* a, const float* s, const float* t, float* out, int n, void* stream);

@@ -19,22 +19,33 @@ def ssf_ada(sd: SD, prefix: str, idx: int, x: Tensor) -> Tensor:
     return x * sd[f"{prefix}ssf_scale_{idx}"] + sd[f"{prefix}ssf_shift_{idx}"]
 
 
-def ssf_attention(sd: SD, p: str, x: Tensor, heads: int) -> Tensor:
+def ssf_attention(sd: SD, p: str, x: Tensor, heads: int, masks=None, layer: int = 0) -> Tensor:
     """ssf.py:104-122: LN -> ssf_0 -> bias-free qkv -> ssf_1 (over 3*inner) -> MHSA (scale after q.k^T) -> to_out -> ssf_2."""
     xn = ssf_ada(sd, p + ".", 0, layer_norm(sd, p + ".norm", x))
     qkv = ssf_ada(sd, p + ".", 1, F.linear(xn, sd[p + ".to_qkv.weight"]))
     q, k, v = (rearrange(t, "b n (h d) -> b h n d", h=heads) for t in qkv.chunk(3, dim=-1))
     dots = torch.matmul(q, k.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
-    out = rearrange(torch.matmul(dots.softmax(dim=-1), v), "b h n d -> b n (h d)")
-    return ssf_ada(sd, p + ".", 2, F.linear(out, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"]))
+    attn = dots.softmax(dim=-1)
+    if masks is not None and ("attn", layer) in masks:       # explicit dropout masks (tests; live only with freeze_vit=False: ssf.py:205-217)
+        attn = attn * masks[("attn", layer)]                  # ssf.py:115
+    out = rearrange(torch.matmul(attn, v), "b h n d -> b n (h d)")
+    y = ssf_ada(sd, p + ".", 2, F.linear(out, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"]))
+    if masks is not None and ("proj", layer) in masks:
+        y = y * masks[("proj", layer)]                        # ssf.py:121: the Dropout of to_out runs AFTER ssf_2
+    return y
 
 
-def ssf_feed_forward(sd: SD, p: str, x: Tensor) -> Tensor:
+def ssf_feed_forward(sd: SD, p: str, x: Tensor, masks=None, layer: int = 0) -> Tensor:
     """ssf.py:64-74: LN -> ssf_0 -> fc1 -> ssf_1 -> erf-GELU -> fc2 -> ssf_2."""
     h = ssf_ada(sd, p + ".", 0, layer_norm(sd, p + ".net.0", x))
     h = ssf_ada(sd, p + ".", 1, F.linear(h, sd[p + ".net.1.weight"], sd[p + ".net.1.bias"]))
     h = F.gelu(h)
-    return ssf_ada(sd, p + ".", 2, F.linear(h, sd[p + ".net.4.weight"], sd[p + ".net.4.bias"]))
+    if masks is not None and ("act", layer) in masks:
+        h = h * masks[("act", layer)]                         # ssf.py:70
+    y = ssf_ada(sd, p + ".", 2, F.linear(h, sd[p + ".net.4.weight"], sd[p + ".net.4.bias"]))
+    if masks is not None and ("ff", layer) in masks:
+        y = y * masks[("ff", layer)]                          # ssf.py:73: after ssf_2
+    return y
 
 
 def ssf_forward(sd: SD, img: Tensor, cfg: dict, taps: Optional[dict] = None) -> Tensor:
@@ -45,12 +56,15 @@ def ssf_forward(sd: SD, img: Tensor, cfg: dict, taps: Optional[dict] = None) -> 
     x = ssf_ada(sd, "", 1, patch_embed(sd, "conv_proj.0", img, patch))
     b, n, _ = x.shape
     x = torch.cat((sd["cls_token"].expand(b, -1, -1), x), dim=1) + sd["pos_embedding"][:, : n + 1]
+    masks = cfg.get("_masks")
+    if masks is not None and ("emb", 0) in masks:
+        x = x * masks[("emb", 0)]                             # self.dropout behind the position embedding
     for i in range(depth):
         p = f"transformer.layers.{i}"
-        x = ssf_attention(sd, p + ".0", x, heads) + x
+        x = ssf_attention(sd, p + ".0", x, heads, masks, i) + x
         if taps is not None:
             taps[f"layer{i}.post_attn"] = x
-        f = ssf_feed_forward(sd, p + ".1", x)
+        f = ssf_feed_forward(sd, p + ".1", x, masks, i)
         x = f + x
         if taps is not None:
             taps[f"layer{i}.ff_out"] = f

@@ -60,6 +60,7 @@ CASES = [("fft", dict(dropout=P, emb_dropout=P), (P, P, 0.0)),
          ("shallow_vpt", dict(dropout=P, emb_dropout=P, num_prompts=8, prompt_dim=64, prompt_dropout=P, freeze_vit=False, deep_prompt=False), (P, P, P)),
          ("dvpt", dict(dropout=P, emb_dropout=P, freeze_vit=False, num_prompts=8), (P, P, 0.0)),
          ("evp", dict(dropout=P, emb_dropout=P, freeze_vit=False), (P, P, 0.0)),
+         ("ssf", dict(dropout=P, emb_dropout=P, freeze_vit=False), (P, P, 0.0)),
          # Gaviko(freeze_vit=False) with the shipped dropout = emb_dropout = 0.1 (gaviko.py:513-528); the MWSA dropouts have their own test below
          ("gaviko", dict(dropout=P, emb_dropout=P, freeze_vit=False, num_prompts=8, prompt_latent_dim=20, local_dim=20, local_k=(3, 6, 6),
                          DHW=(10, 10, 10), attn_drop=0.0, proj_drop=0.0, share_factor=1), (P, P, 0.0)),
@@ -148,7 +149,7 @@ def test_dropout_draws_fresh_masks_every_step_and_eval_is_deterministic(dev):
     assert torch.equal(c, d)
 
 
-@pytest.mark.parametrize("method,extra,live", [c for c in CASES if c[0] in ("fft", "melo", "deep_vpt", "adaptformer", "gaviko", "dvpt", "evp")])
+@pytest.mark.parametrize("method,extra,live", [c for c in CASES if c[0] in ("fft", "melo", "deep_vpt", "adaptformer", "gaviko", "dvpt", "evp", "ssf")])
 def test_fp32_path_with_live_dropout_is_exact_against_the_oracle(dev, method, extra, live):
     """The same masks through exact fp32 arithmetic: logits to 2e-5, every gradient to 2e-4 -- the mask logic itself, free of bf16 noise."""
     from gaviko_amd.utils import synth
