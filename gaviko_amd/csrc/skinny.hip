@@ -556,25 +556,25 @@ __global__ __launch_bounds__(256) void reduce_batch_partial_kernel(ReduceBatch b
     const int o = o0 + oi;
     if (jb.b != nullptr) {
       const int j = o / jb.L, l = o - j * jb.L;
-      for (int m = r0 + sl; m < r1; m += 16) {
-        float av[4], bv[4];
+      for (int m = r0 + sl; m < r1; m += 32) {                // eight rows' loads in flight per thread and pass
+        float av[8], bv[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
           const int mm = m + u * 4;
           av[u] = mm < r1 ? jb.a[(size_t)mm * jb.J + j] : 0.f;
           bv[u] = mm < r1 ? jb.b[(size_t)mm * jb.L + l] : 0.f;
         }
-        acc += (av[0] * bv[0] + av[1] * bv[1]) + (av[2] * bv[2] + av[3] * bv[3]);
+        acc += ((av[0] * bv[0] + av[1] * bv[1]) + (av[2] * bv[2] + av[3] * bv[3])) + ((av[4] * bv[4] + av[5] * bv[5]) + (av[6] * bv[6] + av[7] * bv[7]));
       }
     } else {
-      for (int m = r0 + sl; m < r1; m += 16) {
-        float av[4];
+      for (int m = r0 + sl; m < r1; m += 32) {
+        float av[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
           const int mm = m + u * 4;
           av[u] = mm < r1 ? (mm < jb.M1 ? jb.a[(size_t)mm * jb.J + o] : jb.a2[(size_t)(mm - jb.M1) * jb.J + o]) : 0.f;
         }
-        acc += (av[0] + av[1]) + (av[2] + av[3]);
+        acc += ((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7]));
       }
     }
   }
