@@ -295,6 +295,13 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
         (void)k2; (void)k4;
         tile = best_bm == 64 ? 3064128 : best_bm == 96 ? 3096128 : 3128128;
 #endif
+#ifdef GVK_DIAG
+        // Stream-K (gemm_sk_bf16.hip: one workgroup per CU, equal shares of the k-steps) where 128-row tiles leave CUs idle -- built,
+        // correct, SLOWER (fc2 forward 57 vs 34 us isolated, 616 vs 717 volumes/s: DESIGN 7c.5): measurement build only.
+        // GAVIKO_HIP_GEMM_SK: 1 = where the plain choice is the 128 x 128 tile, 2 = wherever it is supported
+        static const int sk = diag_env("GAVIKO_HIP_GEMM_SK") ? atoi(diag_env("GAVIKO_HIP_GEMM_SK")) : 0;
+        if (sk != 0 && (tile == 3128128 || sk == 2) && gemm_sk_supports(a, EPI)) tile = 5128128;
+#endif
       }
       else if (n768 == 128) tile = 128128;
       else if (n768 == 3064) tile = 3064128;
@@ -319,6 +326,9 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
 #ifdef GVK_DIAG                                                   // experiment kernels (measured, not faster): the diag library only
     case 4128128: return launch_gemm_k4(a, EPI, stream);         // 128 x 128, eight waves = 2 column halves x 4 k quarters (128 x 64 per wave)
     case 9128128: return launch_gemm_k2(a, EPI, stream);         // 128 x 128, eight waves splitting every k-tile, three LDS stages
+#endif
+#ifdef GVK_DIAG
+    case 5128128: return launch_gemm_sk(a, EPI, stream);         // stream-K over the three-stage 128 x 128 tile (epilogues 0, 1, 5, 6)
 #endif
     case 3128128: return launch_gemm<128, 128, EPI, false, 3>(a, stream);
     case 3064128: return launch_gemm<64, 128, EPI, false, 3>(a, stream);     // 64 x 128 with three stages (A/B switch GAVIKO_HIP_GEMM_N768=3064)

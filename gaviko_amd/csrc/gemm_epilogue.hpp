@@ -194,6 +194,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
   }
 }
 
+// gemm_sk_bf16.hip: the three-stage 128 x 128 tile as a stream-K launch (one workgroup per CU, equal shares of the (tile, k-step) units)
+int launch_gemm_sk(const GemmArgs& a, int epilogue, hipStream_t stream);
+bool gemm_sk_supports(const GemmArgs& a, int epilogue);
 // gemm8p_bf16.hip: 256 x 256 tile, eight waves in two groups staggered by one barrier (ping-pong on each SIMD's matrix pipe)
 int launch_gemm8p(const GemmArgs& a, int epilogue, int variant, hipStream_t stream);
 bool gemm8p_supports(int epilogue);

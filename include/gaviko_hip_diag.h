@@ -1,7 +1,7 @@
 /* Diagnostics and experiment kernels of libgaviko_hip_diag.so (`python -m gaviko_amd.build --diag`: the product sources compiled with
  * -DGVK_DIAG plus gemm_k2_bf16.hip, gemm_k4_bf16.hip, patch_gemm.hip).  NOT part of the product ABI: the product library
  * (libgaviko_hip.so, include/gaviko_hip.h) exports none of these, ignores every GAVIKO_HIP_* A/B switch named in the kernel sources
- * (gvk::diag_env) and knows no tile codes 9128128 / 4128128.  tools/ loads the diag library when GAVIKO_HIP_DIAG=1. */
+ * (gvk::diag_env) and knows no tile codes 9128128 / 4128128 (eight waves splitting every k-tile) / 5128128 (stream-K: gemm_sk_bf16.hip).  tools/ loads the diag library when GAVIKO_HIP_DIAG=1. */
 #ifndef GAVIKO_HIP_DIAG_H
 #define GAVIKO_HIP_DIAG_H
 #include "gaviko_hip.h"

@@ -17,6 +17,11 @@ def _bf16_round(x):
     return x.to(torch.bfloat16).float()
 
 
+def _needs_diag():
+    from gaviko_amd import lib
+    return pytest.mark.skipif(not lib.DIAG, reason="experiment kernel of the diag library: GAVIKO_HIP_DIAG=1 + `python -m gaviko_amd.build --diag`")
+
+
 @pytest.mark.parametrize("M,N,K,tile", [(300, 192, 192, 0), (1033, 768, 768, 128128), (1033, 768, 768, 64064),
                                         (2066, 2304, 768, 0), (517, 576, 192, 128064), (517, 768, 3072, 64128),
                                         (517, 768, 3072, 3128128), (300, 256, 64, 3128128), (300, 256, 128, 3128128), (1033, 768, 192, 3128128),
@@ -78,6 +83,58 @@ def test_gemm_epilogues(dev):
     torch.nn.functional.gelu(x).sum().backward()
     want = (a.double() @ w.double().T) * x.grad
     assert (act[:M].cpu().double() - want).abs().max().item() < 2 ** -6 * want.abs().max().item()
+
+
+@_needs_diag()
+@pytest.mark.parametrize("M,N,K", [(4132, 768, 3072), (4132, 768, 768), (4132, 768, 2304), (4132, 768, 3136), (2066, 1024, 4096), (8264, 768, 3072)])
+def test_gemm_stream_k(dev, M, N, K):
+    """(Measurement build: the kernel is correct but slower than one workgroup per tile)
+    gemm_sk_bf16.hip (tile code 5128128): one workgroup per CU, every tile cut between consecutive workgroups at k-step granularity, the
+    pieces added in workgroup order by the one that holds the tile's first k-step.  Every epilogue it is built for against float64 (the
+    residual form with its bf16 twin and the row-statistic partials the LayerNorm fold reads), bitwise repeatable, and within fp32
+    re-association of the one-workgroup-per-tile kernel.  (8264 rows = 390 tiles: more tiles than CUs -- refused, the plain launch runs.)"""
+    from gaviko_amd import ops
+    a = _bf16_round(_rand((M, K), 41))
+    w = _bf16_round(_rand((N, K), 42, 2 / math.sqrt(K)))
+    bias, res = _rand((N,), 43, 0.2), _rand((M, N), 44)
+    ref = a.double() @ w.double().T
+    A = ops.act_zeros(M, K, torch.bfloat16, dev); A[:M] = a.to(dev).bfloat16()
+    W = w.to(dev).bfloat16().contiguous()
+    tiles = ((M + 127) // 128) * (N // 128)
+    if tiles >= 256:
+        with pytest.raises(Exception, match="stream-K"):
+            ops.gemm_nt(A, W, M, ops.act_zeros(M, N, torch.float32, dev), epilogue=ops.EPI_STORE_F32, tile=5128128)
+        return
+    outs = {}
+    for tile in (5128128, 5128128, 3128128):
+        f32 = ops.act_zeros(M, N, torch.float32, dev)
+        ops.gemm_nt(A, W, M, f32, epilogue=ops.EPI_STORE_F32, tile=tile)
+        b16 = ops.act_zeros(M, N, torch.bfloat16, dev)
+        ops.gemm_nt(A, W, M, b16, epilogue=ops.EPI_STORE_BF16, bias=bias.to(dev), tile=tile)
+        R = ops.act_zeros(M, N, torch.float32, dev); R[:M] = res.to(dev)
+        ops.gemm_nt(A, W, M, R, epilogue=ops.EPI_BIAS_RES_F32, bias=bias.to(dev), res=R, tile=tile)
+        R2 = ops.act_zeros(M, N, torch.float32, dev); R2[:M] = res.to(dev)
+        O16 = ops.act_zeros(M, N, torch.bfloat16, dev)
+        part = torch.zeros((N // 64) * M * 2, device=dev)
+        ops.gemm_nt(A, W, M, R2, epilogue=ops.EPI_BIAS_RES_F32_BF16, out1=O16, bias=bias.to(dev), res=R2, stat_part=part, tile=tile)
+        torch.cuda.synchronize()
+        outs.setdefault(tile, []).append((f32, b16, R, R2, O16, part))
+    sk0, sk1 = outs[5128128]
+    for u, v_ in zip(sk0, sk1):
+        assert torch.equal(u, v_)                                                        # deterministic: fixed piece order
+    f32, b16, R, R2, O16, part = sk0
+    scale = ref.abs().max().item()
+    assert (f32[:M].cpu().double() - ref).abs().max().item() < 2e-5 * scale * math.sqrt(K / 768)
+    assert (b16[:M].cpu().double() - (ref + bias.double())).abs().max().item() < 1.5 * 2 ** -8 * scale
+    want = ref + bias.double() + res.double()
+    assert (R[:M].cpu().double() - want).abs().max().item() < 2e-5 * scale * math.sqrt(K / 768) + 1e-5
+    assert torch.equal(R[:M], R2[:M]) and torch.equal(O16[:M], R2[:M].bfloat16())
+    pv = part.view(N // 64, M, 2).cpu().double()
+    blocks = want.view(M, N // 64, 64)
+    assert (pv[:, :, 0].T - blocks.sum(-1)).abs().max().item() < 1e-3 and (pv[:, :, 1].T - (blocks ** 2).sum(-1)).abs().max().item() < 1e-2 * (1 + blocks.abs().max().item() ** 2)
+    plain = outs[3128128][0]
+    assert (f32[:M] - plain[0][:M]).abs().max().item() < 1e-4 * scale                    # same products, another summation order
+    assert (f32[M:] == 0).all() and (b16[M:] == 0).all()                                 # pad rows untouched
 
 
 @pytest.mark.parametrize("M,N,K,tile", [(1033, 768, 192, 0), (4132, 2304, 768, 0), (4132, 2304, 768, 128128), (300, 576, 192, 64064)])
@@ -186,11 +243,6 @@ def test_patch_embed_path(dev):
     assert (g[:, P + 1:] - ref).abs().max().item() < 5e-4
     assert (g[:, : P + 1] == -5.0).all()
     assert (Lo[: B * 1000].view(B, 1000, C_).cpu().double() - ref).abs().max().item() < 5e-4
-
-
-def _needs_diag():
-    from gaviko_amd import lib
-    return pytest.mark.skipif(not lib.DIAG, reason="experiment kernel of the diag library: GAVIKO_HIP_DIAG=1 + `python -m gaviko_amd.build --diag`")
 
 
 @_needs_diag()
