@@ -191,9 +191,13 @@ class HotPathModule(nn.Module):
         if not isinstance(img, torch.Tensor) or not img.is_cuda:
             raise L.GavikoHipError("gaviko_amd runs on MI355X only: move the model and the input to the HIP device "
                                    "(there is no CPU fallback)")
-        params = [p for _, p in self._named_cache()[0] if p.requires_grad]
-        if torch.is_grad_enabled() and params:
-            return _HotPathFn.apply(self, img, self._drop_config(), *params)
+        if torch.is_grad_enabled():
+            # ONE trainable tensor ties the node into the autograd graph (the engine writes every parameter gradient itself and the node
+            # returns None for its inputs): handing all ~200 of them to Function.apply cost the host 0.3 ms per step in argument
+            # processing and as much again in the backward's bookkeeping (tools/host_split.py)
+            anchor = next((p for _, p in self._named_cache()[0] if p.requires_grad), None)
+            if anchor is not None:
+                return _HotPathFn.apply(self, img, self._drop_config(), anchor)
         # no autograd: nothing is saved for a backward, but modules left in training mode still drop (nn.Dropout follows .training)
         return self._engine().forward(img, train=False, drop=self._drop_config())
 
