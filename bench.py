@@ -30,8 +30,17 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The HIP runtime reads GPU_MAX_HW_QUEUES when it starts (first HIP call of the process: torch.cuda.set_device, init_process_group).  A step
+# runs on three streams, plus the collective stream and RCCL's own at N > 1: with the default of 4 hardware queues two of them alias and
+# serialise (5.9 -> 6.9-7.7 ms).  So the variable is set HERE, before torch is even imported, and main() refuses to
+# run if HIP was somehow up before this line took effect (_queues_set_before_hip).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between processes on this driver
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+
+_queues_set_before_hip = not torch.cuda.is_initialized()       # torch imported just now: False only if something initialised HIP at import
 
 MODEL = dict(image_size=160, image_patch_size=16, frames=120, frame_patch_size=12, num_classes=5, channels=1, pool="cls", dim_head=64,
              dropout=0.1, emb_dropout=0.1, method="gaviko", num_prompts=32, prompt_latent_dim=20, local_dim=20, local_k=(6, 6, 6),
@@ -105,20 +114,15 @@ def cpu_baseline(backbone, batch):
                       f"{times[0]:.1f} s, best of {len(times) - 1} timed step(s) ({', '.join(f'{t:.1f}' for t in times[1:])} s)"}
 
 
-# newest committed PMC summary first; each records the sha of the GEMM sources it was measured on and is ignored when that differs
-PMC_TRAFFIC_FILE = next((f for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))),
-                        "r03_pmc_traffic.json")
-GEMM_SOURCES = ("gemm_bf16.hip", "gemm8p_bf16.hip", "gemm_epilogue.hpp", "common.hpp")
+# newest committed PMC summary first; each records the hash of the GEMM sources AS THE PRODUCT BUILD COMPILES THEM (comments and
+# `#ifdef GVK_DIAG` text excluded: gaviko_amd/utils/srchash.py) and is ignored when that differs from this tree's
+PMC_TRAFFIC_FILE = next((f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))),
+                        "r04_pmc_traffic.json")
 
 
 def gemm_source_hash():
-    """sha256 over the GEMM kernel sources: the PMC traffic figures are only valid for the code they were measured on."""
-    import hashlib
-    h = hashlib.sha256()
-    for f in GEMM_SOURCES:
-        with open(os.path.join(ROOT, "gaviko_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+    from gaviko_amd.utils.srchash import gemm_source_hash as h
+    return h()
 
 
 def pmc_traffic(name, stats):
@@ -156,24 +160,49 @@ def pmc_traffic(name, stats):
             "algorithmic_bytes": alg_bytes(stats[name]["shape"])}
 
 
+def rank_cpu_set(local_rank: int, local_world: int, cpus=None):
+    """The disjoint share of this process's allowed CPUs that rank `local_rank` of `local_world` keeps: a contiguous run of
+    len(cpus) // local_world of them (every rank at least one).  N ranks issuing ~500 launches per step from one host would otherwise
+    migrate over each other's cores."""
+    cpus = sorted(os.sched_getaffinity(0)) if cpus is None else sorted(cpus)
+    k = max(1, len(cpus) // max(1, local_world))
+    lo = (local_rank * k) % len(cpus)
+    return cpus[lo: lo + k] or cpus[:1]
+
+
+def pin_rank_cpus(local_rank: int, local_world: int):
+    """Called before any GPU call of a rank (the runtime's helper threads inherit the mask).  Returns the CPU list, or None when the
+    platform has no affinity call or there is a single rank (nothing to separate)."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity") or os.environ.get("GAVIKO_BENCH_NO_PIN") == "1":
+        return None
+    mine = rank_cpu_set(local_rank, local_world)
+    os.sched_setaffinity(0, mine)
+    print(f"bench.py: rank {local_rank}/{local_world} pinned to {len(mine)} CPU(s) {mine[0]}-{mine[-1]}", file=sys.stderr, flush=True)
+    return mine
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` with no launcher: start the N ranks as FRESH child processes (never a re-exec) -- this parent has not
     touched the GPU (importing torch does not initialise HIP) and never will.  Every child gets RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_ADDR / MASTER_PORT like torch.distributed.run would set them and runs this same file; rank 0's stdout (the one JSON line)
-    is relayed, stderr of every rank passes through.  Returns the exit code (first failing rank's, else 0)."""
+    MASTER_ADDR / MASTER_PORT like torch.distributed.run would set them and runs this same file; rank 0's stdout goes to a temporary
+    file (no pipe that could fill up and block it) and is relayed at the end, stderr of every rank passes through.  A wall-clock limit
+    (GAVIKO_BENCH_TIMEOUT seconds, default 1500) ends the exact children started here if a rank hangs in a collective.  Returns the
+    exit code (first failing rank's, 124 on the limit, else 0)."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    limit = float(os.environ.get("GAVIKO_BENCH_TIMEOUT", "1500"))
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), GAVIKO_BENCH_CHILD="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs between processes on this driver
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    rc, out0 = 0, ""
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    rc, t0 = 0, time.monotonic()
     try:
         pending = set(range(n))
         while pending:
@@ -187,16 +216,22 @@ def spawn_ranks(n: int) -> int:
                     print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
                     for q in sorted(pending):
                         procs[q].terminate()                      # the exact child processes started above
+            if pending and time.monotonic() - t0 > limit:
+                print(f"bench.py: ranks {sorted(pending)} still running after {limit:.0f} s; stopping them", file=sys.stderr, flush=True)
+                rc = rc or 124
+                for q in sorted(pending):
+                    procs[q].terminate()
+                limit = float("inf")
             if pending:
-                time.sleep(0.05)                                  # (rank 0 prints one short line at the very end: its pipe cannot fill up)
-        if procs[0].stdout is not None:
-            out0 = procs[0].stdout.read()
+                time.sleep(0.05)
     finally:
         for q in procs:
             if q.poll() is None:
                 q.kill()
-    sys.stdout.write(out0)
+    out0.seek(0)
+    sys.stdout.write(out0.read())
     sys.stdout.flush()
+    out0.close()
     return rc
 
 
@@ -224,9 +259,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one disjoint CPU set per rank, before any GPU call (LOCAL_WORLD_SIZE is set by torch.distributed.run and by spawn_ranks)
+    cpus = pin_rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     if args.launch_check:
-        rec = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GAVIKO_BENCH_CHILD")}
+        rec = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GAVIKO_BENCH_CHILD",
+                                              "GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY")}
         rec["gpu_initialised"] = bool(torch.cuda.is_initialized())
+        rec["queues_set_before_hip"] = bool(_queues_set_before_hip)
+        rec["cpus"] = cpus
         path = os.environ.get("GAVIKO_BENCH_LAUNCH_LOG")
         if path:
             with open(f"{path}.{rank}", "w") as f:
@@ -241,6 +281,10 @@ def main():
     rehearsal = os.environ.get("GAVIKO_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+    if not _queues_set_before_hip or torch.cuda.is_initialized():
+        raise SystemExit("bench.py: the HIP runtime was initialised before GPU_MAX_HW_QUEUES could take effect (something imported ahead of "
+                         "bench.py touched the GPU): the step's streams would share hardware queues and the line would not be the product's")
+    from gaviko_amd import lib as L                    # (sets nothing any more: the variable is already in the environment)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -252,7 +296,6 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     from gaviko_amd import engine as eng_mod
-    from gaviko_amd import lib as L
     from gaviko_amd.utils import synth
     model = build(args.backbone, dev)
     if world > 1:

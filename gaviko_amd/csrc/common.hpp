@@ -111,7 +111,7 @@ __device__ __forceinline__ float quick_gelu_grad(float x) {
 
 // A/B switches of the measurement builds.  The product library is compiled WITHOUT GVK_DIAG: every such switch folds to its measured-best
 // constant there and the environment is never consulted.  `python -m gaviko_amd.build --diag` builds libgaviko_hip_diag.so with GVK_DIAG
-// (plus the experiment kernels of gemm_k2 / gemm_k4 / patch_gemm and the diagnostics of include/gaviko_hip_diag.h) for tools/.
+// (plus the diagnostics of include/gaviko_hip_diag.h) for tools/.
 #include <stdlib.h>
 namespace gvk {
 #ifdef GVK_DIAG

@@ -269,11 +269,6 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     // 60 % of the CUs idle; 198 tiles of 64: 465 -> 488 volumes/s at B = 2, while at B = 4 the small tile costs 6 %)
     static const long t64_hi = diag_env("GAVIKO_HIP_GEMM_T64HI") ? atol(diag_env("GAVIKO_HIP_GEMM_T64HI")) : 130;
     if (bm == 64 && bn == 128 && t128 <= 256 && a.K >= 512 && a.drop_thresh == 0u) {
-      // GAVIKO_HIP_GEMM_K2=1: the same tile on EIGHT waves that split every k-tile (gemm_k2_bf16.hip) -- two waves per SIMD instead of one.
-      // Measured: isolated 32.7 vs 35.9 us (fc2), 23.6 vs 25.2 (qkv dgrad), equal elsewhere; 709-715 vs 713 volumes/s on the step: the
-      // single wave's latency chain is not what bounds the loop.  Opt-in.
-      static const bool k2 = diag_env("GAVIKO_HIP_GEMM_K2") != nullptr && diag_env("GAVIKO_HIP_GEMM_K2")[0] == '1';
-      static const bool k4 = diag_env("GAVIKO_HIP_GEMM_K4") != nullptr && diag_env("GAVIKO_HIP_GEMM_K4")[0] == '1';       // gemm_k4_bf16.hip, A/B switch
       if (n768 == 3128) {
         // One workgroup per CU, three stages: the tile's life is bound by its own L2 -> LDS bytes, (BM + 128) per k-step, and a launch takes
         // ceil(tiles / 256) such lives.  Row tile = the one of {128, 96, 64} with the smallest rounds x (BM + 128):
@@ -288,20 +283,8 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
         static const int force_bm = diag_env("GAVIKO_HIP_GEMM_BM") ? atoi(diag_env("GAVIKO_HIP_GEMM_BM")) : 0;      // A/B switch: 128 / 96 / 64
         if (force_bm == 128 || force_bm == 96 || force_bm == 64) best_bm = force_bm;
         else if (t128 <= t64_hi && best_bm == 128) best_bm = 64;                                           // (the round-2 rule, kept for the shapes it was tuned on)
-#ifdef GVK_DIAG
-        tile = best_bm == 64 ? 3064128 : best_bm == 96 ? 3096128
-             : (k4 && gemm_k4_supports(EPI) ? 4128128 : k2 && gemm_k2_supports(EPI) && a.K >= 192 ? 9128128 : 3128128);
-#else
-        (void)k2; (void)k4;
+        // (eight-wave split-k forms of this tile and a stream-K launch were built and measured slower in rounds 2-3: DESIGN.md 7b.1, 7c.5b)
         tile = best_bm == 64 ? 3064128 : best_bm == 96 ? 3096128 : 3128128;
-#endif
-#ifdef GVK_DIAG
-        // Stream-K (gemm_sk_bf16.hip: one workgroup per CU, equal shares of the k-steps) where 128-row tiles leave CUs idle -- built,
-        // correct, SLOWER (fc2 forward 57 vs 34 us isolated, 616 vs 717 volumes/s: DESIGN 7c.5): measurement build only.
-        // GAVIKO_HIP_GEMM_SK: 1 = where the plain choice is the 128 x 128 tile, 2 = wherever it is supported
-        static const int sk = diag_env("GAVIKO_HIP_GEMM_SK") ? atoi(diag_env("GAVIKO_HIP_GEMM_SK")) : 0;
-        if (sk != 0 && (tile == 3128128 || sk == 2) && gemm_sk_supports(a, EPI)) tile = 5128128;
-#endif
       }
       else if (n768 == 128) tile = 128128;
       else if (n768 == 3064) tile = 3064128;
@@ -323,13 +306,6 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
   switch (tile) {
     case 8256256: return launch_gemm8p(a, EPI, 0, stream);      // eight-phase kernel, LDS-DMA issued in the load sections (default)
     case 7256256: return launch_gemm8p(a, EPI, 1, stream);      // ... issued inside the MFMA clusters (2546 vs 2426 cycles per k-tile)
-#ifdef GVK_DIAG                                                   // experiment kernels (measured, not faster): the diag library only
-    case 4128128: return launch_gemm_k4(a, EPI, stream);         // 128 x 128, eight waves = 2 column halves x 4 k quarters (128 x 64 per wave)
-    case 9128128: return launch_gemm_k2(a, EPI, stream);         // 128 x 128, eight waves splitting every k-tile, three LDS stages
-#endif
-#ifdef GVK_DIAG
-    case 5128128: return launch_gemm_sk(a, EPI, stream);         // stream-K over the three-stage 128 x 128 tile (epilogues 0, 1, 5, 6)
-#endif
     case 3128128: return launch_gemm<128, 128, EPI, false, 3>(a, stream);
     case 3064128: return launch_gemm<64, 128, EPI, false, 3>(a, stream);     // 64 x 128 with three stages (A/B switch GAVIKO_HIP_GEMM_N768=3064)
     case 3096128: return launch_gemm<96, 128, EPI, false, 3>(a, stream);     // 96 x 128 with three stages (M = 2066, N = 1024: 176 tiles in one round)

@@ -194,17 +194,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
   }
 }
 
-// gemm_sk_bf16.hip: the three-stage 128 x 128 tile as a stream-K launch (one workgroup per CU, equal shares of the (tile, k-step) units)
-int launch_gemm_sk(const GemmArgs& a, int epilogue, hipStream_t stream);
-bool gemm_sk_supports(const GemmArgs& a, int epilogue);
 // gemm8p_bf16.hip: 256 x 256 tile, eight waves in two groups staggered by one barrier (ping-pong on each SIMD's matrix pipe)
 int launch_gemm8p(const GemmArgs& a, int epilogue, int variant, hipStream_t stream);
 bool gemm8p_supports(int epilogue);
-// gemm_k2_bf16.hip: the 128 x 128 tile on eight waves that split every k-tile between them (STORE_BF16, BIAS_RES_F32, STORE_F32)
-int launch_gemm_k2(const GemmArgs& a, int epilogue, hipStream_t stream);
-bool gemm_k2_supports(int epilogue);
-// gemm_k4_bf16.hip: the 128 x 128 tile on eight waves = 2 column halves x 4 k quarters, 128 x 64 per wave (same three epilogues)
-int launch_gemm_k4(const GemmArgs& a, int epilogue, hipStream_t stream);
-bool gemm_k4_supports(int epilogue);
 
 }  // namespace gvk

@@ -27,7 +27,7 @@ from . import ops
 
 import os
 
-from .engine_common import (SEED_EMB, SEED_LAYER, SEED_PROMPT, GRAPH_WARMUP, Names, PLAN_TIMING, SIDE_STREAM_PRIORITY, STEP_MODE, USE_GRAPHS, _ABLATE, _EPI_NAMES, _FIX_IN_LN, _LOC_SHIFT, _MODE, _PATCH_IMPLICIT, _SIDE_STREAMS, _on, evp_highpass_operator)  # noqa: F401
+from .engine_common import (SEED_EMB, SEED_LAYER, SEED_PROMPT, GRAPH_WARMUP, Names, PLAN_TIMING, SIDE_STREAM_PRIORITY, STEP_MODE, USE_GRAPHS, _ABLATE, _EPI_NAMES, _FIX_IN_LN, _LOC_SHIFT, _MODE, _SIDE_STREAMS, _on, evp_highpass_operator)  # noqa: F401
 from .engine_gaviko import GavikoPaths
 from .engine_peft import PeftPaths
 
@@ -553,19 +553,9 @@ class Engine(GavikoPaths, PeftPaths):
         pe0 = self._ev_record(cur) if marking else None
         pos = d(nm.root + "pos_embedding")[0]
         G0 = ws["G"][0]
-        # implicit GEMM straight from the fp32 volume (csrc/patch_gemm.hip) wherever nothing else needs the im2col matrix: not EVP (reads
-        # the raw embedding), not a trainable patch conv (its weight gradient contracts over the im2col rows), not the fp32 path
-        conv_trains = self.p[nm.conv() + ".weight"].requires_grad
-        implicit = (_PATCH_IMPLICIT and not self.fp32 and self.kind != "evp" and not conv_trains and C % 128 == 0 and self.patch[2] == 16
-                    and (self.patch[1] * self.patch[2]) % 64 == 0)
-        if implicit:
-            ops.patch_embed(ws["img"], w["conv"], d(nm.conv() + ".bias"), pos[1:], G0, ws["Lc"][0] if self.kind == "gaviko" else None,
-                            self.patch, C, T, self.row_off)
-        else:
-            ops.patchify(ws["img"], ws["cols"], self.patch)
-        if implicit:
-            pass                                              # tokens are already in place
-        elif self.kind == "evp":
+        # im2col -> bf16, then the MFMA GEMM scatters the token rows (a fused gather-GEMM was built in round 2 and measured slower: DESIGN.md 7b.5)
+        ops.patchify(ws["img"], ws["cols"], self.patch)
+        if self.kind == "evp":
             # the raw patch embedding is needed on its own (embedding_generator reads it, evp.py:347-348): conv -> xc, tokens = xc + pos
             ops.gemm_nt(ws["cols"], w["conv"], B * N, ws["xc"], epilogue=ops.EPI_STORE_F32, bias=d(nm.conv() + ".bias"))
             ops.rows_patch(G0, ws["xc"], pos[1:], B, T, N, C, 1, False)

@@ -35,9 +35,6 @@ SEED_EMB, SEED_PROMPT, SEED_LAYER = 900, 950, 1000
 # Dispatch priority of the side-chain streams (negative = higher).  Measured: -1 drops the step rate from 448 to 274 volumes/s
 # (priority queues serialise against the captured graph's main queue on this runtime), so the default stays 0.
 SIDE_STREAM_PRIORITY = int(L.diag_env("GAVIKO_HIP_SIDE_PRIORITY", "0"))
-# Patch embedding as one implicit GEMM (csrc/patch_gemm.hip) instead of the im2col kernel + GEMM: correct and bit-identical, but 74-79 us
-# against 54 us for the pair -- opt-in
-_PATCH_IMPLICIT = L.diag_env("GAVIKO_HIP_PATCH_IMPLICIT", "0") == "1"
 # GPA prompt fix inside the next layer's first LayerNorm (gvk_layernorm_fwd_fix) instead of its own 128-row launch: measured 709-711 vs
 # 719-721 volumes/s -- the 128 prompt rows' waves become the tail of a 4132-row kernel; opt-in
 _FIX_IN_LN = L.diag_env("GAVIKO_HIP_FIX_IN_LN", "0") == "1"

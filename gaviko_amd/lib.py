@@ -185,7 +185,7 @@ STRUCTS = {"gvk_gemm_desc": GemmDesc, "gvk_skinny_down_desc": SkinnyDownDesc, "g
            "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob, "gvk_rowproj_desc": RowProjDesc, "gvk_adam_desc": AdamDesc, "gvk_loss_desc": LossDesc, "gvk_dropout_desc": DropoutDesc, "gvk_ssf_colgrad_desc": SsfColgradDesc, "gvk_dvpt_desc": DvptDesc}
 
 # diag library only (include/gaviko_hip_diag.h): bound when GAVIKO_HIP_DIAG=1 selects libgaviko_hip_diag.so
-DIAG_SIGNATURES = {"gvk_patch_embed_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]}
+DIAG_SIGNATURES = {}
 DIAG_NO_STREAM = {"gvk_plan_nop_stream": (C.c_int, [_P]), "gvk_plan_nop_clear": (C.c_int, [])}
 
 _lib = None

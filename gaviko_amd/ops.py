@@ -95,24 +95,6 @@ def pack_split_bf16(a, dst, col0, rows, b=None, weight_side=False):
             "gvk_pack_split_bf16")
 
 
-def patch_embed(img, w, bias, pos, out0, out1, patch, C_, rows_out, row_off):
-    """Conv3d(kernel = stride = patch) + bias + position rows, scattered into the token rows of out0 (and densely into out1): one implicit
-    GEMM over the fp32 volume.  Experiment kernel (slower than the two-kernel form): diag library only (gaviko_hip_diag.h: gvk_patch_embed_bf16)."""
-    if not L.DIAG:
-        raise L.GavikoHipError("patch_embed (implicit GEMM) is an experiment kernel of the diag library: GAVIKO_HIP_DIAG=1 + `python -m gaviko_amd.build --diag`")
-    B, _, D, H, W = img.shape
-    pd, ph, pw = patch
-    n = (D // pd) * (H // ph) * (W // pw)
-    _chk(img, torch.float32, "patch_embed img")
-    _chk(w, torch.bfloat16, "patch_embed w", C_ * pd * ph * pw)
-    _chk(bias, torch.float32, "patch_embed bias", C_)
-    _chk(pos, torch.float32, "patch_embed pos", n * C_)
-    _chk(out0, torch.float32, "patch_embed out0", B * rows_out * C_)
-    _chk(out1, torch.float32, "patch_embed out1", B * n * C_)
-    L.check(L.load().gvk_patch_embed_bf16(L.ptr(img), L.ptr(w), L.ptr(bias), L.ptr(pos), L.ptr(out0), L.ptr(out1), B, D, H, W, pd, ph, pw, C_,
-                                          rows_out, row_off, L.stream_ptr()), "gvk_patch_embed_bf16")
-
-
 def layernorm_fwd_fix(x, gamma, beta, M, C_, *, y16, mean, rstd, enh, lat, wup, T, P, L_, eps=1e-5):
     """LayerNorm forward (bf16 output) that first applies the previous layer's GPA prompt fix to rows (m % T) < P of x, in place."""
     _chk(x, torch.float32, "ln_fix x", M * C_)

@@ -86,7 +86,7 @@ typedef struct gvk_gemm_desc {
   int32_t lda, ldw, ldo, ldres, ldaux;
   int32_t epilogue;
   int32_t rows_in, rows_out, row_off; /* GVK_EPI_PATCH_F32 only */
-  int32_t tile;       /* 0 = auto, else BM*1000+BN (128128, 128064, 64064, 64128); 3128128 / 3064128 = 128x128 / 64x128 with three LDS stages; 3096128 = 96x128 with three stages; (9128128 / 4128128, eight waves splitting every k-tile, and 5128128, stream-K: diag library only, include/gaviko_hip_diag.h);
+  int32_t tile;       /* 0 = auto, else BM*1000+BN (128128, 128064, 64064, 64128); 3128128 / 3064128 = 128x128 / 64x128 with three LDS stages; 3096128 = 96x128 with three stages;;
                          256256 = eight waves on a 256x256 tile (STORE_BF16, BIAS_GELU_BF16, GELU_BWD_BF16 only);
                          8256256 / 7256256 = the eight-phase 256x256 kernel (gemm8p_bf16.hip: two wave groups one barrier apart, counted
                          vmcnt), LDS-DMA issued in the load sections / inside the MFMA clusters; epilogues 0, 1, 2, 4, 5, N % 256 == 0, K >= 128 */

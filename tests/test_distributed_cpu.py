@@ -111,7 +111,36 @@ def test_bench_starts_its_own_ranks_when_run_bare(tmp_path):
     recs = [json.load(open(f"{tmp_path / 'rank'}.{k}")) for k in range(3)]
     assert [x["RANK"] for x in recs] == ["0", "1", "2"] and [x["LOCAL_RANK"] for x in recs] == ["0", "1", "2"]
     assert len({x["MASTER_PORT"] for x in recs}) == 1 and all(x["WORLD_SIZE"] == "3" and not x["gpu_initialised"] for x in recs)
+    # the hardware-queue setting is in every rank's environment while HIP is still down (it is read when the runtime starts), whatever the
+    # caller's environment held -- the round-3 driver line was measured on the default 4 queues because bench.py set it too late
+    assert all(x["GPU_MAX_HW_QUEUES"] == "8" and x["queues_set_before_hip"] and x["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for x in recs)
+    # every rank keeps a disjoint share of the CPUs this process may use (one each when there are fewer CPUs than ranks)
+    avail = sorted(os.sched_getaffinity(0))
+    sets = [x["cpus"] for x in recs]
+    assert all(s and set(s) <= set(avail) and len(s) == max(1, len(avail) // 3) for s in sets)
+    if len(avail) >= 3:
+        assert len(set().union(*map(set, sets))) == sum(len(s) for s in sets)
     # under a launcher (RANK set) it must NOT spawn again
     env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env2, capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0 and json.loads(r2.stdout.strip().splitlines()[-1])["launch_check"]["GAVIKO_BENCH_CHILD"] is None
+
+
+def test_bench_keeps_a_callers_queue_setting_and_rank_cpu_sets_partition():
+    """GPU_MAX_HW_QUEUES exported by the caller wins (setdefault), and rank_cpu_set cuts any CPU list into disjoint runs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["GPU_MAX_HW_QUEUES"] = "6"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--launch-check"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])["launch_check"]
+    assert rec["GPU_MAX_HW_QUEUES"] == "6" and rec["cpus"] is None and not rec["gpu_initialised"]
+    sys.path.insert(0, root)
+    import bench
+    cpus = list(range(3, 35))                                          # 32 CPUs, 8 ranks -> 4 each
+    parts = [bench.rank_cpu_set(r_, 8, cpus) for r_ in range(8)]
+    assert all(len(p_) == 4 for p_ in parts) and sorted(c for p_ in parts for c in p_) == cpus
+    assert bench.rank_cpu_set(5, 8, [0, 1]) in ([0], [1])                # fewer CPUs than ranks: one each, shared

@@ -177,3 +177,17 @@ def test_dvpt_schema_and_freeze_rule():
     assert tr == sorted(str(k) for k in golden("dvpt_t16_b2")["meta/trainable"]) and len(tr) == 64
     assert all(oracle.dvpt_trainable(k) == named[k].requires_grad for k in named)
     assert m.train() is None and not m.transformer.layers[0][0].attn.training and m.transformer.layers[0][0].prompt_proj.training
+
+
+def test_product_source_hash_ignores_diag_blocks_and_comments():
+    """bench.py attaches profiles/r0N_pmc_traffic.json only when the GEMM sources' hash matches; the hash covers what the PRODUCT build
+    compiles (round 3: a diag-only edit withheld roofline.traffic from the driver's line)."""
+    from gaviko_amd.utils.srchash import gemm_source_hash, product_text
+    base = "int f(int x) {\n  return x + 1;   // add one\n}\n"
+    diag = "int f(int x) {\n#ifdef GVK_DIAG\n  if (getenv(\"A\")) return 0;\n#if FOO\n  x = 2;\n#endif\n#endif\n  /* block\n comment */ return x + 1;\n}\n"
+    assert product_text(base) == product_text(diag)
+    both = "#ifdef GVK_DIAG\nint a;\n#else\nint b;\n#endif\n#ifndef GVK_DIAG\nint c;\n#else\nint d;\n#endif\n#if FOO\nint e;\n#else\nint g;\n#endif\n"
+    assert product_text(both).split("\n") == ["int b;", "int c;", "#if FOO", "int e;", "#else", "int g;", "#endif"]
+    assert product_text(base) != product_text(base.replace("x + 1", "x + 2"))
+    h = gemm_source_hash()
+    assert len(h) == 16 and h == gemm_source_hash()

@@ -1,5 +1,6 @@
 """-m gpu: each HIP kernel (through the C-ABI) against a plain fp32/fp64 torch computation on the CPU."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -15,11 +16,6 @@ def _rand(shape, seed, scale=1.0):
 
 def _bf16_round(x):
     return x.to(torch.bfloat16).float()
-
-
-def _needs_diag():
-    from gaviko_amd import lib
-    return pytest.mark.skipif(not lib.DIAG, reason="experiment kernel of the diag library: GAVIKO_HIP_DIAG=1 + `python -m gaviko_amd.build --diag`")
 
 
 @pytest.mark.parametrize("M,N,K,tile", [(300, 192, 192, 0), (1033, 768, 768, 128128), (1033, 768, 768, 64064),
@@ -83,58 +79,6 @@ def test_gemm_epilogues(dev):
     torch.nn.functional.gelu(x).sum().backward()
     want = (a.double() @ w.double().T) * x.grad
     assert (act[:M].cpu().double() - want).abs().max().item() < 2 ** -6 * want.abs().max().item()
-
-
-@_needs_diag()
-@pytest.mark.parametrize("M,N,K", [(4132, 768, 3072), (4132, 768, 768), (4132, 768, 2304), (4132, 768, 3136), (2066, 1024, 4096), (8264, 768, 3072)])
-def test_gemm_stream_k(dev, M, N, K):
-    """(Measurement build: the kernel is correct but slower than one workgroup per tile)
-    gemm_sk_bf16.hip (tile code 5128128): one workgroup per CU, every tile cut between consecutive workgroups at k-step granularity, the
-    pieces added in workgroup order by the one that holds the tile's first k-step.  Every epilogue it is built for against float64 (the
-    residual form with its bf16 twin and the row-statistic partials the LayerNorm fold reads), bitwise repeatable, and within fp32
-    re-association of the one-workgroup-per-tile kernel.  (8264 rows = 390 tiles: more tiles than CUs -- refused, the plain launch runs.)"""
-    from gaviko_amd import ops
-    a = _bf16_round(_rand((M, K), 41))
-    w = _bf16_round(_rand((N, K), 42, 2 / math.sqrt(K)))
-    bias, res = _rand((N,), 43, 0.2), _rand((M, N), 44)
-    ref = a.double() @ w.double().T
-    A = ops.act_zeros(M, K, torch.bfloat16, dev); A[:M] = a.to(dev).bfloat16()
-    W = w.to(dev).bfloat16().contiguous()
-    tiles = ((M + 127) // 128) * (N // 128)
-    if tiles >= 256:
-        with pytest.raises(Exception, match="stream-K"):
-            ops.gemm_nt(A, W, M, ops.act_zeros(M, N, torch.float32, dev), epilogue=ops.EPI_STORE_F32, tile=5128128)
-        return
-    outs = {}
-    for tile in (5128128, 5128128, 3128128):
-        f32 = ops.act_zeros(M, N, torch.float32, dev)
-        ops.gemm_nt(A, W, M, f32, epilogue=ops.EPI_STORE_F32, tile=tile)
-        b16 = ops.act_zeros(M, N, torch.bfloat16, dev)
-        ops.gemm_nt(A, W, M, b16, epilogue=ops.EPI_STORE_BF16, bias=bias.to(dev), tile=tile)
-        R = ops.act_zeros(M, N, torch.float32, dev); R[:M] = res.to(dev)
-        ops.gemm_nt(A, W, M, R, epilogue=ops.EPI_BIAS_RES_F32, bias=bias.to(dev), res=R, tile=tile)
-        R2 = ops.act_zeros(M, N, torch.float32, dev); R2[:M] = res.to(dev)
-        O16 = ops.act_zeros(M, N, torch.bfloat16, dev)
-        part = torch.zeros((N // 64) * M * 2, device=dev)
-        ops.gemm_nt(A, W, M, R2, epilogue=ops.EPI_BIAS_RES_F32_BF16, out1=O16, bias=bias.to(dev), res=R2, stat_part=part, tile=tile)
-        torch.cuda.synchronize()
-        outs.setdefault(tile, []).append((f32, b16, R, R2, O16, part))
-    sk0, sk1 = outs[5128128]
-    for u, v_ in zip(sk0, sk1):
-        assert torch.equal(u, v_)                                                        # deterministic: fixed piece order
-    f32, b16, R, R2, O16, part = sk0
-    scale = ref.abs().max().item()
-    assert (f32[:M].cpu().double() - ref).abs().max().item() < 2e-5 * scale * math.sqrt(K / 768)
-    assert (b16[:M].cpu().double() - (ref + bias.double())).abs().max().item() < 1.5 * 2 ** -8 * scale
-    want = ref + bias.double() + res.double()
-    assert (R[:M].cpu().double() - want).abs().max().item() < 2e-5 * scale * math.sqrt(K / 768) + 1e-5
-    assert torch.equal(R[:M], R2[:M]) and torch.equal(O16[:M], R2[:M].bfloat16())
-    pv = part.view(N // 64, M, 2).cpu().double()
-    blocks = want.view(M, N // 64, 64)
-    assert (pv[:, :, 0].T - blocks.sum(-1)).abs().max().item() < 1e-3 and (pv[:, :, 1].T - (blocks ** 2).sum(-1)).abs().max().item() < 1e-2 * (1 + blocks.abs().max().item() ** 2)
-    plain = outs[3128128][0]
-    assert (f32[:M] - plain[0][:M]).abs().max().item() < 1e-4 * scale                    # same products, another summation order
-    assert (f32[M:] == 0).all() and (b16[M:] == 0).all()                                 # pad rows untouched
 
 
 @pytest.mark.parametrize("M,N,K,tile", [(1033, 768, 192, 0), (4132, 2304, 768, 0), (4132, 2304, 768, 128128), (300, 576, 192, 64064)])
@@ -243,38 +187,6 @@ def test_patch_embed_path(dev):
     assert (g[:, P + 1:] - ref).abs().max().item() < 5e-4
     assert (g[:, : P + 1] == -5.0).all()
     assert (Lo[: B * 1000].view(B, 1000, C_).cpu().double() - ref).abs().max().item() < 5e-4
-
-
-@_needs_diag()
-@pytest.mark.parametrize("B,C_,P", [(2, 768, 32), (3, 128, 0), (1, 1024, 8)])
-def test_patch_embed_implicit_gemm(dev, B, C_, P):
-    """gvk_patch_embed_bf16 (A operand gathered from the fp32 volume inside the GEMM) == conv3d + flatten/transpose + pos, scattered into
-    rows [P+1 ..] of every sample and densely into the second output -- and bit-identical to the im2col kernel + PATCH GEMM it replaces."""
-    from gaviko_amd import ops
-    from gaviko_amd.utils import synth
-    img = torch.from_numpy(synth.volumes(7, B))
-    w = _rand((C_, 1, 12, 16, 16), 41, math.sqrt(3.0 / 3072) * 1.7)
-    bias = _rand((C_,), 42, 0.05)
-    pos = _rand((1000, C_), 43, 0.3)
-    wb = _bf16_round(w)
-    ref = torch.nn.functional.conv3d(_bf16_round(img).double(), wb.double(), bias.double(), stride=(12, 16, 16))
-    ref = ref.flatten(2).transpose(1, 2) + pos.double()
-    T = P + 1 + 1000
-    W = wb.reshape(C_, 3072).to(dev).bfloat16().contiguous()
-    G = torch.full((ops.pad_rows(B * T), C_), -5.0, dtype=torch.float32, device=dev)
-    Lo = torch.zeros((ops.pad_rows(B * 1000), C_), dtype=torch.float32, device=dev)
-    ops.patch_embed(img.to(dev), W, bias.to(dev), pos.to(dev).contiguous(), G, Lo, (12, 16, 16), C_, T, P + 1)
-    g = G[: B * T].view(B, T, C_).cpu().double()
-    assert (g[:, P + 1:] - ref).abs().max().item() < 5e-4
-    assert (g[:, : P + 1] == -5.0).all()
-    assert (Lo[: B * 1000].view(B, 1000, C_).cpu().double() - ref).abs().max().item() < 5e-4
-    # the two-kernel form: same products, same accumulation order per tile -> the same bits
-    cols = ops.act_zeros(B * 1000, 3072, torch.bfloat16, dev)
-    ops.patchify(img.to(dev), cols, (12, 16, 16))
-    G2 = torch.full((ops.pad_rows(B * T), C_), -5.0, dtype=torch.float32, device=dev)
-    ops.gemm_nt(cols, W, B * 1000, G2, epilogue=ops.EPI_PATCH_F32, bias=bias.to(dev), pos=pos.to(dev).contiguous(), rows_in=1000, rows_out=T,
-                row_off=P + 1, tile=128128)
-    assert torch.equal(G[: B * T], G2[: B * T])
 
 
 @pytest.mark.parametrize("M,C_", [(1033, 768), (77, 192), (515, 1024), (9, 384)])
@@ -395,7 +307,7 @@ def test_attention_fwd_forced_rescale(dev, step):
     assert (lse.cpu().double() - lse_ref).abs().max().item() < 5e-3
 
 
-@pytest.mark.parametrize("var", [0, 1, 2, 3])
+@pytest.mark.parametrize("var", [0, 1, 2, 3] if os.environ.get("GAVIKO_HIP_DIAG", "0") == "1" else [0])     # variants 1-3: measurement build only
 @pytest.mark.parametrize("kb", [96, 128])
 @pytest.mark.parametrize("T", [1033, 1001, 97, 31])
 def test_attention_fwd_key_tiles(dev, monkeypatch, T, kb, var):
@@ -536,36 +448,3 @@ def test_gemm_eight_phase_kernel(dev, M, N, K, tile8):
     ops.gemm_nt(A, W, M, o, epilogue=ops.EPI_STORE_F32, tile=tile8)
     assert (o[:M] - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
 
-
-@_needs_diag()
-@pytest.mark.parametrize("tilek", [9128128, 4128128])
-@pytest.mark.parametrize("M,N,K", [(4132, 768, 3072), (4132, 768, 3136), (4132, 768, 768), (1033, 768, 192), (300, 256, 256), (130, 512, 2304)])
-def test_gemm_split_k_eight_wave_tile(dev, M, N, K, tilek):
-    """tiles 9128128 (gemm_k2_bf16.hip: 128 x 128 on eight waves, waves 0-3 / 4-7 multiplying the two 32-wide halves of every k-tile) and
-    4128128 (gemm_k4_bf16.hip: 2 column halves x 4 k quarters, 128 x 64 per wave), partial tiles summed through LDS: their three epilogues against torch in float32 and against the four-wave kernel (the k halves are summed in a
-    different order, so equal to fp32 rounding, not bit for bit), repeated -- a wrong LDS-DMA / barrier ordering is a race."""
-    from gaviko_amd import ops
-    gen = torch.Generator().manual_seed(11 * M + N + K)
-    A = ops.act_zeros(M, K, torch.bfloat16, dev); A[:M] = torch.randn(M, K, generator=gen).bfloat16().to(dev)
-    W = (torch.randn(N, K, generator=gen) / K ** 0.5).bfloat16().to(dev)
-    bias = torch.randn(N, generator=gen).to(dev)
-    res = ops.act_zeros(M, N, torch.float32, dev); res[:M] = torch.randn(M, N, generator=gen).to(dev)
-    ref = A[:M].float() @ W.float().t()
-    cases = ((ops.EPI_STORE_BF16, dict(), torch.bfloat16, ref), (ops.EPI_STORE_F32, dict(), torch.float32, ref),
-             (ops.EPI_BIAS_RES_F32, dict(bias=bias, res=res), torch.float32, ref + bias + res[:M]))
-    first = {}
-    for rep in range(4):
-        for epi, kw, dt, want in cases:
-            o = ops.act_zeros(M, N, dt, dev)
-            ops.gemm_nt(A, W, M, o, epilogue=epi, tile=tilek, **kw)
-            got = o.float()
-            tol = (1.2e-2 if dt == torch.bfloat16 else 2e-3) * max(1.0, want.abs().max().item())
-            assert (got[:M] - want).abs().max().item() < tol, (epi, rep)
-            assert not got[M:].any(), "rows >= M must not be written"
-            if rep == 0:
-                first[epi] = got.clone()
-                o4 = ops.act_zeros(M, N, dt, dev)
-                ops.gemm_nt(A, W, M, o4, epilogue=epi, tile=128128, **kw)
-                assert (got - o4.float()).abs().max().item() < (1.6e-2 if dt == torch.bfloat16 else 1e-4) * max(1.0, want.abs().max().item())
-            else:
-                assert torch.equal(got, first[epi]), "not reproducible from launch to launch"
