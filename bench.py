@@ -313,11 +313,8 @@ def main():
     if args.loss == "ce-torch":
         criterion = torch.nn.functional.cross_entropy
 
-    params = list(model.parameters())                 # what optimizer.zero_grad() walks: a flat list, not the module tree
-
     def step():
-        for p in params:
-            p.grad = None
+        model.zero_grad(set_to_none=False)                # the optimizer's zero_grad: ONE memset of the flat gradient buffer once it exists
         loss = criterion(model(x), y)
         loss.backward()
         return loss

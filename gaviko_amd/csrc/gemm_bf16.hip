@@ -354,7 +354,7 @@ extern "C" int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream) {
   a.ln_mean = d->ln_mean; a.ln_rstd = d->ln_rstd; a.ln_c1 = d->ln_c1;
   GVK_REQUIRE(d->stat_part == nullptr || (d->epilogue == GVK_EPI_BIAS_RES_F32_BF16 && d->N % 128 == 0 && (d->tile == 0 || d->tile % 1000 == 128)),
               "gvk_gemm_nt_bf16: stat_part needs the BIAS_RES_F32_BF16 epilogue on 128-column tiles (64-column groups)");
-  a.stat_part = d->stat_part;
+  a.stat_part = d->stat_part; a.stat_pivot = d->stat_pivot;
   hipStream_t s = (hipStream_t)stream;
   switch (d->epilogue) {
     case GVK_EPI_STORE_BF16:

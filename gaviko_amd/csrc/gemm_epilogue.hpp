@@ -33,6 +33,7 @@ struct GemmArgs {
   // BIAS_RES_F32_BF16: per-row partial (sum, sum of squares) of the fp32 output over this wave's columns, written to
   // stat_part[(column group)][m] (float2; group = column / (16 * NT)); a later kernel turns the groups of a row into mean / rstd
   float* stat_part;
+  const float* stat_pivot;                               // the partials are sums of (x - stat_pivot[m]) and its square (nullptr: pivot 0)
 };
 
 // LDS swizzles (applied to the 16-byte chunk index of a 128-byte tile row; conflict-free for the ds_read_b128 lane groups)
@@ -72,13 +73,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
       }
     }
   }
-  struct Side { f32x4 r0[NP], r1[NP]; bf16x8 a8[NP]; float mu, rs; };
+  struct Side { f32x4 r0[NP], r1[NP]; bf16x8 a8[NP]; float mu, rs, pv; };
   auto fetch = [&](const int i, Side& sd) {
     const int m = mbase + i * 16 + l15;
     if (m >= p.M) return;
     if constexpr (kFold) {
       if (p.ln_mean != nullptr) { sd.mu = p.ln_mean[m]; sd.rs = p.ln_rstd[m]; }
     }
+    if constexpr (kStat) sd.pv = p.stat_pivot != nullptr ? p.stat_pivot[m] : 0.f;
 #pragma unroll
     for (int jp = 0; jp < NP; ++jp) {
       const int n = nbase + 32 * jp + 8 * lq;
@@ -152,7 +154,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
           if constexpr (EPI == GVK_EPI_BIAS_RES_F32_BF16) {
             store_bf16((bf16*)p.out1 + (size_t)m * p.ldo + n);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { ps1 += v[e]; ps2 = __builtin_fmaf(v[e], v[e], ps2); }
+            for (int e = 0; e < 8; ++e) { const float dv = v[e] - cur.pv; ps1 += dv; ps2 = __builtin_fmaf(dv, dv, ps2); }
           }
         } else if constexpr (EPI == GVK_EPI_BIAS_GELU_BF16) {
           if (p.out0 != nullptr) store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);

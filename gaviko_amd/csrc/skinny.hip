@@ -740,7 +740,8 @@ namespace gvk {
 //   blocks [P*B, ...):    one thread per remaining row: mean / rstd from the GEMM's partials (prompt rows are left to the blocks above)
 __global__ __launch_bounds__(256) void prompt_fix_stats_kernel(const float* __restrict__ enh, const float* __restrict__ lat, const float* __restrict__ w,
                                                                float* __restrict__ out, bf16* __restrict__ out16, const float* __restrict__ part,
-                                                               int nparts, float* __restrict__ mean, float* __restrict__ rstd, int B, int T, int P,
+                                                               int nparts, const float* __restrict__ pivot, float* __restrict__ mean,
+                                                               float* __restrict__ rstd, int B, int T, int P,
                                                                int C, int L, float eps) {
   const int M = B * T;
   if ((int)blockIdx.x >= P * B) {
@@ -751,8 +752,11 @@ __global__ __launch_bounds__(256) void prompt_fix_stats_kernel(const float* __re
       const f32x2 v = *(const f32x2*)(part + ((size_t)g * M + m) * 2);
       s1 += v[0]; s2 += v[1];
     }
-    const float mu = s1 / (float)C;
-    const float var = fmaxf(s2 / (float)C - mu * mu, 0.f);
+    // the partials are sums of d = x - pivot and d^2 with pivot ~ the row mean: E[d^2] - E[d]^2 has nothing to cancel (the unshifted
+    // single-pass form loses the variance when |mean| >> std: 1/sqrt(eps) instead of rstd)
+    const float md = s1 / (float)C;
+    const float var = fmaxf(s2 / (float)C - md * md, 0.f);
+    const float mu = (pivot != nullptr ? pivot[m] : 0.f) + md;
     mean[m] = mu;
     rstd[m] = 1.0f / sqrtf(var + eps);
     return;
@@ -796,12 +800,12 @@ __global__ __launch_bounds__(256) void prompt_fix_stats_kernel(const float* __re
 }  // namespace gvk
 
 extern "C" int gvk_prompt_up_fix_stats(const float* enh, const float* lat, const float* w, float* out, void* out16, const float* part, int nparts,
-                                       float* mean, float* rstd, int B, int T, int P, int C, int L, float eps, void* stream) {
+                                       const float* pivot, float* mean, float* rstd, int B, int T, int P, int C, int L, float eps, void* stream) {
   using namespace gvk;
   GVK_REQUIRE(enh && lat && w && out && out16 && part && mean && rstd, "gvk_prompt_up_fix_stats: null pointer");
   GVK_REQUIRE(B > 0 && P > 0 && P <= T && C > 0 && C <= 1024 && L > 0 && L <= 64 && nparts > 0, "gvk_prompt_up_fix_stats: bad arguments");
   const int nblk = P * B + (B * T + 255) / 256;
-  GVK_LAUNCH(prompt_fix_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, enh, lat, w, out, (bf16*)out16, part, nparts, mean, rstd, B, T, P,
+  GVK_LAUNCH(prompt_fix_stats_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, enh, lat, w, out, (bf16*)out16, part, nparts, pivot, mean, rstd, B, T, P,
              C, L, eps > 0.f ? eps : 1e-5f);
   return check_launch("prompt_up_fix_stats");
 }

@@ -34,6 +34,27 @@ def stream_kind(name: str) -> str:
     return "main"
 
 
+_LAYER_PAT = re.compile(r"\.(?:local_attns|prompt_projs|layers)\.(\d+)\.")
+
+
+def ready_layer(name: str, share_factor: int = 1, layers_per_bucket: int = 4) -> int:
+    """The layer whose backward completes the bucket `name` belongs to (-1: tensors without a layer index -- prompts, head -- final only
+    at the end of the sweep)."""
+    m = _LAYER_PAT.search("." + name)
+    if m is None:
+        return -1
+    first_layer = int(m.group(1)) * (share_factor if ("local_attns" in name or "prompt_projs" in name) else 1)
+    return (first_layer // layers_per_bucket) * layers_per_bucket
+
+
+def flat_order(names: Sequence[str], share_factor: int = 1, layers_per_bucket: int = 4) -> List[str]:
+    """`names` in the order the engine lays the flat gradient buffer out: grouped by completion order of the backward sweep (highest
+    ready layer first, unindexed tensors last), the given order kept inside a group (stable).  Every group of buckets that becomes final
+    together is then ONE contiguous slice of the buffer -- one plain all_reduce per group, public API only."""
+    key = lambda n: (lambda r: (1, 0) if r < 0 else (0, -r))(ready_layer(n, share_factor, layers_per_bucket))
+    return sorted(names, key=key)
+
+
 def plan_buckets(names: Sequence[str], numels: Sequence[int], depth: int, share_factor: int = 1, layers_per_bucket: int = 4, kinds: bool = False):
     """-> list of (ready_layer, start, end) element ranges of the flat buffer, sorted by the order they become ready.
 
@@ -45,16 +66,10 @@ def plan_buckets(names: Sequence[str], numels: Sequence[int], depth: int, share_
     for n in numels:
         offs.append(o)
         o += n
-    pat = re.compile(r"\.(?:local_attns|prompt_projs|layers)\.(\d+)\.")
     ranges: List[Tuple[int, int, int]] = []
     rkinds: List[str] = []
     for name, off, n in zip(names, offs, numels):
-        m = pat.search("." + name)
-        if m is None:
-            ready = -1
-        else:
-            first_layer = int(m.group(1)) * (share_factor if ("local_attns" in name or "prompt_projs" in name) else 1)
-            ready = (first_layer // layers_per_bucket) * layers_per_bucket      # bucket completes at its lowest layer
+        ready = ready_layer(name, share_factor, layers_per_bucket)              # bucket completes at its lowest layer
         kind = stream_kind(name) if ready >= 0 else "main"
         if ranges and ranges[-1][0] == ready and ranges[-1][2] == off and rkinds[-1] == kind:
             ranges[-1] = (ready, ranges[-1][1], off + n)
@@ -91,20 +106,30 @@ class GradReducer:
         except Exception:
             return "none"
 
+    @staticmethod
+    def _merge_adjacent(pieces):
+        """Slices of one buffer that sit back to back become one slice (the engine lays the flat buffer out by completion group --
+        flat_order -- so a group of buckets that is final together is ONE slice; any other layout still works, with more collectives)."""
+        out = []
+        for t in sorted(pieces, key=lambda t: t.data_ptr()):
+            if out and out[-1].data_ptr() + out[-1].numel() * out[-1].element_size() == t.data_ptr() and out[-1].dtype == t.dtype:
+                prev = out[-1]
+                out[-1] = torch.as_strided(prev, (prev.numel() + t.numel(),), (1,))     # same storage, same offset, both slices
+            else:
+                out.append(t)
+        return out
+
     def _mean_pieces(self, pieces):
-        """Mean all-reduce of several slices of the flat buffer as ONE collective launch where the backend can: RCCL takes them as a
-        coalesced group with ReduceOp.AVG (the 1/world factor is applied inside the collective kernel -- no separate scaling launch on the
-        collective stream); gloo (CPU tests, one-GPU rehearsals) has neither, so it sums and scales slice by slice.  For a power-of-two
-        world both forms give the same bits (x / 2^k is exact)."""
+        """Mean all-reduce of a group of slices of the flat buffer: adjacent slices are merged first, so with the engine's layout this is
+        ONE plain all_reduce.  RCCL applies the 1/world factor inside the collective kernel (ReduceOp.AVG: no separate scaling launch
+        on the collective stream); gloo (CPU tests, one-GPU rehearsals) has no AVG, so it sums and scales.  For a power-of-two world both
+        forms give the same bits (x / 2^k is exact)."""
         if not pieces:
             return
+        pieces = self._merge_adjacent(pieces)
         if pieces[0].is_cuda and self._backend() == "nccl":
-            if len(pieces) == 1:
-                dist.all_reduce(pieces[0], op=dist.ReduceOp.AVG, group=self.group)
-            else:
-                with dist.distributed_c10d._coalescing_manager(self.group):
-                    for t in pieces:
-                        dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
+            for t in pieces:
+                dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
             return
         for t in pieces:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

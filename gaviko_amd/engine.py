@@ -146,6 +146,9 @@ class Engine(GavikoPaths, PeftPaths):
         # (and its dependency gap) less per layer on the main stream.  128-column tiles only (C % 128 == 0: ViT-B / ViT-L).
         self._fold_ln1 = (self._fuse_up and self._fuse_proj and dim % 128 == 0 and L.diag_env("GAVIKO_HIP_FOLD_LN1", "1") != "0")
         self._fold: Dict[str, torch.Tensor] = {}
+        self._fold_version = None
+        self._fold_names = frozenset(self._fold_deps()) if self._fold_ln1 else frozenset()
+        self._fold_on = False
         self._marks = []
         self.plan_marks = {}                # plan id -> [(name, event id)]
         self._bucket_marks = {}             # (stream kind, layer) -> event of the pass being issued / recorded: gradients of that layer final
@@ -156,6 +159,8 @@ class Engine(GavikoPaths, PeftPaths):
         self._ws = None
         self._step = 0
         self._flat_grad = None
+        self._flat_names = None
+        self.bucket_layers = 4              # layout of the flat gradient buffer: completion groups of this many layers (set_bucket_layers)
         self._saved = None
 
     def _gemm(self, a, w, M, out0, alg_k=None, **kw):
@@ -231,16 +236,41 @@ class Engine(GavikoPaths, PeftPaths):
                     w[f"{tag}{i}"] = ops.to_operand(src, None if self.fp32 else w.get(f"{tag}{i}"), self.adt)   # fp32: the parameter itself
                 if need_dgrad and (stale or not self._have_dgrad):
                     w[f"{tag}{i}_t"] = ops.transpose_operand(src, w.get(f"{tag}{i}_t"), self.adt)
-        if self._fold_ln1 and (stale or not self._fold) and not self.p[self.names.qkv_weight(0)].requires_grad:      # (unused when the backbone trains)
-            for i in range(1, self.depth):
-                a = self.names.attn(i)
-                Wq, g, b = self._d(self.names.qkv_weight(i)), self._d(a + ".norm.weight"), self._d(a + ".norm.bias")
-                w16 = ops.to_operand((Wq * g[None, :]).contiguous(), self._fold.get(f"w{i}"), self.adt)
-                self._fold[f"w{i}"] = w16
-                self._fold[f"c1_{i}"] = w16.float().sum(1).contiguous()          # row sums of the bf16 operand the MFMAs actually multiply
-                self._fold[f"c2_{i}"] = (Wq * b[None, :]).sum(1).contiguous()      # beta . W^T
         self._have_dgrad = self._have_dgrad and not stale or need_dgrad
         self._w16_version = version
+
+    def _fold_deps(self) -> List[str]:
+        """Every tensor the folded qkv operands of layers 1.. are built from: the projection weight AND the LayerNorm affine."""
+        n = []
+        for i in range(1, self.depth):
+            a = self.names.attn(i)
+            n += [self.names.qkv_weight(i), a + ".norm.weight", a + ".norm.bias"]
+        return n
+
+    def _ensure_fold(self) -> bool:
+        """Folded operands (gamma o W in bf16, c1 = its row sums, c2 = beta . W^T) of every layer > 0, rebuilt IN PLACE (recorded plans keep
+        their pointers) whenever one of their sources changed -- whichever tensors train.  Called by every forward that may take the
+        folded path (the ones that keep no GEMM inputs: a frozen backbone, or any eval / no-grad forward), so the path never meets a
+        missing or stale operand (a Gaviko(freeze_vit=False) eval forward at ViT-B used to raise KeyError 'w1' here)."""
+        if not self._fold_ln1:
+            return False
+        names = self._fold_deps()
+        version = tuple(self.p[n]._version for n in names) + tuple(self.p[n].data_ptr() for n in names)
+        if version == self._fold_version and self._fold:
+            return True
+        for i in range(1, self.depth):
+            a = self.names.attn(i)
+            Wq, g, b = self._d(self.names.qkv_weight(i)), self._d(a + ".norm.weight"), self._d(a + ".norm.bias")
+            w16 = ops.to_operand((Wq * g[None, :]).contiguous(), self._fold.get(f"w{i}"), self.adt)
+            self._fold[f"w{i}"] = w16
+            for key, val in ((f"c1_{i}", w16.float().sum(1)),                # row sums of the bf16 operand the MFMAs actually multiply
+                             (f"c2_{i}", (Wq * b[None, :]).sum(1))):          # beta . W^T
+                if key in self._fold:
+                    self._fold[key].copy_(val)
+                else:
+                    self._fold[key] = val.contiguous()
+        self._fold_version = version
+        return True
 
     # ------------------------------------------------------------------ workspace
     def _seed_base(self, train: bool) -> int:
@@ -264,6 +294,8 @@ class Engine(GavikoPaths, PeftPaths):
         With `names`, only if one of them is a backbone weight the engine keeps operand shadows of."""
         if names is None or any(n in self._shadowed for n in names):
             self._w16_version = None
+        if names is None or any(n in self._fold_names for n in names):
+            self._fold_version = None
 
     def workspace(self, B: int, device, train: bool):
         key = (B, train, str(device))
@@ -527,6 +559,7 @@ class Engine(GavikoPaths, PeftPaths):
             self._bb_buffers(ws, B, img.device, sv["wgrad"])
         key = (B, train, sv["attn_drop"], sv["proj_drop"], len(bb), sv["wgrad"], sv["bdrop"], sv["edrop"], sv["pdrop"])
         self._keep_inputs = bool(sv["wgrad"])
+        self._fold_on = (not self._keep_inputs) and self._ensure_fold()      # ONE place decides: operands are current whenever the fold is taken
         self._run("fwd", key, lambda: self._forward_impl(ws, sv))
         self._saved = sv if train else None
         self._saved_key = key
@@ -641,7 +674,7 @@ class Engine(GavikoPaths, PeftPaths):
                 with torch.cuda.stream(gpa):
                     self._gpa_fwd_latents(ws, i, si, ws["G1"][si], ws["Lc"][go], M, B, False)
             up_in_fc2 = gaviko and fused and fuse_up
-            fold_next = bool(up_in_fc2 and self._fold_ln1 and i + 1 < self.depth and _on("noside") and not _FIX_IN_LN and not self._keep_inputs)
+            fold_next = bool(up_in_fc2 and self._fold_on and i + 1 < self.depth and _on("noside") and not _FIX_IN_LN)
             # fc2 carries proj_up of the PLAIN latents of every row (ready right behind the LayerNorm); the GPA has the two GEMMs' time
             # to finish, and only the P prompt rows it replaces are fixed up afterwards
             self._mlp_block_fwd(ws, i, si, ws["G1"][si], gout, Mi, train, sv["bdrop"],
@@ -661,7 +694,7 @@ class Engine(GavikoPaths, PeftPaths):
                     self._wait(None, "gpa")                          # enh ready
                     sn = ws["stat"][si + 1 if train else 0]
                     ops.prompt_up_fix_stats(pending_fix["enh"], pending_fix["lat"], pending_fix["wup"], ws["G"][go], ws["xg16"], ws["spart"],
-                                            sn[0], sn[1], B, self.T, self.P, C, self.Lat)
+                                            sn[0], sn[1], B, self.T, self.P, C, self.Lat, pivot=ws["stat"][si][2])
                     pending_fix = None
                 elif i + 1 == self.depth or not _FIX_IN_LN:
                     self._wait(None, "gpa")                          # enh ready
@@ -768,7 +801,8 @@ class Engine(GavikoPaths, PeftPaths):
                     ldo=self.ldx, drop_p=pdrop, seed=SEED_LAYER + 8 * i + 2, seed_ptr=ws["seed"])
         if self._keep_inputs:
             ops.copy_(ws["sav"]["act"][si], ws["act"])
-        so = dict(epilogue=ops.EPI_BIAS_RES_F32_BF16, out1=ws["xg16"], stat_part=ws["spart"]) if stats_out else dict(epilogue=ops.EPI_BIAS_RES_F32)
+        so = (dict(epilogue=ops.EPI_BIAS_RES_F32_BF16, out1=ws["xg16"], stat_part=ws["spart"], stat_pivot=ws["stat"][si][2]) if stats_out     # pivot = mean of the residual row (LN2)
+              else dict(epilogue=ops.EPI_BIAS_RES_F32))
         self._gemm(ws["act"], w[f"fc2{i}"], M, gout, bias=d(m + ".net.4.bias"), res=g1,
                    K=self.ldx if up_in_fc2 else self.mlp,      # the GPA latents ride this GEMM as 64 extra K columns (self._fuse_up)
                    alg_k=self.mlp + self.Lat if up_in_fc2 else None,
@@ -778,8 +812,27 @@ class Engine(GavikoPaths, PeftPaths):
     def trainable_names(self) -> List[str]:
         return [k for k, p in self.p.items() if p.requires_grad]
 
+    def flat_names(self) -> List[str]:
+        """Trainable tensors in the order of the flat gradient buffer: grouped by the bucket of the backward sweep that completes them
+        (distributed.flat_order), so that what the data-parallel reducer sends together is one contiguous slice."""
+        from .distributed import flat_order
+        key = (tuple(self.trainable_names()), self.bucket_layers)
+        if self._flat_names is None or self._flat_names[0] != key:
+            self._flat_names = (key, flat_order(key[0], self.cfg.get("share_factor", 1) if self.kind == "gaviko" else 1, self.bucket_layers))
+        return self._flat_names[1]
+
+    def set_bucket_layers(self, k: int) -> None:
+        """Layers per gradient bucket of the flat layout (model.make_reducer passes its own).  Changing it moves gradient views: recorded
+        plans hold their addresses, so they are dropped."""
+        k = int(k)
+        if k != self.bucket_layers:
+            self.bucket_layers = k
+            self._flat_grad = None
+            self._graphs.clear()
+            self._calls.clear()
+
     def _grad_views(self, device) -> Dict[str, torch.Tensor]:
-        names = self.trainable_names()
+        names = self.flat_names()
         sig = tuple((n, tuple(self.p[n].shape)) for n in names)
         if self._flat_grad is None or self._flat_grad["sig"] != sig or self._flat_grad["buf"].device != device:
             total = sum(self.p[n].numel() for n in names)

@@ -26,7 +26,7 @@ if os.environ.get("GPU_MAX_HW_QUEUES") is None:
     except Exception:
         pass
 
-ABI_VERSION = 8                                   # gvk_abi_version() of the library these declarations describe
+ABI_VERSION = 9                                   # gvk_abi_version() of the library these declarations describe
 # GAVIKO_HIP_DIAG=1 (tools/ only): load the measurement build libgaviko_hip_diag.so (`python -m gaviko_amd.build --diag`) -- the product
 # library ignores every A/B switch of the kernel sources and exports no diagnostics (include/gaviko_hip_diag.h)
 DIAG = os.environ.get("GAVIKO_HIP_DIAG", "0") == "1"
@@ -47,7 +47,7 @@ class GemmDesc(C.Structure):
         ("epilogue", C.c_int32), ("rows_in", C.c_int32), ("rows_out", C.c_int32), ("row_off", C.c_int32),
         ("tile", C.c_int32), ("drop_p", C.c_float), ("seed", C.c_uint64),
         ("scale_cols", C.c_int32), ("col_scale", C.c_float),
-        ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p), ("ln_c1", C.c_void_p), ("stat_part", C.c_void_p),
+        ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p), ("ln_c1", C.c_void_p), ("stat_part", C.c_void_p), ("stat_pivot", C.c_void_p),
     ]
 
 
@@ -115,7 +115,7 @@ SIGNATURES = {
     "gvk_layernorm_bwd_affine": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gvk_attention_fwd_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "gvk_qkv_prescale_bf16": [_P, _I, _I, _I, _F, _P],
-    "gvk_prompt_up_fix_stats": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "gvk_prompt_up_fix_stats": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "gvk_attention_bwd_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "gvk_attention_fwd_f32_dropout": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P, _P],
     "gvk_attention_bwd_f32_dropout": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P, _P],

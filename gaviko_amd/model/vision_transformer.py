@@ -85,11 +85,31 @@ class _HotPathFn(torch.autograd.Function):
     def backward(ctx, dlogits):
         owner = ctx.owner
         eng = owner._engine()
+        # The node hands autograd no input gradients (the engine writes every parameter's .grad itself), so torch.autograd.grad(loss, params)
+        # or backward(inputs=...) would come back with None for all of them without a word.  Those calls run the engine with a non-empty
+        # execution plan; a plain loss.backward() runs it with an empty one, for which _will_engine_execute_node answers True for any node.
+        probe = getattr(torch._C, "_will_engine_execute_node", None)
+        node = next((fn for fn, _ in ctx.next_functions if fn is not None), None)
+        if probe is not None and node is not None:
+            try:
+                plain = bool(probe(node))
+            except RuntimeError:
+                plain = False                   # (a leaf that autograd.grad captures: the probe refuses to answer -- same situation)
+            if not plain:
+                raise L.GavikoHipError("gaviko_amd models write parameter gradients into .grad themselves: use loss.backward() "
+                                       "(torch.autograd.grad(loss, params) / backward(inputs=...) would silently receive None for every "
+                                       "parameter); read the gradients from p.grad afterwards")
         if eng._fwd_gen != ctx.gen:
             raise L.GavikoHipError("backward() of a forward whose saved activations were overwritten by a later training-mode forward of the "
                                    "same model (e.g. loss = f(model(x1), model(x2))): the engine keeps one forward's state -- concatenate "
                                    "the inputs into one batch, or call backward() before the next forward")
         named = owner._named_cache()[1]
+        if owner.__dict__.get("_grads_zeroed"):
+            # model.zero_grad(set_to_none=False) has just zeroed the flat buffer in ONE launch and verified that every trainable .grad is
+            # its view: the engine overwrites, nothing to walk (the per-parameter bookkeeping below costs the host ~0.6 ms per step)
+            owner.__dict__["_grads_zeroed"] = False
+            eng.backward(dlogits, reducer=owner.__dict__.get("_reducer"))
+            return (None, None, None) + (None,) * ctx.nparams
         had_grads = [n for n in eng.trainable_names() if named[n].grad is not None]
         if not had_grads:
             gv = eng.backward(dlogits, reducer=owner.__dict__.get("_reducer"))
@@ -140,6 +160,23 @@ class HotPathModule(nn.Module):
     def _drop_config(self) -> dict:
         return {}
 
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        """nn.Module.zero_grad.  set_to_none=False on a model whose gradients are already the views of the engine's flat buffer (i.e. after
+        the first backward) is ONE memset of that buffer instead of a walk over 442 tensors; the next backward then overwrites it without
+        per-parameter bookkeeping.  Everything else (set_to_none=True, the first step, gradients assigned by the caller) takes
+        torch's own path."""
+        self.__dict__["_grads_zeroed"] = False
+        eng = self.__dict__.get("_eng")
+        if not set_to_none and eng is not None and eng._flat_grad is not None:
+            named, views = self._named_cache()[1], eng._flat_grad["views"]
+            names = eng.trainable_names()
+            if len(views) == len(names) and all(named[n].grad is views.get(n) for n in names) and \
+                    all(p.grad is None for n, p in named.items() if n not in views):
+                eng._flat_grad["buf"].zero_()
+                self.__dict__["_grads_zeroed"] = True
+                return
+        super().zero_grad(set_to_none=set_to_none)
+
     def _load_backbone(self) -> None:
         """The constructor step of vision_transformer.py:140-145 (and its five copies): converted timm weights loaded with
         strict=False.  Offline: the raw timm state dict is read from ./pretrained/<timm model name> -- where the reference leaves it
@@ -179,10 +216,12 @@ class HotPathModule(nn.Module):
         into one plan per bucket (every cut joins the three streams: +0.7 ms per step at ViT-B gaviko, tools/bench_reducer.py)."""
         from ..distributed import GradReducer
         named = dict(self.named_parameters())
-        names = [n for n, p in named.items() if p.requires_grad]
         depth = mapping_vit(self._cfg["backbone"])[0]
         if layers_per_bucket is None:
             layers_per_bucket = 4 if mode == "events" else depth
+        eng = self._engine()
+        eng.set_bucket_layers(layers_per_bucket)
+        names = eng.flat_names()                      # the flat buffer's own order: every ready group of buckets is one contiguous slice
         r = GradReducer(names, [named[n].numel() for n in names], depth, self._cfg.get("share_factor", 1), layers_per_bucket, group, mode)
         self.attach_reducer(r)
         return r

@@ -41,7 +41,7 @@ def _chk(t, dtype, what, min_elems=0):
 
 def gemm_nt(a, w, M, out0, *, epilogue, out1=None, bias=None, res=None, aux=None, pos=None,
             lda=None, ldo=None, ldres=None, ldaux=None, rows_in=0, rows_out=0, row_off=0, tile=0, N=None, K=None,
-            drop_p=0.0, seed=0, seed_ptr=None, scale_cols=0, col_scale=1.0, ln_mean=None, ln_rstd=None, ln_c1=None, stat_part=None):
+            drop_p=0.0, seed=0, seed_ptr=None, scale_cols=0, col_scale=1.0, ln_mean=None, ln_rstd=None, ln_c1=None, stat_part=None, stat_pivot=None):
     """Y[M,N] = A[M,K] . W[N,K]^T with a fused epilogue.  The operand dtype picks the kernel: bf16 -> gvk_gemm_nt_bf16 (MFMA
     bf16, fp32 accumulate), fp32 -> gvk_gemm_nt_f32 (every 16-bit slot of the epilogue table then carries fp32)."""
     adt = a.dtype
@@ -66,11 +66,12 @@ def gemm_nt(a, w, M, out0, *, epilogue, out1=None, bias=None, res=None, aux=None
                    L.ptr(seed_ptr) if (seed_ptr is not None and drop_p > 0) else None,
                    M, N, K, lda, ldw, ldo, (N if ldres is None else ldres), (N if ldaux is None else ldaux),
                    epilogue, rows_in, rows_out, row_off, tile, float(drop_p), int(seed), int(scale_cols), float(col_scale),
-                   L.ptr(ln_mean), L.ptr(ln_rstd), L.ptr(ln_c1), L.ptr(stat_part))
+                   L.ptr(ln_mean), L.ptr(ln_rstd), L.ptr(ln_c1), L.ptr(stat_part), L.ptr(stat_pivot))
     _chk(ln_mean, torch.float32, "gemm ln_mean", M)
     _chk(ln_rstd, torch.float32, "gemm ln_rstd", M)
     _chk(ln_c1, torch.float32, "gemm ln_c1", N)
     _chk(stat_part, torch.float32, "gemm stat_part", (N // 64) * M * 2)
+    _chk(stat_pivot, torch.float32, "gemm stat_pivot", M)
     if adt == torch.float32:
         L.check(L.load().gvk_gemm_nt_f32(C.byref(d), L.stream_ptr()), "gvk_gemm_nt_f32")
     else:
@@ -119,7 +120,7 @@ def prompt_up_fix(enh, lat, w, out, B, T, P, C_, L_):
     L.check(L.load().gvk_prompt_up_fix(L.ptr(enh), L.ptr(lat), L.ptr(w), L.ptr(out), B, T, P, C_, L_, L.stream_ptr()), "gvk_prompt_up_fix")
 
 
-def prompt_up_fix_stats(enh, lat, w, out, out16, part, mean, rstd, B, T, P, C_, L_, eps=1e-5):
+def prompt_up_fix_stats(enh, lat, w, out, out16, part, mean, rstd, B, T, P, C_, L_, eps=1e-5, pivot=None):
     """prompt_up_fix + the bf16 copy of the fixed rows + mean / rstd of EVERY row from the fc2 GEMM's per-row partials (the first LayerNorm of
     the next layer is folded into its qkv projection; gaviko_hip.h: gvk_prompt_up_fix_stats)."""
     _chk(enh, torch.float32, "prompt_up_fix enh", B * P * L_)
@@ -131,7 +132,8 @@ def prompt_up_fix_stats(enh, lat, w, out, out16, part, mean, rstd, B, T, P, C_, 
     _chk(part, torch.float32, "prompt_up_fix part", nparts * B * T * 2)
     _chk(mean, torch.float32, "prompt_up_fix mean", B * T)
     _chk(rstd, torch.float32, "prompt_up_fix rstd", B * T)
-    L.check(L.load().gvk_prompt_up_fix_stats(L.ptr(enh), L.ptr(lat), L.ptr(w), L.ptr(out), L.ptr(out16), L.ptr(part), nparts, L.ptr(mean), L.ptr(rstd),
+    _chk(pivot, torch.float32, "prompt_up_fix pivot", B * T)
+    L.check(L.load().gvk_prompt_up_fix_stats(L.ptr(enh), L.ptr(lat), L.ptr(w), L.ptr(out), L.ptr(out16), L.ptr(part), nparts, L.ptr(pivot), L.ptr(mean), L.ptr(rstd),
                                              B, T, P, C_, L_, eps, L.stream_ptr()), "gvk_prompt_up_fix_stats")
 
 

@@ -103,7 +103,7 @@ class FusedAdamOneCycle:
             if eng.flat_grad is None:
                 raise L.GavikoHipError("FusedAdamOneCycle.step(): run a backward first (the engine owns the flat gradient buffer)")
             named = dict(self.model.named_parameters())
-            params = [named[n] for n in eng.trainable_names()]
+            params = [named[n] for n in eng.flat_names()]              # the flat gradient buffer's layout
             flat = eng.flat_grad
         else:
             params, flat = self._params, self._flat

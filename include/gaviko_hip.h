@@ -22,7 +22,7 @@ extern "C" {
 const char* gvk_last_error(void);
 /* returns 950 when the code object loaded on the current device is gfx950, else <0 */
 int gvk_device_check(void);
-int gvk_abi_version(void);   /* 8 */
+int gvk_abi_version(void);   /* 9 */
 
 /* ------------------------------------------------------------------ launch plans
  * The reference drives its step from the Python interpreter (train.py:296-319: one autograd node per op).  Here one
@@ -101,8 +101,12 @@ typedef struct gvk_gemm_desc {
      bias[n] = sum_c beta[c] W[n][c] -- LayerNorm(x) . W^T (vision_transformer.py:49,61-62) without the LayerNorm launch.  NULL = off */
   const float* ln_mean; const float* ln_rstd; const float* ln_c1;
   /* GVK_EPI_BIAS_RES_F32_BF16: also write per-row partial (sum, sum of squares) of the fp32 output, f32 [N / 64][M][2] (64-column groups
-     of the 128-wide tiles); gvk_prompt_up_fix_stats turns them into the mean / rstd the folded consumer reads.  NULL = off */
+     of the 128-wide tiles); gvk_prompt_up_fix_stats turns them into the mean / rstd the folded consumer reads.  NULL = off.
+     The partials are taken of (x - stat_pivot[m]), stat_pivot f32 [M] = any per-row estimate of the row mean (the engine passes the
+     mean of the residual row, which its LayerNorm has just computed): shifted sums do not cancel when |mean| >> std, which the plain
+     E[x^2] - mean^2 form does.  stat_pivot NULL = pivot 0 */
   float* stat_part;
+  const float* stat_pivot;
 } gvk_gemm_desc;
 int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream);
 /* number of 64-column groups gvk_gemm_desc.stat_part is indexed by for an N-column output */
@@ -273,9 +277,10 @@ int gvk_skinny_up(const gvk_skinny_up_desc* d, void* stream);
 int gvk_prompt_up_fix(const float* enh, const float* lat, const float* w, float* out, int B, int T, int P, int C, int L, void* stream);
 /* The same for a layer whose FIRST LayerNorm is folded into its qkv projection (gvk_gemm_desc.ln_mean): besides fixing the P prompt rows of
  * out (and of its bf16 copy out16, the folded GEMM's A operand) it finishes the row statistics -- mean / rstd f32 [B*T] of every row, from
- * the per-row partials part f32 [nparts][B*T][2] the fc2 GEMM left (gvk_gemm_desc.stat_part), of the prompt rows from the rows themselves. */
+ * the per-row partials part f32 [nparts][B*T][2] the fc2 GEMM left (gvk_gemm_desc.stat_part: sums of (x - pivot[m]) and of its square;
+ * pivot f32 [B*T] = that GEMM's stat_pivot, NULL = 0), of the prompt rows from the rows themselves (two-pass). */
 int gvk_prompt_up_fix_stats(const float* enh, const float* lat, const float* w, float* out, void* out16, const float* part, int nparts,
-                            float* mean, float* rstd, int B, int T, int P, int C, int L, float eps, void* stream);
+                            const float* pivot, float* mean, float* rstd, int B, int T, int P, int C, int L, float eps, void* stream);
 
 /* outer: out[l][c] (transposed=0) or out[c][l] (transposed=1) (+)= sum_m narrow[m][l] * wide'[m][c];
  *        colsum[c] (+)= sum_m wide'[m][c] (optional).  wide' = LN(wide) when mean/rstd(/gamma/beta) are given, times the

@@ -144,3 +144,39 @@ def test_bench_keeps_a_callers_queue_setting_and_rank_cpu_sets_partition():
     parts = [bench.rank_cpu_set(r_, 8, cpus) for r_ in range(8)]
     assert all(len(p_) == 4 for p_ in parts) and sorted(c for p_ in parts for c in p_) == cpus
     assert bench.rank_cpu_set(5, 8, [0, 1]) in ([0], [1])                # fewer CPUs than ranks: one each, shared
+
+
+def test_flat_layout_makes_every_ready_group_one_contiguous_slice():
+    """The engine lays the flat gradient buffer out by completion group (distributed.flat_order): what becomes final together is ONE slice,
+    reduced by one plain all_reduce (public API; round 3 used the private coalescing manager).  Any other layout still reduces correctly,
+    with more collectives."""
+    from gaviko_amd.distributed import flat_order, ready_layer
+    names, numels = _trainable(CFG)
+    size = dict(zip(names, numels))
+    for share, lpb in ((1, 4), (2, 4), (1, 12), (1, 1)):
+        cfg = dict(CFG, share_factor=share)
+        names, numels = _trainable(cfg)
+        size = dict(zip(names, numels))
+        order = flat_order(names, share, lpb)
+        assert sorted(order) == sorted(names)
+        # stable inside a group: the gate parameters of one GPA module stay contiguous and in module order (the kernel writes them as one slice)
+        for s in range(12 // share):
+            mod = [n for n in names if f".prompt_projs.{s}." in "." + n]
+            at = order.index(mod[0])
+            assert order[at: at + len(mod)] == mod
+        red = GradReducer(order, [size[n] for n in order], depth=12, share_factor=share, layers_per_bucket=lpb)
+        flat = torch.zeros(sum(numels))
+        groups = red.ready_groups()
+        want_groups = len({ready_layer(n, share, lpb) for n in names if ready_layer(n, share, lpb) >= 0})       # the lowest one carries the unindexed tensors too
+        assert len(groups) == want_groups
+        for _, members in groups:
+            pieces = [flat[red.ranges[i][1]: red.ranges[i][2]] for i in members]
+            merged = GradReducer._merge_adjacent(pieces)
+            assert len(merged) == 1 and merged[0].numel() == sum(p.numel() for p in pieces)
+            assert merged[0].data_ptr() == min(p.data_ptr() for p in pieces)
+    # the parameter order of the module tree is NOT contiguous per group (why the layout exists) -- and still merges what it can
+    names, numels = _trainable(CFG)
+    red = GradReducer(names, numels, depth=12, share_factor=1, layers_per_bucket=4)
+    flat = torch.zeros(sum(numels))
+    counts = [len(GradReducer._merge_adjacent([flat[red.ranges[i][1]: red.ranges[i][2]] for i in members])) for _, members in red.ready_groups()]
+    assert max(counts) > 1

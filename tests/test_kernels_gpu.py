@@ -163,6 +163,41 @@ def test_layernorm_folded_into_gemm(dev, M, C_, N):
     assert err < 1.2e-2 and err < 2.5 * err2 + 2e-3
 
 
+@pytest.mark.parametrize("offset", [0.0, 40.0, 3000.0])
+def test_fold_row_statistics_with_large_common_offset(dev, offset):
+    """Rows whose mean dwarfs their spread (|mean| / std up to 1500): the fc2 epilogue accumulates its (sum, sum of squares) partials of
+    x - pivot[m] (pivot = the residual row's mean, as the engine passes it), so mean / rstd match the two-pass LayerNorm kernel; the
+    unshifted single-pass form E[x^2] - mean^2 returns var = 0 (rstd = 1/sqrt(eps)) at the largest offset."""
+    from gaviko_amd import ops
+    B, T, P, Lt, K0, C_ = 2, 300, 4, 20, 128, 768
+    M = B * T
+    a0 = _bf16_round(_rand((M, K0), 41))
+    w0 = _bf16_round(_rand((C_, K0), 42, 2.0 / math.sqrt(K0)))
+    bias0 = _rand((C_,), 43, 0.3)
+    res = _rand((M, C_), 44, 1.0) + offset * (1.0 + _rand((M, 1), 45, 0.5))      # every row its own large offset
+    A = ops.act_zeros(M, K0, torch.bfloat16, dev); A[:M] = a0.to(dev).bfloat16()
+    G = ops.act_zeros(M, C_, torch.float32, dev)
+    R = ops.act_zeros(M, C_, torch.float32, dev); R[:M] = res.to(dev)
+    G16 = ops.act_zeros(M, C_, torch.bfloat16, dev)
+    part = torch.zeros((C_ // 64) * M * 2, device=dev)
+    pivot = R[:M].mean(1).contiguous()
+    ops.gemm_nt(A, w0.to(dev).bfloat16().contiguous(), M, G, epilogue=ops.EPI_BIAS_RES_F32_BF16, out1=G16, bias=bias0.to(dev), res=R, stat_part=part,
+                stat_pivot=pivot)
+    mean, rstd = torch.zeros(M, device=dev), torch.zeros(M, device=dev)
+    enh, lat, wup = _rand((B, P, Lt), 46), _rand((M, Lt), 47), _rand((C_, Lt), 48, 0.3)
+    ops.prompt_up_fix_stats(enh.to(dev).contiguous(), lat.to(dev).contiguous(), wup.to(dev).contiguous(), G, G16, part, mean, rstd, B, T, P, C_, Lt,
+                            pivot=pivot)
+    m2, r2 = torch.zeros(M, device=dev), torch.zeros(M, device=dev)
+    xn = ops.act_zeros(M, C_, torch.bfloat16, dev)
+    ops.layernorm_fwd(G, torch.ones(C_, device=dev), torch.zeros(C_, device=dev), M, C_, y16=xn, mean=m2, rstd=r2)     # two-pass kernel, same rows
+    torch.cuda.synchronize()
+    x = G[:M].cpu().double()
+    mu_ref, rs_ref = x.mean(1), (x.var(1, unbiased=False) + 1e-5).rsqrt()
+    assert (mean.cpu().double() - mu_ref).abs().max().item() < 2e-6 * max(1.0, mu_ref.abs().max().item())
+    assert ((rstd.cpu().double() - rs_ref) / rs_ref).abs().max().item() < 2e-4
+    assert ((rstd - r2) / r2).abs().max().item() < 2e-4
+
+
 def test_patch_embed_path(dev):
     """patchify + GEMM(PATCH epilogue) == conv3d + flatten/transpose + pos, scattered into [P+1 .. ] rows."""
     from gaviko_amd import ops

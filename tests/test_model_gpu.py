@@ -481,3 +481,35 @@ def test_gaviko_eval_forward_equals_train_forward_without_dropout(dev, backbone,
         outs = [m(x).detach().clone() for _ in range(4)]
     for o in outs:
         assert torch.equal(o, train_logits)
+
+
+def test_unfrozen_gaviko_vit_b_eval_forward_after_an_optimizer_step(dev):
+    """Gaviko(freeze_vit=False) at ViT-B (dim % 128 == 0: the LayerNorm-1 fold is on): an eval / no-grad forward keeps no GEMM inputs and so
+    takes the FOLDED qkv path, whose operands (gamma o W, c1, c2) depend on tensors that now train.  A training step, a torch Adam step on
+    every tensor, then an eval forward must give the oracle's logits for the UPDATED weights (round 3: KeyError 'w1', or silently the
+    pre-update operands), and a second update must be picked up as well."""
+    import oracle
+    from gaviko_amd.utils import synth
+    m, cfg = build("gaviko", "vit-b16", dict(GAVIKO, freeze_vit=False), dev)
+    eng = m._engine()
+    assert eng._fold_ln1, "ViT-B gaviko is expected to fold LayerNorm 1 into the qkv projection"
+    x = torch.from_numpy(synth.volumes(0, 2))
+    y = torch.from_numpy(synth.labels(0, 2))
+    opt = torch.optim.Adam(m.parameters(), lr=2e-3)
+    prev = None
+    for _ in range(2):
+        m.train()
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(m(x.to(dev)), y.to(dev)).backward()
+        opt.step()
+        m.eval()
+        with torch.no_grad():
+            got = m(x.to(dev)).cpu().double()
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        with torch.no_grad():
+            want = oracle.gaviko_forward(sd, x, dict(cfg, attn_drop=0.0, proj_drop=0.0)).double()
+        d, r = note("gaviko_b16_unfrozen_eval", "logits after an Adam step (folded LN1 operands rebuilt)", got, want)
+        assert r < 1.2e-2, (d, r)
+        if prev is not None:
+            assert (got - prev).abs().max().item() > 1e-4, "the second update must change the eval logits"
+        prev = got

@@ -131,3 +131,91 @@ def test_second_forward_before_backward_raises(dev):
     with pytest.raises(lib.GavikoHipError, match="saved activations"):
         (a.sum() + b.sum()).backward()
     model(x[:1]).sum().backward()                            # a single forward / backward pair still works afterwards
+
+
+def test_fft_stepped_by_torch_adam_and_clip_grad_norm(dev):
+    """What the unchanged train.py does (train.py:185-189,315-318): torch.optim.Adam over the trainable tensors + clip_grad_norm_ on an
+    UNFROZEN model.  torch's in-place updates bump the parameters' version counters, which is what refreshes the engine's bf16 operand
+    shadows: after a few steps the logits must equal those of a FRESH model loaded with the trained state_dict, and the clipped norm
+    torch reports must be the norm of the engine's flat gradient buffer."""
+    from gaviko_amd.registry import build_model
+    from gaviko_amd.utils import synth
+    cfg = _tiny_cfg("fft")
+    model = build_model(cfg)
+    filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    model.to(dev).train()
+    x = torch.from_numpy(synth.volumes(0, 2)).to(dev)
+    y = torch.from_numpy(synth.labels(0, 2)).to(dev)
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-3, eps=1e-8)
+    first = None
+    for step in range(3):
+        opt.zero_grad()
+        logits = model(x)
+        if first is None:
+            first = logits.detach().clone()
+        torch.nn.functional.cross_entropy(logits, y).backward()
+        flat_norm = model._engine().flat_grad.norm().item()
+        total = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0).item()
+        assert abs(total - flat_norm) < 1e-4 * max(1.0, flat_norm)
+        opt.step()
+    model.eval()
+    with torch.no_grad():
+        got = model(x).clone()
+    assert (got - first).abs().max().item() > 1e-4
+    fresh = build_model(cfg)
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    fresh.to(dev).eval()
+    with torch.no_grad():
+        want = fresh(x)
+    assert torch.equal(got, want), f"stale operand shadows after torch.optim.Adam: max diff {(got - want).abs().max().item():.3e}"
+
+
+def test_autograd_grad_on_a_hot_path_model_fails_loudly(dev):
+    """The autograd node returns no input gradients (the engine writes .grad itself, one anchor parameter ties the node into the graph):
+    torch.autograd.grad must raise instead of handing back None for every tensor."""
+    from gaviko_amd import lib
+    from gaviko_amd.registry import build_model
+    from gaviko_amd.utils import synth
+    model = build_model(_tiny_cfg("linear"))
+    filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    model.to(dev).train()
+    x = torch.from_numpy(synth.volumes(0, 1)).to(dev)
+    y = torch.from_numpy(synth.labels(0, 1)).to(dev)
+    params = [p for p in model.parameters() if p.requires_grad]
+    with pytest.raises(lib.GavikoHipError, match="loss.backward"):
+        torch.autograd.grad(torch.nn.functional.cross_entropy(model(x), y), params, allow_unused=True)
+    with pytest.raises(lib.GavikoHipError, match="loss.backward"):
+        torch.autograd.grad(torch.nn.functional.cross_entropy(model(x), y), params[-1:], allow_unused=True)     # one tensor, not the anchor
+    torch.nn.functional.cross_entropy(model(x), y).backward()          # the supported call still works afterwards
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+
+
+def test_zero_grad_fast_path_equals_the_walk(dev):
+    """model.zero_grad(set_to_none=False) after the first backward is one memset of the flat buffer and lets the next backward skip its
+    per-parameter bookkeeping: gradients must be bit-identical to the set_to_none=True route, and accumulation (no zero_grad between two
+    backwards) must still add."""
+    from gaviko_amd.registry import build_model
+    from gaviko_amd.utils import synth
+    cfg = _tiny_cfg("gaviko", num_prompts=8, prompt_latent_dim=20, local_dim=20, local_k=(3, 6, 6), DHW=(10, 10, 10), attn_drop=0.0, proj_drop=0.0,
+                    freeze_vit=True, share_factor=1)
+    model = build_model(cfg)
+    filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    model.to(dev)
+    model.train()
+    x = torch.from_numpy(synth.volumes(0, 2)).to(dev)
+    y = torch.from_numpy(synth.labels(0, 2)).to(dev)
+    step = lambda: torch.nn.functional.cross_entropy(model(x), y).backward()
+    model.zero_grad(set_to_none=True); step()
+    ref = model._engine().flat_grad.clone()
+    for _ in range(4):                                                  # past the warm-up: replayed plans
+        model.zero_grad(set_to_none=False)
+        assert model.__dict__["_grads_zeroed"] and float(model._engine().flat_grad.abs().max()) == 0.0
+        step()
+        assert torch.equal(model._engine().flat_grad, ref)
+    step()                                                              # no zero_grad: torch semantics = accumulate
+    assert torch.allclose(model._engine().flat_grad, 2 * ref, rtol=1e-6, atol=1e-12)
+    model.zero_grad(set_to_none=True)
+    assert all(p.grad is None for p in model.parameters())
