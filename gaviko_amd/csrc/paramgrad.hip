@@ -7,16 +7,22 @@
 // i.e. outer products  D[l][c] = sum_m narrow'[m][l] * wide'[m][c]  over M = 4..8 k token rows, plus a handful of tiny column sums /
 // (J x L) products over the same rows.
 //
-// Structure.  The grid is a job list: [outer job 0 | outer job 1 | small jobs].  An outer-product workgroup (4 waves) owns one 64-column
-// tile and FOUR row slabs (one per wave, <= 64 rows each: the whole slab's wide rows are requested before the first MFMA -- one HBM round
-// trip per wave), multiplies on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products), sums its four waves' tiles through
-// LDS and writes ONE partial tile [(L+1)][64] (row L = column sum of wide').  The partial tiles of a column tile are then summed by the
-// workgroup that arrives LAST at the tile's ticket counter -- in slab order, so the result does not depend on who that is: deterministic,
-// no second launch, no 5-us dependent hop.  The hand-off between workgroups is the agent-scope release / ticket / acquire form
-// (cdna_hip_programming.md Guideline 16): plain partial stores, every wave drains its stores, workgroup barrier, ONE lane releases at
-// agent scope and takes the ticket; the last arriver acquires at agent scope before any wave of it loads a partial.  The ticket words are
-// zero at allocation and the last arriver writes its word back to zero, so a replayed plan needs no memset (launches that share ticket
-// words are ordered by their stream).
+// Structure.  The grid is a job list: [outer jobs | small jobs], sized to about one workgroup per CU (beside the backbone's GEMM
+// workgroups a CU has registers for one more 4-wave workgroup at most, so a grid of several rounds only queues: the first form of this
+// kernel, 700-1000 workgroups of 64 rows per wave, ran 46-72 us per launch).  An outer-product workgroup (4 waves) owns one 64-column tile
+// and a contiguous range of rows, a quarter per wave; a wave streams its rows in chunks of 32 through two register buffers (the next
+// chunk's loads are always in flight behind the current chunk's MFMAs; every load is unconditional, out-of-range rows are clamped and
+// zeroed afterwards, so the compiler can count vmcnt exactly), multiplies on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32
+// products) and keeps ONE accumulator tile for all its rows.  The four waves' tiles are summed through LDS and the workgroup writes ONE
+// partial tile [(L+1)][64] (row L = column sum of wide').  The partial tiles of a column tile (7-14 of them) are then summed by the
+// workgroup that arrives LAST at the tile's ticket counter -- in row-range order, so the result does not depend on who that is:
+// deterministic, no second launch, no 5-us dependent hop.  The hand-off between workgroups is recipe R1 of cdna_hip_programming.md
+// Guideline 16: the partial tiles are stored WRITE-THROUGH (sc1: they leave the XCD's L2 at once, so no release fence -- an agent-scope
+// release is a write-back of every dirty line of that L2, and beside the backbone's GEMMs, whose fp32 outputs sit dirty in it, hundreds
+// of workgroups doing that cost the step 12 %), every storing wave drains its stores, workgroup barrier, ONE lane takes the ticket
+// (agent-scope atomic); the last arriver acquires at agent scope (drops its CU's stale L1 lines) before any wave of it loads a partial.
+// The ticket words are zero at allocation and the last arriver writes its word back to zero, so a replayed plan needs no memset
+// (launches that share ticket words are ordered by their stream).
 #include "common.hpp"
 #include "dropout.hpp"
 #include "../../include/gaviko_hip.h"
@@ -24,11 +30,13 @@
 
 namespace gvk {
 
-constexpr int kPgRows = 64;          // rows per wave (one slab)
-constexpr int kPgMaxOuter = 2;
+constexpr int kPgCh = 32;            // rows per chunk per wave
+constexpr int kPgMaxOuter = 3;
 constexpr int kPgMaxSmall = 8;
-constexpr int kPgMaxSg = 40;         // slab groups per outer job (M <= 40 * 256 rows)
+constexpr int kPgMaxSg = 64;         // row ranges (workgroups) per column tile of an outer job
 constexpr int kPgRedSlabs = 32;      // row slabs of a small job
+constexpr int kPgTargetWgs = 240;    // outer-product workgroups per launch: about one per CU
+constexpr int kPgMinRows = 128;      // ... but never fewer rows per workgroup than this
 
 struct PgOuter {
   const float* narrow; const float* wide; const float* narrow2; const float* wide2;   // rows M1.. come from (narrow2, wide2)
@@ -38,7 +46,8 @@ struct PgOuter {
   const float* aff_w; const float* aff_g; const float* aff_b; float* aff_dgamma; float* aff_dbeta; float* aff_dbias;
   unsigned long long seed; unsigned int drop_thresh; float inv_keep;                // wide' *= dropout mask of element (m, c)
   int M, M1, T, P, transposed, accumulate;
-  int wg0, nsg, tick0; long scr0;                                                    // first workgroup / slab groups / first ticket / scratch offset (floats)
+  int C, nct;                                                                       // columns (= row stride) of wide, 64-column tiles
+  int wg0, nsg, tick0; long scr0;                                                    // first workgroup / row ranges / first ticket / scratch offset (floats)
 };
 struct PgSmall {
   const float* a; const float* b; const float* a2; float* out;                       // as gvk_reduce_job
@@ -48,16 +57,21 @@ struct PgArgs {
   PgOuter o[kPgMaxOuter];
   PgSmall s[kPgMaxSmall];
   float* scratch; int* tickets; const unsigned long long* seed_ptr;
-  int nouter, nsmall, small_wg0, C, L;
+  int nouter, nsmall, small_wg0, L;
 };
 
-// One lane publishes the workgroup's partial stores and takes the ticket; returns (to every thread) whether this workgroup arrived last.
+// write-through (sc1) stores of a partial: 16 bytes through a buffer resource over the workgroup's slab, 4 bytes as an agent-scope atomic store
+__device__ __forceinline__ void pg_store16_wt(__amdgpu_buffer_rsrc_t rsrc, int byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(*(u32x4*)&v, rsrc, byte_off, 0, 16);     // aux 16 = sc1
+}
+__device__ __forceinline__ void pg_store4_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The workgroup's partial stores (all sc1) are drained and ONE lane takes the ticket; returns (to every thread) whether this workgroup
+// arrived last.
 __device__ __forceinline__ bool pg_arrive_last(int* ticket, int n, int* s_flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains its partial stores ...
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains its write-through stores ...
   __syncthreads();                                           // ... before the one lane that signals for all of them
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // write the XCD L2's dirty lines back
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (kept explicit: the compiler may drop the fence's own wait)
     const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (t == n - 1) ? 1 : 0;
     if (last) {
@@ -74,11 +88,12 @@ __device__ __forceinline__ bool pg_arrive_last(int* ticket, int n, int* s_flag) 
 template <int NT>
 __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
   constexpr int NW = NT * 16;                                // padded narrow width (L + 1 <= NW)
-  __shared__ float lds[4 * kPgRows * 32];                    // narrow rows of the four slabs, later the four waves' accumulator tiles (32 KiB)
-  __shared__ float st[4][kPgRows][2];
+  constexpr int kNP = 4;                                     // narrow float4 pieces per lane and chunk (32 rows x L / 4 <= 7 pieces)
+  __shared__ float lds[4 * 2 * kPgCh * 32];                  // [wave][buffer][row][NW] narrow rows, later the four waves' accumulator tiles (32 KiB)
+  __shared__ float st[4][2][kPgCh][2];
   __shared__ float sw[4][32];
   __shared__ int s_flag;
-  const int C = p.C, L = p.L;
+  const int L = p.L;
   const int lane = lane_id(), wave = wave_id();
   const int bid = blockIdx.x;
 
@@ -127,7 +142,7 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
     lds[threadIdx.x] = acc;
     __syncthreads();
     float* part = p.scratch + jb.scr0 + (size_t)chunk * jb.nslab * 64;
-    if (sl == 0 && oi < no) part[slab * 64 + oi] = (lds[oi] + lds[64 + oi]) + (lds[128 + oi] + lds[192 + oi]);
+    if (sl == 0 && oi < no) pg_store4_wt(part + slab * 64 + oi, (lds[oi] + lds[64 + oi]) + (lds[128 + oi] + lds[192 + oi]));
     if (!pg_arrive_last(p.tickets + jb.tick0 + chunk, jb.nslab, &s_flag)) return;
     if (threadIdx.x < no) {
       float a4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -144,101 +159,127 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
   }
 
   // -------------------------------------------------------------------- outer products
-  const int k = (p.nouter > 1 && bid >= p.o[1].wg0) ? 1 : 0;
-  const PgOuter& J = p.o[k];
-  const int nct = C >> 6;
+  int k = 0;
+#pragma unroll
+  for (int q = 1; q < kPgMaxOuter; ++q)
+    if (q < p.nouter && bid >= p.o[q].wg0) k = q;
+  const PgOuter J = p.o[k];                                   // BY VALUE: scalar loads into SGPRs (through a reference hipcc indexed the kernarg block per lane: a dependent vector load + vmcnt(0) in front of every data load)
+  const int C = J.C, nct = J.nct;
   const int local = bid - J.wg0;
   const int ct = local % nct, sg = local / nct;
-  const int rows_per = (J.M + 4 * J.nsg - 1) / (4 * J.nsg);      // <= kPgRows by the host's choice of nsg
-  const int r0 = min(J.M, (4 * sg + wave) * rows_per);
-  const int nr = min(J.M, r0 + rows_per) - r0;
+  const int rows_wg = (J.M + J.nsg - 1) / J.nsg;
+  const int rw = (rows_wg + 3) >> 2;                           // rows per wave
+  const int wg_lo = min(J.M, sg * rows_wg), wg_hi = min(J.M, wg_lo + rows_wg);
+  const int r0 = min(wg_hi, wg_lo + wave * rw), r1 = min(wg_hi, r0 + rw);
+  const int nr = r1 - r0;
   const int j = lane & 15, kq = lane >> 4;
   const int c = ct * 64 + 4 * j;
+  const bool cok = c < C;
+  const int cl = cok ? c : 0;                                  // clamped column of this lane's loads
+  const int L4 = L >> 2;                                       // (the host admits L % 4 == 0 only)
   unsigned long long seed = J.seed;
   if (J.drop_thresh != 0u && p.seed_ptr != nullptr) seed += *p.seed_ptr;
-  float (*nar)[NW] = (float (*)[NW])(lds + wave * kPgRows * 32);
+  float (*nar)[kPgCh][NW] = (float (*)[kPgCh][NW])(lds + wave * 2 * kPgCh * 32);     // [buffer][row][NW]
+  const int mlast = max(J.M - 1, 0);
 
-  // the whole slab's wide rows: 16 float4 per lane requested before anything else waits
-  auto wide_row = [&](int gm) -> const float* {
-    return (J.narrow2 != nullptr && gm >= J.M1) ? J.wide2 + (size_t)(gm - J.M1) * C : J.wide + (size_t)gm * C;
+  auto narrow_row = [&](int m) -> const float* {
+    const float* src = (J.narrow2 != nullptr && m >= J.M1) ? J.narrow2 + (size_t)(m - J.M1) * L : J.narrow + (size_t)m * L;
+    if (J.lat_override != nullptr) {
+      const int s = m / J.T, t = m - s * J.T;
+      if (t < J.P) src = J.lat_override + ((size_t)s * J.P + t) * L;
+    }
+    return src;
   };
-  f32x4 xr[4][4];
+  auto wide_row = [&](int m) -> const float* {
+    return (J.narrow2 != nullptr && m >= J.M1) ? J.wide2 + (size_t)(m - J.M1) * C : J.wide + (size_t)m * C;
+  };
+  // one chunk's loads: 8 float4 of wide, up to 4 float4 of narrow, the row statistics.  UNCONDITIONAL (rows / columns clamped): the
+  // waits in front of a chunk's consumers are then exact counts, and the chunk behind stays in flight
+  auto load = [&](f32x4 (&x)[8], f32x4 (&nv)[kNP], float& mu, float& rs, int ch) {
+    const int rb = r0 + kPgCh * ch;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int r = 16 * i + 4 * u + kq;
-      xr[i][u] = (r < nr) ? *(const f32x4*)(wide_row(r0 + r) + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  // this wave's narrow rows -> LDS (column L = 1: row L of the result is the column sum of wide'), four elements per lane and pass
-  for (int i0 = lane; i0 < nr * NW; i0 += 4 * 64) {
-    float v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * 64;
-      const int r = i / NW, l = i - r * NW, m = r0 + r;
-      v[u] = (l == L) ? 1.f : 0.f;
-      if (i < nr * NW && l < L) {
-        const float* src = (J.narrow2 != nullptr && m >= J.M1) ? J.narrow2 + (size_t)(m - J.M1) * L : J.narrow + (size_t)m * L;
-        if (J.lat_override != nullptr) {
-          const int s = m / J.T, t = m - s * J.T;
-          if (t < J.P) src = J.lat_override + ((size_t)s * J.P + t) * L;
-        }
-        v[u] = src[l];
-      }
+    for (int t = 0; t < kNP; ++t) {
+      const int e = lane + 64 * t;
+      const int r = e / L4, pc = e - r * L4;
+      nv[t] = *(const f32x4*)(narrow_row(min(rb + r, mlast)) + 4 * min(pc, L4 - 1));
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * 64;
-      if (i < nr * NW) nar[i / NW][i % NW] = v[u];
+    for (int u = 0; u < 8; ++u) x[u] = *(const f32x4*)(wide_row(min(rb + 4 * u + kq, mlast)) + cl);
+    if (J.mean != nullptr) {
+      const int m = min(rb + (lane & 31), mlast);
+      mu = J.mean[m];
+      rs = J.rstd[m];
     }
-  }
-  if (J.mean != nullptr && lane < nr) {
-    st[wave][lane][0] = J.mean[r0 + lane];
-    st[wave][lane][1] = J.rstd[r0 + lane];
-  }
-  __syncthreads();
-  if (J.aff_w != nullptr && lane < NW) {                       // S[l] = sum_m narrow[m][l] over this wave's rows (the affine epilogue needs it)
-    float s = 0.f;
-    for (int r = 0; r < nr; ++r) s += nar[r][lane];
-    sw[wave][lane] = s;
-  }
+  };
   f32x4 acc[NT][4];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[t][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};                          // affine jobs: this lane's column (l = lane) of S = sum_m narrow[m][l]
+  auto compute = [&](f32x4 (&x)[8], f32x4 (&nv)[kNP], float mu, float rs, const int buf, int ch) {
+    const int rb = r0 + kPgCh * ch;
+    if (rb >= r1) return;                                      // wave-uniform: a chunk wholly past this wave's rows (its loads were issued anyway)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (16 * i >= nr) break;                                   // wave-uniform
+    for (int t = 0; t < kNP; ++t) {
+      const int e = lane + 64 * t;
+      const int r = e / L4, pc = e - r * L4;
+      if (r < kPgCh) *(f32x4*)(&nar[buf][r][4 * pc]) = (rb + r < r1) ? nv[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (J.mean != nullptr && lane < kPgCh) { st[wave][buf][lane][0] = mu; st[wave][buf][lane][1] = rs; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (wave-private LDS region: program order is enough, the compiler must keep it)
+    __builtin_amdgcn_wave_barrier();
+    if (J.aff_w != nullptr && lane < NW) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int r = 16 * i + 4 * u + kq;
-      f32x4 xv = xr[i][u];
-      if (r < nr) {
-        if (J.drop_thresh != 0u) {
+      for (int r = 0; r < kPgCh; ++r) s4[r & 3] += nar[buf][r][lane];
+    }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) xv[e] *= drop_scale(seed, (unsigned long long)(r0 + r) * C + c + e, J.drop_thresh, J.inv_keep);
-        }
-        if (J.mean != nullptr) {
-          const float mu = st[wave][r][0], rs = st[wave][r][1];
+    for (int u = 0; u < 8; ++u) {
+      if (rb + 4 * u >= r1) break;                             // wave-uniform: k-steps wholly past the rows
+      const int r = 4 * u + kq;
+      const bool ok = (rb + r < r1) && cok;
+      f32x4 xv = x[u];
+      if (J.drop_thresh != 0u) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) xv[e] = (xv[e] - mu) * rs;
-        }
+        for (int e = 0; e < 4; ++e) xv[e] *= drop_scale(seed, (unsigned long long)(rb + r) * C + c + e, J.drop_thresh, J.inv_keep);
       }
-      if (16 * i + 4 * u < nr) {                               // wave-uniform: skip k-steps wholly past the slab
+      if (J.mean != nullptr) {
+        const float m_ = st[wave][buf][r][0], r_ = st[wave][buf][r][1];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const float a = (r < nr) ? nar[r][t * 16 + j] : 0.f;
+        for (int e = 0; e < 4; ++e) xv[e] = (xv[e] - m_) * r_;
+      }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[t][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xv[e], acc[t][e], 0, 0, 0);
-        }
+      for (int e = 0; e < 4; ++e) xv[e] = ok ? xv[e] : 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float a = nar[buf][r][t * 16 + j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xv[e], acc[t][e], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_wave_barrier();
+  };
+  // columns L.. of every narrow row never change: [1, 0, 0, ...] (row L of the result is the column sum of wide')
+  for (int i = lane; i < 2 * kPgCh * (NW - L); i += 64) {
+    const int r = i / (NW - L), l = L + (i - r * (NW - L));
+    nar[0][r][l] = (l == L) ? 1.f : 0.f;                       // (rows 32.. of "buffer 0" are buffer 1)
   }
+  {
+    const int nch = (nr + kPgCh - 1) / kPgCh;
+    f32x4 xa[8], xb[8], na[kNP], nb[kNP];
+    float mua = 0.f, rsa = 0.f, mub = 0.f, rsb = 0.f;
+    load(xa, na, mua, rsa, 0);
+    for (int ch = 0; ch < nch; ch += 2) {
+      load(xb, nb, mub, rsb, ch + 1);
+      compute(xa, na, mua, rsa, 0, ch);
+      load(xa, na, mua, rsa, ch + 2);
+      compute(xb, nb, mub, rsb, 1, ch + 1);
+    }
+  }
+  if (J.aff_w != nullptr && lane < NW) sw[wave][lane] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
   // the four waves' tiles -> one: every wave leaves its 16 NT accumulator registers in LDS, wave w then sums its share in wave order
-  __syncthreads();                                             // (every wave is done reading its narrow rows)
-  float (*red)[16 * NT][64] = (float (*)[16 * NT][64])lds;     // [wave][register][lane], 16 KiB per tile row NT = 1, 32 KiB NT = 2
+  __syncthreads();                                             // (every wave is done with its narrow rows)
+  float (*red)[16 * NT][64] = (float (*)[16 * NT][64])lds;     // [wave][register][lane]
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -246,8 +287,10 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) red[wave][(t * 4 + e) * 4 + q][lane] = acc[t][e][q];
   __syncthreads();
-  float* slab = p.scratch + J.scr0 + ((size_t)ct * J.nsg + sg) * ((L + 2) * 64);
-  // wave w finishes tile row t = w / (4 / NT) ... : the (t, q) pairs are dealt to the waves; a lane then holds the four e of one (l, 4 columns)
+  const int stride = (L + 2) * 64;
+  float* slab = p.scratch + J.scr0 + ((size_t)ct * J.nsg + sg) * stride;
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, stride * 4, 0x00020000);
+  // the (t, q) pairs are dealt to the waves; a lane then holds the four e of one (l, 4 columns)
   for (int tq = wave; tq < NT * 4; tq += 4) {
     const int t = tq >> 2, q = tq & 3;
     const int l = t * 16 + 4 * kq + q;                         // D row = 4 * (lane >> 4) + register
@@ -257,24 +300,22 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
       const int rg = (t * 4 + e) * 4 + q;
       o[e] = (red[0][rg][lane] + red[1][rg][lane]) + (red[2][rg][lane] + red[3][rg][lane]);
     }
-    if (l <= L) *(f32x4*)(slab + l * 64 + 4 * j) = o;
+    if (l <= L) pg_store16_wt(srs, (l * 64 + 4 * j) * 4, o);
   }
   if (J.aff_w != nullptr && wave == 0 && lane < NW)
-    slab[(L + 1) * 64 + lane] = (sw[0][lane] + sw[1][lane]) + (sw[2][lane] + sw[3][lane]);
+    pg_store4_wt(slab + (L + 1) * 64 + lane, (sw[0][lane] + sw[1][lane]) + (sw[2][lane] + sw[3][lane]));
 
   if (!pg_arrive_last(p.tickets + J.tick0 + ct, J.nsg, &s_flag)) return;
 
-  // ---- last arriver of this column tile: sum the slab groups' tiles in slab order, then the epilogue
-  const float* tile0 = p.scratch + J.scr0 + (size_t)ct * J.nsg * ((L + 2) * 64);
-  const int stride = (L + 2) * 64;
+  // ---- last arriver of this column tile: sum the row ranges' tiles in range order, then the epilogue
+  const float* tile0 = p.scratch + J.scr0 + (size_t)ct * J.nsg * stride;
   float (*qt)[64] = (float (*)[64])lds;                       // affine epilogue: the summed tile [L + 1][64] and S behind it
   const int ngran = (L + 1) * 16 + ((J.aff_w != nullptr) ? NW / 4 : 0);     // float4 granules: the tile (+ the S row)
   for (int g = threadIdx.x; g < ngran; g += 256) {
     f32x4 a4[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) a4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int s = 0; s < kPgMaxSg; s += 4) {
+    for (int s = 0; s < J.nsg; s += 4) {
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (s + u < J.nsg) a4[u] += *(const f32x4*)(tile0 + (size_t)(s + u) * stride + 4 * g);
@@ -285,6 +326,7 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
       *(f32x4*)(&qt[0][0] + 4 * g) = v;                        // rows 0..L-1 = Q, row L = column sum (unused), row L+1.. = S
       continue;
     }
+    if (cc >= C) continue;
     if (l < L) {
       if (J.out != nullptr) {
 #pragma unroll
@@ -293,7 +335,7 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
           *o = J.accumulate ? *o + v[e] : v[e];
         }
       }
-    } else if (J.colsum != nullptr) {
+    } else if (l == L && J.colsum != nullptr) {
       f32x4* o = (f32x4*)(J.colsum + cc);
       *o = J.accumulate ? *o + v : v;
     }
@@ -303,7 +345,7 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
   //   dWd[l][c] = g_c Q[l][c] + b_c S[l],  dgamma_c = sum_l Wd[l][c] Q[l][c],  dbeta_c = sum_l Wd[l][c] S[l],  dbias_l = S[l]
   __syncthreads();
   const float* S = &qt[L + 1][0];
-  if (threadIdx.x < 64) {
+  if (threadIdx.x < 64 && ct * 64 + (int)threadIdx.x < C) {
     const int cc = ct * 64 + threadIdx.x;
     const float gc = J.aff_g[cc], bc = J.aff_b[cc];
     float dg = 0.f, db = 0.f;
@@ -326,15 +368,27 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
 
 static unsigned int pg_drop_threshold(float p) { return drop_threshold_u32(p); }
 
+// rows per outer-product workgroup: the jobs' (rows x column tiles) dealt to about kPgTargetWgs workgroups
+static int pg_rows_target(const gvk_pgrad_outer* outer, int n_outer, int C) {
+  long total = 0;
+  for (int k = 0; k < n_outer; ++k) {
+    const int Cj = outer[k].C > 0 ? outer[k].C : C;
+    total += (long)(outer[k].M + (outer[k].narrow2 ? outer[k].M2 : 0)) * ((Cj + 63) / 64);
+  }
+  return (int)std::max<long>(kPgMinRows, (total + kPgTargetWgs - 1) / kPgTargetWgs);
+}
+static int pg_nsg(int rows, int target) { return std::min(kPgMaxSg, std::max(1, (rows + target - 1) / target)); }
+
 }  // namespace gvk
 
 extern "C" int64_t gvk_param_grads_scratch(const gvk_pgrad_outer* outer, int n_outer, const gvk_reduce_job* small, int n_small, int C, int L) {
   using namespace gvk;
   int64_t n = 0;
+  const int target = n_outer > 0 ? pg_rows_target(outer, n_outer, C) : kPgMinRows;
   for (int k = 0; k < n_outer; ++k) {
     const int M = outer[k].M + (outer[k].narrow2 ? outer[k].M2 : 0);
-    const int nsg = std::max(1, (M + 4 * kPgRows - 1) / (4 * kPgRows));
-    n += (int64_t)(C / 64) * nsg * (L + 2) * 64;
+    const int Cj = outer[k].C > 0 ? outer[k].C : C;
+    n += (int64_t)((Cj + 63) / 64) * pg_nsg(M, target) * (L + 2) * 64;
   }
   for (int k = 0; k < n_small; ++k) {
     const int nout = small[k].b ? small[k].J * small[k].L : small[k].J;
@@ -348,18 +402,19 @@ extern "C" int gvk_param_grads(const gvk_pgrad_outer* outer, int n_outer, const 
   using namespace gvk;
   GVK_REQUIRE(scratch && tickets && n_outer >= 0 && n_outer <= kPgMaxOuter && n_small >= 0 && n_small <= kPgMaxSmall && n_outer + n_small > 0,
               "gvk_param_grads: up to %d outer and %d small jobs, scratch and tickets required", kPgMaxOuter, kPgMaxSmall);
-  GVK_REQUIRE(C > 0 && C % 64 == 0 && L > 0 && L <= 31, "gvk_param_grads: C=%d must be a multiple of 64 and L=%d at most 31", C, L);
+  GVK_REQUIRE(C > 0 && C % 4 == 0 && L > 0 && L <= 28 && L % 4 == 0, "gvk_param_grads: C=%d must be a multiple of 4, L=%d a multiple of 4 up to 28", C, L);
   GVK_REQUIRE(n_outer == 0 || outer != nullptr, "gvk_param_grads: null outer job list");
   GVK_REQUIRE(n_small == 0 || small != nullptr, "gvk_param_grads: null small job list");
   PgArgs a{};
-  a.scratch = scratch; a.tickets = tickets; a.seed_ptr = (const unsigned long long*)seed_ptr; a.C = C; a.L = L;
+  a.scratch = scratch; a.tickets = tickets; a.seed_ptr = (const unsigned long long*)seed_ptr; a.L = L;
   a.nouter = n_outer; a.nsmall = n_small;
   int wg = 0, tick = 0;
   long scr = 0;
-  const int nct = C / 64;
+  const int target = n_outer > 0 ? pg_rows_target(outer, n_outer, C) : kPgMinRows;
   for (int k = 0; k < n_outer; ++k) {
     const gvk_pgrad_outer& d = outer[k];
     GVK_REQUIRE(d.narrow && d.wide && d.M > 0 && (d.out || d.colsum), "gvk_param_grads: outer job %d: null pointer / empty", k);
+    GVK_REQUIRE(d.C >= 0 && d.C % 4 == 0, "gvk_param_grads: outer job %d: C=%d must be a multiple of 4 (0 = the call's C)", k, d.C);
     GVK_REQUIRE((d.mean == nullptr) == (d.rstd == nullptr), "gvk_param_grads: outer job %d: mean / rstd must come together", k);
     GVK_REQUIRE(d.narrow2 == nullptr || (d.wide2 != nullptr && d.M2 > 0 && d.mean == nullptr && d.lat_override == nullptr && d.drop_p <= 0.f),
                 "gvk_param_grads: outer job %d: the second source takes plain rows only", k);
@@ -373,10 +428,10 @@ extern "C" int gvk_param_grads(const gvk_pgrad_outer* outer, int n_outer, const 
     o.aff_w = d.aff_w; o.aff_g = d.aff_gamma; o.aff_b = d.aff_beta; o.aff_dgamma = d.aff_dgamma; o.aff_dbeta = d.aff_dbeta; o.aff_dbias = d.aff_dbias;
     o.seed = d.seed; o.drop_thresh = pg_drop_threshold(d.drop_p); o.inv_keep = d.drop_p > 0.f ? 1.f / (1.f - d.drop_p) : 1.f;
     o.M1 = d.M; o.M = d.M + (d.narrow2 ? d.M2 : 0); o.T = d.T; o.P = d.P; o.transposed = d.transposed; o.accumulate = d.accumulate;
-    o.nsg = std::max(1, (o.M + 4 * kPgRows - 1) / (4 * kPgRows));
-    GVK_REQUIRE(o.nsg <= kPgMaxSg, "gvk_param_grads: outer job %d: %d rows exceed %d", k, o.M, kPgMaxSg * 4 * kPgRows);
+    o.C = d.C > 0 ? d.C : C; o.nct = (o.C + 63) / 64;
+    o.nsg = pg_nsg(o.M, target);
     o.wg0 = wg; o.tick0 = tick; o.scr0 = scr;
-    wg += nct * o.nsg; tick += nct; scr += (long)nct * o.nsg * (L + 2) * 64;
+    wg += o.nct * o.nsg; tick += o.nct; scr += (long)o.nct * o.nsg * (L + 2) * 64;
   }
   a.small_wg0 = wg;
   for (int k = 0; k < n_small; ++k) {
@@ -387,7 +442,7 @@ extern "C" int gvk_param_grads(const gvk_pgrad_outer* outer, int n_outer, const 
     const int rows = j.M + (j.a2 ? j.M2 : 0);
     PgSmall& s = a.s[k];
     s.a = j.a; s.b = j.b; s.a2 = j.a2; s.out = j.out; s.M = rows; s.M1 = j.a2 ? j.M : 0x7fffffff; s.J = j.J; s.L = j.L; s.accumulate = j.accumulate;
-    s.nslab = std::min(kPgRedSlabs, std::max(1, (rows + 127) / 128));
+    s.nslab = std::min(kPgRedSlabs, std::max(1, (rows + 255) / 256));
     const int nchunk = (nout + 63) / 64;
     s.wg0 = wg; s.tick0 = tick; s.scr0 = scr;
     wg += nchunk * s.nslab; tick += nchunk; scr += (long)nchunk * kPgRedSlabs * 64;

@@ -134,6 +134,9 @@ class Engine(GavikoPaths, PeftPaths):
         self._fuse_bnd = self._fuse_local and L.diag_env("GAVIKO_HIP_FUSE_BOUNDARY", "1") != "0"
         self._fuse_next = self._fuse_local and L.diag_env("GAVIKO_HIP_FUSE_NEXT", "1") != "0"
         self._mwsa_pending = None
+        # every parameter gradient of a side-path module of one layer in ONE launch per stream (csrc/paramgrad.hip; round 4)
+        self._pgrad = (kind == "gaviko" and ops.param_grads_supported(cfg.get("prompt_latent_dim", 20), dim)
+                       and L.diag_env("GAVIKO_HIP_PGRAD", "1") != "0")
         # GPA up-projection as K-concatenation of the MLP's second Linear: 64 spare K columns carry the rank-L product in split-bf16 form,
         # A' = [act | lat_hi | lat_lo | lat_hi | 1 | 1], W' = [W_fc2 | Wup_hi | Wup_hi | Wup_lo | b_hi | b_lo] (fp32-grade: the dropped
         # lo.lo term is 2^-16 relative), so x + ff(x) + proj_up(.) (gaviko.py:187 after vision_transformer.py:34) is ONE GEMM and the
@@ -394,6 +397,12 @@ class Engine(GavikoPaths, PeftPaths):
                 ws["rscratch"] = mk(32 * (ng + 2 * Lt * Lt + 3 * Lt + 3 * Lt * Lt + 64))
                 ws["scratch_l"] = mk(max(ops.outer_scratch_elems(Lt, C), 128 * C))      # the MWSA chain runs on its own stream
                 ws["rscratch_l"] = mk(32 * (3 * Lt * Lt + Lt + 64))
+                if self._pgrad:                                                          # one scratch + ticket block per stream (gvk_param_grads)
+                    nct = (C + 63) // 64
+                    ws["pscratch"] = mk(ops.param_grads_scratch_elems(Lt, [nct, nct], [ng, Lt * Lt, Lt, Lt * Lt, Lt, Lt]))
+                    ws["pscratch_l"] = mk(ops.param_grads_scratch_elems(Lt, [nct, nct, 1], []))
+                    ws["ptick"] = torch.zeros(ops.PGRAD_TICKETS, dtype=torch.int32, device=device)
+                    ws["ptick_l"] = torch.zeros(ops.PGRAD_TICKETS, dtype=torch.int32, device=device)
             elif self.kind == "dvpt":
                 Lt, P = self.Lat, self.P
                 mk = lambda *s_: torch.zeros(s_, device=device)

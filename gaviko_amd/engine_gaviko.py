@@ -117,8 +117,6 @@ class GavikoPaths:
         d, C, Lt, P, T, N = self._d, self.C, self.Lat, self.P, self.T, self.N
         g, bw, sc = ws["gp"][i], ws["bw"], ws["scratch"]
         acc = self._acc(i)
-        ops.outer_reduce(narrow=g["xl"], wide=dGout, lat_override=g["enh"], scratch=sc, out=gv[pre + ".proj_up.weight"],
-                         colsum=gv[pre + ".proj_up.bias"], M=M, C=C, L=Lt, T=T, P=P, transposed=1, accumulate=acc)
         # gate parameters: one contiguous slice of the flat gradient buffer, in the kernel's order
         ng = ops.gpa_gate_param_count(Lt, P)
         first = gv[names["ca0_g"]]
@@ -127,10 +125,23 @@ class GavikoPaths:
         gwd, gbd = gv[pre + ".proj_down.0.weight"], gv[pre + ".proj_down.0.bias"]
         BP = B * P
         dqg, dql, prm = bw["dqg"].view(BP, Lt), bw["dql"].view(BP, Lt), g["prm"].view(BP, Lt)
-        ops.reduce_batch([(bw["gate_partials"], None, gate_flat, acc),
-                          (dqg, prm, gv[names["wgq"]], acc), (dqg, None, gv[names["bgq"]], acc),
-                          (dql, prm, gv[names["wlq"]], acc), (dql, None, gv[names["blq"]], acc),
-                          (bw["dzx"], None, gbd, acc, bw["dzl"][par])], ws["rscratch"])      # proj_down bias: both token streams
+        small = [(bw["gate_partials"], None, gate_flat, acc),
+                 (dqg, prm, gv[names["wgq"]], acc), (dqg, None, gv[names["bgq"]], acc),
+                 (dql, prm, gv[names["wlq"]], acc), (dql, None, gv[names["blq"]], acc),
+                 (bw["dzx"], None, gbd, acc, bw["dzl"][par])]                                 # proj_down bias: both token streams
+        if self._pgrad:
+            # ONE launch: proj_up (dWup = dGout^T . comb, dbup = colsum dGout; gaviko.py:187), proj_down fed by both token streams
+            # (dWd = dzx^T . G1 + dzl^T . L'; gaviko.py:155-156) and the six small reductions; partial tiles summed by the last-arriving workgroup
+            ops.param_grads(
+                [dict(narrow=g["xl"], wide=dGout, lat_override=g["enh"], out=gv[pre + ".proj_up.weight"], colsum=gv[pre + ".proj_up.bias"], M=M, T=T, P=P,
+                      transposed=1, accumulate=acc),
+                 dict(narrow=bw["dzx"], wide=ws["G1"][i], narrow2=bw["dzl"][par], wide2=ws["Lc"][i + 1], out=gwd, M=M, M2=B * N, transposed=0,
+                      accumulate=acc)],
+                small, ws["pscratch"], ws["ptick"], C, Lt)
+            return
+        ops.outer_reduce(narrow=g["xl"], wide=dGout, lat_override=g["enh"], scratch=sc, out=gv[pre + ".proj_up.weight"],
+                         colsum=gv[pre + ".proj_up.bias"], M=M, C=C, L=Lt, T=T, P=P, transposed=1, accumulate=acc)
+        ops.reduce_batch(small, ws["rscratch"])
         # proj_down (shared by both streams): dWd = dzx^T.G1 + dzl^T.Lnew
         if M + B * N <= ops.OUTER_MAX_ROWS:                                   # both token streams in one pass
             ops.outer_reduce(narrow=bw["dzx"], wide=ws["G1"][i], narrow2=bw["dzl"][par], wide2=ws["Lc"][i + 1], scratch=sc, out=gwd, M=M, M2=B * N,
@@ -222,7 +233,8 @@ class GavikoPaths:
         if _on("loc_noupdown") and not have_dctx:
             ops.skinny_down(x=dLout, w=d(pre + ".proj_up.weight"), y=bw["dctx"], M=BN, C=C, L=Lt, act=0, w_layout=1, drop_p=pd, seed=seed_p,
                             seed_ptr=sp)
-        if _on("loc_noouter"):
+        pgrad = self._pgrad and _on("loc_noouter") and _on("loc_nosmall") and (3 * Lt) % 4 == 0
+        if _on("loc_noouter") and not pgrad:
             ops.outer_reduce(narrow=m["ctx"], wide=dLout, scratch=sc, out=gv[pre + ".proj_up.weight"], colsum=gv[pre + ".proj_up.bias"],
                              M=BN, C=C, L=Lt, transposed=1, accumulate=acc, drop_p=pd, seed=seed_p, seed_ptr=sp)
         if _on("nowin"):
@@ -233,11 +245,22 @@ class GavikoPaths:
             ops.skinny_down(x=bw["dqkv"], w=d(pre + ".qkv.weight"), y=bw["dlat"], M=BN, C=3 * Lt, L=Lt, act=0, w_layout=1)
         wd = d(pre + ".proj_down.weight")
         g_, b_ = d(pre + ".norm.weight"), d(pre + ".norm.bias")
-        if _on("loc_noouter"):
+        if pgrad:
+            # ONE launch at the tail of the layer's chain (dLout stays untouched until the layer after next rewrites its buffer): proj_up behind
+            # proj_drop (gaviko.py:242-243), LayerNorm + proj_down through Q = dlat^T . xhat and S = colsum dlat (gaviko.py:231-232), the qkv matrix
+            ops.param_grads(
+                [dict(narrow=m["ctx"], wide=dLout, out=gv[pre + ".proj_up.weight"], colsum=gv[pre + ".proj_up.bias"], M=BN, transposed=1, accumulate=acc,
+                      drop_p=pd, seed=seed_p),
+                 dict(narrow=bw["dlat"], wide=lin, mean=m["mean"], rstd=m["rstd"], out=gv[pre + ".proj_down.weight"], aff_w=wd, aff_gamma=g_, aff_beta=b_,
+                      aff_dgamma=gv[pre + ".norm.weight"], aff_dbeta=gv[pre + ".norm.bias"], aff_dbias=gv[pre + ".proj_down.bias"], M=BN, accumulate=acc),
+                 # the qkv matrix (gaviko.py:205,233): dWqkv[c][l] = sum_m dqkv[m][c] lat[m][l] -- the same outer product with a 3L-wide "wide"
+                 dict(narrow=m["lat"], wide=bw["dqkv"], out=gv[pre + ".qkv.weight"], M=BN, C=3 * Lt, transposed=1, accumulate=acc)],
+                [], ws["pscratch_l"], ws["ptick_l"], C, Lt, seed_ptr=sp)
+        if _on("loc_noouter") and not pgrad:
             # Q[l][c] = sum_m dlat[m][l] xhat[m][c], S[l] = sum_m dlat[m][l]  ->  dWd, dbd, dgamma, dbeta in one tiny kernel
             ops.outer_reduce(narrow=bw["dlat"], wide=lin, mean=m["mean"], rstd=m["rstd"], scratch=sc, out=bw["Q"], M=BN, C=C, L=Lt,
                              transposed=0, accumulate=0)
-        if _on("loc_nosmall"):
+        if _on("loc_nosmall") and not pgrad:
             # qkv weight gradient (dqkv^T . lat) and S[l] = sum_m dlat[m][l] in one two-stage reduction
             ops.reduce_batch([(bw["dqkv"], m["lat"], gv[pre + ".qkv.weight"], acc), (bw["dlat"], None, bw["S"], 0)], ws["rscratch_l"])
             ops.ln_lowrank_affine(bw["Q"], bw["S"], wd, g_, b_, gv[pre + ".proj_down.weight"], gv[pre + ".norm.weight"],

@@ -86,6 +86,9 @@ LossDesc = _struct("LossDesc", ["logits", "target", "weights", "loss", "dlogits"
 DropoutDesc = _struct("DropoutDesc", ["x", "out32", "out16", "seed_ptr"], ["M", "N", "ld", "rows_in", "rows_out", "row_off"], ["drop_p"], ["seed"])
 RowProjDesc = _struct("RowProjDesc", ["w", "bias", "y", "z", "y_split"], ["L", "w_layout", "act", "ld_split", "col_split"])
 ReduceJob = _struct("ReduceJob", ["a", "b", "out", "a2"], ["M", "J", "L", "accumulate", "M2"])
+PgradOuter = _struct("PgradOuter", ["narrow", "wide", "narrow2", "wide2", "lat_override", "mean", "rstd", "out", "colsum",
+                                    "aff_w", "aff_gamma", "aff_beta", "aff_dgamma", "aff_dbeta", "aff_dbias"],
+                     ["M", "M2", "T", "P", "transposed", "accumulate", "C"], ["drop_p"], ["seed"])
 HeadDesc = _struct("HeadDesc", ["g", "ln_gamma", "ln_beta", "wh", "bh", "logits", "pooled", "dlogits", "dg", "dwh", "dbh"],
                    ["B", "T", "C", "K", "r0", "R", "accumulate"])
 
@@ -128,6 +131,7 @@ SIGNATURES = {
     "gvk_ln_lowrank_affine": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gvk_colsum": [_P, _P, _P, _I, _I, _I, _P],
     "gvk_reduce_batch": [C.POINTER(ReduceJob), _I, _P, _P],
+    "gvk_param_grads": [C.POINTER(PgradOuter), _I, C.POINTER(ReduceJob), _I, _P, _L, _P, _I, _P, _I, _I, _P],
     "gvk_window_attn_fwd": [C.POINTER(WindowAttnDesc), _P],
     "gvk_window_attn_bwd": [C.POINTER(WindowAttnDesc), _P],
     "gvk_gpa_fwd": [C.POINTER(GpaDesc), _P],
@@ -175,6 +179,7 @@ SIGNATURES = {
 }
 NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, []), "gvk_abi_version": (C.c_int, []),
              "gvk_gpa_gate_param_count": (C.c_int, [C.c_int, C.c_int]), "gvk_gemm_stat_parts": (C.c_int, [C.c_int]), "gvk_minmax_partials": (C.c_int, []),
+             "gvk_param_grads_scratch": (C.c_int64, [C.POINTER(PgradOuter), C.c_int, C.POINTER(ReduceJob), C.c_int, C.c_int, C.c_int]),
              "gvk_plan_begin": (C.c_int, []), "gvk_plan_end": (C.c_int, []), "gvk_plan_abort": (C.c_int, []),
              "gvk_plan_size": (C.c_int, [C.c_int]), "gvk_plan_replay": (C.c_int, [C.c_int]), "gvk_plan_free": (C.c_int, [C.c_int]),
              "gvk_plan_event_record": (C.c_int, [_P]), "gvk_plan_event_wait": (C.c_int, [_P, C.c_int]),
@@ -182,7 +187,7 @@ NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, [
              "gvk_plan_set_timing": (C.c_int, [C.c_int]),
              "gvk_plan_event_elapsed": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)])}
 STRUCTS = {"gvk_gemm_desc": GemmDesc, "gvk_skinny_down_desc": SkinnyDownDesc, "gvk_skinny_up_desc": SkinnyUpDesc,
-           "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob, "gvk_rowproj_desc": RowProjDesc, "gvk_adam_desc": AdamDesc, "gvk_loss_desc": LossDesc, "gvk_dropout_desc": DropoutDesc, "gvk_ssf_colgrad_desc": SsfColgradDesc, "gvk_dvpt_desc": DvptDesc}
+           "gvk_outer_desc": OuterDesc, "gvk_window_attn_desc": WindowAttnDesc, "gvk_gpa_desc": GpaDesc, "gvk_head_desc": HeadDesc, "gvk_reduce_job": ReduceJob, "gvk_pgrad_outer": PgradOuter, "gvk_rowproj_desc": RowProjDesc, "gvk_adam_desc": AdamDesc, "gvk_loss_desc": LossDesc, "gvk_dropout_desc": DropoutDesc, "gvk_ssf_colgrad_desc": SsfColgradDesc, "gvk_dvpt_desc": DvptDesc}
 
 # diag library only (include/gaviko_hip_diag.h): bound when GAVIKO_HIP_DIAG=1 selects libgaviko_hip_diag.so
 DIAG_SIGNATURES = {}

@@ -413,6 +413,72 @@ def outer_scratch_elems(Lat, C_):
     return 128 * (Lat + 1) * C_
 
 
+def _reduce_jobs(jobs, what):
+    arr = (L.ReduceJob * max(1, len(jobs)))()
+    for k, job in enumerate(jobs):
+        a, b, out, acc = job[:4]
+        a2 = job[4] if len(job) > 4 else None
+        for t, n in ((a, "a"), (b, "b"), (out, "out"), (a2, "a2")):
+            _chk(t, torch.float32, f"{what} {n}")
+        M, J = a.shape[0], a.numel() // a.shape[0]
+        Lb = 0 if b is None else b.numel() // b.shape[0]
+        if b is not None and b.shape[0] != M:
+            raise L.GavikoHipError(f"{what}: a and b must have the same number of rows")
+        if out.numel() < (J * Lb if b is not None else J):
+            raise L.GavikoHipError(f"{what}: out too small")
+        if a2 is not None and (b is not None or a2.numel() // a2.shape[0] != J):
+            raise L.GavikoHipError(f"{what}: a2 goes with column sums of the same width only")
+        arr[k] = L.ReduceJob(L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(a2), M, J, Lb, int(bool(acc)), 0 if a2 is None else a2.shape[0])
+    return arr
+
+
+def param_grads_supported(Lat, C_):
+    return C_ % 4 == 0 and 0 < Lat <= 28 and Lat % 4 == 0
+
+
+PGRAD_TICKETS = 256           # ticket words one gvk_param_grads call may need: column tiles of the outer jobs + 64-output chunks of the small jobs (56 for the GPA gates)
+
+
+def param_grads(outer, small, scratch, tickets, C_, Lat, seed_ptr=None):
+    """One launch for every parameter gradient of a rank-L side-path module of one layer (gaviko_hip.h: gvk_param_grads).
+    outer: list of dicts with the gvk_pgrad_outer fields (tensors or None); small: list of (a, b or None, out, accumulate[, a2])."""
+    arr = (L.PgradOuter * max(1, len(outer)))()
+    fields = [f for f, _ in L.PgradOuter._fields_]
+    for k, o in enumerate(outer):
+        bad = set(o) - set(fields)
+        if bad:
+            raise L.GavikoHipError(f"param_grads: unknown field(s) {sorted(bad)}")
+        vals = {}
+        for f, ct in L.PgradOuter._fields_:
+            v = o.get(f)
+            if ct is C.c_void_p:
+                _chk(v, torch.float32, f"param_grads outer[{k}].{f}")
+                vals[f] = L.ptr(v)
+            elif ct is C.c_float:
+                vals[f] = float(v or 0.0)
+            else:
+                vals[f] = int(v or 0)
+        M, M2, Cj = vals["M"], vals["M2"], vals["C"] or C_
+        for f, n in (("narrow", M * Lat), ("wide", M * Cj), ("narrow2", M2 * Lat), ("wide2", M2 * Cj), ("mean", M), ("rstd", M), ("colsum", Cj),
+                     ("out", Lat * Cj), ("aff_w", Lat * Cj), ("aff_gamma", Cj), ("aff_beta", Cj), ("aff_dgamma", Cj), ("aff_dbeta", Cj), ("aff_dbias", Lat)):
+            if o.get(f) is not None and o[f].numel() < n:
+                raise L.GavikoHipError(f"param_grads outer[{k}].{f}: needs >= {n} elements, has {o[f].numel()}")
+        arr[k] = L.PgradOuter(**vals)
+    jobs = _reduce_jobs(small, "param_grads small")
+    _chk(scratch, torch.float32, "param_grads scratch")
+    if tickets is None or tickets.dtype != torch.int32 or not tickets.is_cuda:
+        raise L.GavikoHipError("param_grads: tickets must be an int32 tensor on the HIP device (zero at allocation)")
+    L.check(L.load().gvk_param_grads(arr, len(outer), jobs, len(small), L.ptr(scratch), scratch.numel(), L.ptr(tickets), tickets.numel(),
+                                     L.ptr(seed_ptr), C_, Lat, L.stream_ptr()), "gvk_param_grads")
+
+
+def param_grads_scratch_elems(Lat, col_tiles, small_outputs):
+    """Upper bound of the scratch floats of one gvk_param_grads call: col_tiles = 64-column tiles of each outer job (the kernel deals the
+    jobs' rows to ~240 workgroups, at most 64 row ranges per column tile), small_outputs = outputs of each small job."""
+    slabs = min(240 + sum(col_tiles), 64 * sum(col_tiles))
+    return slabs * (Lat + 2) * 64 + sum(((o + 63) // 64) * 32 * 64 for o in small_outputs)
+
+
 def small_wgrad(a, b, out, scratch, M, J, Lb, accumulate=False):
     for t, n in ((a, "a"), (b, "b"), (out, "out"), (scratch, "scratch")):
         _chk(t, torch.float32, "small_wgrad " + n)

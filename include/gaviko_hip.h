@@ -314,6 +314,30 @@ typedef struct gvk_reduce_job {
   int32_t M, J, L, accumulate, M2;
 } gvk_reduce_job;
 int gvk_reduce_batch(const gvk_reduce_job* jobs, int njobs, float* scratch, void* stream);
+/* Every parameter gradient of one rank-L side-path module of one layer in ONE launch (csrc/paramgrad.hip): up to 3 outer products
+ *   out[l][c] (transposed=0) or out[c][l] (transposed=1) (+)= sum_m narrow'[m][l] * wide'[m][c],   colsum[c] (+)= sum_m wide'[m][c]
+ * (narrow f32 [M][L], wide f32 [M][C]; narrow' = narrow with the rows t < P of every T-row sample taken from lat_override [.][P][L];
+ * wide' = (wide - mean[m]) * rstd[m] when mean / rstd are given, times the dropout mask of element (m, c) when drop_p > 0; a second
+ * source (narrow2, wide2, M2 plain rows) extends the same sum -- one weight fed by two token streams, gaviko.py:155-156), and up to 8
+ * small reductions (gvk_reduce_job) over the same rows.  With aff_w (f32 [L][C] = the projection weight behind a LayerNorm, wide' = xhat)
+ * the product Q is not stored: out[l][c] (+)= gamma_c Q[l][c] + beta_c S[l], aff_dgamma[c] (+)= sum_l w[l][c] Q[l][c],
+ * aff_dbeta[c] (+)= sum_l w[l][c] S[l], aff_dbias[l] (+)= S[l] with S[l] = sum_m narrow[m][l] (gaviko.py:231: autograd of LN + proj_down).
+ * Deterministic: partial tiles are summed in slab order by the workgroup that arrives last at a column tile's ticket word (agent-scope
+ * release / acquire); no atomics on data.  scratch f32 [gvk_param_grads_scratch(...)], tickets int32 [n_tickets] ZERO at allocation (the
+ * kernel leaves them zero); calls that share scratch / tickets must be ordered by their stream.  C % 4 == 0, L % 4 == 0, L <= 28. */
+typedef struct gvk_pgrad_outer {
+  const float* narrow; const float* wide; const float* narrow2; const float* wide2; const float* lat_override;
+  const float* mean; const float* rstd;
+  float* out; float* colsum;
+  const float* aff_w; const float* aff_gamma; const float* aff_beta; float* aff_dgamma; float* aff_dbeta; float* aff_dbias;
+  int32_t M, M2, T, P, transposed, accumulate;
+  int32_t C;                         /* columns (= row stride) of THIS job's wide operand; 0 = the call's C */
+  float drop_p;
+  uint64_t seed;
+} gvk_pgrad_outer;
+int64_t gvk_param_grads_scratch(const gvk_pgrad_outer* outer, int n_outer, const gvk_reduce_job* small, int n_small, int C, int L);
+int gvk_param_grads(const gvk_pgrad_outer* outer, int n_outer, const gvk_reduce_job* small, int n_small, float* scratch,
+                    int64_t scratch_elems, int32_t* tickets, int n_tickets, const void* seed_ptr, int C, int L, void* stream);
 /* out[c] (+)= sum_m x[m][c]; scratch f32 [64*C] */
 int gvk_colsum(const float* x, float* out, float* scratch, int M, int C, int accumulate, void* stream);
 

@@ -545,3 +545,86 @@ def test_skinny_up_with_next_layer_entry_matches_two_kernels(dev, M, C, p):
     _close(rstd_b, rstd_a.double().cpu(), 2e-6, "next rstd")
     _close(lat_b, lat_a.double().cpu(), 1e-5, "next lat")
     _close(qkv_b, qkv_a.double().cpu(), 1e-5, "next qkv")
+
+
+@pytest.mark.parametrize("C,L,B", [(768, 20, 4), (192, 20, 2), (1024, 20, 2), (768, 8, 1)])
+def test_param_grads_one_launch(dev, C, L, B):
+    """gvk_param_grads (csrc/paramgrad.hip): every parameter gradient of a side-path module of one layer in ONE launch -- two outer
+    products (override rows, a second token stream, a dropout mask, the LayerNorm-affine epilogue) and the small reductions -- against
+    float64, in both job mixes the engine issues (GPA stream / MWSA stream); overwrite and accumulate; bitwise repeatable (the partial
+    tiles are summed in slab order whichever workgroup arrives last) and the ticket words come back zero."""
+    import dropmask
+    from gaviko_amd import ops
+    gen = torch.Generator().manual_seed(11 + C + L)
+    r = lambda *s: torch.randn(*s, generator=gen).to(dev)  # noqa: E731
+    T, P, N = 1033, 32, 1000
+    M, BN = B * T, B * N
+    tick = torch.zeros(ops.PGRAD_TICKETS, dtype=torch.int32, device=dev)
+    seedw = torch.full((1,), 77123, dtype=torch.int64, device=dev)
+    # ---- GPA mix: proj_up (override rows, transposed, colsum), proj_down over two token streams, six small jobs
+    xl, enh, dG = r(M, L), r(B, P, L), r(M, C)
+    dzx, G1, dzl, Lc = r(M, L), r(M, C), r(BN, L), r(BN, C)
+    gp, dq, prm = r(B, 3525), r(B * P, L), r(B * P, L)
+    nct = (C + 63) // 64
+    sc = torch.zeros(ops.param_grads_scratch_elems(L, [nct, nct], [3525, L * L, L, L * L, L, L]), device=dev)
+    outs = {}
+    for acc in (0, 1, 1):
+        if acc == 0:
+            dWup, dbup, dWd = torch.zeros(C, L, device=dev), torch.zeros(C, device=dev), torch.zeros(L, C, device=dev)
+            gflat, wq, bq, wq2, bq2, bd = (torch.zeros(n, device=dev) for n in (3525, L * L, L, L * L, L, L))
+        ops.param_grads(
+            [dict(narrow=xl, wide=dG, lat_override=enh, out=dWup, colsum=dbup, M=M, T=T, P=P, transposed=1, accumulate=acc),
+             dict(narrow=dzx, wide=G1, narrow2=dzl, wide2=Lc, out=dWd, M=M, M2=BN, transposed=0, accumulate=acc)],
+            [(gp, None, gflat, acc), (dq, prm, wq, acc), (dq, None, bq, acc), (dq, prm, wq2, acc), (dq, None, bq2, acc), (dzx, None, bd, acc, dzl)],
+            sc, tick, C, L)
+        outs[len(outs)] = [t.clone() for t in (dWup, dbup, dWd, gflat, wq, bq, bd)]
+    comb = xl.double().view(B, T, L).clone()
+    comb[:, :P] = enh.double()
+    comb = comb.view(M, L)
+    want = [dG.double().t() @ comb, dG.double().sum(0), dzx.double().t() @ G1.double() + dzl.double().t() @ Lc.double(), gp.double().sum(0),
+            (dq.double().t() @ prm.double()).reshape(-1), dq.double().sum(0), dzx.double().sum(0) + dzl.double().sum(0)]
+    for k, (got, w) in enumerate(zip(outs[0], want)):
+        assert (got.double() - w).abs().max().item() < 2e-5 * max(1.0, w.abs().max().item()) * (M ** 0.5), k
+    for k, (got, w) in enumerate(zip(outs[2], want)):                 # overwrite + two accumulating calls = 3 x
+        assert (got.double() - 3 * w).abs().max().item() < 6e-5 * max(1.0, w.abs().max().item()) * (M ** 0.5), k
+    assert int(tick.abs().max()) == 0
+    # bitwise repeatable
+    a1, a2 = torch.zeros(L, C, device=dev), torch.zeros(L, C, device=dev)
+    for dst in (a1, a2):
+        ops.param_grads([dict(narrow=dzx, wide=G1, narrow2=dzl, wide2=Lc, out=dst, M=M, M2=BN)], [], sc, tick, C, L)
+    assert torch.equal(a1, a2)
+    # ---- MWSA mix: proj_up behind proj_drop (mask regenerated), LayerNorm + proj_down through the affine epilogue, the qkv matrix
+    p_drop, site = 0.2, 2 * 7 + 1
+    ctx, dL = r(BN, L), r(BN, C)
+    dlat, lin = r(BN, L), r(BN, C) * 2 + 0.5
+    mean, var = lin.mean(1), lin.var(1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    Wd, gam, bet = r(L, C) * 0.1, 1 + 0.2 * r(C), 0.1 * r(C)
+    dqkv, lat = r(BN, 3 * L), r(BN, L)
+    sc2 = torch.zeros(ops.param_grads_scratch_elems(L, [nct, nct, 1], [3 * L * L]), device=dev)
+    res = {}
+    for acc in (0, 1):
+        if acc == 0:
+            dWu, dbu, dWdn = torch.zeros(C, L, device=dev), torch.zeros(C, device=dev), torch.zeros(L, C, device=dev)
+            dgam, dbet, dbias, dWqkv = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(L, device=dev), torch.zeros(3 * L, L, device=dev)
+            dWqkv2 = torch.zeros(3 * L, L, device=dev)
+        ops.param_grads(
+            [dict(narrow=ctx, wide=dL, out=dWu, colsum=dbu, M=BN, transposed=1, accumulate=acc, drop_p=p_drop, seed=site),
+             dict(narrow=dlat, wide=lin, mean=mean, rstd=rstd, out=dWdn, aff_w=Wd, aff_gamma=gam, aff_beta=bet, aff_dgamma=dgam, aff_dbeta=dbet,
+                  aff_dbias=dbias, M=BN, accumulate=acc),
+             dict(narrow=lat, wide=dqkv, out=dWqkv, M=BN, C=3 * L, transposed=1, accumulate=acc)],          # a 3L-wide "wide": the qkv matrix
+            [(dqkv, lat, dWqkv2, acc)], sc2, tick, C, L, seed_ptr=seedw)
+        res[acc] = [t.clone() for t in (dWu, dbu, dWdn, dgam, dbet, dbias, dWqkv, dWqkv2)]
+    mask = torch.from_numpy(dropmask.rows_mask(site + 77123, BN, C, p_drop)).to(dev).double()
+    dLm = dL.double() * mask
+    xhat = (lin.double() - mean.double()[:, None]) * rstd.double()[:, None]
+    Q, S = dlat.double().t() @ xhat, dlat.double().sum(0)
+    want2 = [dLm.t() @ ctx.double(), dLm.sum(0), gam.double()[None, :] * Q + bet.double()[None, :] * S[:, None], (Wd.double() * Q).sum(0),
+             (Wd.double() * S[:, None]).sum(0), S, dqkv.double().t() @ lat.double(), dqkv.double().t() @ lat.double()]
+    for k, (got, w) in enumerate(zip(res[0], want2)):
+        assert (got.double() - w).abs().max().item() < 2e-5 * max(1.0, w.abs().max().item()) * (BN ** 0.5), k
+    for k, (got, w) in enumerate(zip(res[1], want2)):
+        assert (got.double() - 2 * w).abs().max().item() < 4e-5 * max(1.0, w.abs().max().item()) * (BN ** 0.5), k
+    assert int(tick.abs().max()) == 0
+    with pytest.raises(Exception, match="scratch holds"):
+        ops.param_grads([dict(narrow=ctx, wide=dL, out=dWu, M=BN, transposed=1)], [], torch.zeros(64, device=dev), tick, C, L)

@@ -2,6 +2,7 @@
 # The GPU-box command sequences behind profiles/ and DESIGN.md, as ONE script:  gpurun -- 'bash tools/gpu/run.sh <what> [args]'
 #   ab [names..]      headline bench + timing ablations (diag build; results of ablated runs are garbage, only the rate is read)
 #   final <tag>       the measurement set of a round: PMC traffic -> bench lines -> kernel trace (stats + per shape) -> cfg5 -> plan marks
+#   trace [bench args] rocprofv3 --kernel-trace --stats of the bench command -> per-kernel and per-shape tables
 #   tests [expr]      pytest -m gpu (optionally -k expr), output under gpurun_out/
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -49,10 +50,21 @@ final)
   timeout -k 10 200 python tools/plan_marks.py 4 vit-b16 > $O/marks_cfg2.txt 2>&1
   for b in 2 8; do python bench.py --batch $b --steps 30 --warmup 10 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c1-200; done
   ;;
+trace)
+  # kernel trace of the bench command -> per-kernel stats and the per-shape table (no PMC): gpurun_out/trace/
+  O=$R/gpurun_out/trace; mkdir -p $O
+  cd /tmp && export TMPDIR=/tmp
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $O/trace.log 2>&1
+  cd $R
+  cp $(find $O/raw -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
+  python tools/kernel_stats_by_shape.py $O/raw --out $O/by_shape.csv 2> $O/by_shape.err
+  rm -rf $O/raw
+  head -40 $O/kernel_stats.csv | cut -c1-160
+  ;;
 tests)
   O=$R/gpurun_out/tests; mkdir -p $O
   if [ -n "$1" ]; then python -m pytest tests -m gpu -x -q -k "$1" > $O/pytest.log 2>&1; else python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; fi
   tail -5 $O/pytest.log
   ;;
-*) echo "usage: run.sh ab|final|tests" >&2; exit 2 ;;
+*) echo "usage: run.sh ab|final|trace|tests" >&2; exit 2 ;;
 esac
