@@ -58,19 +58,20 @@ __device__ __forceinline__ void cross_one(const float (&q)[L], const float* __re
   for (int l = 0; l < L; ++l) ctx[l] = wave_sum(c[l] * f) * inv;
 }
 
-// dq (already-scaled query space) of softmax cross attention: dq[l] = sum_n A_n (dA_n - delta) tok_n[l]
-template <int L>
+// dq (already-scaled query space) of softmax cross attention: dq[l] = sum_n A_n (dA_n - delta) tok_n[l].  U tokens per lane in flight
+// (4 = one round trip for ~250 tokens per wave; 2 keeps the wave under 128 registers at L = 20)
+template <int L, int U = 4>
 __device__ __forceinline__ void cross_dq(const float (&q)[L], const float (&dc)[L], const float* __restrict__ src, int n, int lane, float lse,
                                          float delta, float (&dq)[L]) {
   float a[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) a[l] = 0.f;
-  for (int i0 = lane; i0 < n; i0 += 256) {
-    float t[4][L];
+  for (int i0 = lane; i0 < n; i0 += 64 * U) {
+    float t[U][L];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) load_tok<L>(src, i0 + 64 * u, n, t[u]);
+    for (int u = 0; u < U; ++u) load_tok<L>(src, i0 + 64 * u, n, t[u]);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       float d = 0.f, da = 0.f;
 #pragma unroll
       for (int l = 0; l < L; ++l) { d = __builtin_fmaf(q[l], t[u][l], d); da = __builtin_fmaf(dc[l], t[u][l], da); }

@@ -6,7 +6,7 @@
 //              global tokens = rows 2P+2 .. T-1 of the global latent (the reference slices [P+1:] twice: 106-107,170)
 //              local tokens  = all N local latents                                            gaviko.py:118-119,172
 //   enh[b][p]  = (gw * ctx_g + (1 - gw) * ctx_l) * imp[b][p]                                 gaviko.py:175,178
-// and the whole backward of the above.  ~25 tiny ATen launches per layer become 2 forward / 3 backward kernels.
+// and the whole backward of the above.  ~25 tiny ATen launches per layer become ONE forward and ONE backward kernel.
 // One wave per (sample, prompt) for the cross-attention (lanes over the ~1000 tokens); the token-side gradient is a
 // gather over the P prompts (no atomics).
 #include "common.hpp"
@@ -160,19 +160,28 @@ __global__ __launch_bounds__(576) void gpa_fwd_kernel(GpaArgs p) {
   if (lane == 0) { p.lse_g[b * p.P + pi] = ls[0]; p.lse_l[b * p.P + pi] = ls[1]; }
 }
 
-// ---- backward, prompt side: same workgroup shape as the forward -- eight waves, waves 0-3 a quarter each of the global tokens, waves 4-7 of
-// the local tokens (dq is a plain sum over tokens: the quarters' partial sums are added through LDS in a fixed order); wave 0 finishes.
+// ---- backward (round 4): ONE launch.  The grid of a sample is [token-side workgroups | the gates' workgroup | one workgroup per prompt].
+// Nothing in it waits for another workgroup: what the token side and the gates need of the prompt side (dctx, delta, d importance, d balance)
+// are a few hundred flops per prompt from tensors the FORWARD saved (cg, cl, imp, gw) and the incoming gradient's prompt rows, so they
+// recompute them instead of reading them from a kernel that had to finish first; the only product of the prompt side's token loop, dq,
+// goes to the prompt's own latent row (which the prompt workgroup writes itself) and to the query projections' parameter gradients.
+// Three dependent kernels (prompt side -> gates -> token side, ~75 us of latency per layer in round 2, two kernels / ~50 us in round 3)
+// are one kernel of max(...) instead of sum(...).
+//
+// prompt side: eight waves, waves 0-3 a quarter each of the global tokens, waves 4-7 of the local tokens (dq is a plain sum over tokens:
+// the quarters' partial sums are added through LDS in a fixed order); waves 0 and 4 finish.
 template <int L>
-__global__ __launch_bounds__(512) void gpa_cross_bwd_p_kernel(GpaArgs p) {
-  __shared__ float dq_s[8][L], dpr_s[L];
-  const int b = blockIdx.y, pi = blockIdx.x, wave = wave_id(), lane = lane_id();
+__device__ __forceinline__ void gpa_bwd_prompt_body(const GpaArgs& p, const int b, const int pi, float (*dq_s)[L], float* dpr_s) {
+  const int wave = wave_id(), lane = lane_id();
   const int side = wave >> 2, quarter = wave & 3;
   const size_t o = ((size_t)b * p.P + pi) * L;
   const float gw = p.gw[b], im = p.imp[b * p.P + pi];
   const int ll_ = lane < L ? lane : 0;
   const bool in = lane < L;
-  const float denh_l = p.dcomb[((size_t)b * p.T + pi) * L + ll_];
+  const size_t prow = (size_t)b * p.T + pi;
+  const float denh_l = p.dcomb[prow * L + ll_];
   const float cg_l = p.cg[o + ll_], cl_l = p.cl[o + ll_];
+  const float zx_l = p.zx[prow * L + ll_];
   const float fused_l = gw * cg_l + (1.f - gw) * cl_l;
   const float df_l = denh_l * im;
   const float dcg_l = gw * df_l, dcl_l = (1.f - gw) * df_l;
@@ -204,51 +213,11 @@ __global__ __launch_bounds__(512) void gpa_cross_bwd_p_kernel(GpaArgs p) {
   }
   __syncthreads();                                       // (waves 0 and 4 only: the others have left)
   if (side == 0) {
-    if (in) { p.dqg[o + lane] = dq_l; p.dcg[o + lane] = dcg_l; p.dprm[o + lane] = dpr_l + dpr_s[lane]; }
-    const float dimp = wave_sum(in ? denh_l * fused_l : 0.f);
-    const float dgw = wave_sum(in ? df_l * (cg_l - cl_l) : 0.f);
-    if (lane == 0) { p.dimp[b * p.P + pi] = dimp; p.dgw_part[b * p.P + pi] = dgw; p.delta_g[b * p.P + pi] = del; }
-  }
-}
-
-// ---- backward, prompt side, two-wave form (wave 0 global, wave 1 local): GAVIKO_HIP_GPA_BWD_WAVES=2
-template <int L>
-__global__ __launch_bounds__(128) void gpa_cross_bwd_p2_kernel(GpaArgs p) {
-  __shared__ float dpr_s[L];
-  const int b = blockIdx.y, pi = blockIdx.x, wave = wave_id(), lane = lane_id();
-  const size_t o = ((size_t)b * p.P + pi) * L;
-  const float gw = p.gw[b], im = p.imp[b * p.P + pi];
-  const int ll_ = lane < L ? lane : 0;
-  const bool in = lane < L;
-  const float denh_l = p.dcomb[((size_t)b * p.T + pi) * L + ll_];
-  const float cg_l = p.cg[o + ll_], cl_l = p.cl[o + ll_];
-  const float fused_l = gw * cg_l + (1.f - gw) * cl_l;
-  const float df_l = denh_l * im;
-  const float dcg_l = gw * df_l, dcl_l = (1.f - gw) * df_l;
-  const float dc_l = wave == 0 ? dcg_l : dcl_l;
-  const float del = wave_sum(in ? dc_l * (wave == 0 ? cg_l : cl_l) : 0.f);
-  const float q_l = (wave == 0 ? p.qg : p.ql)[o + ll_];
-  float dc[L], q[L], dq[L];
-#pragma unroll
-  for (int l = 0; l < L; ++l) { dc[l] = __shfl(dc_l, l, 64); q[l] = __shfl(q_l, l, 64); }
-  if (wave == 0) cross_dq<L>(q, dc, p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L, p.T - (2 * p.P + 2), lane, p.lse_g[b * p.P + pi], del, dq);
-  else cross_dq<L>(q, dc, p.ll + (size_t)b * p.N * L, p.N, lane, p.lse_l[b * p.P + pi], del, dq);
-  // unscaled-query gradients (q_scaled = scale * (W prompt + b)), and this query path's share of the prompt latent gradient
-  const float* wq = wave == 0 ? p.wgq : p.wlq;
-  float dpr_l = 0.f, dq_l = 0.f;
-#pragma unroll
-  for (int j = 0; j < L; ++j) {
-    dq[j] *= p.scale;
-    dpr_l = __builtin_fmaf(wq[j * L + ll_], dq[j], dpr_l);
-    dq_l = (lane == j) ? dq[j] : dq_l;
-  }
-  if (wave == 1) {
-    if (in) { dpr_s[lane] = dpr_l; p.dql[o + lane] = dq_l; p.dcl[o + lane] = dcl_l; }
-    if (lane == 0) p.delta_l[b * p.P + pi] = del;
-  }
-  __syncthreads();
-  if (wave == 0) {
-    if (in) { p.dqg[o + lane] = dq_l; p.dcg[o + lane] = dcg_l; p.dprm[o + lane] = dpr_l + dpr_s[lane]; }
+    if (in) {
+      const float dpr = dpr_l + dpr_s[lane];
+      p.dqg[o + lane] = dq_l; p.dcg[o + lane] = dcg_l; p.dprm[o + lane] = dpr;
+      p.dzx[prow * L + lane] = dpr * quick_gelu_grad(zx_l);       // prompt rows only feed the queries (gaviko.py:159,84-94)
+    }
     const float dimp = wave_sum(in ? denh_l * fused_l : 0.f);
     const float dgw = wave_sum(in ? df_l * (cg_l - cl_l) : 0.f);
     if (lane == 0) { p.dimp[b * p.P + pi] = dimp; p.dgw_part[b * p.P + pi] = dgw; p.delta_g[b * p.P + pi] = del; }
@@ -271,24 +240,32 @@ __device__ __forceinline__ void gpa_gates_bwd_body(const GpaArgs& p, const int b
   float* o_gl1w = o_gl0b + L; float* o_gl1b = o_gl1w + L;
   // One wave per sample on a busy chip: every dependent round trip to memory costs microseconds, so EVERYTHING this kernel reads is
   // requested here, before the first use (the loop form interleaved loads with stores to `out` and paid ~8 round trips: 24 us).
-  float w1[L], cls[L], hn[L], gn[L];
+  float cls[L], hn[L], gn[L];
 #pragma unroll
-  for (int l = 0; l < L; ++l) { w1[l] = p.ca1_w[lane * L + l]; cls[l] = p.xl[((size_t)b * p.T + P) * L + l]; dcls[l] = 0.f; }
+  for (int l = 0; l < L; ++l) { cls[l] = p.xl[((size_t)b * p.T + P) * L + l]; dcls[l] = 0.f; }
   for (int q = 0; q < P && q < 64; ++q) w3_s[q][lane] = p.ca3_w[q * 64 + lane];
   const float b1 = p.ca1_b[lane];
-  float d3 = 0.f;
+  // d importance / d balance of prompt q = lane, from what the forward saved and the incoming gradient's prompt rows (gaviko.py:175,178):
+  //   dimp_q = sum_l denh[q][l] fused[q][l],  dgw_q = sum_l denh[q][l] imp_q (cg - cl)[q][l],  fused = gw cg + (1 - gw) cl
+  const float gwv = p.gw[b];
+  float d3 = 0.f, dgw = 0.f;
   if (lane < P) {
     const float im = p.imp[b * P + lane];
-    d3 = p.dimp[b * P + lane] * im * (1.f - im);
+    const size_t o = ((size_t)b * P + lane) * L;
+    float dimp = 0.f;
+#pragma unroll 4
+    for (int l = 0; l < L; ++l) {
+      const float de = p.dcomb[((size_t)b * p.T + lane) * L + l], cgv = p.cg[o + l], clv = p.cl[o + l];
+      dimp = __builtin_fmaf(de, gwv * cgv + (1.f - gwv) * clv, dimp);
+      dgw = __builtin_fmaf(de * im, cgv - clv, dgw);
+    }
+    d3 = dimp * im * (1.f - im);
   }
-  float dgw = (lane < P) ? p.dgw_part[b * P + lane] : 0.f;
-  for (int q = lane + 64; q < P; q += 64) dgw += p.dgw_part[b * P + q];
-  const float gwv = p.gw[b];
   float mean_a, rstd_a, mean_g, rstd_g;
   ln_small<L>(cls, p.ca0_g, p.ca0_b, hn, mean_a, rstd_a);
   float pre1 = b1;
 #pragma unroll
-  for (int l = 0; l < L; ++l) pre1 += w1[l] * hn[l];
+  for (int l = 0; l < L; ++l) pre1 += p.ca1_w[lane * L + l] * hn[l];
   a1_s[lane] = gelu_erf(pre1);
   // layer 3 (P outputs): dpre3[q] = dimp * imp * (1 - imp)
   if (lane < P) o_ca3b[lane] = d3;
@@ -311,7 +288,7 @@ __device__ __forceinline__ void gpa_gates_bwd_body(const GpaArgs& p, const int b
 #pragma unroll
   for (int l = 0; l < L; ++l) {
     o_ca1w[lane * L + l] = dpre1 * hn[l];
-    dhn_s[lane][l] = dpre1 * w1[l];
+    dhn_s[lane][l] = dpre1 * p.ca1_w[lane * L + l];      // (re-read, L2-resident: holding the row across the kernel spilled registers)
   }
   __syncthreads();
   float dhn[L];
@@ -327,6 +304,7 @@ __device__ __forceinline__ void gpa_gates_bwd_body(const GpaArgs& p, const int b
   }
   ln_small_bwd<L>(cls, mean_a, rstd_a, p.ca0_g, dhn, dcls);
   // PCF balance gate
+  __builtin_amdgcn_sched_barrier(0);                     // (keeps the second gate's operand loads from being hoisted over the first: spills at 128 registers)
   ln_small<L>(cls, p.gl0_g, p.gl0_b, gn, mean_g, rstd_g);
   dgw = wave_sum(dgw);
   const float dpre = dgw * gwv * (1.f - gwv);
@@ -345,17 +323,20 @@ __device__ __forceinline__ void gpa_gates_bwd_body(const GpaArgs& p, const int b
   }
 }
 
-// ---- backward, token side: four lanes per latent row (global rows first, then local rows).
-// Gathers over the P prompts (staged in LDS), adds the proj_up / gate / query-path gradients, applies QuickGELU'.
+// ---- token side: four lanes per latent row (global rows first, then local rows), 128 rows per workgroup.
+// Gathers over the P prompts (staged in LDS), adds the proj_up gradient, applies QuickGELU'.
 template <int L>
-__global__ __launch_bounds__(256) void gpa_bwd_tok_kernel(GpaArgs p) {
+__global__ __launch_bounds__(512) void gpa_bwd_kernel(GpaArgs p, int ntok) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.y, P = p.P;
-  if (blockIdx.x == gridDim.x - 1) {
-    // The extra workgroup of every sample: the two gates' backward (one wave; gaviko.py:160-170) and, with it, the CLS row -- the only token
-    // row the gates' gradient reaches, and one that attends to nothing (t = P < 2P + 2), so dz = (dcomb + dcls) o QuickGELU'(z) is all of it.
-    // This used to be a launch of its own BETWEEN the prompt-side and the token-side kernels: 16 us + a dispatch on the chain the backbone
-    // stream waits for.
+  __shared__ float dq_s[8][L], dpr_s[L];
+  const int b = blockIdx.y, P = p.P, bx = blockIdx.x;
+  if (bx > ntok) {                                           // one workgroup per prompt
+    gpa_bwd_prompt_body<L>(p, b, bx - ntok - 1, dq_s, dpr_s);
+    return;
+  }
+  if (bx == ntok) {
+    // The gates' workgroup of the sample (one wave; gaviko.py:160-170) and, with it, the CLS row -- the only token row the gates' gradient
+    // reaches, and one that attends to nothing (t = P < 2P + 2), so dz = (dcomb + dcls) o QuickGELU'(z) is all of it.
     if (threadIdx.x >= 64) return;
     float dcls[L];
     gpa_gates_bwd_body<L>(p, b, (int)threadIdx.x, dcls);
@@ -370,23 +351,31 @@ __global__ __launch_bounds__(256) void gpa_bwd_tok_kernel(GpaArgs p) {
   float* dc_s = q_s + 2 * P * L;          // [2][P][L]  dctx
   float* ls_s = dc_s + 2 * P * L;         // [2][P]     lse
   float* de_s = ls_s + 2 * P;             // [2][P]     delta
-  for (int i = threadIdx.x; i < P * L; i += 256) {
+  const float gwv = p.gw[b];
+  for (int i = threadIdx.x; i < P * L; i += 512) {
     const size_t o = (size_t)b * P * L + i;
-    q_s[i] = p.qg[o]; q_s[P * L + i] = p.ql[o]; dc_s[i] = p.dcg[o]; dc_s[P * L + i] = p.dcl[o];
+    const int pi = i / L, l = i - pi * L;
+    const float df = p.dcomb[((size_t)b * p.T + pi) * L + l] * p.imp[b * P + pi];     // d fused = d enh * importance
+    q_s[i] = p.qg[o]; q_s[P * L + i] = p.ql[o];
+    dc_s[i] = gwv * df; dc_s[P * L + i] = (1.f - gwv) * df;
   }
-  for (int i = threadIdx.x; i < P; i += 256) {
-    ls_s[i] = p.lse_g[b * P + i]; ls_s[P + i] = p.lse_l[b * P + i];
-    de_s[i] = p.delta_g[b * P + i]; de_s[P + i] = p.delta_l[b * P + i];
+  for (int i = threadIdx.x; i < P; i += 512) { ls_s[i] = p.lse_g[b * P + i]; ls_s[P + i] = p.lse_l[b * P + i]; }
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * P) {                            // delta = dctx . ctx per (side, prompt)
+    const int side = (int)threadIdx.x / P, pi = (int)threadIdx.x - side * P;
+    const float* cv = (side == 0 ? p.cg : p.cl) + ((size_t)b * P + pi) * L;
+    float d = 0.f;
+#pragma unroll
+    for (int l = 0; l < L; ++l) d = __builtin_fmaf(dc_s[(side * P + pi) * L + l], cv[l], d);
+    de_s[side * P + pi] = d;
   }
   __syncthreads();
-  // four lanes per latent row, each taking every fourth prompt: one thread per row left this kernel at one wave per SIMD on 32 CUs,
-  // 35 us of exposed LDS latency at the head of the GPA backward chain that the main stream waits for
   const int part = threadIdx.x & 3;
-  const int r = blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int r = bx * 128 + (threadIdx.x >> 2);
   if (r >= p.T + p.N) return;                              // (whole quads leave together)
   const bool is_local = r >= p.T;
   const int t = is_local ? r - p.T : r;
-  if (!is_local && t == P) return;                         // the CLS row belongs to the gates' workgroup
+  if (!is_local && t <= P) return;                         // prompt rows: their own workgroups; the CLS row: the gates' workgroup
   const size_t row = is_local ? (size_t)b * p.N + t : (size_t)b * p.T + t;
   const float* lat = (is_local ? p.ll : p.xl) + row * L;
   float tok[L], g[L];
@@ -414,13 +403,8 @@ __global__ __launch_bounds__(256) void gpa_bwd_tok_kernel(GpaArgs p) {
   }
   if (part != 0) return;
   if (!is_local) {
-    if (t < P) {
 #pragma unroll
-      for (int l = 0; l < L; ++l) g[l] = p.dprm[((size_t)b * P + t) * L + l];     // prompt rows only feed the queries
-    } else {
-#pragma unroll
-      for (int l = 0; l < L; ++l) g[l] += p.dcomb[row * L + l];                  // image rows pass through proj_up
-    }
+    for (int l = 0; l < L; ++l) g[l] += p.dcomb[row * L + l];                    // image rows pass through proj_up
   }
   const float* z = (is_local ? p.zl : p.zx) + row * L;
   float* dz = (is_local ? p.dzl : p.dzx) + row * L;
@@ -485,14 +469,17 @@ extern "C" int gvk_gpa_bwd(const gvk_gpa_desc* d, void* stream) {
   GpaArgs a{};
   fill_gpa(a, d);
   hipStream_t s = (hipStream_t)stream;
-  static const bool two_waves = diag_env("GAVIKO_HIP_GPA_BWD_WAVES") != nullptr && diag_env("GAVIKO_HIP_GPA_BWD_WAVES")[0] == '2';   // A/B switch
-  if (two_waves) { GVK_GPA_LAUNCH(gpa_cross_bwd_p2_kernel, dim3(d->P, d->B), dim3(128), 0); }
-  else { GVK_GPA_LAUNCH(gpa_cross_bwd_p_kernel, dim3(d->P, d->B), dim3(512), 0); }
-  rc = check_launch("gpa_cross_bwd_p");
-  if (rc) return rc;
+  const int ntok = (d->T + d->N + 127) / 128;
   const int lds = (4 * d->P * d->L + 4 * d->P) * 4;
-  GVK_GPA_LAUNCH(gpa_bwd_tok_kernel, dim3((d->T + d->N + 63) / 64 + 1, d->B), dim3(256), lds);   // + the gates' workgroup of every sample
-  return check_launch("gpa_bwd_tok");
+  switch (d->L) {
+    case 4: GVK_LAUNCH((gpa_bwd_kernel<4>), dim3(ntok + 1 + d->P, d->B), dim3(512), lds, s, a, ntok); break;
+    case 8: GVK_LAUNCH((gpa_bwd_kernel<8>), dim3(ntok + 1 + d->P, d->B), dim3(512), lds, s, a, ntok); break;
+    case 16: GVK_LAUNCH((gpa_bwd_kernel<16>), dim3(ntok + 1 + d->P, d->B), dim3(512), lds, s, a, ntok); break;
+    case 20: GVK_LAUNCH((gpa_bwd_kernel<20>), dim3(ntok + 1 + d->P, d->B), dim3(512), lds, s, a, ntok); break;
+    case 32: GVK_LAUNCH((gpa_bwd_kernel<32>), dim3(ntok + 1 + d->P, d->B), dim3(512), lds, s, a, ntok); break;
+    default: return set_error(-2, "gvk_gpa_bwd: L=%d unsupported (4, 8, 16, 20, 32)", d->L);
+  }
+  return check_launch("gpa_bwd");
 }
 
 extern "C" int gvk_gpa_gate_param_count(int L, int P) { return 4 * L + 64 * L + 64 + 64 * P + P + L + 1; }

@@ -2,6 +2,7 @@
 # The GPU-box command sequences behind profiles/ and DESIGN.md, as ONE script:  gpurun -- 'bash tools/gpu/run.sh <what> [args]'
 #   ab [names..]      headline bench + timing ablations (diag build; results of ablated runs are garbage, only the rate is read)
 #   final <tag>       the measurement set of a round: PMC traffic -> bench lines -> kernel trace (stats + per shape) -> cfg5 -> plan marks
+#   libs a.so b.so..  interleaved bench of several builds of the library (GAVIKO_HIP_LIB), three rounds
 #   trace [bench args] rocprofv3 --kernel-trace --stats of the bench command -> per-kernel and per-shape tables
 #   tests [expr]      pytest -m gpu (optionally -k expr), output under gpurun_out/
 set -e
@@ -50,6 +51,13 @@ final)
   timeout -k 10 200 python tools/plan_marks.py 4 vit-b16 > $O/marks_cfg2.txt 2>&1
   for b in 2 8; do python bench.py --batch $b --steps 30 --warmup 10 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c1-200; done
   ;;
+libs)
+  # interleaved A/B of library builds on one box: run.sh libs gaviko_amd/libgaviko_hip.so gaviko_amd/libgaviko_hip_b.so ...
+  O=$R/gpurun_out/libs; mkdir -p $O
+  for i in 1 2 3; do
+    for l in "$@"; do echo -n "$l: "; env GAVIKO_HIP_LIB=$R/$l python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-roofline 2>/dev/null | grep -o '"value": [0-9.]*'; done
+  done | tee $O/libs.txt
+  ;;
 trace)
   # kernel trace of the bench command -> per-kernel stats and the per-shape table (no PMC): gpurun_out/trace/
   O=$R/gpurun_out/trace; mkdir -p $O
@@ -66,5 +74,5 @@ tests)
   if [ -n "$1" ]; then python -m pytest tests -m gpu -x -q -k "$1" > $O/pytest.log 2>&1; else python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; fi
   tail -5 $O/pytest.log
   ;;
-*) echo "usage: run.sh ab|final|trace|tests" >&2; exit 2 ;;
+*) echo "usage: run.sh ab|final|libs|trace|tests" >&2; exit 2 ;;
 esac
