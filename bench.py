@@ -42,17 +42,29 @@ import torch  # noqa: E402
 
 _queues_set_before_hip = not torch.cuda.is_initialized()       # torch imported just now: False only if something initialised HIP at import
 
-MODEL = dict(image_size=160, image_patch_size=16, frames=120, frame_patch_size=12, num_classes=5, channels=1, pool="cls", dim_head=64,
-             dropout=0.1, emb_dropout=0.1, method="gaviko", num_prompts=32, prompt_latent_dim=20, local_dim=20, local_k=(6, 6, 6),
-             DHW=(10, 10, 10), attn_drop=0.2, proj_drop=0.2, freeze_vit=True, share_factor=1, fp16=False)   # configs/gaviko.yaml:13-39
-PEAK_BF16_TFLOPS = 2516.0      # 256 CU x 2.4 GHz x 4096 flop/clk/CU (MI355X dense bf16)
-GF_PER_VOLUME = {"vit-b16": 482.44, "vit-l16": 1590.06, "vit-t16": None}   # BASELINE.md section 2 (fwd+bwd, gaviko)
+_COMMON = dict(image_size=160, image_patch_size=16, frames=120, frame_patch_size=12, num_classes=5, channels=1, pool="cls", dim_head=64,
+               dropout=0.1, emb_dropout=0.1, freeze_vit=True, fp16=False)
+# the `model:` blocks of the reference's shipped configs (src/configs/*.yaml), one per BASELINE.json configuration
+METHODS = {
+    "gaviko": dict(_COMMON, method="gaviko", num_prompts=32, prompt_latent_dim=20, local_dim=20, local_k=(6, 6, 6), DHW=(10, 10, 10),
+                   attn_drop=0.2, proj_drop=0.2, share_factor=1),                                  # gaviko.yaml:13-39   (cfg2, cfg5)
+    "deep_vpt": dict(_COMMON, method="deep_vpt", num_prompts=8, prompt_dropout=0.1, prompt_dim=64, deep_prompt=True),   # vpt.yaml:13-34      (cfg3)
+    "adaptformer": dict(_COMMON, method="adaptformer"),                                            # adaptformer.yaml    (cfg4)
+    "melo": dict(_COMMON, method="melo", r=4, alpha=4, lora_layer=None),                           # melo.yaml:13-34     (cfg4)
+}
+MODEL = METHODS["gaviko"]
+DEFAULT_BATCH = {"gaviko": 4, "deep_vpt": 4, "adaptformer": 8, "melo": 8}          # volumes per GPU (BASELINE.json configs)
+PEAK_TFLOPS = {"bf16": 2516.0, "fp32": 157.3}   # dense MFMA peaks of MI355X: 256 CU x 2.4 GHz x 4096 (bf16) / 256 (fp32 in, fp32 acc) flop/clk/CU
+PEAK_BF16_TFLOPS = PEAK_TFLOPS["bf16"]
+# fwd + bwd GF per volume (2.M.N.K over GEMM-like ops, frozen linears dgrad x1, attention x2, trainable x2)
+GF_PER_VOLUME = {("gaviko", "vit-b16"): 482.44, ("gaviko", "vit-l16"): 1590.06, ("deep_vpt", "vit-b16"): 460.13,
+                 ("adaptformer", "vit-b16"): 462.70, ("melo", "vit-b16"): 456.50}
 
 
-def build(backbone, device):
+def build(backbone, device, method="gaviko", precision="bf16"):
     from gaviko_amd.registry import build_model
     from gaviko_amd.utils import synth
-    m = build_model(dict(MODEL, backbone=backbone))
+    m = build_model(dict(METHODS[method], backbone=backbone, precision=precision))
     filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
     m.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
     m.to(device)
@@ -85,15 +97,15 @@ def host_cores():
     return max(1, n), how
 
 
-def cpu_baseline(backbone, batch):
+def cpu_baseline(backbone, batch, method="gaviko"):
     """Oracle on the host cores: fwd + CE + bwd steps of the same batch, every core this process may use, one
     warm-up step, best of three timed ones (dropouts off: the oracle has none)."""
     import oracle
     from gaviko_amd.utils import synth
     avail, how = host_cores()
     torch.set_num_threads(avail)
-    cfg = dict(MODEL, backbone=backbone)
-    sd = {k: torch.from_numpy(v).requires_grad_(oracle.gaviko_trainable(k)) for k, v in synth.fill_state_dict(oracle.gaviko_param_shapes(cfg)).items()}
+    cfg = dict(METHODS[method], backbone=backbone)
+    sd = {k: torch.from_numpy(v).requires_grad_(oracle.trainable(method, k, cfg)) for k, v in synth.fill_state_dict(oracle.SHAPES[method](cfg)).items()}
     x = torch.from_numpy(synth.volumes(0, batch))
     y = torch.from_numpy(synth.labels(0, batch))
     times = []
@@ -101,7 +113,7 @@ def cpu_baseline(backbone, batch):
         for v in sd.values():
             v.grad = None
         t0 = time.perf_counter()
-        loss = torch.nn.functional.cross_entropy(oracle.gaviko_forward(sd, x, cfg), y)
+        loss = torch.nn.functional.cross_entropy(oracle.FORWARD[method](sd, x, cfg), y)
         loss.backward()
         times.append(time.perf_counter() - t0)
         print(f"[cpu_baseline] step {it}: {times[-1]:.1f} s on {avail} threads", file=sys.stderr, flush=True)
@@ -240,8 +252,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=4, help="volumes per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="volumes per GPU (default: the BASELINE configuration's: 4, or 8 for adaptformer / melo)")
     ap.add_argument("--backbone", default="vit-b16")
+    ap.add_argument("--method", default="gaviko", choices=sorted(METHODS),
+                    help="which --method of train.py:111-153 to time: gaviko = the headline (cfg2 / cfg5), deep_vpt = cfg3, adaptformer / melo = cfg4")
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp32"],
+                    help="operand precision (default bf16; adaptformer / melo default to fp32, BASELINE cfg4's precision)")
     ap.add_argument("--loss", default="ce", choices=["ce", "focal", "ce-torch"])   # ce-torch: torch's own op, for A/B only
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -250,6 +266,10 @@ def main():
                     help="diagnostics only: run on the measurement build (GAVIKO_HIP_DIAG=1: A/B switches and timing ablations live there); the "
                          "output line is marked INVALID")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = DEFAULT_BATCH[args.method]
+    if args.precision is None:
+        args.precision = "fp32" if args.method in ("adaptformer", "melo") else "bf16"
     if os.environ.get("GAVIKO_HIP_DIAG", "0") == "1" and not args.allow_diag:
         raise SystemExit("bench.py: GAVIKO_HIP_DIAG=1 selects the measurement build (A/B switches, timing ablations that compute WRONG results): "
                          "not a benchmark; unset it (or pass --allow-diag: the line is then marked INVALID)")
@@ -297,7 +317,7 @@ def main():
 
     from gaviko_amd import engine as eng_mod
     from gaviko_amd.utils import synth
-    model = build(args.backbone, dev)
+    model = build(args.backbone, dev, args.method, args.precision)
     if world > 1:
         model.make_reducer()
     B = args.batch
@@ -339,20 +359,27 @@ def main():
         dt = t.item()
     vps = world * B * args.steps / dt
 
-    out = {"metric": "MRI volumes/sec (fwd+bwd) ViT-B/16 gaviko, 120x160x160" if args.backbone == "vit-b16" else
-           f"MRI volumes/sec (fwd+bwd) {args.backbone} gaviko, 120x160x160",
+    bbname = {"vit-b16": "ViT-B/16", "vit-l16": "ViT-L/16", "vit-t16": "ViT-T/16"}.get(args.backbone, args.backbone)
+    eng0 = model._engine()
+    what = {"gaviko": "frozen ViT; prompts+MWSA+GPA+head train; attn_drop=proj_drop=0.2 live",
+            "deep_vpt": "frozen ViT; deep prompts + prompt_proj + head train; backbone dropout 0.1 and prompt_dropout 0.1 live (no train() override of the inner ViT)",
+            "adaptformer": "frozen ViT; adapters + head train",
+            "melo": "frozen ViT; LoRA (r=4) on q and v + head train; backbone dropout 0.1 live (no train() override)"}[args.method]
+    arith = "bf16 MFMA operands / fp32 accumulate" if args.precision == "bf16" else "exact fp32 (f32-input MFMA, fp32 flash attention)"
+    out = {"metric": f"MRI volumes/sec (fwd+bwd) {bbname} {args.method}, 120x160x160",
            "value": round(vps, 3), "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": f"{args.backbone} --method gaviko bf16 MFMA operands / fp32 accumulate, batch={B}/GPU, fwd + "
-                                  f"{'CrossEntropy' if args.loss == 'ce' else 'Focal(1.2)'} + bwd (frozen ViT; prompts+MWSA+GPA+head train), "
-                                  f"attn_drop=proj_drop=0.2 live, grads all-reduced over {world} rank(s)",
-                      "global_batch": world * B, "tokens": 1033, "parallelism": f"dp{world}"}}
+           "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+           "config": {"workload": f"{args.backbone} --method {args.method} {arith}, batch={B}/GPU, fwd + "
+                                  f"{'CrossEntropy' if args.loss != 'focal' else 'Focal(1.2)'} + bwd ({what}), "
+                                  f"grads all-reduced over {world} rank(s)",
+                      "global_batch": world * B, "tokens": eng0.T, "parallelism": f"dp{world}"}}
     if os.environ.get("GAVIKO_HIP_DIAG", "0") == "1":
         out["INVALID_measurement_build"] = {k: v for k, v in os.environ.items() if k.startswith("GAVIKO_HIP_")}
-    gf = GF_PER_VOLUME.get(args.backbone)
+    peak = PEAK_TFLOPS[args.precision]
+    gf = GF_PER_VOLUME.get((args.method, args.backbone))
     if gf:
-        out["mfma_roofline_frac_whole_step"] = round(vps / world * gf / 1e3 / PEAK_BF16_TFLOPS, 4)
+        out["mfma_roofline_frac_whole_step"] = round(vps / world * gf / 1e3 / peak, 4)
 
     if not args.no_roofline:
         # (every rank runs this pass -- its steps contain the gradient all-reduce -- but only rank 0 reports)
@@ -387,18 +414,19 @@ def main():
             name, s = max(stats.items(), key=lambda kv: kv[1]["total_ms"])
             raw_us, pair_us = s["avg_ms"] * 1e3, s["overhead_ms"] * 1e3
             tf = s["flops_per_launch"] / (s["avg_ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None, "avg_launch_us": round(raw_us, 2), "launches": s["n"],
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(tf / peak, 4), "traffic": None, "avg_launch_us": round(raw_us, 2), "launches": s["n"],
                                "flop_per_launch": s["flops_per_launch"], "shape": s["shape"], "event_pair_us": round(pair_us, 2),
                                "avg_launch_us_minus_event_pair": round(max(raw_us - pair_us, 0.0), 2),
                                "timing": "RAW HIP event pairs on the launch stream inside the replayed plan (nothing subtracted; an empty "
                                          "pair costs event_pair_us); flop_per_launch = 2*M*N*K_algorithmic (padding columns of the "
-                                         "K-concatenated fc2 operand excluded); cross-check: profiles/r03_kernel_stats_by_shape.csv"}
-            out["roofline"].update(pmc_traffic(name, stats))
+                                         "K-concatenated fc2 operand excluded); cross-check: profiles/r04_kernel_stats_by_shape.csv"}
+            if args.method == "gaviko" and args.precision == "bf16":
+                out["roofline"].update(pmc_traffic(name, stats))
             out["gemm_classes"] = {k: {"avg_us": round(v["avg_ms"] * 1e3, 2), "n": v["n"], "tflops": round(v["flops_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12, 1)}
                                    for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.backbone, B)
+        out["cpu_baseline"] = cpu_baseline(args.backbone, B, args.method)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

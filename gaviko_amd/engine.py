@@ -174,7 +174,7 @@ class Engine(GavikoPaths, PeftPaths):
             return ops.gemm_nt(a, w, M, out0, **kw)
         N, K = w.shape[0], int(kw.get("K") or w.shape[1])
         ka = int(alg_k) if alg_k is not None else K
-        key = f"gemm_nt_bf16[{_EPI_NAMES[kw['epilogue']]}] M={M} N={N} K={K}"
+        key = f"gemm_nt_{'f32' if self.fp32 else 'bf16'}[{_EPI_NAMES[kw['epilogue']]}] M={M} N={N} K={K}"
         cur = torch.cuda.current_stream()
         e0 = self._ev_record(cur)
         ops.gemm_nt(a, w, M, out0, **kw)
