@@ -114,8 +114,36 @@ __device__ __forceinline__ void block_range(int dfirst, int dlast, int below, in
   b1 = (min((dhi + 1) * HW, N) + 15) >> 4;
 }
 
+// ---- round 4.  (1) Token coordinates (d, h, w) come from a table in LDS, filled once per workgroup: decode() is two integer divisions
+// by run-time values, ~50 VALU instructions per iteration.  (2) The key side of the backward no longer reads the query side's delta:
+// delta_i = dctx_i . ctx_i comes from the rows it loads anyway, and the four (lse, delta) a lane needs are lane shuffles of its own
+// row's values instead of eight more loads -- the two backward kernels are independent launches.  Together: 740 -> 747 volumes/s.
+// Measured on the same box and NOT adopted (compile-time switches below, one box, three interleaved runs each):
+//   * GVK_WIN_MERGE=1, both backward sides in ONE launch of 504 workgroups: the kernels' summed time drops from 70 to 37 us per layer
+//     and the STEP gets 2 % slower (729 vs 747) -- twice the waves resident beside the flash-attention backward on the main stream;
+//   * GVK_WIN_RING=3 / 2, partner blocks prefetched three / two ahead instead of one (all loads unconditional with clamped indices so
+//     that vmcnt is counted exactly): 741 vs 747 -- 146 registers instead of ~100 cost more than the hidden L2 latency returns.
+// Once more: what the backbone pays for is the side kernels' resident registers x time, not their duration.
+#ifndef GVK_WIN_RING
+#define GVK_WIN_RING 1
+#endif
+#ifndef GVK_WIN_MERGE
+#define GVK_WIN_MERGE 0
+#endif
+constexpr int kRing = GVK_WIN_RING;
+
+__device__ __forceinline__ int pack_tok(const Tok& t) { return t.d | (t.h << 10) | (t.w << 20); }
+__device__ __forceinline__ Tok unpack_tok(int v) { Tok t; t.d = v & 1023; t.h = (v >> 10) & 1023; t.w = v >> 20; return t; }
+// coordinates of every token of a sample, one packed word each; entries N.. (up to the next multiple of 16) repeat the last token
+__device__ __forceinline__ void fill_tok_table(int* tab, int N, int H, int W, int nthreads) {
+  const int n16 = (N + 15) & ~15;
+  for (int i = threadIdx.x; i < n16; i += nthreads) tab[i] = pack_tok(decode(min(i, N - 1), H, W));
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(64 * kSplit) void win_mfma_fwd_kernel(WinArgs p) {
+  extern __shared__ __attribute__((aligned(16))) int tokc[];
   __shared__ float sm_m[kSplit][16], sm_l[kSplit][16], sm_o[kSplit][kL][16];
   if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
   const int HW = p.H * p.W, N = p.D * HW, nblk = (N + 15) >> 4;
@@ -124,28 +152,37 @@ __global__ __launch_bounds__(64 * kSplit) void win_mfma_fwd_kernel(WinArgs p) {
   const float* base = p.qkv + (size_t)b * N * kRow;
   const int q = min(qb * 16 + l16, N - 1);
   const unsigned long long row = (unsigned long long)b * N + q;
-  const Box bx = fwd_box(decode(q, p.H, p.W), p);
   RowOp Q = load_rowop(base + (size_t)q * kRow, g);
   Q.v *= p.scale; Q.x *= p.scale;
   int kb0, kb1;
   block_range((qb * 16) / HW, min(qb * 16 + 15, N - 1) / HW, p.kd / 2, p.kd - 1 - p.kd / 2, p.D, HW, N, kb0, kb1);
+  struct In { RowOp K; ColOp V; };
+  auto fetch = [&](int kb) {
+    In r;
+    const int k0 = min(kb, kb1 - 1) * 16;                 // (past the range: re-reads the last block, never used)
+    r.K = load_rowop(base + (size_t)min(k0 + l16, N - 1) * kRow + kL, g);
+    r.V = load_colop(base + 2 * kL, kRow, k0, N, g, l16);
+    return r;
+  };
+  In ring[kRing];
+#pragma unroll
+  for (int r = 0; r < kRing; ++r) ring[r] = fetch(kb0 + wave + r * kSplit);
+  fill_tok_table(tokc, N, p.H, p.W, 64 * kSplit);
+  const Box bx = fwd_box(unpack_tok(tokc[q]), p);
   float m = -INFINITY, l = 0.f;
   f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
-  RowOp K = load_rowop(base + (size_t)min((kb0 + wave) * 16 + l16, N - 1) * kRow + kL, g);
-  ColOp V = load_colop(base + 2 * kL, kRow, (kb0 + wave) * 16, N, g, l16);
-  for (int kb = kb0 + wave; kb < kb1; kb += kSplit) {
-    const int key0 = kb * 16, nxt = min(kb + kSplit, kb1 - 1) * 16;          // (the last prefetch re-reads a live block)
-    const RowOp Kn = load_rowop(base + (size_t)min(nxt + l16, N - 1) * kRow + kL, g);
-    const ColOp Vn = load_colop(base + 2 * kL, kRow, nxt, N, g, l16);
-    const f32x4 s = dot_tile(K, Q);                      // [key0 + 4g + i][query]
-    Tok tk = decode(key0 + 4 * g, p.H, p.W);
+  auto step = [&](const In& in, int kb) {
+    if (kb >= kb1) return;                                 // wave-uniform
+    const int key0 = kb * 16;
+    const f32x4 s = dot_tile(in.K, Q);                    // [key0 + 4g + i][query]
+    const int4 tk4 = *(const int4*)(tokc + key0 + 4 * g);
+    const int tkv[4] = {tk4.x, tk4.y, tk4.z, tk4.w};
     float sv[4], mb = -INFINITY;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool ok = key0 + 4 * g + i < N && bx.has(tk);
+      const bool ok = key0 + 4 * g + i < N && bx.has(unpack_tok(tkv[i]));
       sv[i] = ok ? s[i] : -INFINITY;
       mb = fmaxf(mb, sv[i]);
-      next(tk, p.H, p.W);
     }
     const float mn = fmaxf(m, xmax(mb));
     const float ms = mn == -INFINITY ? 0.f : mn;         // a tile wholly outside this query's window leaves everything at zero
@@ -159,8 +196,14 @@ __global__ __launch_bounds__(64 * kSplit) void win_mfma_fwd_kernel(WinArgs p) {
       pv[i] = p.drop_thresh != 0u ? e * keep_scale(p, row, N, key0 + 4 * g + i) : e;
     }
     m = mn;
-    col_acc(V, pv, o0, o1);
-    K = Kn; V = Vn;
+    col_acc(in.V, pv, o0, o1);
+  };
+  for (int kb = kb0 + wave; kb < kb1; kb += kRing * kSplit) {
+#pragma unroll
+    for (int r = 0; r < kRing; ++r) {
+      step(ring[r], kb + r * kSplit);
+      ring[r] = fetch(kb + (kRing + r) * kSplit);
+    }
   }
   l = xsum(l);
   if (g == 0) { sm_m[wave][l16] = m; sm_l[wave][l16] = l; }
@@ -200,16 +243,13 @@ __global__ __launch_bounds__(64 * kSplit) void win_mfma_fwd_kernel(WinArgs p) {
 
 // ------------------------------------------------------------------------------------------------------------------ backward, query side
 // delta_i = dctx_i . ctx_i ;  dq_i = scale * sum_j p_ij (mask_ij dctx_i . v_j - delta_i) k_j
-__global__ __launch_bounds__(64 * kSplit) void win_mfma_bwd_q_kernel(WinArgs p) {
-  __shared__ float sm_o[kSplit][kL][16];
-  if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
-  const int HW = p.H * p.W, N = p.D * HW, nblk = (N + 15) >> 4;
-  const int b = blockIdx.x / nblk, qb = blockIdx.x - b * nblk;
+__device__ __forceinline__ void win_bwd_q_body(const WinArgs& p, const int* tokc, float (*sm_o)[kL][16], const int b, const int qb) {
+  const int HW = p.H * p.W, N = p.D * HW;
   const int wave = wave_id(), lane = lane_id(), g = lane >> 4, l16 = lane & 15;
   const float* base = p.qkv + (size_t)b * N * kRow;
   const int q = min(qb * 16 + l16, N - 1);
   const unsigned long long row = (unsigned long long)b * N + q;
-  const Box bx = fwd_box(decode(q, p.H, p.W), p);
+  const Box bx = fwd_box(unpack_tok(tokc[q]), p);
   RowOp Q = load_rowop(base + (size_t)q * kRow, g);
   Q.v *= p.scale; Q.x *= p.scale;
   const RowOp Dc = load_rowop(p.dctx + row * kL, g), Cx = load_rowop(p.ctx + row * kL, g);
@@ -218,27 +258,41 @@ __global__ __launch_bounds__(64 * kSplit) void win_mfma_bwd_q_kernel(WinArgs p) 
   int kb0, kb1;
   block_range((qb * 16) / HW, min(qb * 16 + 15, N - 1) / HW, p.kd / 2, p.kd - 1 - p.kd / 2, p.D, HW, N, kb0, kb1);
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-  const float* krow0 = base + (size_t)min((kb0 + wave) * 16 + l16, N - 1) * kRow;
-  RowOp K = load_rowop(krow0 + kL, g), V = load_rowop(krow0 + 2 * kL, g);
-  ColOp Kc = load_colop(base + kL, kRow, (kb0 + wave) * 16, N, g, l16);
-  for (int kb = kb0 + wave; kb < kb1; kb += kSplit) {
-    const int key0 = kb * 16, nxt = min(kb + kSplit, kb1 - 1) * 16;
-    const float* krow = base + (size_t)min(nxt + l16, N - 1) * kRow;
-    const RowOp Kn = load_rowop(krow + kL, g), Vn = load_rowop(krow + 2 * kL, g);
-    const ColOp Kcn = load_colop(base + kL, kRow, nxt, N, g, l16);
-    const f32x4 s = dot_tile(K, Q), dp = dot_tile(V, Dc);   // [key][query]
-    Tok tk = decode(key0 + 4 * g, p.H, p.W);
+  struct In { RowOp K, V; ColOp Kc; };
+  auto fetch = [&](int kb) {
+    In r;
+    const int k0 = min(kb, kb1 - 1) * 16;
+    const float* krow = base + (size_t)min(k0 + l16, N - 1) * kRow;
+    r.K = load_rowop(krow + kL, g);
+    r.V = load_rowop(krow + 2 * kL, g);
+    r.Kc = load_colop(base + kL, kRow, k0, N, g, l16);
+    return r;
+  };
+  In ring[kRing];
+#pragma unroll
+  for (int r = 0; r < kRing; ++r) ring[r] = fetch(kb0 + wave + r * kSplit);
+  auto step = [&](const In& in, int kb) {
+    if (kb >= kb1) return;
+    const int key0 = kb * 16;
+    const f32x4 s = dot_tile(in.K, Q), dp = dot_tile(in.V, Dc);   // [key][query]
+    const int4 tk4 = *(const int4*)(tokc + key0 + 4 * g);
+    const int tkv[4] = {tk4.x, tk4.y, tk4.z, tk4.w};
     f32x4 ds;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool ok = key0 + 4 * g + i < N && bx.has(tk);
+      const bool ok = key0 + 4 * g + i < N && bx.has(unpack_tok(tkv[i]));
       const float pr = ok ? __expf(s[i] - lse) : 0.f;
       const float dpm = p.drop_thresh != 0u ? dp[i] * keep_scale(p, row, N, key0 + 4 * g + i) : dp[i];
       ds[i] = pr * (dpm - delta) * p.scale;
-      next(tk, p.H, p.W);
     }
-    col_acc(Kc, ds, a0, a1);
-    K = Kn; V = Vn; Kc = Kcn;
+    col_acc(in.Kc, ds, a0, a1);
+  };
+  for (int kb = kb0 + wave; kb < kb1; kb += kRing * kSplit) {
+#pragma unroll
+    for (int r = 0; r < kRing; ++r) {
+      step(ring[r], kb + r * kSplit);
+      ring[r] = fetch(kb + (kRing + r) * kSplit);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -264,60 +318,67 @@ __global__ __launch_bounds__(64 * kSplit) void win_mfma_bwd_q_kernel(WinArgs p) 
 
 // ------------------------------------------------------------------------------------------------------------------ backward, key side
 // over the reverse window: dk_j = scale * sum_i p_ij (mask_ij dctx_i . v_j - delta_i) q_i ;  dv_j = sum_i p_ij mask_ij dctx_i
-__global__ __launch_bounds__(64 * kSplit) void win_mfma_bwd_kv_kernel(WinArgs p) {
-  __shared__ float sm_o[kSplit][2][kL][16];
-  if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
-  const int HW = p.H * p.W, N = p.D * HW, nblk = (N + 15) >> 4;
-  const int b = blockIdx.x / nblk, kb = blockIdx.x - b * nblk;
+__device__ __forceinline__ void win_bwd_kv_body(const WinArgs& p, const int* tokc, float (*sm_o)[2][kL][16], const int b, const int kb) {
+  const int HW = p.H * p.W, N = p.D * HW;
   const int wave = wave_id(), lane = lane_id(), g = lane >> 4, l16 = lane & 15;
   const float* base = p.qkv + (size_t)b * N * kRow;
   const float* dcb = p.dctx + (size_t)b * N * kL;
+  const float* cxb = p.ctx + (size_t)b * N * kL;
   const int key = min(kb * 16 + l16, N - 1);
-  const Box bx = rev_box(decode(key, p.H, p.W), p);
+  const Box bx = rev_box(unpack_tok(tokc[key]), p);
   const RowOp K = load_rowop(base + (size_t)key * kRow + kL, g), V = load_rowop(base + (size_t)key * kRow + 2 * kL, g);
   int qb0, qb1;
   block_range((kb * 16) / HW, min(kb * 16 + 15, N - 1) / HW, p.kd - 1 - p.kd / 2, p.kd / 2, p.D, HW, N, qb0, qb1);
   f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, v0 = k0, v1 = k0;
-  struct In { RowOp Q, Dc; ColOp Qc, Dcc; float lse[4], del[4]; };
-  auto fetch = [&](int q0) {
+  // per query block: its rows as row operands (Q, dctx -- and ctx, for delta_i = dctx_i . ctx_i of the row this lane holds) and as column
+  // operands; lse of the lane's row.  The four (lse, delta) a lane needs (rows 4g + i) are lane shuffles of those.
+  struct In { RowOp Q, Dc, Cx; ColOp Qc, Dcc; float lse; };
+  auto fetch = [&](int qb) {
     In r;
+    const int q0 = min(qb, qb1 - 1) * 16;
     const int qr = min(q0 + l16, N - 1);
     r.Q = load_rowop(base + (size_t)qr * kRow, g);
     r.Dc = load_rowop(dcb + (size_t)qr * kL, g);
+    r.Cx = load_rowop(cxb + (size_t)qr * kL, g);
     r.Qc = load_colop(base, kRow, q0, N, g, l16);
     r.Dcc = load_colop(dcb, kL, q0, N, g, l16);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const size_t gi = (size_t)b * N + min(q0 + 4 * g + i, N - 1);
-      r.lse[i] = p.lse[gi]; r.del[i] = p.delta[gi];
-    }
+    r.lse = p.lse[(size_t)b * N + qr];
     return r;
   };
-  In cur = fetch((qb0 + wave) * 16);
-  for (int qb = qb0 + wave; qb < qb1; qb += kSplit) {
+  In ring[kRing];
+#pragma unroll
+  for (int r = 0; r < kRing; ++r) ring[r] = fetch(qb0 + wave + r * kSplit);
+  auto step = [&](const In& in, int qb) {
+    if (qb >= qb1) return;
     const int q0 = qb * 16;
-    const In nx = fetch(min(qb + kSplit, qb1 - 1) * 16);
-    RowOp Q = cur.Q;
+    RowOp Q = in.Q;
     Q.v *= p.scale; Q.x *= p.scale;
-    const RowOp& Dc = cur.Dc;
-    const ColOp& Qc = cur.Qc; const ColOp& Dcc = cur.Dcc;
-    const f32x4 s = dot_tile(Q, K), dp = dot_tile(Dc, V);   // [query q0 + 4g + i][key]
-    Tok tq = decode(q0 + 4 * g, p.H, p.W);
+    const float del_row = xsum(in.Dc.v[0] * in.Cx.v[0] + in.Dc.v[1] * in.Cx.v[1] + in.Dc.v[2] * in.Cx.v[2] + in.Dc.v[3] * in.Cx.v[3] +
+                               in.Dc.x * in.Cx.x);          // delta of query q0 + l16, in all four lane groups
+    const f32x4 s = dot_tile(Q, K), dp = dot_tile(in.Dc, V);   // [query q0 + 4g + i][key]
+    const int4 tq4 = *(const int4*)(tokc + q0 + 4 * g);
+    const int tqv[4] = {tq4.x, tq4.y, tq4.z, tq4.w};
     f32x4 ds, pt;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int qi = q0 + 4 * g + i;
-      const bool ok = qi < N && bx.has(tq);
+      const bool ok = qi < N && bx.has(unpack_tok(tqv[i]));
       const unsigned long long gi = (unsigned long long)b * N + min(qi, N - 1);
-      const float pr = ok ? __expf(s[i] - cur.lse[i]) : 0.f;
+      const float lse_i = __shfl(in.lse, 4 * g + i, 16), del_i = __shfl(del_row, 4 * g + i, 16);   // (width 16: lane 4g + i of this lane's own group)
+      const float pr = ok ? __expf(s[i] - lse_i) : 0.f;
       const float msk = p.drop_thresh != 0u ? keep_scale(p, gi, N, key) : 1.f;
-      ds[i] = pr * (dp[i] * msk - cur.del[i]) * p.scale;
+      ds[i] = pr * (dp[i] * msk - del_i) * p.scale;
       pt[i] = pr * msk;
-      next(tq, p.H, p.W);
     }
-    col_acc(Qc, ds, k0, k1);
-    col_acc(Dcc, pt, v0, v1);
-    cur = nx;
+    col_acc(in.Qc, ds, k0, k1);
+    col_acc(in.Dcc, pt, v0, v1);
+  };
+  for (int qb = qb0 + wave; qb < qb1; qb += kRing * kSplit) {
+#pragma unroll
+    for (int r = 0; r < kRing; ++r) {
+      step(ring[r], qb + r * kSplit);
+      ring[r] = fetch(qb + (kRing + r) * kSplit);
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -343,6 +404,21 @@ __global__ __launch_bounds__(64 * kSplit) void win_mfma_bwd_kv_kernel(WinArgs p)
   }
 }
 
+// kv_side = 0 / 1: one side per launch (default);  -1: ONE launch, workgroups [0, B * nblk) = the query side (dq, delta),
+// [B * nblk, 2 B * nblk) = the key side (dk, dv) -- they share nothing
+__global__ __launch_bounds__(64 * kSplit) void win_mfma_bwd_kernel(WinArgs p) {
+  extern __shared__ __attribute__((aligned(16))) int tokc[];
+  __shared__ float sm_o[kSplit][2][kL][16];
+  if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
+  const int N = p.D * p.H * p.W, nblk = (N + 15) >> 4;
+  fill_tok_table(tokc, N, p.H, p.W, 64 * kSplit);
+  const int side = p.kv_side >= 0 ? p.kv_side : ((int)blockIdx.x >= p.B * nblk ? 1 : 0);
+  const int id = p.kv_side >= 0 ? (int)blockIdx.x : (int)blockIdx.x - side * p.B * nblk;
+  const int b = id / nblk, blk = id - b * nblk;
+  if (side == 0) win_bwd_q_body(p, tokc, (float (*)[kL][16])sm_o, b, blk);
+  else win_bwd_kv_body(p, tokc, sm_o, b, blk);
+}
+
 bool mfma_enabled() {
   static const bool on = [] { const char* e = diag_env("GAVIKO_HIP_WIN_MFMA"); return !(e && e[0] == '0'); }();   // A/B switch
   return on;
@@ -353,19 +429,27 @@ bool mfma_enabled() {
 int launch_win_mfma_fwd(const WinArgs& a, int L, hipStream_t s) {
   if (L != kL || !mfma_enabled()) return 1;
   const int N = a.D * a.H * a.W;
-  GVK_LAUNCH(win_mfma_fwd_kernel, dim3(a.B * ((N + 15) / 16)), dim3(64 * kSplit), 0, s, a);
+  if (a.D > 1023 || a.H > 1023 || a.W > 1023 || N > 12288) return 1;          // packed token coordinates, 48 KiB table
+  GVK_LAUNCH(win_mfma_fwd_kernel, dim3(a.B * ((N + 15) / 16)), dim3(64 * kSplit), ((N + 15) & ~15) * 4, s, a);
   return check_launch("window_attn_fwd (mfma)");
 }
 
 int launch_win_mfma_bwd(const WinArgs& a, int L, hipStream_t s) {
   if (L != kL || !mfma_enabled()) return 1;
   const int N = a.D * a.H * a.W;
-  const dim3 grid(a.B * ((N + 15) / 16)), block(64 * kSplit);
-  GVK_LAUNCH(win_mfma_bwd_q_kernel, grid, block, 0, s, a);
-  int rc = check_launch("window_attn_bwd/q (mfma)");
-  if (rc) return rc;
-  GVK_LAUNCH(win_mfma_bwd_kv_kernel, grid, block, 0, s, a);
-  return check_launch("window_attn_bwd/kv (mfma)");
+  if (a.D > 1023 || a.H > 1023 || a.W > 1023 || N > 12288) return 1;
+#if GVK_WIN_MERGE
+  WinArgs m = a;
+  m.kv_side = -1;
+  GVK_LAUNCH(win_mfma_bwd_kernel, dim3(2 * a.B * ((N + 15) / 16)), dim3(64 * kSplit), ((N + 15) & ~15) * 4, s, m);
+#else
+  WinArgs m = a;
+  m.kv_side = 0;
+  GVK_LAUNCH(win_mfma_bwd_kernel, dim3(a.B * ((N + 15) / 16)), dim3(64 * kSplit), ((N + 15) & ~15) * 4, s, m);
+  m.kv_side = 1;
+  GVK_LAUNCH(win_mfma_bwd_kernel, dim3(a.B * ((N + 15) / 16)), dim3(64 * kSplit), ((N + 15) & ~15) * 4, s, m);
+#endif
+  return check_launch("window_attn_bwd (mfma)");
 }
 
 }  // namespace gvk
