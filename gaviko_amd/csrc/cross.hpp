@@ -16,19 +16,19 @@ __device__ __forceinline__ void load_tok(const float* __restrict__ src, int i, i
   }
 }
 
-// softmax(q . tok^T) . tok over n tokens; returns ctx (all lanes) and lse
-template <int L>
+// softmax(q . tok^T) . tok over n tokens; returns ctx (all lanes) and lse.  U tokens per lane in flight.
+template <int L, int U = 4>
 __device__ __forceinline__ void cross_one(const float (&q)[L], const float* __restrict__ src, int n, int lane, float (&ctx)[L], float& lse) {
   float m = -INFINITY, s = 0.f, c[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) c[l] = 0.f;
-  for (int i0 = lane; i0 < n; i0 += 256) {
-    float t[4][L], d[4];
+  for (int i0 = lane; i0 < n; i0 += 64 * U) {
+    float t[U][L], d[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) load_tok<L>(src, i0 + 64 * u, n, t[u]);
+    for (int u = 0; u < U; ++u) load_tok<L>(src, i0 + 64 * u, n, t[u]);
     float mb = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       float a = 0.f;
 #pragma unroll
       for (int l = 0; l < L; ++l) a = __builtin_fmaf(q[l], t[u][l], a);
@@ -41,7 +41,7 @@ __device__ __forceinline__ void cross_one(const float (&q)[L], const float* __re
 #pragma unroll
     for (int l = 0; l < L; ++l) c[l] *= sc;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const float e = __expf(d[u] - mn);                 // invalid token: exp(-inf) = 0
       s += e;
 #pragma unroll

@@ -13,6 +13,13 @@
 #include "cross.hpp"
 #include "../../include/gaviko_hip.h"
 
+#ifndef GVK_GPA_FWD_U
+#define GVK_GPA_FWD_U 4
+#endif
+#ifndef GVK_GPA_BWD_U
+#define GVK_GPA_BWD_U 4
+#endif
+
 namespace gvk {
 
 struct GpaArgs {
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(576) void gpa_fwd_kernel(GpaArgs p) {
   const int n = side == 0 ? p.T - (2 * p.P + 2) : p.N;
   const int per = (n + 3) >> 2, lo = quarter * per, cnt = min(per, n - lo);
   if (cnt > 0) {
-    cross_one<L>(q, base + (size_t)lo * L, cnt, lane, c, lse);
+    cross_one<L, GVK_GPA_FWD_U>(q, base + (size_t)lo * L, cnt, lane, c, lse);
   } else {
     lse = -INFINITY;
 #pragma unroll
@@ -194,7 +201,7 @@ __device__ __forceinline__ void gpa_bwd_prompt_body(const GpaArgs& p, const int 
   const float* base = side == 0 ? p.xl + ((size_t)b * p.T + 2 * p.P + 2) * L : p.ll + (size_t)b * p.N * L;
   const int n = side == 0 ? p.T - (2 * p.P + 2) : p.N;
   const int per = (n + 3) >> 2, lo = quarter * per, cnt = max(0, min(per, n - lo));
-  cross_dq<L>(q, dc, base + (size_t)lo * L, cnt, lane, (side == 0 ? p.lse_g : p.lse_l)[b * p.P + pi], del, dq);   // cnt = 0: zeros
+  cross_dq<L, GVK_GPA_BWD_U>(q, dc, base + (size_t)lo * L, cnt, lane, (side == 0 ? p.lse_g : p.lse_l)[b * p.P + pi], del, dq);   // cnt = 0: zeros
   float dq_l = 0.f;
 #pragma unroll
   for (int j = 0; j < L; ++j) dq_l = (lane == j) ? dq[j] : dq_l;

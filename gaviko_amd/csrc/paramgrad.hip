@@ -30,12 +30,19 @@
 
 namespace gvk {
 
-constexpr int kPgCh = 32;            // rows per chunk per wave
+#ifndef GVK_PG_CH
+#define GVK_PG_CH 16
+#endif
+constexpr int kPgCh = GVK_PG_CH;     // rows per chunk per wave (a multiple of 4; 32 and 16 are measured)
+constexpr int kPgKS = kPgCh / 4;     // MFMA k-steps (four rows each) per chunk
 constexpr int kPgMaxOuter = 3;
 constexpr int kPgMaxSmall = 8;
 constexpr int kPgMaxSg = 64;         // row ranges (workgroups) per column tile of an outer job
 constexpr int kPgRedSlabs = 32;      // row slabs of a small job
-constexpr int kPgTargetWgs = 240;    // outer-product workgroups per launch: about one per CU
+#ifndef GVK_PG_WGS
+#define GVK_PG_WGS 240
+#endif
+constexpr int kPgTargetWgs = GVK_PG_WGS;    // outer-product workgroups per launch: about one per CU
 constexpr int kPgMinRows = 128;      // ... but never fewer rows per workgroup than this
 
 struct PgOuter {
@@ -88,7 +95,7 @@ __device__ __forceinline__ bool pg_arrive_last(int* ticket, int n, int* s_flag) 
 template <int NT>
 __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
   constexpr int NW = NT * 16;                                // padded narrow width (L + 1 <= NW)
-  constexpr int kNP = 4;                                     // narrow float4 pieces per lane and chunk (32 rows x L / 4 <= 7 pieces)
+  constexpr int kNP = (kPgCh * 7 + 63) / 64;                 // narrow float4 pieces per lane and chunk (kPgCh rows x L / 4 <= 7 pieces)
   __shared__ float lds[4 * 2 * kPgCh * 32];                  // [wave][buffer][row][NW] narrow rows, later the four waves' accumulator tiles (32 KiB)
   __shared__ float st[4][2][kPgCh][2];
   __shared__ float sw[4][32];
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
   };
   // one chunk's loads: 8 float4 of wide, up to 4 float4 of narrow, the row statistics.  UNCONDITIONAL (rows / columns clamped): the
   // waits in front of a chunk's consumers are then exact counts, and the chunk behind stays in flight
-  auto load = [&](f32x4 (&x)[8], f32x4 (&nv)[kNP], float& mu, float& rs, int ch) {
+  auto load = [&](f32x4 (&x)[kPgKS], f32x4 (&nv)[kNP], float& mu, float& rs, int ch) {
     const int rb = r0 + kPgCh * ch;
 #pragma unroll
     for (int t = 0; t < kNP; ++t) {
@@ -204,9 +211,9 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
       nv[t] = *(const f32x4*)(narrow_row(min(rb + r, mlast)) + 4 * min(pc, L4 - 1));
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) x[u] = *(const f32x4*)(wide_row(min(rb + 4 * u + kq, mlast)) + cl);
+    for (int u = 0; u < kPgKS; ++u) x[u] = *(const f32x4*)(wide_row(min(rb + 4 * u + kq, mlast)) + cl);
     if (J.mean != nullptr) {
-      const int m = min(rb + (lane & 31), mlast);
+      const int m = min(rb + (lane & (kPgCh - 1)), mlast);
       mu = J.mean[m];
       rs = J.rstd[m];
     }
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[t][e] = f32x4{0.f, 0.f, 0.f, 0.f};
   float s4[4] = {0.f, 0.f, 0.f, 0.f};                          // affine jobs: this lane's column (l = lane) of S = sum_m narrow[m][l]
-  auto compute = [&](f32x4 (&x)[8], f32x4 (&nv)[kNP], float mu, float rs, const int buf, int ch) {
+  auto compute = [&](f32x4 (&x)[kPgKS], f32x4 (&nv)[kNP], float mu, float rs, const int buf, int ch) {
     const int rb = r0 + kPgCh * ch;
     if (rb >= r1) return;                                      // wave-uniform: a chunk wholly past this wave's rows (its loads were issued anyway)
 #pragma unroll
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
       for (int r = 0; r < kPgCh; ++r) s4[r & 3] += nar[buf][r][lane];
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < kPgKS; ++u) {
       if (rb + 4 * u >= r1) break;                             // wave-uniform: k-steps wholly past the rows
       const int r = 4 * u + kq;
       const bool ok = (rb + r < r1) && cok;
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
   }
   {
     const int nch = (nr + kPgCh - 1) / kPgCh;
-    f32x4 xa[8], xb[8], na[kNP], nb[kNP];
+    f32x4 xa[kPgKS], xb[kPgKS], na[kNP], nb[kNP];
     float mua = 0.f, rsa = 0.f, mub = 0.f, rsb = 0.f;
     load(xa, na, mua, rsa, 0);
     for (int ch = 0; ch < nch; ch += 2) {
