@@ -96,7 +96,9 @@ template <int NT>
 __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
   constexpr int NW = NT * 16;                                // padded narrow width (L + 1 <= NW)
   constexpr int kNP = (kPgCh * 7 + 63) / 64;                 // narrow float4 pieces per lane and chunk (kPgCh rows x L / 4 <= 7 pieces)
-  __shared__ float lds[4 * 2 * kPgCh * 32];                  // [wave][buffer][row][NW] narrow rows, later the four waves' accumulator tiles (32 KiB)
+  // [wave][buffer][row][NW] narrow rows, later the four waves' accumulator tiles [wave][16 NT registers][64 lanes] (the larger of the two)
+  constexpr int kLdsFloats = (4 * 2 * kPgCh * 32 > 4 * 16 * NT * 64) ? 4 * 2 * kPgCh * 32 : 4 * 16 * NT * 64;
+  __shared__ float lds[kLdsFloats];
   __shared__ float st[4][2][kPgCh][2];
   __shared__ float sw[4][32];
   __shared__ int s_flag;
@@ -316,6 +318,7 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
 
   // ---- last arriver of this column tile: sum the row ranges' tiles in range order, then the epilogue
   const float* tile0 = p.scratch + J.scr0 + (size_t)ct * J.nsg * stride;
+  static_assert(kLdsFloats >= 30 * 64, "the affine epilogue stages [L + 2][64] floats");
   float (*qt)[64] = (float (*)[64])lds;                       // affine epilogue: the summed tile [L + 1][64] and S behind it
   const int ngran = (L + 1) * 16 + ((J.aff_w != nullptr) ? NW / 4 : 0);     // float4 granules: the tile (+ the S row)
   for (int g = threadIdx.x; g < ngran; g += 256) {
