@@ -45,14 +45,18 @@ struct HeadArgs {
   int B, T, C, K, r0, R, accumulate;
 };
 
-__global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs p) {
+// One workgroup per sample, SIXTEEN waves: the final LayerNorm of the R pooled rows (gaviko.py:306,316: prompts + CLS), their mean, the
+// head.  A wave's rows are a chain of dependent round trips (load, two wave reductions); with four waves the 33 rows of GAViKO were nine
+// such links, 22 us at the end of every forward -- sixteen waves make it three.
+constexpr int kHeadWaves = 16;
+__global__ __launch_bounds__(64 * kHeadWaves) void head_fwd_kernel(HeadArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* pool_s = (float*)smem;   // [4][C] then reduced into [0][C]
+  float* pool_s = (float*)smem;   // [kHeadWaves][C] then reduced into [0][C]
   const int b = blockIdx.x, lane = lane_id(), wave = wave_id(), C = p.C;
   f32x4 acc[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int r = wave; r < p.R; r += 4) {
+  for (int r = wave; r < p.R; r += kHeadWaves) {
     const float* xr = p.g + ((size_t)b * p.T + p.r0 + r) * C;
     f32x4 v[4];
     float s = 0.f;
@@ -91,23 +95,20 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs p) {
   }
   __syncthreads();
   const float invR = 1.f / (float)p.R;
-  float tsum[4];
+  float tsum = 0.f;
+  const int c0 = threadIdx.x;                              // C <= 1024 = the workgroup's threads: one column each
+  if (c0 < C) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = k * 256 + threadIdx.x;
-    tsum[k] = (c < C) ? (pool_s[c] + pool_s[C + c] + pool_s[2 * C + c] + pool_s[3 * C + c]) * invR : 0.f;
+    for (int w = 0; w < kHeadWaves; ++w) tsum += pool_s[w * C + c0];          // wave order: deterministic
+    tsum *= invR;
   }
   __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = k * 256 + threadIdx.x;
-    if (c < C) {
-      pool_s[c] = tsum[k];
-      if (p.pooled) p.pooled[(size_t)b * C + c] = tsum[k];
-    }
+  if (c0 < C) {
+    pool_s[c0] = tsum;
+    if (p.pooled) p.pooled[(size_t)b * C + c0] = tsum;
   }
   __syncthreads();
-  for (int k = wave; k < p.K; k += 4) {
+  for (int k = wave; k < p.K; k += kHeadWaves) {
     float a = 0.f;
     for (int c = lane; c < C; c += 64) a += pool_s[c] * p.wh[(size_t)k * C + c];
     a = wave_sum(a);
@@ -233,7 +234,13 @@ extern "C" int gvk_head_fwd(const gvk_head_desc* d, void* stream) {
   int rc = head_fill(a, d);
   if (rc) return rc;
   GVK_REQUIRE(d->logits, "gvk_head_fwd: logits null");
-  GVK_LAUNCH(head_fwd_kernel, dim3(d->B), dim3(256), 4 * d->C * 4, (hipStream_t)stream, a);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kHeadWaves * 1024 * 4);
+    if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(head_fwd): %s", hipGetErrorString(e));
+    attr = true;
+  }
+  GVK_LAUNCH(head_fwd_kernel, dim3(d->B), dim3(64 * kHeadWaves), kHeadWaves * d->C * 4, (hipStream_t)stream, a);
   return check_launch("head_fwd");
 }
 

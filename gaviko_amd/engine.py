@@ -635,11 +635,14 @@ class Engine(GavikoPaths, PeftPaths):
             self._wait("loc", None)                                  # Lc[0] written by the patch GEMM
             self._wait("gpa", None)
             fuse_up = self._fuse_up and sv["bdrop"] <= 0             # (dropout behind fc2 must not touch the up-projection)
-            if fuse_up and "noside" not in _ABLATE:
-                with torch.cuda.stream(gpa):                         # the trainable half of W': off the main stream, once per step
-                    for i in range(self.depth):
-                        pre, _ = self._gpa_names(i)
-                        ops.pack_split_bf16(d(pre + ".proj_up.weight"), self._w16[f"fc2{i}"], self.mlp, C, b=d(pre + ".proj_up.bias"), weight_side=True)
+            # The trainable half of W'_fc2 (gvk_pack_split_bf16) is written on the GPA stream, layer i+1's in the idle time behind layer i's GPA:
+            # all twelve at the head of the step made layer 0's GPA -- and with it the main stream's prompt fix -- wait for them.
+            def side_weights(i):
+                if fuse_up and "noside" not in _ABLATE and i + 1 < self.depth:
+                    with torch.cuda.stream(gpa):
+                        pre, _ = self._gpa_names(i + 1)
+                        ops.pack_split_bf16(d(pre + ".proj_up.weight"), self._w16[f"fc2{i + 1}"], self.mlp, C, b=d(pre + ".proj_up.bias"), weight_side=True)
+            side_weights(-1)                                         # (layer 0's operand)
         pending_fix = None
         folded_in = False                                            # this layer's first LayerNorm rides its qkv GEMM (self._fold_ln1)
         for i in range(self.depth):
@@ -672,6 +675,7 @@ class Engine(GavikoPaths, PeftPaths):
                 self._wait("gpa", "loc")                             # L' ready
                 with torch.cuda.stream(gpa):
                     self._gpa_fwd_latents(ws, i, si, ws["G1"][si], ws["Lc"][go], M, B, True)
+                side_weights(i)
             if self.kind == "adaptformer":
                 self._adapter_fwd_down(ws, i, si, ws["G1"][si], Mi)
             if self.kind == "dvpt":
@@ -682,6 +686,7 @@ class Engine(GavikoPaths, PeftPaths):
                 self._wait("gpa", "loc")                             # ll ready (the MWSA chain projects its own L')
                 with torch.cuda.stream(gpa):
                     self._gpa_fwd_latents(ws, i, si, ws["G1"][si], ws["Lc"][go], M, B, False)
+                side_weights(i)
             up_in_fc2 = gaviko and fused and fuse_up
             fold_next = bool(up_in_fc2 and self._fold_on and i + 1 < self.depth and _on("noside") and not _FIX_IN_LN)
             # fc2 carries proj_up of the PLAIN latents of every row (ready right behind the LayerNorm); the GPA has the two GEMMs' time

@@ -1,7 +1,7 @@
 """GPU box: isolated timing of the bf16 attention kernels at the cfg2 shape (B=4, T=1033, H=12).  Every variant is a launch plan of 50
 launches; the plans are replayed in interleaved rounds inside ONE process (min / median over rounds).
 usage: python tools/bench_attn.py [B T H] [--fwd-variants]"""
-import os, sys
+import os, statistics, sys
 os.environ.setdefault("GAVIKO_HIP_DIAG", "1")      # kernel variants / A/B switches live in the measurement build (python -m gaviko_amd.build --diag), statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
