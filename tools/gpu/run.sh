@@ -5,6 +5,7 @@
 #   libs a.so b.so..  interleaved bench of several builds of the library (GAVIKO_HIP_LIB), three rounds
 #   trace [bench args] rocprofv3 --kernel-trace --stats of the bench command -> per-kernel and per-shape tables
 #   tests [expr]      pytest -m gpu (optionally -k expr), output under gpurun_out/
+#   pmc <tag>         SQ counters of the GEMM and attention kernels (rocprofv3 --pmc, kernel trace only) + isolated GEMMs beside the vendor library
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 what=$1; shift || true
@@ -74,5 +75,24 @@ tests)
   if [ -n "$1" ]; then python -m pytest tests -m gpu -x -q -k "$1" > $O/pytest.log 2>&1; else python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; fi
   tail -5 $O/pytest.log
   ;;
-*) echo "usage: run.sh ab|final|libs|trace|tests" >&2; exit 2 ;;
+pmc)
+  tag=${1:-r04}; O=$R/gpurun_out/$tag; mkdir -p $O
+  C1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY"
+  A1="SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES"
+  A2="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+  export PMC_GEMM_ORDER=$O/pmc_gemm_order.json
+  cd /tmp && export TMPDIR=/tmp
+  echo "[1] GEMM SQ counters (product tile choice, tile=0)"
+  timeout -k 10 300 rocprofv3 --pmc $C1 --kernel-trace --output-format csv -d $O/pg_a -- python3 $R/tools/pmc_gemm.py run 0 > $O/pg_a.log 2>&1
+  python3 $R/tools/pmc_gemm.py sum $O/pg_a $O/${tag}_pmc_gemm_sq_counters.json > $O/pg_sum.log 2>&1
+  echo "[2] attention SQ counters"
+  timeout -k 10 300 rocprofv3 --pmc $A1 --kernel-trace --output-format csv -d $O/pa_a -- python3 $R/tools/pmc_attn.py run > $O/pa_a.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $A2 --kernel-trace --output-format csv -d $O/pa_b -- python3 $R/tools/pmc_attn.py run > $O/pa_b.log 2>&1
+  python3 $R/tools/pmc_attn.py sum $O/pa_a $O/pa_b $O/${tag}_pmc_attention.json > $O/pa_sum.log 2>&1
+  rm -rf $O/pg_a $O/pa_a $O/pa_b
+  cd $R
+  echo "[3] isolated GEMMs vs the vendor library"
+  python3 tools/gemm_vs_lib.py $O/${tag}_gemm_isolated_vs_lib.csv
+  ;;
+*) echo "usage: run.sh ab|final|libs|trace|tests|pmc" >&2; exit 2 ;;
 esac

@@ -31,11 +31,12 @@ def load(d, counter):
 
 def clusters(reads, writes):
     """One kernel instantiation may serve several shapes (e.g. the bias+residual GEMM: out-proj K=768 and fc2 K=3072): split its
-    dispatches into groups whose read traffic differs by more than 1.5x."""
+    dispatches into groups at every gap of more than 15 % between consecutive sorted read figures (fc1 dgrad K=3072 and qkv dgrad K=2304 share
+    the plain-store instantiation and differ by 1.3x; launches of one shape repeat within a few per cent)."""
     order = sorted(range(len(reads)), key=lambda i: reads[i])
     groups = []
     for i in order:
-        if groups and reads[i] <= 1.5 * groups[-1][0][0] + 1:
+        if groups and reads[i] <= 1.15 * groups[-1][-1][0] + 1:
             groups[-1].append((reads[i], writes[i] if i < len(writes) else 0.0))
         else:
             groups.append([(reads[i], writes[i] if i < len(writes) else 0.0)])
@@ -59,6 +60,8 @@ def main():
         rd, wr = 2 * sum(fetch[k]) / n * 1024, (sum(write.get(k, [0.0])) / max(1, len(write.get(k, [0.0])))) * 1024
         out["kernels"][short] = {"launches": n, "read_bytes": round(rd), "write_bytes": round(wr), "total_bytes": round(rd + wr),
                                  "clusters": clusters(fetch[k], write.get(k, []))}
+        if "gemm" in short:                     # the per-launch figures the clusters were cut from (KiB as counted, sorted)
+            out["kernels"][short]["fetch_kib_sorted"] = [round(x) for x in sorted(fetch[k])]
     pk = [k for k in out["kernels"] if k.startswith("patchify_kernel")]
     if pk:
         out["calibration"] = {"kernel": pk[0], "expected_read": 4 * 120 * 160 * 160 * 4, "expected_write": 4 * 1000 * 3072 * 2, **out["kernels"][pk[0]]}
