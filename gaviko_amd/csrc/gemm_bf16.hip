@@ -58,7 +58,19 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs p) {
   const int grp = wg / gsz, first_m = grp * GROUP_M;
   const int gm = min(p.nbm - first_m, GROUP_M);
   const int rem = wg - grp * gsz;
-  const int tile_m = first_m + rem % gm, tile_n = rem / gm;
+  int tile_m = first_m + rem % gm, tile_n = rem / gm;
+  if (p.xcd_panels > 0) {
+    // One-round launches: WHOLE row panels per XCD (nbm / 8 each, the first nbm % 8 XCDs one more), every column tile of a panel on the XCD
+    // that owns it -- an activation panel is then fetched by exactly one L2 (a run of 24.75 tiles per XCD cut most groups of four panels in
+    // two: rocprofv3 FETCH_SIZE of the fc1 dgrad 81 MB against 63 with each XCD reading the 4.7 MB weight once).  The grid holds
+    // 8 * xcd_panels * nbn workgroups; those beyond their XCD's share leave at once.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int base = p.nbm >> 3, extra = p.nbm & 7;
+    const int pm = base + (xcd < extra ? 1 : 0);
+    if (slot >= pm * p.nbn) return;
+    tile_m = xcd * base + min(xcd, extra) + slot % pm;
+    tile_n = slot / pm;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int lane = lane_id();
@@ -234,7 +246,18 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     static const int force = diag_env("GAVIKO_HIP_GEMM_GROUP_M") ? atoi(diag_env("GAVIKO_HIP_GEMM_GROUP_M")) : 0;     // A/B switch (8 = the round-2 mapping)
     p.group_m = force > 0 ? force : g;
   }
-  GVK_LAUNCH((gemm_nt_kernel<BM, BN, EPI, BK, DROP, NS, NW>), dim3(p.nbm * p.nbn), dim3(64 * NW), lds, stream, p);
+  int grid = p.nbm * p.nbn;
+  p.xcd_panels = 0;
+  {
+    // panel-aligned XCD mapping for launches that fit one round with it: at most 32 tiles (one per CU) on the fullest XCD
+    static const int mode = diag_env("GAVIKO_HIP_GEMM_XCD_PANELS") ? atoi(diag_env("GAVIKO_HIP_GEMM_XCD_PANELS")) : 1;     // A/B switch
+    const int per = (p.nbm + 7) / 8;
+    if (mode != 0 && NS >= 3 && p.nbm >= 8 && per * p.nbn <= 32) {
+      p.xcd_panels = per;
+      grid = 8 * per * p.nbn;
+    }
+  }
+  GVK_LAUNCH((gemm_nt_kernel<BM, BN, EPI, BK, DROP, NS, NW>), dim3(grid), dim3(64 * NW), lds, stream, p);
   return check_launch("gemm_nt_bf16");
 }
 
