@@ -60,16 +60,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs p) {
   const int rem = wg - grp * gsz;
   int tile_m = first_m + rem % gm, tile_n = rem / gm;
   if (p.xcd_panels > 0) {
-    // One-round launches: WHOLE row panels per XCD (nbm / 8 each, the first nbm % 8 XCDs one more), every column tile of a panel on the XCD
-    // that owns it -- an activation panel is then fetched by exactly one L2 (a run of 24.75 tiles per XCD cut most groups of four panels in
-    // two: rocprofv3 FETCH_SIZE of the fc1 dgrad 81 MB against 63 with each XCD reading the 4.7 MB weight once).  The grid holds
-    // 8 * xcd_panels * nbn workgroups; those beyond their XCD's share leave at once.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int base = p.nbm >> 3, extra = p.nbm & 7;
-    const int pm = base + (xcd < extra ? 1 : 0);
-    if (slot >= pm * p.nbn) return;
-    tile_m = xcd * base + min(xcd, extra) + slot % pm;
-    tile_n = slot / pm;
+    // One-round launches (every tile resident at once, <= one per CU): the XCD's contiguous run of tiles in PANEL-MAJOR order, so that a row
+    // panel's column tiles sit on one XCD and an activation panel is fetched by one L2 -- except the panel a run boundary cuts (7 of 33
+    // at M = 4132).  The grouped order above (m fastest inside groups of four panels, built for multi-round launches) let a run of 24.75
+    // tiles spill a few tiles into the next group and pull ALL its panels: rocprofv3 FETCH_SIZE of the fc1 dgrad 81 MB against
+    // 25.4 (activation) + 8 x 4.7 (the weight once per XCD) = 63.  (Whole panels per XCD -- 5,4,4,... -- fetch the least, 63.8 MB, but give
+    // one XCD 30 tiles against 24: its L2 -> LDS stream then sets the kernel time, +2.3 us on the K = 3072 shapes.)
+    tile_m = wg / p.nbn;
+    tile_n = wg - tile_m * p.nbn;
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -246,16 +244,12 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     static const int force = diag_env("GAVIKO_HIP_GEMM_GROUP_M") ? atoi(diag_env("GAVIKO_HIP_GEMM_GROUP_M")) : 0;     // A/B switch (8 = the round-2 mapping)
     p.group_m = force > 0 ? force : g;
   }
-  int grid = p.nbm * p.nbn;
+  const int grid = p.nbm * p.nbn;
   p.xcd_panels = 0;
   {
-    // panel-aligned XCD mapping for launches that fit one round with it: at most 32 tiles (one per CU) on the fullest XCD
+    // panel-major tile order for the one-round launches of the three-stage (one workgroup per CU) kernel
     static const int mode = diag_env("GAVIKO_HIP_GEMM_XCD_PANELS") ? atoi(diag_env("GAVIKO_HIP_GEMM_XCD_PANELS")) : 1;     // A/B switch
-    const int per = (p.nbm + 7) / 8;
-    if (mode != 0 && NS >= 3 && p.nbm >= 8 && per * p.nbn <= 32) {
-      p.xcd_panels = per;
-      grid = 8 * per * p.nbn;
-    }
+    if (mode != 0 && NS >= 3 && grid <= 256) p.xcd_panels = 1;
   }
   GVK_LAUNCH((gemm_nt_kernel<BM, BN, EPI, BK, DROP, NS, NW>), dim3(grid), dim3(64 * NW), lds, stream, p);
   return check_launch("gemm_nt_bf16");

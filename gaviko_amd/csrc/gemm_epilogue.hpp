@@ -22,7 +22,7 @@ struct GemmArgs {
   int rows_in, rows_out, row_off;
   int nbm, nbn;
   int group_m;                                           // row panels per rasterisation group (4-wave kernel; set by launch_gemm)
-  int xcd_panels;                                        // > 0: whole row panels per XCD (launch_gemm: a one-round launch), the grid is 8 * xcd_panels * nbn
+  int xcd_panels;                                        // > 0: panel-major tile order inside each XCD's run (launch_gemm: one-round launches)
   int a_rows;                                            // rows the A buffer really has (M padded to 128): the 256-row tile clamps to it
   // DROP instantiations only (nn.Dropout behind a Linear of the unfrozen-backbone methods): mask index m * N + n
   unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;
