@@ -655,7 +655,7 @@ class Engine(GavikoPaths, PeftPaths):
             if gaviko:
                 if not train and i > 0:
                     self._wait("loc", "gpa")                         # eval ping-pongs Lc: the GPA of layer i-1 must be done with it
-                if train and _LOC_LEAD >= 0:
+                if train and _LOC_LEAD >= 0 and M >= 3000:           # (M = 2066 -- B = 2, ViT-L cfg5 -- is latency-bound: 0.3-0.6 % slower with it)
                     # The MWSA chain depends on nothing but itself and would run all twelve layers during the backbone's first four (its
                     # kernels, the GPA's and the GEMMs then share those layers' CUs: fc1 forward up to 67 us there against a median of 29);
                     # held to at most _LOC_LEAD layers ahead of the backbone its kernels spread over the whole sweep: 748.8 vs 745.1 volumes/s
