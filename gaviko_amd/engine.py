@@ -27,7 +27,7 @@ from . import ops
 
 import os
 
-from .engine_common import (SEED_EMB, SEED_LAYER, SEED_PROMPT, GRAPH_WARMUP, Names, PLAN_TIMING, SIDE_STREAM_PRIORITY, STEP_MODE, USE_GRAPHS, _ABLATE, _EPI_NAMES, _FIX_IN_LN, _LOC_LEAD, _LOC_SHIFT, _MODE, _SIDE_STREAMS, _on, evp_highpass_operator)  # noqa: F401
+from .engine_common import (SEED_EMB, SEED_LAYER, SEED_PROMPT, GRAPH_WARMUP, Names, PLAN_TIMING, SIDE_STREAM_PRIORITY, STEP_MODE, USE_GRAPHS, _ABLATE, _EPI_NAMES, _FIX_IN_LN, _LOC_SHIFT, _MODE, _SIDE_STREAMS, _on, evp_highpass_operator)  # noqa: F401
 from .engine_gaviko import GavikoPaths
 from .engine_peft import PeftPaths
 
@@ -643,7 +643,6 @@ class Engine(GavikoPaths, PeftPaths):
                         pre, _ = self._gpa_names(i + 1)
                         ops.pack_split_bf16(d(pre + ".proj_up.weight"), self._w16[f"fc2{i + 1}"], self.mlp, C, b=d(pre + ".proj_up.bias"), weight_side=True)
             side_weights(-1)                                         # (layer 0's operand)
-        _lead_ev = {}
         pending_fix = None
         folded_in = False                                            # this layer's first LayerNorm rides its qkv GEMM (self._fold_ln1)
         for i in range(self.depth):
@@ -655,13 +654,6 @@ class Engine(GavikoPaths, PeftPaths):
             if gaviko:
                 if not train and i > 0:
                     self._wait("loc", "gpa")                         # eval ping-pongs Lc: the GPA of layer i-1 must be done with it
-                if train and _LOC_LEAD >= 0 and M >= 3000:           # (M = 2066 -- B = 2, ViT-L cfg5 -- is latency-bound: 0.3-0.6 % slower with it)
-                    # The MWSA chain depends on nothing but itself and would run all twelve layers during the backbone's first four (its
-                    # kernels, the GPA's and the GEMMs then share those layers' CUs: fc1 forward up to 67 us there against a median of 29);
-                    # held to at most _LOC_LEAD layers ahead of the backbone its kernels spread over the whole sweep: 748.8 vs 745.1 volumes/s
-                    _lead_ev[i] = self._ev_record(torch.cuda.current_stream())       # the backbone is about to start layer i
-                    if i - _LOC_LEAD >= 1:
-                        self._ev_wait(loc, _lead_ev[i - _LOC_LEAD])
                 with torch.cuda.stream(loc):
                     # with the 16-row-tile kernels the MWSA up-projection also emits GPA's proj_down of the rows it writes
                     fuse_local = self._fuse_proj and self._fuse_local

@@ -42,7 +42,6 @@ _SIDE_STREAMS = {}                       # (device index, kind) -> the process-w
 # MWSA backward chain held behind the layer's attention backward: measured 669 vs 688 volumes/s -- the chain then slows the dgrad GEMMs
 # of the next layer by as much as it slowed the attention kernels before (start->fc1d 82 -> 98 us); opt-in only
 _LOC_SHIFT = L.diag_env("GAVIKO_HIP_LOC_SHIFT", "0") == "1"
-_LOC_LEAD = int(L.diag_env("GAVIKO_HIP_LOC_LEAD", "2"))     # forward: layers the MWSA chain may run ahead of the backbone (-1: unthrottled; A/B switch)
 _EPI_NAMES = {0: "store_bf16", 1: "bias_res_f32", 2: "bias_gelu_bf16", 3: "patch_f32", 4: "gelu_bwd_bf16", 5: "store_f32", 6: "bias_res_f32_bf16",
               7: "bias_relu_bf16", 8: "relu_bwd_bf16"}
 
