@@ -191,3 +191,22 @@ def test_product_source_hash_ignores_diag_blocks_and_comments():
     assert product_text(base) != product_text(base.replace("x + 1", "x + 2"))
     h = gemm_source_hash()
     assert len(h) == 16 and h == gemm_source_hash()
+
+
+def test_pmc_traffic_clusters_split_shapes_of_one_instantiation():
+    """tools/pmc_traffic.py: one GEMM instantiation serving two shapes whose read traffic differs by 1.3x (fc1 dgrad K = 3072 and qkv dgrad
+    K = 2304 share the plain-store kernel) must come out as two clusters -- bench.py attaches `roofline.traffic` only then -- while the
+    launch-to-launch spread of one shape (a few per cent) must not split it."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("pmc_traffic", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "pmc_traffic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    a = [24800 + 37 * i for i in range(72)]            # KiB as counted (reads are doubled afterwards): +-5 %
+    b = [33000 + 29 * i for i in range(72)]
+    reads = [v for pair in zip(a, b) for v in pair]    # the two shapes alternate in launch order
+    writes = [12400.0] * len(reads)
+    cl = mod.clusters(reads, writes)
+    assert [c["launches"] for c in cl] == [72, 72]
+    assert cl[0]["read_bytes"] < cl[1]["read_bytes"] and abs(cl[1]["read_bytes"] / cl[0]["read_bytes"] - 1.33) < 0.05
+    one = mod.clusters(a, [12400.0] * len(a))
+    assert len(one) == 1 and one[0]["launches"] == 72
