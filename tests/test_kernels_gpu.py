@@ -403,7 +403,7 @@ def test_gemm_f32_epilogues(dev, M, N, K):
     assert out0[M:].abs().max() == 0                      # rows beyond M are never stored
 
 
-@pytest.mark.parametrize("B,T,H", [(2, 197, 2), (1, 1001, 1), (2, 65, 3)])
+@pytest.mark.parametrize("B,T,H", [(2, 197, 2), (1, 1001, 1), (2, 65, 3), (1, 7, 2), (2, 33, 1), (1, 129, 1), (1, 1, 1)])
 def test_attention_f32_fwd_bwd(dev, B, T, H):
     """fp32 flash attention (vision_transformer.py:63-71 and its autograd) against float64 torch."""
     from gaviko_amd import ops
