@@ -362,7 +362,7 @@ def main():
     bbname = {"vit-b16": "ViT-B/16", "vit-l16": "ViT-L/16", "vit-t16": "ViT-T/16"}.get(args.backbone, args.backbone)
     eng0 = model._engine()
     what = {"gaviko": "frozen ViT; prompts+MWSA+GPA+head train; attn_drop=proj_drop=0.2 live",
-            "deep_vpt": "frozen ViT; deep prompts + prompt_proj + head train; backbone dropout 0.1 and prompt_dropout 0.1 live (no train() override of the inner ViT)",
+            "deep_vpt": "frozen ViT, its transformer and dropouts in eval (vpt.py:106-115); deep prompts + prompt_proj + head train; prompt_dropout 0.1 live",
             "adaptformer": "frozen ViT; adapters + head train",
             "melo": "frozen ViT; LoRA (r=4) on q and v + head train; backbone dropout 0.1 live (no train() override)"}[args.method]
     arith = "bf16 MFMA operands / fp32 accumulate" if args.precision == "bf16" else "exact fp32 (f32-input MFMA, fp32 flash attention)"
