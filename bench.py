@@ -128,8 +128,8 @@ def cpu_baseline(backbone, batch, method="gaviko"):
 
 # newest committed PMC summary first; each records the hash of the GEMM sources AS THE PRODUCT BUILD COMPILES THEM (comments and
 # `#ifdef GVK_DIAG` text excluded: gaviko_amd/utils/srchash.py) and is ignored when that differs from this tree's
-PMC_TRAFFIC_FILE = next((f for f in ("r04_pmc_traffic.json", "r03_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))),
-                        "r04_pmc_traffic.json")
+PMC_TRAFFIC_FILE = next((f for f in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f))),
+                        "r05_pmc_traffic.json")
 
 
 def gemm_source_hash():
@@ -137,39 +137,49 @@ def gemm_source_hash():
     return h()
 
 
-def pmc_traffic(name, stats):
+def gemm_alg_bytes(epi: int, shape):
+    """Algorithmic HBM bytes of one GEMM launch: bf16 operands in + (aux in, out) per epilogue id -- 0 bf16 out; 2 bias+gelu ->
+    pre-act + act bf16 out; 4 pre-act in, bf16 out; 1 fp32 residual read-modify-write; 5 fp32 out; 6 residual + bf16 copy."""
+    M, N, K = shape
+    return 2 * (M * K + N * K) + M * N * {0: 2, 1: 8, 2: 4, 4: 4, 5: 4, 6: 10}.get(epi, 4)
+
+
+def gemm_kernel_epilogue(kernel_name: str):
+    """Epilogue id of a GEMM kernel instantiation as rocprofv3 prints it, or None for other kernels."""
+    m = re.match(r"gemm_nt_kernel<\d+, \d+, (\d+), \d+(, false)?(, \d+)*>", kernel_name) or re.match(r"gemm8p_kernel<(\d+), \d+>", kernel_name)
+    return int(m.group(1)) if m else None
+
+
+def pmc_traffic(name, stats, path=None):
     """HBM-side bytes per launch of the dominant GEMM from the committed PMC passes (profiles/r0N_pmc_traffic.json, produced
     by tools/pmc_traffic.py from two `rocprofv3 --pmc` runs of this same command: FETCH_SIZE and WRITE_SIZE, KiB units, reads
-    x2 on gfx950).  PMC counters cannot be read from inside the process, so the figure is the last profiled one; it is only
-    attached when the kernel instantiation (epilogue id) is used by exactly one GEMM shape of this run, else traffic stays null."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_TRAFFIC_FILE)
+    x2 on gfx950).  PMC counters cannot be read from inside the process, so the figure is the last profiled one.  The profiler sees
+    kernel instantiations, not shapes, so tools/pmc_traffic.py records with every traffic cluster the [M, N, K] it was measured on
+    (from `bench.py --dump-gemm-shapes` of the profiled command); a figure is attached ONLY when exactly one cluster of this
+    kernel's instantiation carries this run's shape -- a PMC file taken at another workload (other batch / backbone), or one
+    without recorded shapes, yields `traffic_note` and no number."""
+    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_TRAFFIC_FILE)
     m = re.match(r"gemm_nt_bf16\[(\w+)\]", name)
     if not (m and os.path.exists(path)):
         return {}
-    from gaviko_amd import engine as eng_mod
-    epi = {v: k for k, v in eng_mod._EPI_NAMES.items()}[m.group(1)]
+    from gaviko_amd.engine_common import _EPI_NAMES
+    epi = {v: k for k, v in _EPI_NAMES.items()}[m.group(1)]
     with open(path) as f:
         doc = json.load(f)
+    base = os.path.basename(path)
     if doc.get("gemm_source_sha") != gemm_source_hash():     # measured on other code: no figure rather than a stale one
-        return {"traffic_note": f"{os.path.basename(path)} was measured on GEMM sources {doc.get('gemm_source_sha')}, this build is {gemm_source_hash()}: traffic withheld"}
-    ker = doc["kernels"]
-    hits = [v for k, v in ker.items() if re.match(rf"gemm_nt_kernel<\d+, \d+, {epi}, \d+(, false)?(, \d+)*>", k) or re.match(rf"gemm8p_kernel<{epi}, \d+>", k)]
+        return {"traffic_note": f"{base} was measured on GEMM sources {doc.get('gemm_source_sha')}, this build is {gemm_source_hash()}: traffic withheld"}
+    shape = list(stats[name]["shape"])
+    cl = [c for k, v in doc["kernels"].items() if gemm_kernel_epilogue(k) == epi for c in (v.get("clusters") or [v])]
+    if not any("shape" in c for c in cl):
+        return {"traffic_note": f"{base} records no [M, N, K] with its traffic clusters (taken before round 5): traffic withheld"}
+    hits = [c for c in cl if c.get("shape") == shape]
     if len(hits) != 1:
-        return {}
-
-    def alg_bytes(shape):
-        # bf16 operands in + (aux in, out) per epilogue: 0 bf16 out; 2 bias+gelu -> pre-act + act bf16 out; 4 pre-act in, bf16 out;
-        # 1 fp32 residual read-modify-write; 5 fp32 out
-        M, N, K = shape
-        return 2 * (M * K + N * K) + M * N * {0: 2, 1: 8, 2: 4, 4: 4, 5: 4, 6: 10}.get(epi, 4)
-
-    # the instantiation may serve several shapes of this run: match its traffic clusters to them by ascending algorithmic bytes
-    same = sorted((k for k in stats if k.startswith(f"gemm_nt_bf16[{m.group(1)}]")), key=lambda k: alg_bytes(stats[k]["shape"]))
-    cl = hits[0].get("clusters") or [hits[0]]
-    if len(cl) != len(same):
-        return {}
-    return {"traffic": cl[same.index(name)]["total_bytes"], "traffic_source": f"profiles/{PMC_TRAFFIC_FILE} (2*FETCH_SIZE + WRITE_SIZE, KiB; GEMM sources {doc.get('gemm_source_sha')})",
-            "algorithmic_bytes": alg_bytes(stats[name]["shape"])}
+        return {"traffic_note": f"{base} holds {len(hits)} cluster(s) measured on M, N, K = {shape} for epilogue '{m.group(1)}' "
+                                f"(its workload: {doc.get('workload')}): traffic withheld"}
+    return {"traffic": hits[0]["total_bytes"], "traffic_source": f"profiles/{base} (2*FETCH_SIZE + WRITE_SIZE, KiB; GEMM sources {doc.get('gemm_source_sha')}; "
+                                                                 f"cluster measured on M, N, K = {shape})",
+            "algorithmic_bytes": gemm_alg_bytes(epi, shape)}
 
 
 def rank_cpu_set(local_rank: int, local_world: int, cpus=None):
@@ -261,6 +271,9 @@ def main():
     ap.add_argument("--loss", default="ce", choices=["ce", "focal", "ce-torch"])   # ce-torch: torch's own op, for A/B only
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-gemm-shapes", default=None, metavar="FILE",
+                    help="write {workload, classes: {GEMM class: [M, N, K]}} of this run's instrumented pass to FILE (tools/pmc_traffic.py attaches "
+                         "the shapes to the traffic clusters of a PMC pass of the same command)")
     ap.add_argument("--launch-check", action="store_true", help="every rank reports its launcher environment and exits before any GPU call (tests)")
     ap.add_argument("--allow-diag", "--allow-ablate", dest="allow_diag", action="store_true",
                     help="diagnostics only: run on the measurement build (GAVIKO_HIP_DIAG=1: A/B switches and timing ablations live there); the "
@@ -406,10 +419,19 @@ def main():
         if rank != 0:
             pe, stats = None, {}
         if pe:
-            # HBM-bound stage: algorithmic bytes = fp32 volume in + fp32 token rows out (global + local stream), per launch
-            out["patch_embed"] = {"bound": "hbm", "achieved": round(pe["bytes"] / (pe["avg_ms"] * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                                  "frac": round(pe["bytes"] / (pe["avg_ms"] * 1e-3) / 8e12, 4), "avg_us": round(pe["avg_ms"] * 1e3, 1),
-                                  "algorithmic_bytes": pe["bytes"], "note": "im2col(bf16) + MFMA GEMM with fused bias/pos/scatter epilogue"}
+            # HBM-bound stage on the bf16 path: algorithmic bytes = fp32 volume in + fp32 token rows out (global + local stream), per launch.
+            # On the exact-fp32 path the same stage is bound by the fp32 matrix rate (1/16 of bf16): labelled and priced against that peak.
+            hbm = {"achieved": round(pe["bytes"] / (pe["avg_ms"] * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                   "frac": round(pe["bytes"] / (pe["avg_ms"] * 1e-3) / 8e12, 4)}
+            if args.precision == "fp32":
+                pflop = 2.0 * B * 1000 * 3072 * eng0.C
+                ptf = pflop / (pe["avg_ms"] * 1e-3) / 1e12
+                out["patch_embed"] = {"bound": "mfma_f32", "achieved": round(ptf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ptf / peak, 4),
+                                      "avg_us": round(pe["avg_ms"] * 1e3, 1), "flop_per_launch": pflop, "algorithmic_bytes": pe["bytes"], "hbm_side": hbm,
+                                      "note": "im2col(fp32) + f32-input MFMA GEMM with fused bias/pos/scatter epilogue"}
+            else:
+                out["patch_embed"] = {"bound": "hbm", **hbm, "avg_us": round(pe["avg_ms"] * 1e3, 1),
+                                      "algorithmic_bytes": pe["bytes"], "note": "im2col(bf16) + MFMA GEMM with fused bias/pos/scatter epilogue"}
         if stats:
             name, s = max(stats.items(), key=lambda kv: kv[1]["total_ms"])
             raw_us, pair_us = s["avg_ms"] * 1e3, s["overhead_ms"] * 1e3
@@ -420,9 +442,13 @@ def main():
                                "avg_launch_us_minus_event_pair": round(max(raw_us - pair_us, 0.0), 2),
                                "timing": "RAW HIP event pairs on the launch stream inside the replayed plan (nothing subtracted; an empty "
                                          "pair costs event_pair_us); flop_per_launch = 2*M*N*K_algorithmic (padding columns of the "
-                                         "K-concatenated fc2 operand excluded); cross-check: profiles/r04_kernel_stats_by_shape.csv"}
+                                         "K-concatenated fc2 operand excluded); cross-check: profiles/r05_kernel_stats_by_shape.csv"}
             if args.method == "gaviko" and args.precision == "bf16":
                 out["roofline"].update(pmc_traffic(name, stats))
+            if args.dump_gemm_shapes:
+                with open(args.dump_gemm_shapes, "w") as f:
+                    json.dump({"workload": {"backbone": args.backbone, "method": args.method, "batch": B, "precision": args.precision},
+                               "classes": {k: v["shape"] for k, v in stats.items()}}, f, indent=1)
             out["gemm_classes"] = {k: {"avg_us": round(v["avg_ms"] * 1e3, 2), "n": v["n"], "tflops": round(v["flops_per_launch"] / (v["avg_ms"] * 1e-3) / 1e12, 1)}
                                    for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["total_ms"])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -210,3 +210,49 @@ def test_pmc_traffic_clusters_split_shapes_of_one_instantiation():
     assert cl[0]["read_bytes"] < cl[1]["read_bytes"] and abs(cl[1]["read_bytes"] / cl[0]["read_bytes"] - 1.33) < 0.05
     one = mod.clusters(a, [12400.0] * len(a))
     assert len(one) == 1 and one[0]["launches"] == 72
+
+
+def test_pmc_traffic_is_attached_only_to_the_shape_it_was_measured_on(tmp_path):
+    """Round 4 shipped a cfg5 line carrying the cfg2 kernel's PMC bytes: bench.py paired traffic clusters with this run's shapes by rank
+    order.  Now tools/pmc_traffic.py stores [M, N, K] with every cluster and bench.pmc_traffic attaches a figure only on an exact match:
+    a PMC file taken at cfg2 must yield `traffic` for cfg2's fc1 dgrad and NOTHING but a note for cfg5's."""
+    import importlib.util, json, os, sys
+    root = os.path.dirname(os.path.dirname(__file__))
+    sys.path.insert(0, root)
+    import bench
+    spec = importlib.util.spec_from_file_location("pmc_traffic", os.path.join(root, "tools", "pmc_traffic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from gaviko_amd.engine_common import _EPI_NAMES
+    kname = "gemm_nt_kernel<128, 128, 5, 64, false, 3, 4>(GemmArgs)"
+    assert bench.gemm_kernel_epilogue(kname) == 5 and bench.gemm_kernel_epilogue("gemm8p_kernel<2, 0>(GemmArgs)") == 2
+    assert bench.gemm_kernel_epilogue("param_grads_kernel<2>(PgArgs)") is None
+    kernels = {kname: {"launches": 144, "clusters": [{"launches": 72, "total_bytes": 63526960}, {"launches": 72, "total_bytes": 80435275}]},
+               "param_grads_kernel<2>(PgArgs)": {"launches": 144, "clusters": [{"launches": 144, "total_bytes": 49017128}]}}
+    cfg2 = {"workload": {"backbone": "vit-b16", "method": "gaviko", "batch": 4, "precision": "bf16"},
+            "classes": {"gemm_nt_bf16[store_f32] M=4132 N=768 K=3072": [4132, 768, 3072], "gemm_nt_bf16[store_f32] M=4132 N=768 K=2304": [4132, 768, 2304],
+                        "gemm_nt_bf16[store_bf16] M=4132 N=768 K=768": [4132, 768, 768]}}
+    mod.attach_shapes(kernels, cfg2, bench.gemm_kernel_epilogue, bench.gemm_alg_bytes, _EPI_NAMES)
+    cl = kernels[kname]["clusters"]
+    assert cl[0]["shape"] == [4132, 768, 2304] and cl[1]["shape"] == [4132, 768, 3072]          # ascending bytes <-> ascending K
+    assert "shape" not in kernels["param_grads_kernel<2>(PgArgs)"]["clusters"][0]
+    doc = {"gemm_source_sha": bench.gemm_source_hash(), "workload": cfg2["workload"], "kernels": kernels}
+    path = tmp_path / "pmc.json"
+    path.write_text(json.dumps(doc))
+    name2 = "gemm_nt_bf16[store_f32] M=4132 N=768 K=3072"
+    r = bench.pmc_traffic(name2, {name2: {"shape": [4132, 768, 3072]}, "gemm_nt_bf16[store_f32] M=4132 N=768 K=2304": {"shape": [4132, 768, 2304]}}, path=str(path))
+    assert r["traffic"] == 80435275 and r["algorithmic_bytes"] == bench.gemm_alg_bytes(5, [4132, 768, 3072])
+    # cfg5: same instantiation, two classes as well (so rank-order pairing would have "matched"), other M / N / K
+    name5 = "gemm_nt_bf16[store_f32] M=2066 N=1024 K=4096"
+    r5 = bench.pmc_traffic(name5, {name5: {"shape": [2066, 1024, 4096]}, "gemm_nt_bf16[store_f32] M=2066 N=1024 K=3072": {"shape": [2066, 1024, 3072]}}, path=str(path))
+    assert "traffic" not in r5 and "withheld" in r5["traffic_note"]
+    # a file without recorded shapes (rounds 1-4) gives no number either
+    for c in cl:
+        c.pop("shape")
+    path.write_text(json.dumps(doc))
+    r_old = bench.pmc_traffic(name2, {name2: {"shape": [4132, 768, 3072]}}, path=str(path))
+    assert "traffic" not in r_old and "no [M, N, K]" in r_old["traffic_note"]
+    # clusters that moved fewer bytes than the paired shape needs are left unlabelled (the pairing cannot be right)
+    tiny = {kname: {"clusters": [{"total_bytes": 1000}, {"total_bytes": 2000}]}}
+    mod.attach_shapes(tiny, cfg2, bench.gemm_kernel_epilogue, bench.gemm_alg_bytes, _EPI_NAMES)
+    assert all("shape" not in c for c in tiny[kname]["clusters"])

@@ -20,13 +20,14 @@ ab)
   done | tee $O/abl.txt
   ;;
 final)
-  tag=${1:-r04}; O=$R/gpurun_out/$tag; mkdir -p $O
+  tag=${1:-r05}; O=$R/gpurun_out/$tag; mkdir -p $O
   cd /tmp && export TMPDIR=/tmp
   echo "[1] PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, kernel trace only)"
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-roofline > $O/pmc_fetch.log 2>&1
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-roofline > $O/pmc_write.log 2>&1
   cd $R
-  python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/${tag}_pmc_traffic.json > $O/pmc_traffic.log 2>&1
+  python bench.py --steps 2 --warmup 2 --no-cpu-baseline --dump-gemm-shapes $O/gemm_shapes.json > /dev/null 2> $O/shapes.err
+  python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/${tag}_pmc_traffic.json $O/gemm_shapes.json > $O/pmc_traffic.log 2>&1
   cp $O/${tag}_pmc_traffic.json profiles/${tag}_pmc_traffic.json        # bench.py reads it from profiles/ in step [2]
   rm -rf $O/pmc_fetch $O/pmc_write
   echo "[2] bench (default flags, then 30/10)"

@@ -4,7 +4,13 @@ profiles/<tag>_pmc_traffic.json: HBM-side bytes per launch for every GEMM instan
 
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-roofline
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ...   (same command)
-  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
+  python bench.py --steps 2 --warmup 2 --no-cpu-baseline --dump-gemm-shapes gpurun_out/gemm_shapes.json      (same workload flags)
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r05_pmc_traffic.json gpurun_out/gemm_shapes.json
+
+The profiler names kernel INSTANTIATIONS; one instantiation serves several GEMM shapes (fc1 dgrad K = 3072 and qkv dgrad K = 2304 share
+the plain-store kernel) and the same instantiation serves other shapes at another batch / backbone.  The fourth argument (bench.py's
+own list of this workload's GEMM classes) lets every traffic cluster be stored WITH the [M, N, K] it was measured on; bench.py
+attaches a figure to a roofline line only when that shape equals the line's.
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM): both counters are in KiB; FETCH_SIZE reports exactly half the bytes of a wide
 coalesced read stream, so reads = 2 * FETCH_SIZE * 1024.  Calibrated here on patchify_kernel, whose traffic is known exactly
@@ -47,6 +53,27 @@ def clusters(reads, writes):
     return out
 
 
+def attach_shapes(kernels, shapes_doc, epi_of, alg_bytes, epi_names):
+    """Give every cluster of a GEMM instantiation the [M, N, K] (and class name) it was measured on: the workload's classes with that
+    epilogue, in ascending algorithmic bytes, against the clusters in ascending traffic -- only when the counts agree and no cluster
+    moved fewer bytes than its shape needs (then the pairing cannot be right and the clusters stay unlabelled)."""
+    for k, v in kernels.items():
+        epi = epi_of(k)
+        if epi is None or epi not in epi_names:
+            continue
+        cand = sorted((c for c in shapes_doc["classes"] if c.startswith(f"gemm_nt_bf16[{epi_names[epi]}]")),
+                      key=lambda c: alg_bytes(epi, shapes_doc["classes"][c]))
+        cl = v.get("clusters") or []
+        if not cand or len(cand) != len(cl):
+            continue
+        if any(c["total_bytes"] < 0.9 * alg_bytes(epi, shapes_doc["classes"][n]) for c, n in zip(cl, cand)):
+            continue
+        for c, n in zip(cl, cand):
+            c["shape"] = list(shapes_doc["classes"][n])
+            c["class"] = n
+            c["algorithmic_bytes"] = alg_bytes(epi, c["shape"])
+
+
 def main():
     fetch = load(sys.argv[1], "FETCH_SIZE")
     write = load(sys.argv[2], "WRITE_SIZE")
@@ -62,6 +89,11 @@ def main():
                                  "clusters": clusters(fetch[k], write.get(k, []))}
         if "gemm" in short:                     # the per-launch figures the clusters were cut from (KiB as counted, sorted)
             out["kernels"][short]["fetch_kib_sorted"] = [round(x) for x in sorted(fetch[k])]
+    if len(sys.argv) > 4:
+        from gaviko_amd.engine_common import _EPI_NAMES
+        shapes_doc = json.load(open(sys.argv[4]))
+        out["workload"] = shapes_doc["workload"]
+        attach_shapes(out["kernels"], shapes_doc, bench.gemm_kernel_epilogue, bench.gemm_alg_bytes, _EPI_NAMES)
     pk = [k for k in out["kernels"] if k.startswith("patchify_kernel")]
     if pk:
         out["calibration"] = {"kernel": pk[0], "expected_read": 4 * 120 * 160 * 160 * 4, "expected_write": 4 * 1000 * 3072 * 2, **out["kernels"][pk[0]]}
