@@ -182,14 +182,16 @@ def pmc_traffic(name, stats, path=None):
             "algorithmic_bytes": gemm_alg_bytes(epi, shape)}
 
 
-def rank_cpu_set(local_rank: int, local_world: int, cpus=None):
-    """The disjoint share of this process's allowed CPUs that rank `local_rank` of `local_world` keeps: a contiguous run of
-    len(cpus) // local_world of them (every rank at least one).  N ranks issuing ~500 launches per step from one host would otherwise
-    migrate over each other's cores."""
-    cpus = sorted(os.sched_getaffinity(0)) if cpus is None else sorted(cpus)
-    k = max(1, len(cpus) // max(1, local_world))
-    lo = (local_rank * k) % len(cpus)
-    return cpus[lo: lo + k] or cpus[:1]
+def rank_cpu_set(local_rank: int, local_world: int, cpus=None, sys_root="/sys"):
+    """The share of this process's allowed CPUs that rank `local_rank` of `local_world` keeps (gaviko_amd/utils/cputopo.py): whole
+    PHYSICAL cores -- a core's hardware threads never go to two ranks -- on the NUMA node of the rank's GPU, the node's cores split
+    evenly among the ranks whose GPUs hang off it; read from sysfs (thread_siblings_list, node*/cpulist, the KFD topology and the
+    GPU's PCI numa_node), all before any HIP call.  Where sysfs has nothing it falls back to equal contiguous runs.  N ranks issuing
+    ~360 launches per step from one host would otherwise migrate over each other's cores -- or, cut by logical id, share them as
+    hyper-thread siblings."""
+    from gaviko_amd.utils import cputopo
+    table, _ = cputopo.rank_cpu_table(local_world, cpus, sys_root)
+    return table[local_rank % len(table)]
 
 
 def pin_rank_cpus(local_rank: int, local_world: int):
@@ -197,10 +199,25 @@ def pin_rank_cpus(local_rank: int, local_world: int):
     platform has no affinity call or there is a single rank (nothing to separate)."""
     if local_world <= 1 or not hasattr(os, "sched_setaffinity") or os.environ.get("GAVIKO_BENCH_NO_PIN") == "1":
         return None
-    mine = rank_cpu_set(local_rank, local_world)
+    from gaviko_amd.utils import cputopo
+    table, how = cputopo.rank_cpu_table(local_world)
+    mine = table[local_rank % len(table)]
     os.sched_setaffinity(0, mine)
-    print(f"bench.py: rank {local_rank}/{local_world} pinned to {len(mine)} CPU(s) {mine[0]}-{mine[-1]}", file=sys.stderr, flush=True)
+    print(f"bench.py: rank {local_rank}/{local_world} pinned to {len(mine)} CPU(s) {cputopo_ranges(mine)} [{how}]", file=sys.stderr, flush=True)
     return mine
+
+
+def cputopo_ranges(cpus):
+    """[0, 1, 2, 3, 128, 129] -> '0-3,128-129'"""
+    out, cpus = [], sorted(cpus)
+    i = 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
 
 
 def spawn_ranks(n: int) -> int:
@@ -300,6 +317,7 @@ def main():
         rec["gpu_initialised"] = bool(torch.cuda.is_initialized())
         rec["queues_set_before_hip"] = bool(_queues_set_before_hip)
         rec["cpus"] = cpus
+        rec["cpu_ranges"] = cputopo_ranges(cpus) if cpus else None
         path = os.environ.get("GAVIKO_BENCH_LAUNCH_LOG")
         if path:
             with open(f"{path}.{rank}", "w") as f:
