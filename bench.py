@@ -286,6 +286,9 @@ def main():
     ap.add_argument("--precision", default=None, choices=["bf16", "fp32"],
                     help="operand precision (default bf16; adaptformer / melo default to fp32, BASELINE cfg4's precision)")
     ap.add_argument("--loss", default="ce", choices=["ce", "focal", "ce-torch"])   # ce-torch: torch's own op, for A/B only
+    ap.add_argument("--zero-grad", default="none", choices=["none", "flat"],
+                    help="none (default): optimizer.zero_grad() as train.py:296 calls it (set_to_none=True); flat: zero_grad(set_to_none=False), one "
+                         "memset of the flat gradient buffer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dump-gemm-shapes", default=None, metavar="FILE",
@@ -364,8 +367,16 @@ def main():
     if args.loss == "ce-torch":
         criterion = torch.nn.functional.cross_entropy
 
+    # The step opens the way train.py:296 does: `optimizer.zero_grad()` of the optimizer the loop would own (gaviko_amd.optim.FusedAdamOneCycle,
+    # never stepped here: the optimizer step is outside the fwd+bwd metric).  Its default is torch's (set_to_none=True: every .grad dropped,
+    # the backward re-attaches ~300 views, ~0.6 ms of host time); `--zero-grad flat` times zero_grad(set_to_none=False) instead, which is ONE
+    # memset of the flat gradient buffer and lets the backward skip that bookkeeping.  DESIGN.md 7e quotes both.
+    from gaviko_amd.optim import FusedAdamOneCycle
+    optimizer = FusedAdamOneCycle(model, lr=3e-4, eps=1e-8)
+    to_none = args.zero_grad == "none"
+
     def step():
-        model.zero_grad(set_to_none=False)                # the optimizer's zero_grad: ONE memset of the flat gradient buffer once it exists
+        optimizer.zero_grad(set_to_none=to_none)
         loss = criterion(model(x), y)
         loss.backward()
         return loss
@@ -404,7 +415,8 @@ def main():
            "config": {"workload": f"{args.backbone} --method {args.method} {arith}, batch={B}/GPU, fwd + "
                                   f"{'CrossEntropy' if args.loss != 'focal' else 'Focal(1.2)'} + bwd ({what}), "
                                   f"grads all-reduced over {world} rank(s)",
-                      "global_batch": world * B, "tokens": eng0.T, "parallelism": f"dp{world}"}}
+                      "global_batch": world * B, "tokens": eng0.T, "parallelism": f"dp{world}",
+                      "zero_grad": "optimizer.zero_grad() [set_to_none=True]" if to_none else "optimizer.zero_grad(set_to_none=False) [one memset]"}}
     if os.environ.get("GAVIKO_HIP_DIAG", "0") == "1":
         out["INVALID_measurement_build"] = {k: v for k, v in os.environ.items() if k.startswith("GAVIKO_HIP_")}
     peak = PEAK_TFLOPS[args.precision]

@@ -400,7 +400,7 @@ class Engine(GavikoPaths, PeftPaths):
                 if self._pgrad:                                                          # one scratch + ticket block per stream (gvk_param_grads)
                     nct = (C + 63) // 64
                     ws["pscratch"] = mk(ops.param_grads_scratch_elems(Lt, [nct, nct], [ng, Lt * Lt, Lt, Lt * Lt, Lt, Lt]))
-                    ws["pscratch_l"] = mk(ops.param_grads_scratch_elems(Lt, [nct, nct, 1], []))
+                    ws["pscratch_l"] = mk(ops.param_grads_scratch_elems(Lt, [nct, nct, (3 * Lt + 63) // 64], []))   # third job: the qkv weight, 3 Lat columns (two tiles from Lat = 24)
                     ws["ptick"] = torch.zeros(ops.PGRAD_TICKETS, dtype=torch.int32, device=device)
                     ws["ptick_l"] = torch.zeros(ops.PGRAD_TICKETS, dtype=torch.int32, device=device)
             elif self.kind == "dvpt":

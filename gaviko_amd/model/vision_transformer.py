@@ -104,12 +104,17 @@ class _HotPathFn(torch.autograd.Function):
                                    "same model (e.g. loss = f(model(x1), model(x2))): the engine keeps one forward's state -- concatenate "
                                    "the inputs into one batch, or call backward() before the next forward")
         named = owner._named_cache()[1]
-        if owner.__dict__.get("_grads_zeroed"):
-            # model.zero_grad(set_to_none=False) has just zeroed the flat buffer in ONE launch and verified that every trainable .grad is
-            # its view: the engine overwrites, nothing to walk (the per-parameter bookkeeping below costs the host ~0.6 ms per step)
-            owner.__dict__["_grads_zeroed"] = False
-            eng.backward(dlogits, reducer=owner.__dict__.get("_reducer"))
-            return (None, None, None) + (None,) * ctx.nparams
+        token = owner.__dict__.get("_grads_zeroed")
+        owner.__dict__["_grads_zeroed"] = None
+        if token is not None:
+            # model.zero_grad(set_to_none=False) zeroed the flat buffer in ONE launch after verifying that every trainable .grad is its view:
+            # the engine overwrites, nothing to walk (the per-parameter bookkeeping below costs the host ~0.6 ms per step).  That was THEN:
+            # a torch optimizer's zero_grad() (set_to_none=True) since, or a re-allocated flat buffer (make_reducer / set_bucket_layers, a
+            # requires_grad flip), and the engine would write into a buffer no .grad points at -- re-check against the state at backward.
+            views = eng._grad_views(dlogits.device)              # (re-allocates when the trainable set changed)
+            if eng._flat_grad is token and all(named[n].grad is v for n, v in views.items()):
+                eng.backward(dlogits, reducer=owner.__dict__.get("_reducer"))
+                return (None, None, None) + (None,) * ctx.nparams
         had_grads = [n for n in eng.trainable_names() if named[n].grad is not None]
         if not had_grads:
             gv = eng.backward(dlogits, reducer=owner.__dict__.get("_reducer"))
@@ -165,7 +170,7 @@ class HotPathModule(nn.Module):
         the first backward) is ONE memset of that buffer instead of a walk over 442 tensors; the next backward then overwrites it without
         per-parameter bookkeeping.  Everything else (set_to_none=True, the first step, gradients assigned by the caller) takes
         torch's own path."""
-        self.__dict__["_grads_zeroed"] = False
+        self.__dict__["_grads_zeroed"] = None
         eng = self.__dict__.get("_eng")
         if not set_to_none and eng is not None and eng._flat_grad is not None:
             named, views = self._named_cache()[1], eng._flat_grad["views"]
@@ -173,7 +178,7 @@ class HotPathModule(nn.Module):
             if len(views) == len(names) and all(named[n].grad is views.get(n) for n in names) and \
                     all(p.grad is None for n, p in named.items() if n not in views):
                 eng._flat_grad["buf"].zero_()
-                self.__dict__["_grads_zeroed"] = True
+                self.__dict__["_grads_zeroed"] = eng._flat_grad      # the buffer object this promise holds for (checked again at backward)
                 return
         super().zero_grad(set_to_none=set_to_none)
 

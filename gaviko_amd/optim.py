@@ -95,6 +95,7 @@ class FusedAdamOneCycle:
         self.t = 0                      # optimizer steps taken == scheduler steps taken
         self._tabs = None
         self.m = self.v = None
+        self._layout = None             # [(name, numel)] in the order m / v are stored in (= the flat gradient buffer's at the last bind)
 
     # ---- tables
     def _bind(self):
@@ -103,10 +104,12 @@ class FusedAdamOneCycle:
             if eng.flat_grad is None:
                 raise L.GavikoHipError("FusedAdamOneCycle.step(): run a backward first (the engine owns the flat gradient buffer)")
             named = dict(self.model.named_parameters())
-            params = [named[n] for n in eng.flat_names()]              # the flat gradient buffer's layout
+            names = list(eng.flat_names())                             # the flat gradient buffer's layout
+            params = [named[n] for n in names]
             flat = eng.flat_grad
         else:
             params, flat = self._params, self._flat
+            names = [f"#{i}" for i in range(len(params))]
         sig = (flat.data_ptr(),) + tuple(p.data_ptr() for p in params)
         if self._tabs is not None and self._tabs["sig"] == sig:
             return self._tabs
@@ -126,10 +129,35 @@ class FusedAdamOneCycle:
                     ptr=torch.tensor([p.data_ptr() for p in params], dtype=torch.int64, device=dev),
                     blk=torch.tensor(rows, dtype=torch.int32, device=dev).contiguous(),
                     scratch=torch.zeros(256, device=dev), norm_sq=torch.zeros(1, device=dev))
-        if self.m is None or self.m.numel() != total or self.m.device != dev:
+        layout = [(n, p.numel()) for n, p in zip(names, params)]
+        if self.m is None:
             self.m, self.v = torch.zeros(total, device=dev), torch.zeros(total, device=dev)
+        else:
+            # The moments are positional in the flat layout, and that layout moves: make_reducer(mode=...) / set_bucket_layers regroup the
+            # buffer by completion bucket, a checkpoint may come from another reducer mode.  Follow the names, never the positions.
+            self.m, self.v = (self._relayout(t.to(dev), self._layout, layout) for t in (self.m, self.v))
+        self._layout = layout
         self._tabs = tabs
         return tabs
+
+    @staticmethod
+    def _relayout(t: torch.Tensor, old, new) -> torch.Tensor:
+        """Moment vector stored in layout `old` ([(name, numel)]) -> layout `new`.  Same tensors in another order are permuted; anything
+        else (a tensor missing, added or resized) is an error -- silently keeping positions would pair moments with the wrong parameters."""
+        if old is None:
+            raise L.GavikoHipError("FusedAdamOneCycle: optimizer state without a recorded layout")
+        if old == new:
+            return t
+        where, off = {}, 0
+        for n, k in old:
+            where[n] = (off, k)
+            off += k
+        if off != t.numel() or sorted(old) != sorted(new):
+            only_old = sorted(set(dict(old)) - set(dict(new)))[:3]
+            only_new = sorted(set(dict(new)) - set(dict(old)))[:3]
+            raise L.GavikoHipError(f"FusedAdamOneCycle: the optimizer state covers other tensors than the model trains now "
+                                   f"(state only: {only_old}, model only: {only_new}, or sizes differ): cannot carry Adam moments over")
+        return torch.cat([t[where[n][0]: where[n][0] + k] for n, k in new]) if new else t
 
     # ---- the step
     def current(self):
@@ -169,18 +197,39 @@ class FusedAdamOneCycle:
         return [self.current()[0]]
 
     def zero_grad(self, set_to_none: bool = True) -> None:
-        ps = self._params if self.model is None else self.model.parameters()
-        for p in ps:
+        """torch.optim.Optimizer.zero_grad.  Bound to a model it is the model's own zero_grad, so that set_to_none=False is the ONE memset of
+        the flat gradient buffer (HotPathModule.zero_grad) and the following backward skips the per-tensor bookkeeping."""
+        if self.model is not None:
+            self.model.zero_grad(set_to_none=set_to_none)
+            return
+        for p in self._params:
             if set_to_none:
                 p.grad = None
             elif p.grad is not None:
                 p.grad.zero_()
 
     def state_dict(self):
+        """`names` / `numels` say which tensor every stretch of exp_avg / exp_avg_sq belongs to (the flat layout at save time)."""
         return {"t": self.t, "exp_avg": None if self.m is None else self.m.clone(),
-                "exp_avg_sq": None if self.v is None else self.v.clone()}
+                "exp_avg_sq": None if self.v is None else self.v.clone(),
+                "names": None if self._layout is None else [n for n, _ in self._layout],
+                "numels": None if self._layout is None else [k for _, k in self._layout]}
 
     def load_state_dict(self, sd):
+        """The moments are re-ordered to the current flat layout at the next step (by name); a state saved before names were recorded
+        (round <= 4) is taken to be in `named_parameters()` order of the trainable tensors, which is what those rounds stored."""
         self.t = int(sd["t"])
-        if sd["exp_avg"] is not None:
-            self.m, self.v = sd["exp_avg"].clone(), sd["exp_avg_sq"].clone()
+        self._tabs = None
+        if sd["exp_avg"] is None:
+            self.m = self.v = self._layout = None
+            return
+        self.m, self.v = sd["exp_avg"].clone(), sd["exp_avg_sq"].clone()
+        if sd.get("names") is not None:
+            self._layout = list(zip(sd["names"], (int(k) for k in sd["numels"])))
+        elif self.model is not None:
+            eng = self.model._engine()
+            self._layout = [(n, eng.p[n].numel()) for n in eng.trainable_names()]
+        else:
+            self._layout = [(f"#{i}", p.numel()) for i, p in enumerate(self._params)]
+        if sum(k for _, k in self._layout) != self.m.numel():
+            raise L.GavikoHipError("FusedAdamOneCycle.load_state_dict: exp_avg does not have the size its layout says")

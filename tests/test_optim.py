@@ -77,3 +77,65 @@ def test_fused_optimizer_drives_a_model(dev):
     assert losses[-1] < losses[0], losses
     frozen = [p for n, p in m.named_parameters() if not p.requires_grad]
     assert all(p.grad is None for p in frozen)
+
+
+@pytest.mark.gpu
+def test_adam_moments_follow_names_when_the_flat_layout_moves(dev):
+    """exp_avg / exp_avg_sq are positional in the flat gradient layout, and that layout is regrouped by make_reducer(mode=...)
+    / set_bucket_layers; a same-size buffer used to be kept as is -- Adam state silently permuted against the parameters.  Step, change
+    the layout, step again: every parameter must equal torch.optim.Adam's fed with the same gradients; the state dict carries the names
+    and a state saved under one layout loads under another."""
+    import test_model_gpu as tm
+    from gaviko_amd.optim import FusedAdamOneCycle
+    from gaviko_amd.utils import synth
+    m, cfg = tm.build("gaviko", "vit-t16", dict(tm.GAVIKO), dev)
+    named = dict(m.named_parameters())
+    eng = m._engine()
+    tr = eng.trainable_names()
+    ref_p = {n: torch.nn.Parameter(named[n].detach().clone()) for n in tr}
+    ref = torch.optim.Adam(list(ref_p.values()), lr=2e-3, eps=1e-8)
+    opt = FusedAdamOneCycle(m, lr=2e-3, eps=1e-8, max_norm=None)
+    x = torch.from_numpy(synth.volumes(0, 2)).to(dev)
+    y = torch.from_numpy(synth.labels(0, 2)).to(dev)
+
+    def one():
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(m(x), y).backward()
+        for n in tr:
+            ref_p[n].grad = named[n].grad.detach().clone()
+        ref.step()
+        opt.step()
+        torch.cuda.synchronize()
+
+    def check(tag):
+        for n in tr:
+            assert torch.allclose(named[n].detach(), ref_p[n].detach(), rtol=2e-5, atol=2e-7), (tag, n)
+
+    one(); one()
+    check("before")
+    order0 = list(eng.flat_names())
+    sd = opt.state_dict()
+    assert sd["names"] == order0 and sum(sd["numels"]) == sd["exp_avg"].numel()
+    eng.set_bucket_layers(1)                                            # what make_reducer(layers_per_bucket=1) does to the layout
+    assert list(eng.flat_names()) != order0
+    one(); one()
+    check("after the layout moved")
+    # a state saved under the first layout, loaded into a fresh optimizer that binds under the second
+    opt2 = FusedAdamOneCycle(m, lr=2e-3, eps=1e-8, max_norm=None)
+    opt2.load_state_dict(sd)
+    opt2._bind()
+    off_new = {}
+    o = 0
+    for n in eng.flat_names():
+        off_new[n] = o
+        o += named[n].numel()
+    o = 0
+    for n, k in zip(sd["names"], sd["numels"]):
+        assert torch.equal(opt2.m[off_new[n]: off_new[n] + k], sd["exp_avg"][o: o + k]), n
+        o += k
+    # a state that covers other tensors than the model trains is an error, not a silent reuse
+    bad = dict(sd, names=["nope"] + sd["names"][1:])
+    opt3 = FusedAdamOneCycle(m, lr=2e-3, eps=1e-8, max_norm=None)
+    opt3.load_state_dict(bad)
+    with pytest.raises(Exception, match="covers other tensors"):
+        opt3._bind()

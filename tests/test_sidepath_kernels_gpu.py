@@ -628,3 +628,40 @@ def test_param_grads_one_launch(dev, C, L, B):
     assert int(tick.abs().max()) == 0
     with pytest.raises(Exception, match="scratch holds"):
         ops.param_grads([dict(narrow=ctx, wide=dL, out=dWu, M=BN, transposed=1)], [], torch.zeros(64, device=dev), tick, C, L)
+
+
+def test_param_grads_hand_off_beside_a_stream_that_dirties_the_caches(dev):
+    """The cross-workgroup hand-off of gvk_param_grads (write-through partials, drained, ticket, last arriver acquires) issues no release
+    fence (gaviko_hip.h), and its bitwise-repeat check above runs on an otherwise idle GPU.  Here it runs the way the step runs it: on a
+    side stream, while another stream streams and REWRITES a buffer far larger than the L2s (dirty lines in every XCD, every CU's L1
+    warm with foreign lines), launch after launch with the previous call's partials still in the scratch -- every result must equal the
+    quiet one bit for bit and float64 within the usual bound, and the tickets must come back zero."""
+    from gaviko_amd import ops
+    C, L, B, T, N = 768, 20, 4, 1033, 1000
+    gen = torch.Generator().manual_seed(5)
+    r = lambda *s_: torch.randn(*s_, generator=gen).to(dev)  # noqa: E731
+    M, BN = B * T, B * N
+    dzx, G1, dzl, Lc = r(M, L), r(M, C), r(BN, L), r(BN, C)
+    nct = (C + 63) // 64
+    sc = torch.zeros(ops.param_grads_scratch_elems(L, [nct], []), device=dev)
+    tick = torch.zeros(ops.PGRAD_TICKETS, dtype=torch.int32, device=dev)
+    job = lambda dst: ops.param_grads([dict(narrow=dzx, wide=G1, narrow2=dzl, wide2=Lc, out=dst, M=M, M2=BN)], [], sc, tick, C, L)  # noqa: E731
+    quiet = torch.zeros(L, C, device=dev)
+    job(quiet)
+    torch.cuda.synchronize()
+    want = dzx.double().t() @ G1.double() + dzl.double().t() @ Lc.double()
+    assert (quiet.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item()) * (M ** 0.5)
+    big = torch.zeros(96 * 1024 * 1024, device=dev)                       # 384 MiB: beyond the 32 MiB of L2 and the Infinity Cache
+    side, noise = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = [torch.zeros(L, C, device=dev) for _ in range(12)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(noise):
+        for _ in range(24):
+            big.add_(1.0)                                                 # read-modify-write of every line, on every CU
+    with torch.cuda.stream(side):
+        for o in outs:
+            sc.normal_()                                                  # stale partials of "the previous layer" in the scratch
+            job(o)
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, quiet) for o in outs)
+    assert int(tick.abs().max()) == 0

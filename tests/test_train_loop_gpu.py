@@ -219,3 +219,47 @@ def test_zero_grad_fast_path_equals_the_walk(dev):
     assert torch.allclose(model._engine().flat_grad, 2 * ref, rtol=1e-6, atol=1e-12)
     model.zero_grad(set_to_none=True)
     assert all(p.grad is None for p in model.parameters())
+
+
+def test_zero_grad_fast_path_is_rechecked_at_backward(dev):
+    """the fast path trusted a flag set at zero_grad time.  A torch optimizer's zero_grad() (set_to_none=True: it never calls
+    model.zero_grad) or a re-allocated flat buffer (make_reducer / set_bucket_layers) between model.zero_grad(set_to_none=False) and
+    backward() left every .grad None / pointing at the old buffer while the engine wrote elsewhere -- optimizer.step() then skipped or used
+    stale zeros without a word.  The promise is now tied to the buffer object and re-checked against the .grad views in backward."""
+    from gaviko_amd.registry import build_model
+    from gaviko_amd.utils import synth
+    cfg = _tiny_cfg("gaviko", num_prompts=8, prompt_latent_dim=20, local_dim=20, local_k=(3, 6, 6), DHW=(10, 10, 10), attn_drop=0.0, proj_drop=0.0,
+                    freeze_vit=True, share_factor=1)
+    model = build_model(cfg)
+    filled = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in filled.items()})
+    model.to(dev)
+    model.train()
+    x = torch.from_numpy(synth.volumes(0, 2)).to(dev)
+    y = torch.from_numpy(synth.labels(0, 2)).to(dev)
+    step = lambda: torch.nn.functional.cross_entropy(model(x), y).backward()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.0)
+    model.zero_grad(set_to_none=True); step()
+    named = dict(model.named_parameters())
+    ref = {n: named[n].grad.clone() for n in model._engine().trainable_names()}
+    # (1) torch optimizer's zero_grad between the arming and the backward
+    model.zero_grad(set_to_none=False)
+    assert model.__dict__["_grads_zeroed"] is not None
+    opt.zero_grad()                                                     # set_to_none=True: every .grad is None now
+    assert all(p.grad is None for p in params)
+    step()
+    assert all(named[n].grad is not None and torch.equal(named[n].grad, ref[n]) for n in ref)
+    # (2) the flat buffer re-allocated in between (another bucket layout)
+    model.zero_grad(set_to_none=False)
+    old_buf = model._engine().flat_grad
+    model._engine().set_bucket_layers(1)
+    step()
+    eng = model._engine()
+    assert eng.flat_grad is not old_buf
+    for n in ref:
+        assert named[n].grad.data_ptr() == eng._flat_grad["views"][n].data_ptr(), n     # .grad follows the NEW buffer
+        assert torch.allclose(named[n].grad, ref[n], rtol=1e-6, atol=1e-12), n
+    # (3) and the fast path itself still runs when nothing happened in between
+    model.zero_grad(set_to_none=False); step()
+    assert all(torch.allclose(named[n].grad, ref[n], rtol=1e-6, atol=1e-12) for n in ref)
