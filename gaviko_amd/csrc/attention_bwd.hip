@@ -354,6 +354,416 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
   store_rows_t(dqt, scale, smem + wave * 4096, dqkv + ((size_t)b * T + qw) * ld_qkv + head * 64, (size_t)ld_qkv, T - qw, lane);
 }
 
+// ------------------------------------------------------------------------------------------------ one pass: dQ, dK, dV (round 5)
+// The two passes above compute S and dP twice (seven MFMA products, every score exponentiated twice).  This kernel is the dK/dV pass
+// extended by the fifth product: five products per (query, key) block, one exponential per score.
+//   * workgroup = 128 keys of one (batch, head), exactly as the dK/dV pass (key on the lane; dK^T, dV^T of the wave's 32 keys stay in its
+//     accumulators for the whole sweep);
+//   * dS crosses LDS once per 32-query sub-block: every lane packs its accumulator registers 4g..4g+3 (queries 8g + 4h ..+3 of its key)
+//     into one 8-byte unit of a [key][query] image (64-byte rows, units swizzled so that the writes and the transposed reads below are
+//     conflict-free); after ONE barrier per sub-block the four waves each take a 16-wide d slab of dQ^T[d][q] = K^T.dS^T over all 128 keys:
+//     eight v_mfma_f32_16x16x32_bf16 whose A operand (K^T of the slab, 16 registers) was gathered once and whose B operand comes
+//     straight out of the image by ds_read_b64_tr_b16;
+//   * dQ is summed over the key blocks of a (batch, head) by an ORDERED hand-off, no float atomics, bitwise reproducible: workgroup k
+//     starts its sweep at query tile floor(k.nqt/nkb) and walks the tiles cyclically, so for every tile the nkb workgroups arrive at
+//     distinct steps, one tile-time apart; the order of arrival IS the summation order (a function of (tile, k) alone).  The running
+//     sum of a sub-block lives in one 8-KB scratch slab: a member waits until the slab's progress word equals its position, adds its
+//     own 16 x 32 slab piece (16-byte sc1 loads, write-through sc1 stores), and the word is advanced behind the NEXT sub-block's
+//     barrier, when every wave has drained its stores (s_waitcnt vmcnt(0)); the last member writes bf16 dQ and leaves the word at zero
+//     for the next launch.  A member only ever waits for members at EARLIER steps, the workgroups of a group are consecutive in their
+//     XCD's dispatch order, and a spin is bounded (status word), so a group that is only partly resident cannot hang the chip.
+// delta = rowsum(dO o O) comes from a small kernel in front (attn_delta_kernel); the dropout variants keep the two-pass kernels.
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict__ o_fwd, const bf16* __restrict__ d_o, float* __restrict__ delta, int M,
+                                                         int T, int H, int ld_o) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;          // ((row * H + head) * 8 + chunk)
+  const int c = gid & 7, rh = gid >> 3;
+  const int row = min(rh / H, M - 1), head = rh - (rh / H) * H;
+  const size_t off = (size_t)row * ld_o + head * 64 + c * 8;
+  const bf16x8 a = *(const bf16x8*)(o_fwd + off), b = *(const bf16x8*)(d_o + off);
+  float v = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v += (float)a[j] * (float)b[j];
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  if (c == 0 && rh < M * H) {
+    const int bb = row / T, t = row - bb * T;
+    delta[((size_t)bb * H + head) * T + t] = v;
+  }
+}
+
+// byte offset of the 8-byte unit (key row 0..127, g = query group 0..3, h = half 0..1) of a dS^T image
+__device__ __forceinline__ int ds_unit(int keyl, int g, int h) {
+  return keyl * 64 + ((g ^ ((keyl >> 2) & 3)) << 4) + ((h ^ ((keyl >> 4) & 1)) << 3);
+}
+
+// VAR (measurement build only; results wrong unless 0): bit 0 = no waiting / no running-sum loads, bit 1 = no running-sum stores,
+// bit 2 = no dQ product at all, bit 3 = write-through stores whatever the successor's XCD, bit 4 = no polling (sums loaded whatever their state)
+template <int QT, int VAR>
+__global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o, const float* __restrict__ lse,
+                                                             const float* __restrict__ delta, bf16* __restrict__ dqkv, float* dq_acc, int* prog,
+                                                             int* xcc_tab, int* status, int T, int H, int ld_qkv, int ld_o, float scale, float dk_scale) {
+  constexpr int NSB = QT / 32;
+  constexpr int kTileQ = QT * 128;                // bytes of a [QT][64] bf16 tile
+  constexpr int kBuf = 2 * kTileQ + 2 * 128 * 4;  // Q tile | dO tile | lse 128 f32 | delta 128 f32
+  constexpr int kDS = 128 * 64;                   // one dS^T image: [128 keys][32 queries] bf16
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][kBuf] | [2][kDS] | start tiles of the key blocks (int [256])
+  char* const sDSbase = smem + 2 * kBuf;      // (the two images first hold the K tile, once)
+  int* const stab = (int*)(sDSbase + 2 * kDS);
+  const int nkb = (T + 127) / 128, nqt = (T + QT - 1) / QT;
+  const int nsv = (T + 31) / 32;                   // 32-query sub-blocks that hold rows of the sequence
+  int bh, kblk;
+  xcd_group_block(blockIdx.x, nkb, gridDim.x / nkb, bh, kblk);   // all key blocks of a (batch, head) on one XCD, consecutive in its dispatch order
+  const int b = bh / H, head = bh - b * H, k0 = kblk * 128;
+  const int lane = lane_id(), wave = wave_id();
+  const int r31 = lane & 31, hh = lane >> 5;
+  const int inner = H * 64;
+  const bf16* qbase = qkv + (size_t)b * T * ld_qkv + head * 64;
+  const bool active = k0 + wave * 32 < T;          // a wave whose 32 keys all lie past the sequence computes on copies of the last key and stores nothing
+
+  // where this workgroup runs: the hand-off keeps a sum inside the XCD's L2 when producer and consumer share it (speed only; see finish)
+  int my_xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(my_xcc));
+  int* const xrow = xcc_tab + bh * nkb;
+  if (threadIdx.x == 0) __hip_atomic_store((GVK_GLOBAL int*)(xrow + kblk), my_xcc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  // K, V fragments of this wave's 32 keys: B operands (col = key, k = d)
+  const int key = k0 + wave * 32 + r31;
+  const int keyc = min(key, T - 1);
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kf[ks] = *(const bf16x8*)(qbase + inner + (size_t)keyc * ld_qkv + 16 * ks + 8 * hh);
+    vf[ks] = *(const bf16x8*)(qbase + 2 * inner + (size_t)keyc * ld_qkv + 16 * ks + 8 * hh);
+  }
+
+  // staging: Q rows (from qkv), dO rows, lse / delta (one 4-byte LDS-DMA per wave: waves 0,1 the two 64-row halves of lse, waves 2,3 of delta)
+  const int nB = (int)gridDim.x / (nkb * H);
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, nB * T * ld_qkv * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)d_o, 0, nB * T * ld_o * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(wave < 2 ? lse : delta), 0, nB * H * T * 4, 0x00020000);
+  const int nsub = nqt * NSB;                      // sub-block slots of a (batch, head): one running-sum slab and one progress word each
+  const __amdgpu_buffer_rsrc_t racc = __builtin_amdgcn_make_buffer_rsrc((void*)(dq_acc + (size_t)bh * nsub * 2048), 0, nsub * 8192, 0x00020000);
+  float* const accb = dq_acc + (size_t)bh * nsub * 2048;
+  int* const progb = prog + (size_t)bh * nsub * 32;     // one progress word per 128-byte line: polls and advances of 432 workgroups spread over the memory channels
+  const int rsub = lane >> 3, slot = lane & 7;
+  int voq[NSB], vod[NSB];
+#pragma unroll
+  for (int r = 0; r < NSB; ++r) {
+    const int row = r * 32 + wave * 8 + rsub;
+    const int col = head * 64 + ((slot ^ attn_swz(row)) << 3);
+    voq[r] = ((b * T + row) * ld_qkv + col) * 2;
+    vod[r] = ((b * T + row) * ld_o + col) * 2;
+  }
+  const int lrow = (wave & 1) * 64 + lane;                         // row of the tile whose constant this lane fetches
+  const int vol = ((b * H + head) * T + lrow) * 4;
+  auto stage = [&](int buf, int qt) {
+    char* sQ = smem + buf * kBuf;
+    char* sD = sQ + kTileQ;
+    char* sL = sD + kTileQ;
+    const bool last = qt == nqt - 1;
+    const int soq = qt * QT * ld_qkv * 2, sod = qt * QT * ld_o * 2, sol = qt * QT * 4;
+#pragma unroll
+    for (int r = 0; r < NSB; ++r) {
+      const int over = last ? max(qt * QT + r * 32 + wave * 8 + rsub - (T - 1), 0) : 0;
+      const int vq = voq[r] - over * ld_qkv * 2, vd = vod[r] - over * ld_o * 2;
+      lds_dma16(rq, sQ + (r * 32 + wave * 8) * 128, vq, soq);
+      lds_dma16(rd, sD + (r * 32 + wave * 8) * 128, vd, sod);
+    }
+    const int overl = last ? max(qt * QT + lrow - (T - 1), 0) : 0;
+    const int vl = vol - overl * 4;
+    lds_dma4(rl, sL + (wave >> 1) * 512 + (wave & 1) * 256, vl, sol);
+  };
+
+  const int start = (kblk * nqt) / nkb;            // first tile of this workgroup's cyclic sweep
+  if ((int)threadIdx.x < nkb) stab[threadIdx.x] = ((int)threadIdx.x * nqt) / nkb;     // every member's (one division each, here, instead of nkb per tile)
+  // ---- prologue: the K tile of the workgroup through LDS (once), first query tile
+  GVK_LOADS_LANDED();
+  {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                  // 128 key rows x 128 B into the (not yet used) dS^T images, rows past the sequence = copies of the last key
+      const int row = r * 32 + wave * 8 + rsub;
+      const int rowc = min(k0 + row, T - 1);
+      lds_dma16(rq, sDSbase + (r * 32 + wave * 8) * 128, ((b * T + rowc) * ld_qkv + inner + head * 64 + ((slot ^ attn_swz(row)) << 3)) * 2, 0);
+    }
+  }
+  stage(0, start);
+  GVK_DMA_DRAIN();
+  __syncthreads();
+  // K^T of this wave's d slab (16 wide) over all 128 keys: A operands of dQ^T = K^T.dS^T (row = d, k = key), by transposed reads of the
+  // row-major tile; keys past the sequence are ZERO here, which is what keeps their (finite) dS out of dQ
+  const int G = lane >> 4, li = lane & 15, tq = (lane & 15) >> 2, tp = lane & 3;
+  bf16x8 ktf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int chunk = 2 * wave + (tp >> 1);
+    const int ra = 32 * kk + 8 * G + tq, rb = ra + 4;
+    const bf16x4 a0 = lds_read_tr16(sDSbase + ra * 128 + ((chunk ^ attn_swz(ra)) << 4) + (tp & 1) * 8);
+    const bf16x4 a1 = lds_read_tr16(sDSbase + rb * 128 + ((chunk ^ attn_swz(rb)) << 4) + (tp & 1) * 8);
+    ktf[kk] = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+  }
+  if (k0 + 128 > T) {                               // (last key block only)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k0 + 32 * kk + 8 * G + j >= T) ktf[kk][j] = (bf16)0.f;
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): the fragments are in registers ...
+  __syncthreads();                                 // ... in every wave, before the first dS^T image overwrites the K tile
+
+  f32x16 dkt[2], dvt[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { dkt[i] = f32x16{}; dvt[i] = f32x16{}; }
+  const bf16x8 sel_s = aug_sel_first(true, hh);
+  const bf16x8 sel_d = aug_sel_second(hh);
+  const int g = lane >> 4;
+  const int keyl = wave * 32 + r31;                // this lane's key row in the dS^T images
+  // transposed-read addresses of the dQ product inside an image: lane 4q'+p of group G supplies key row 32kk + 8G + 4rd + q', unit (2qh + (p>>1), p&1)
+  int dsr[2][2];                                   // [qh][rd] for kk = 0; kk adds 32 rows = 2048 bytes (the swizzle terms repeat every 32 rows)
+#pragma unroll
+  for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) dsr[qh][rd] = ds_unit(8 * G + 4 * rd + tq, 2 * qh + (tp >> 1), tp & 1);
+
+  // ---- the sweep.  One iteration = one 32-query sub-block from barrier to barrier, software-pipelined over THREE sub-blocks so that no
+  // global latency and no dependent MFMA chain sits alone on a wave's critical path:
+  //     [n-1: add the predecessor's sum (requested one iteration ago), store]   dK, dV of n; dS^T(n) -> image   [drain, poll n, barrier]
+  //     [word of n-1 advanced]  [sum of n requested]  [poll word of n+1 requested]   dQ(n) product  ||  S, dP, exp of n+1 (one basic block)
+  // position of this workgroup in a tile's summation chain = members that reach the tile at an earlier step; its successor = the next one
+  auto chain = [&](int qt, int& pos, int& succ) {
+    int mine = qt - start;
+    if (mine < 0) mine += nqt;
+    pos = 0;
+    succ = -1;
+    int best = 1 << 30;
+    for (int k2 = 0; k2 < nkb; ++k2) {
+      int st = qt - stab[k2];
+      if (st < 0) st += nqt;
+      pos += st < mine ? 1 : 0;
+      if (st > mine && st < best) { best = st; succ = k2; }
+    }
+    pos = __builtin_amdgcn_readfirstlane(pos);
+    succ = __builtin_amdgcn_readfirstlane(succ);
+  };
+  // S' = Q'.K^T - lse2 and dP' = dO.V^T - delta of sub-block (tile buffer, sub); then (soft) P = exp2(S'), dS = P.dP'
+  f32x16 s, dp;
+  auto scores = [&](int buf, int sub, int qrow0) {
+    const char* sQ = smem + buf * kBuf + sub * 32 * 128;
+    const char* sD = sQ + kTileQ;
+    const float* sL0 = (const float*)(smem + buf * kBuf + 2 * kTileQ);
+    const float l2 = sL0[sub * 32 + r31] * 1.44269504088896340736f;
+    const float dl = sL0[128 + sub * 32 + r31];
+    const bf16x8 qaug = aug_const(l2, qrow0 + r31 >= T, dl, hh);
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qaug, sel_s, f32x16{}, 0, 0, 0);
+    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qaug, sel_d, f32x16{}, 0, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int chunk = 2 * ks + hh;
+      const bf16x8 qa = *(const bf16x8*)(sQ + r31 * 128 + ((chunk ^ attn_swz(r31)) << 4));
+      const bf16x8 da = *(const bf16x8*)(sD + r31 * 128 + ((chunk ^ attn_swz(r31)) << 4));
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
+    }
+  };
+  auto soft = [&]() {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pr = __builtin_amdgcn_exp2f(s[r]);
+      s[r] = pr;
+      dp[r] = pr * dp[r];
+    }
+  };
+
+  int pend_word = -1, pend_val = 0;                // progress word to advance behind the next barrier
+  // a sub-block's share of dQ: add the predecessor's sum (requested behind the barrier, consumed here a whole product later), pass it on
+  auto finish = [&](f32x4 (&hdq)[2], const u32x4 (&hld)[2], int gsub, int q0, int ppos, bool add, bool last, bool plain) {
+    const int aoff = gsub * 8192 + wave * 2048 + lane * 16;
+    {   // (a select, not a branch: the requested sum is always consumed, so its registers are never overwritten while in flight -- the
+        //  compiler answers that hazard with a full s_waitcnt vmcnt(0), which would also wait for the stores below)
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      hdq[0] += add ? __builtin_bit_cast(f32x4, hld[0]) : z;
+      hdq[1] += add ? __builtin_bit_cast(f32x4, hld[1]) : z;
+    }
+    if (last) {
+#pragma unroll
+      for (int qh = 0; qh < 2; ++qh) {
+        const int q = q0 + 16 * qh + li;
+        const bf16x4 o = {(bf16)(hdq[qh][0] * scale), (bf16)(hdq[qh][1] * scale), (bf16)(hdq[qh][2] * scale), (bf16)(hdq[qh][3] * scale)};
+        if (q < T) *(bf16x4*)(dqkv + ((size_t)b * T + q) * ld_qkv + head * 64 + 16 * wave + 4 * G) = o;
+      }
+    } else if (plain) {
+      // the successor runs on this XCD: plain stores leave the sum in the shared L2, where its L1-bypassing loads find it (a write-through
+      // store would drop the lines from the L2 and send every one of those loads to the fabric: 228 MB per launch)
+#pragma unroll
+      for (int qh = 0; qh < 2; ++qh) *(f32x4*)((char*)accb + aoff + qh * 1024) = hdq[qh];
+    } else {
+#pragma unroll
+      for (int qh = 0; qh < 2; ++qh) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hdq[qh]), racc, aoff + qh * 1024, 0, 16);   // aux 16 = sc1
+    }
+    pend_word = gsub;
+    pend_val = (last || (VAR & 7) != 0) ? 0 : ppos + 1;      // (the timing ablations never leave a progress word set)
+  };
+
+  // current sub-block
+  int gcur = start * NSB;                          // slot index: tile * NSB + sub (slots of the last tile past the sequence are never visited)
+  int qt = start, sub = 0, buf = 0;
+  int pos, succ;
+  chain(qt, pos, succ);
+  if constexpr ((VAR & 1) != 0) pos = 0;
+  int tv = 0;                                      // tiles visited so far (the first two are requested before the loop)
+  // every member's XCD + 1, lane k2 = member k2 (0: had not started when this was read, a few microseconds into the kernel -> write-through
+  // towards it).  Read ONCE: a load inside the loop whose result is carried around it makes the compiler drain the queue (WAW on the
+  // carried register) in every iteration.
+  const int xall = __hip_atomic_load((GVK_GLOBAL int*)(xrow + min(lane, nkb - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_s_waitcnt(0x0F70);              // (vmcnt(0), visible to the compiler: otherwise its wait for xall lands inside the loop)
+  int xs = succ >= 0 ? __builtin_amdgcn_readlane(xall, succ & 63) : 0;      // the successor's (key blocks past 64: unknown)
+  if (succ >= 64) xs = 0;
+  int pv = 0;                                      // progress word of the current sub-block (wave 0 only), requested one iteration ahead
+  if (nqt > 1) stage(1, start + 1 < nqt ? start + 1 : 0);
+  scores(0, 0, start * QT);
+  soft();
+  int par = 0;
+  [[maybe_unused]] unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;     // VAR bit 6: shader-clock totals of the loop's phases (wave 0 of a few workgroups)
+#define GVK_PH(k)                                                             \
+  if constexpr ((VAR & 64) != 0) {                                            \
+    const unsigned long long tnow = __builtin_amdgcn_s_memtime();             \
+    if (i >= 4 && i < 28) ph[k] += tnow - tprev;                              \
+    tprev = tnow;                                                             \
+  }
+  for (int i = 0; i < nsv; ++i) {
+    const int qrow0 = qt * QT + sub * 32;
+    const bool lastm = (VAR & 2) ? true : pos == nkb - 1;
+    char* sDS = sDSbase + par * kDS;
+    GVK_PH(5)
+    {
+      const char* sQ = smem + buf * kBuf + sub * 32 * 128;
+      const char* sD = sQ + kTileQ;
+      // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key];  dS^T -> the image
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk) {
+        bf16x8 pf, dsf;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) { pf[jj] = (bf16)s[8 * sk + jj]; dsf[jj] = (bf16)dp[8 * sk + jj]; }
+        const u32x4 dsw = __builtin_bit_cast(u32x4, dsf);
+        *(u32x2*)(sDS + ds_unit(keyl, 2 * sk, hh)) = u32x2{dsw[0], dsw[1]};
+        *(u32x2*)(sDS + ds_unit(keyl, 2 * sk + 1, hh)) = u32x2{dsw[2], dsw[3]};
+        const int q0r = 16 * sk + 4 * (g >> 1);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
+          const int ra = q0r + tq, rb = q0r + 8 + tq;
+          const int oa = ra * 128 + ((chunk ^ attn_swz(ra)) << 4) + (tp & 1) * 8;
+          const int ob = rb * 128 + ((chunk ^ attn_swz(rb)) << 4) + (tp & 1) * 8;
+          const bf16x4 da0 = lds_read_tr16(sD + oa), da1 = lds_read_tr16(sD + ob);
+          const bf16x4 qa0 = lds_read_tr16(sQ + oa), qa1 = lds_read_tr16(sQ + ob);
+          const bf16x8 dof = {da0[0], da0[1], da0[2], da0[3], da1[0], da1[1], da1[2], da1[3]};
+          const bf16x8 qf = {qa0[0], qa0[1], qa0[2], qa0[3], qa1[0], qa1[1], qa1[2], qa1[3]};
+          dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dvt[db], 0, 0, 0);
+          dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, dsf, dkt[db], 0, 0, 0);
+        }
+      }
+    }
+    GVK_PH(1)
+    // drain: this wave's stores of the previous sub-block have been acknowledged, the poll word and the next tile's rows have arrived
+    if constexpr ((VAR & 128) == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv) : : "memory");
+    GVK_PH(2)
+    if constexpr ((VAR & 16) == 0) {
+      if (wave == 0 && pos > 0 && pv != pos) {     // (rare) the predecessor's sum is not complete yet: wave 0 waits in front of the barrier for all
+        for (unsigned spins = 0;; ++spins) {
+          __builtin_amdgcn_s_sleep(4);
+          pv = __hip_atomic_load((GVK_GLOBAL int*)(progb + gcur * 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (pv == pos) break;
+          if (spins > (1u << 16)) { if (lane == 0) atomicAdd(status, 1); break; }     // (never seen: bounded so that a broken chain ends the launch)
+        }
+#ifdef GVK_DIAG
+        if (lane == 0) atomicAdd(status + 1, 1);            // waits that were not satisfied by the early read
+#endif
+      }
+    }
+    if constexpr ((VAR & 128) != 0) {             // (timing ablation: a barrier that does not wait for the vector-memory queue)
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();
+    }
+    GVK_PH(3)
+    if (pend_word >= 0 && threadIdx.x == 0)
+      __hip_atomic_store((GVK_GLOBAL int*)(progb + pend_word * 32), pend_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pend_word = -1;
+    // this sub-block's place in its chain; the predecessor's sum is requested here and added behind the products below
+    const int h_gsub = gcur, h_q0 = qrow0, h_pos = pos;
+    const bool h_last = lastm, h_add = pos > 0, h_plain = (VAR & 8) == 0 && xs == my_xcc + 1;
+    f32x4 hdq[2];
+    u32x4 hld[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+    if constexpr ((VAR & 37) == 0) {               // (unconditional: a load under a branch would leave registers in flight on the other path)
+      const int aoff = gcur * 8192 + wave * 2048 + lane * 16;
+      hld[0] = __builtin_amdgcn_raw_buffer_load_b128(racc, aoff, 0, 16);              // aux 16 = sc1: past this CU's L1, served by the L2
+      hld[1] = __builtin_amdgcn_raw_buffer_load_b128(racc, aoff + 1024, 0, 16);
+    }
+    // the next sub-block (cyclic over the nsv valid ones); a new tile: its successor tile is requested into the buffer just left
+    int gn = gcur + 1, qtn = qt, subn = sub + 1, bufn = buf;
+    if (subn == NSB || qt * QT + subn * 32 >= T) {
+      subn = 0;
+      qtn = qt + 1 < nqt ? qt + 1 : 0;
+      gn = qtn * NSB;
+      bufn = buf ^ 1;
+      if (i + 1 < nsv) {
+        ++tv;
+        if (tv + 1 < nqt) stage(buf, qtn + 1 < nqt ? qtn + 1 : 0);       // the tile after the one being entered, into the buffer just left
+        chain(qtn, pos, succ);
+        if constexpr ((VAR & 1) != 0) pos = 0;
+        xs = succ >= 0 && succ < 64 ? __builtin_amdgcn_readlane(xall, succ & 63) : 0;
+      }
+    }
+    if (i + 1 >= nsv) { gn = gcur; qtn = qt; subn = sub; bufn = buf; }    // (last iteration: the scores below are recomputed and unused)
+    if constexpr ((VAR & 16) == 0) {
+      if (wave == 0) asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(pv) : "v"(0), "s"(progb + gn * 32) : "memory");
+    }
+    GVK_PH(4)
+    // dQ^T[16 d of this wave][32 q] of THIS sub-block over the workgroup's 128 keys, in one block with the scores of the NEXT one
+    hdq[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    hdq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr ((VAR & 4) == 0) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh) {
+          const bf16x4 b0 = lds_read_tr16(sDS + kk * 2048 + dsr[qh][0]), b1 = lds_read_tr16(sDS + kk * 2048 + dsr[qh][1]);
+          const bf16x8 bb = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+          hdq[qh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[kk], bb, hdq[qh], 0, 0, 0);
+        }
+    }
+    scores(bufn, subn, qtn * QT + subn * 32);
+    GVK_PH(0)
+    // between the two halves of the next sub-block's scores: the requested sum has had the products above to arrive, the stores have the
+    // exponentials and the dK / dV products below to be acknowledged before the drain in front of the next barrier
+    if constexpr ((VAR & 4) == 0 && (VAR & 32) == 0) finish(hdq, hld, h_gsub, h_q0, h_pos, h_add, h_last, h_plain);
+    soft();
+    if constexpr ((VAR & 32) != 0) {               // (dQ product kept alive, nothing loaded or stored)
+      if (hdq[0][0] + hdq[1][3] == 123.456f) atomicAdd(status + 3, 1);
+    }
+    gcur = gn; qt = qtn; sub = subn; buf = bufn;
+    par ^= 1;
+  }
+#undef GVK_PH
+  if constexpr ((VAR & 64) != 0) {
+    if (lane == 0 && (blockIdx.x == 3 || blockIdx.x == 100 || blockIdx.x == 259))
+      for (int k = 0; k < 6; ++k) ((unsigned long long*)(status + 16))[(blockIdx.x == 3 ? 0 : blockIdx.x == 100 ? 1 : 2) * 32 + wave * 8 + k] = ph[k];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (pend_word >= 0) __hip_atomic_store((GVK_GLOBAL int*)(progb + pend_word * 32), pend_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((GVK_GLOBAL int*)(xrow + kblk), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // nobody asks for this workgroup's XCD any more
+  }
+  if (!active) return;
+  const int kw = k0 + wave * 32;
+  bf16* dk_rows = dqkv + ((size_t)b * T + kw) * ld_qkv + inner + head * 64;
+  store_rows_t(dkt, dk_scale, smem + wave * 8192, dk_rows, (size_t)ld_qkv, T - kw, lane);
+  store_rows_t(dvt, 1.0f, smem + wave * 8192 + 4096, dk_rows + inner, (size_t)ld_qkv, T - kw, lane);
+}
+
 template <int KB, bool DROP>
 static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int T, int H,
                            int ld_qkv, int ld_out, float scale, AttnDrop dr, hipStream_t s) {
@@ -398,6 +808,70 @@ extern "C" int gvk_attention_bwd_bf16_dropout(const void* qkv, const void* out, 
     return launch_attn_bwd<96, true>(qkv, out, dout, lse, delta, dqkv, B, T, H, ld_qkv, ld_out, scale, dr, s);
   return kb == 96 ? launch_attn_bwd<96, false>(qkv, out, dout, lse, delta, dqkv, B, T, H, ld_qkv, ld_out, scale, dr, s)
                   : launch_attn_bwd<128, false>(qkv, out, dout, lse, delta, dqkv, B, T, H, ld_qkv, ld_out, scale, dr, s);
+}
+
+// workspace of the one-pass backward: [progress words: cap lines of 128 B, one word each | XCD table: cap int32, together padded to 256 B | status word, 256 B | running
+// dQ sums: cap slabs of 8 KB].
+// The layout follows from the workspace SIZE alone (cap = slabs it can hold), never from T: a model whose layers run different sequence
+// lengths through one workspace (deep VPT) then keeps its progress words in one place, where every launch leaves them zero.
+static constexpr int kFusedQT = 96;                 // staging tile of the query sweep (sub-blocks past the sequence are skipped, so its padding costs nothing)
+static size_t fused_slabs(int B, int T, int H) { return (size_t)B * H * ((T + kFusedQT - 1) / kFusedQT) * (kFusedQT / 32); }
+static size_t fused_ws_cap(size_t ws_bytes) { return ws_bytes < 1024 ? 0 : (ws_bytes - 1024) / (8192 + 128 + 4); }
+static size_t fused_status_off(size_t ws_bytes) { return (fused_ws_cap(ws_bytes) * 132 + 255) / 256 * 256; }
+
+extern "C" size_t gvk_attention_bwd_ws_bytes(int B, int T, int H) {
+  if (B <= 0 || T <= 0 || H <= 0) return 0;
+  return fused_slabs(B, T, H) * (8192 + 128 + 4) + 1024;
+}
+extern "C" size_t gvk_attention_bwd_status_offset(size_t ws_bytes) { return fused_status_off(ws_bytes); }
+
+extern "C" int gvk_attention_bwd_bf16_fused(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, void* ws,
+                                            size_t ws_bytes, int B, int T, int H, int ld_qkv, int ld_out, float scale, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(qkv && out && dout && lse && delta && dqkv && ws, "gvk_attention_bwd_bf16_fused: null pointer");
+  GVK_REQUIRE(B > 0 && T > 0 && H > 0, "gvk_attention_bwd_bf16_fused: empty shape");
+  GVK_REQUIRE(ld_qkv >= 3 * H * 64 && ld_qkv % 8 == 0 && ld_out >= H * 64 && ld_out % 8 == 0,
+              "gvk_attention_bwd_bf16_fused: head dim is fixed at 64; ld_qkv=%d ld_out=%d inconsistent with H=%d", ld_qkv, ld_out, H);
+  GVK_REQUIRE((int64_t)B * T * ld_qkv * 2 < (int64_t)1 << 31, "gvk_attention_bwd_bf16_fused: the qkv tensor must stay below 2 GiB (32-bit buffer offsets)");
+  const size_t need = gvk_attention_bwd_ws_bytes(B, T, H);
+  GVK_REQUIRE(ws_bytes >= need && ((uintptr_t)ws & 255) == 0, "gvk_attention_bwd_bf16_fused: workspace of %zu bytes (256-byte aligned) needed, %zu given", need, ws_bytes);
+  GVK_REQUIRE(fused_ws_cap(ws_bytes) >= fused_slabs(B, T, H), "gvk_attention_bwd_bf16_fused: workspace layout cannot hold %zu slabs", fused_slabs(B, T, H));
+  const size_t off_status = fused_status_off(ws_bytes), off_acc = off_status + 256;
+  const size_t nsub = (size_t)((T + kFusedQT - 1) / kFusedQT) * (kFusedQT / 32);
+  GVK_REQUIRE(nsub * 8192 < ((size_t)1 << 31) && (T + 127) / 128 <= 256, "gvk_attention_bwd_bf16_fused: sequence too long (32-bit slab offsets, 256 key blocks)");
+  hipStream_t s = (hipStream_t)stream;
+  constexpr unsigned lds = 2 * (2 * kFusedQT * 128 + 2 * 128 * 4) + 2 * 128 * 64 + 1024;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<kFusedQT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#ifdef GVK_DIAG
+    auto set1 = [&](const void* f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds); };
+    set1(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<kFusedQT, 1>)); set1(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<kFusedQT, 3>));
+    set1(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<kFusedQT, 7>)); set1(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<kFusedQT, 8>));
+    set1(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<kFusedQT, 11>)); set1(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<kFusedQT, 15>));
+    set1(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<kFusedQT, 16>)); set1(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<kFusedQT, 64>)); set1(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<kFusedQT, 33>)); set1(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<kFusedQT, 129>)); set1(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<kFusedQT, 144>));
+#endif
+    if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(attn_bwd_fused): %s", hipGetErrorString(e));
+    attr = true;
+  }
+  const int M = B * T;
+  GVK_LAUNCH(attn_delta_kernel, dim3((unsigned)(((size_t)M * H * 8 + 255) / 256)), dim3(256), 0, s, (const bf16*)out, (const bf16*)dout, delta, M, T, H, ld_out);
+  int rc = check_launch("attention_bwd/delta");
+  if (rc) return rc;
+  const float dk_scale = 0.69314718055994530942f;      // dK = scale . dS^T.Q = dS^T.Q' / log2(e)
+  char* w = (char*)ws;
+  const dim3 grid(((T + 127) / 128) * H * B);
+#define GVK_FUSED(V)                                                                                                                          \
+  GVK_LAUNCH((attn_bwd_fused_kernel<kFusedQT, V>), grid, dim3(256), lds, s, (const bf16*)qkv, (const bf16*)dout, lse, (const float*)delta, \
+             (bf16*)dqkv, (float*)(w + off_acc), (int*)w, (int*)w + fused_ws_cap(ws_bytes) * 32, (int*)(w + off_status), T, H, ld_qkv, ld_out, scale, dk_scale)
+#ifdef GVK_DIAG
+  const int var = diag_env("GAVIKO_HIP_ATTN_VAR") ? atoi(diag_env("GAVIKO_HIP_ATTN_VAR")) : 0;      // timing ablations (wrong results)
+  if (var == 1) GVK_FUSED(1); else if (var == 3) GVK_FUSED(3); else if (var == 7) GVK_FUSED(7); else if (var == 8) GVK_FUSED(8);
+  else if (var == 11) GVK_FUSED(11); else if (var == 15) GVK_FUSED(15); else if (var == 16) GVK_FUSED(16); else if (var == 64) GVK_FUSED(64); else if (var == 33) GVK_FUSED(33); else if (var == 129) GVK_FUSED(129); else if (var == 144) GVK_FUSED(144); else
+#endif
+  GVK_FUSED(0);
+#undef GVK_FUSED
+  return check_launch("attention_bwd/fused");
 }
 
 extern "C" int gvk_attention_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,

@@ -9,6 +9,29 @@ namespace gvk {
 // reads and the 4x16 transposed reads (ds_read_b64_tr_b16)
 __device__ __forceinline__ int attn_swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
+// LDS-DMA through inline asm (the one-pass backward only).  hipcc's wait-count pass cannot tell LDS buffers apart: behind a
+// `buffer_load ... lds` it KNOWS of, every later LDS read first waits for that load, and its counted waits for loop-invariant register
+// loads land inside the loop, where they drain whatever else is in flight.  In a loop that also carries global loads and stores of a
+// hand-off that turns into a full s_waitcnt vmcnt(0) in front of every tile's first fragment reads.  Issued from asm the compiler does
+// not see the LDS write; the kernel drains the queue itself (GVK_DMA_DRAIN) in front of the barrier that hands a tile to the other
+// waves.  (Measured on the forward and the two-pass backward, which carry nothing else: no difference, they keep the builtin.)
+// lds_wave_base: wave-uniform; lane l writes 16 (4) bytes at base + 16 l (4 l).
+__device__ __forceinline__ unsigned lds_addr_u32(const void* p) { return (unsigned)(size_t)(GVK_LDS const char*)p; }
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, const void* lds_wave_base, int voff, int soff) {
+  const unsigned a = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds_wave_base));
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(a), "v"(voff), "s"(r), "s"(soff) : "memory", "m0");
+}
+__device__ __forceinline__ void lds_dma4(__amdgpu_buffer_rsrc_t r, const void* lds_wave_base, int voff, int soff) {
+  const unsigned a = __builtin_amdgcn_readfirstlane(lds_addr_u32(lds_wave_base));
+  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(a), "v"(voff), "s"(r), "s"(soff) : "memory", "m0");
+}
+#define GVK_DMA_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// In front of a loop that issues asm LDS-DMA: every load the compiler tracks (the prologue's fragment loads) is waited for HERE, with the
+// builtin the compiler's scoreboard understands.  Otherwise it places the counted waits for those loop-invariant loads INSIDE the loop
+// (s_waitcnt vmcnt(7) ... vmcnt(0) in front of their first uses), where -- blind to the DMA requests -- they drain the prefetch on
+// every iteration.
+#define GVK_LOADS_LANDED() __builtin_amdgcn_s_waitcnt(0x0F70)
+
 // attention-probability dropout (vision_transformer.py:68, live for the unfrozen-backbone methods): the softmax statistics are taken
 // of the undropped scores, the dropped and rescaled P feeds the P.V product; mask element (b*H + head, query, key) -- dropout.hpp
 struct AttnDrop { unsigned long long seed; const unsigned long long* seed_ptr; unsigned int thresh; float inv_keep; };

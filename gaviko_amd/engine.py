@@ -35,6 +35,9 @@ from .engine_peft import PeftPaths
 # bench.py instrumentation: when set to a dict, plans recorded from then on bracket every GEMM launch (and the patch-embed
 # stage) with timestamped plan events, so the kernels are timed inside the real three-stream schedule of a replayed step.
 GEMM_MARKS = None
+# the bf16 attention backward as ONE pass (csrc/attention_bwd.hip::attn_bwd_fused_kernel, round 5): built, bit-compatible, and 5 % slower
+# than the two passes at T = 1033 -- the two-pass kernels stay the path; GAVIKO_HIP_ATTN_BWD=fused (measurement build) is the A/B
+_ATTN_FUSED = L.diag_env("GAVIKO_HIP_ATTN_BWD", "2pass") == "fused"
 
 
 # classes whose backbone tensors can train (engine_peft.py `_bb_*`): the plain ViT (`fft` / `bitfit`); every class that freezes by default, with freeze_vit=False
@@ -383,6 +386,8 @@ class Engine(GavikoPaths, PeftPaths):
             ws["dctx"] = z(M, C, bf16)
             ws["dqkv"] = z(M, 3 * C, bf16)
             ws["delta"] = torch.zeros((B, self.heads, T), device=device)
+            if not self.fp32 and _ATTN_FUSED:                                     # one-pass attention backward: progress words + running dQ sums
+                ws["attn_ws"] = ops.attention_bwd_workspace(B, T, self.heads, device)
             if self.kind == "gaviko":
                 Lt, P, BN = self.Lat, self.P, B * N
                 mk = lambda *s: torch.zeros(s, device=device)
@@ -1059,7 +1064,7 @@ class Engine(GavikoPaths, PeftPaths):
             self._gemm(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
             self._mark(f"b{i}:outd")
             ops.attention_bwd(ws["qkv"][i], ws["ctx"][i], ws["dctx"], ws["lse"][i], ws["delta"], ws["dqkv"], B, T, self.heads, 64 ** -0.5,
-                              drop_p=pd_, seed=SEED_LAYER + 8 * i, seed_ptr=ws["seed"], q_prescaled=True)
+                              drop_p=pd_, seed=SEED_LAYER + 8 * i, seed_ptr=ws["seed"], q_prescaled=True, ws=ws.get("attn_ws") if _ATTN_FUSED else None)
             self._mark(f"b{i}:attnb")
             if gaviko and shift:
                 self._mwsa_chain_bwd(ws, sv, gv, i, par, B, loc, self._ev_record(torch.cuda.current_stream()))

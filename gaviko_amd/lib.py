@@ -26,7 +26,7 @@ if os.environ.get("GPU_MAX_HW_QUEUES") is None:
     except Exception:
         pass
 
-ABI_VERSION = 9                                   # gvk_abi_version() of the library these declarations describe
+ABI_VERSION = 10                                  # gvk_abi_version() of the library these declarations describe
 # GAVIKO_HIP_DIAG=1 (tools/ only): load the measurement build libgaviko_hip_diag.so (`python -m gaviko_amd.build --diag`) -- the product
 # library ignores every A/B switch of the kernel sources and exports no diagnostics (include/gaviko_hip_diag.h)
 DIAG = os.environ.get("GAVIKO_HIP_DIAG", "0") == "1"
@@ -120,6 +120,7 @@ SIGNATURES = {
     "gvk_qkv_prescale_bf16": [_P, _I, _I, _I, _F, _P],
     "gvk_prompt_up_fix_stats": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "gvk_attention_bwd_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "gvk_attention_bwd_bf16_fused": [_P, _P, _P, _P, _P, _P, _P, C.c_size_t, _I, _I, _I, _I, _I, _F, _P],
     "gvk_attention_fwd_f32_dropout": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P, _P],
     "gvk_attention_bwd_f32_dropout": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P, _P],
     "gvk_attention_fwd_bf16_dropout": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P, _P],
@@ -178,6 +179,8 @@ SIGNATURES = {
     "gvk_head_bwd": [C.POINTER(HeadDesc), _P],
 }
 NO_STREAM = {"gvk_last_error": (C.c_char_p, []), "gvk_device_check": (C.c_int, []), "gvk_abi_version": (C.c_int, []),
+             "gvk_attention_bwd_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+             "gvk_attention_bwd_status_offset": (C.c_size_t, [C.c_size_t]),
              "gvk_gpa_gate_param_count": (C.c_int, [C.c_int, C.c_int]), "gvk_gemm_stat_parts": (C.c_int, [C.c_int]), "gvk_minmax_partials": (C.c_int, []),
              "gvk_param_grads_scratch": (C.c_int64, [C.POINTER(PgradOuter), C.c_int, C.POINTER(ReduceJob), C.c_int, C.c_int, C.c_int]),
              "gvk_plan_begin": (C.c_int, []), "gvk_plan_end": (C.c_int, []), "gvk_plan_abort": (C.c_int, []),

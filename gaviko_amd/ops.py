@@ -544,7 +544,21 @@ def head_bwd(**kw):
     L.check(L.load().gvk_head_bwd(C.byref(d), L.stream_ptr()), "gvk_head_bwd")
 
 
-def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, scale, drop_p=0.0, seed=0, seed_ptr=None, q_prescaled=False):
+def attention_bwd_workspace(B, T, H, device):
+    """Zeroed workspace of the one-pass bf16 backward (gvk_attention_bwd_bf16_fused): progress words + the running dQ sums of the
+    ordered hand-off.  One per stream that issues the call (launches sharing it must be ordered)."""
+    n = int(L.load().gvk_attention_bwd_ws_bytes(B, T, H))
+    return torch.zeros((n + 3) // 4, dtype=torch.int32, device=device)
+
+
+def attention_bwd_timeouts(ws) -> int:
+    """Hand-off waits of the one-pass backward that ran into their bound since the workspace was made (0 unless a launch was broken)."""
+    return int(ws[int(L.load().gvk_attention_bwd_status_offset(ws.numel() * 4)) // 4].item())
+
+
+def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, scale, drop_p=0.0, seed=0, seed_ptr=None, q_prescaled=False, ws=None):
+    """ws (attention_bwd_workspace): run the one-pass kernel (five products, ordered dQ hand-off); without it, or with attention
+    dropout, the two-pass kernels."""
     inner = H * 64
     if qkv.dtype == torch.float32:
         for t, n, k in ((qkv, "qkv", 3), (out, "out", 1), (dout, "dout", 1), (dqkv, "dqkv", 3)):
@@ -567,6 +581,11 @@ def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, scale, drop_p=0.0, 
         L.check(L.load().gvk_attention_bwd_bf16_dropout(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), B, T, H,
                                                         3 * inner, inner, scale, float(drop_p), int(seed), L.ptr(seed_ptr), L.stream_ptr()),
                 "gvk_attention_bwd_bf16_dropout")
+        return
+    if ws is not None:
+        _chk(ws, torch.int32, "attn_bwd ws", (int(L.load().gvk_attention_bwd_ws_bytes(B, T, H)) + 3) // 4)
+        L.check(L.load().gvk_attention_bwd_bf16_fused(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), L.ptr(ws),
+                                                      ws.numel() * 4, B, T, H, 3 * inner, inner, scale, L.stream_ptr()), "gvk_attention_bwd_bf16_fused")
         return
     L.check(L.load().gvk_attention_bwd_bf16(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), B, T, H,
                                             3 * inner, inner, scale, L.stream_ptr()), "gvk_attention_bwd_bf16")

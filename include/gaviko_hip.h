@@ -22,7 +22,7 @@ extern "C" {
 const char* gvk_last_error(void);
 /* returns 950 when the code object loaded on the current device is gfx950, else <0 */
 int gvk_device_check(void);
-int gvk_abi_version(void);   /* 9 */
+int gvk_abi_version(void);   /* 10 */
 
 /* ------------------------------------------------------------------ launch plans
  * The reference drives its step from the Python interpreter (train.py:296-319: one autograd node per op).  Here one
@@ -210,6 +210,18 @@ int gvk_qkv_prescale_bf16(void* qkv, int rows, int H, int ld_qkv, float scale, v
  * consumes) -- from qkv (q block pre-scaled as above), out (forward output, for delta = rowsum(dout*out)), dout and lse.  delta f32 [B][H][T] is scratch.  Deterministic (no atomics). */
 int gvk_attention_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                            int B, int T, int H, int ld_qkv, int ld_out, float scale, void* stream);
+/* ONE-PASS form of the same backward (round 5; ABI 10): five MFMA products per (query, key) block instead of seven and one exponential
+ * per score instead of two -- each workgroup owns dK / dV of its 128 keys and also forms dQ's share of those keys; the shares of a
+ * (batch, head)'s key blocks are summed by an ordered hand-off between the workgroups (fixed order per query tile: bitwise reproducible,
+ * no float atomics).  ws: at least gvk_attention_bwd_ws_bytes(B, T, H) bytes, 256-byte aligned, ZERO at allocation (the kernel leaves its
+ * progress words zero); its layout depends on ws_bytes only, so ONE workspace sized for the longest sequence serves shorter ones too.
+ * The int32 at byte gvk_attention_bwd_status_offset(ws_bytes) counts hand-off waits that ran into their bound and stays 0.  Calls that
+ * share a workspace must be ordered by their stream.  Same arguments and results as gvk_attention_bwd_bf16 otherwise (delta f32
+ * [B][H][T] is written by a small kernel in front). */
+size_t gvk_attention_bwd_ws_bytes(int B, int T, int H);
+size_t gvk_attention_bwd_status_offset(size_t ws_bytes);
+int gvk_attention_bwd_bf16_fused(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, void* ws,
+                                 size_t ws_bytes, int B, int T, int H, int ld_qkv, int ld_out, float scale, void* stream);
 /* the same with nn.Dropout(drop_p) on the attention probabilities (vision_transformer.py:52,68 -- live in training for the methods
  * that do not freeze the backbone): softmax statistics of the undropped scores, out = (P * mask / (1 - drop_p)) . V; the backward
  * regenerates mask(seed + *seed_ptr; b*H + head, query, key).  drop_p = 0 is the plain call. */

@@ -26,12 +26,15 @@ def _close(got, want, rtol, name=""):
     assert err <= rtol * ref, f"{name}: max err {err:.3e} vs scale {ref:.3e} (tol {rtol})"
 
 
-@pytest.mark.parametrize("kb", [0, 96, 128])
-@pytest.mark.parametrize("B,T,H", [(2, 1033, 3), (1, 1001, 2), (2, 65, 1), (1, 393, 3), (1, 31, 2)])
+@pytest.mark.parametrize("kb", [0, 96, 128, "fused"])
+@pytest.mark.parametrize("B,T,H", [(2, 1033, 3), (1, 1001, 2), (2, 65, 1), (1, 393, 3), (1, 31, 2), (3, 129, 2), (1, 1, 1), (2, 257, 12)])
 def test_attention_bwd(dev, monkeypatch, B, T, H, kb):
-    """kb: tile size of both passes (0 = the launcher's choice: whichever pads the sequence less)."""
+    """kb: tile size of both passes of the two-pass kernels (0 = the launcher's choice: whichever pads the sequence less); "fused" = the
+    one-pass kernel (five products, dQ summed over the key blocks by the ordered hand-off), which must also be bitwise repeatable and
+    leave its progress words zero."""
     from gaviko_amd import ops
-    if kb:
+    fused = kb == "fused"
+    if kb and not fused:
         monkeypatch.setenv("GAVIKO_HIP_ATTN_KB", str(kb))
     inner = H * 64
     C_ = 0.125 * 1.4426950408889634
@@ -56,12 +59,24 @@ def test_attention_bwd(dev, monkeypatch, B, T, H, kb):
     DO[: B * T] = dO.reshape(B * T, -1).to(dev).bfloat16()
     DQ = ops.act_zeros(B * T, 3 * inner, torch.bfloat16, dev)
     delta = torch.zeros((B, H, T), device=dev)
-    ops.attention_bwd(Q, O, DO, lse, delta, DQ, B, T, H, 0.125, q_prescaled=True)
+    wsp = ops.attention_bwd_workspace(B, T, H, dev) if fused else None
+    ops.attention_bwd(Q, O, DO, lse, delta, DQ, B, T, H, 0.125, q_prescaled=True, ws=wsp)
     torch.cuda.synchronize()
+    if fused:
+        st = int(ops.L.load().gvk_attention_bwd_status_offset(wsp.numel() * 4)) // 4
+        assert ops.attention_bwd_timeouts(wsp) == 0 and int(wsp[:st].abs().max()) == 0          # no bounded wait hit, every progress word back at zero
+        _close(delta, (o.detach() * dO).reshape(B, T, H, 64).sum(-1).permute(0, 2, 1), 2e-2, "delta")
+        first = DQ.clone()
+        for _ in range(3):                                  # the hand-off order is a function of (tile, key block) only: bit-equal every time
+            DQ.zero_()
+            ops.attention_bwd(Q, O, DO, lse, delta, DQ, B, T, H, 0.125, q_prescaled=True, ws=wsp)
+            torch.cuda.synchronize()
+            assert torch.equal(DQ, first)
+        assert ops.attention_bwd_timeouts(wsp) == 0 and int(wsp[:st].abs().max()) == 0
     got = DQ[: B * T].view(B, T, 3 * inner).cpu().double()
     want = qkv.grad
     for name, sl in (("dq", slice(0, inner)), ("dk", slice(inner, 2 * inner)), ("dv", slice(2 * inner, 3 * inner))):
-        e = (got[..., sl] - want[..., sl]).abs().max().item() / want[..., sl].abs().max().item()
+        e = (got[..., sl] - want[..., sl]).abs().max().item() / max(want[..., sl].abs().max().item(), 1e-30)     # (T = 1: dq = dk = 0 exactly)
         print(f"attention_bwd B={B} T={T} H={H} kb={kb} {name}: rel err {e:.2e}")
         _close(got[..., sl], want[..., sl], 2.5e-2, name)
 

@@ -62,5 +62,32 @@ if "--fwd-variants" in sys.argv:
             cases.append((n, plan(fwd, {"GAVIKO_HIP_ATTN_KB": str(kb), "GAVIKO_HIP_ATTN_VAR": str(var)})))
             flops[n] = f
 cases.append(("attention_fwd (default)", plan(fwd))); flops[cases[-1][0]] = f
-cases.append(("attention_bwd (5 products)", plan(bwd))); flops[cases[-1][0]] = 2.5 * f
+cases.append(("attention_bwd two-pass (7 products)", plan(bwd))); flops[cases[-1][0]] = 2.5 * f
+wsp = ops.attention_bwd_workspace(B, T, H, dev)
+bwd1 = lambda: ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, 0.125, q_prescaled=True, ws=wsp)
+cases.append(("attention_bwd one-pass (5 products)", plan(bwd1))); flops[cases[-1][0]] = 2.5 * f
+if "--fused-variants" in sys.argv:        # timing ablations of the one-pass kernel (measurement build; results of VAR != 0 are wrong)
+    for var, what in ((1, "no waits / sum loads"), (3, "no hand-off at all"), (7, "no dQ product, no hand-off"), (8, "no per-sub-block vmcnt drain"),
+                      (11, "no hand-off, no drain"), (15, "no dQ, no hand-off, no drain"), (16, "no polling, sums loaded + stored"), (33, "dQ product only: no loads, stores, polls"), (129, "stores only, barrier without vmcnt drain"), (144, "loads + stores, no polls, barrier without vmcnt drain")):
+        n = f"one-pass VAR={var} ({what})"
+        cases.append((n, plan(bwd1, {"GAVIKO_HIP_ATTN_VAR": str(var)}))); flops[n] = 2.5 * f
+    wsp.zero_()
 race(cases, flops)
+print('hand-off timeouts:', ops.attention_bwd_timeouts(wsp))
+so = int(l.gvk_attention_bwd_status_offset(wsp.numel() * 4)) // 4
+wsp[so:so + 4] = 0
+for _ in range(10): bwd1()
+torch.cuda.synchronize()
+print('per launch: late waits', wsp[so + 1].item() / 10, 'of', B * H * ((T + 127) // 128 - 1) * ((T + 31) // 32), ' polls', wsp[so + 2].item() / 10)
+
+if "--stamps" in sys.argv:          # phase totals of the one-pass kernel's loop (VAR = 64, measurement build): sub-blocks 4..27 of wave w of three workgroups
+    os.environ["GAVIKO_HIP_ATTN_VAR"] = "64"
+    for _ in range(5): bwd1()
+    torch.cuda.synchronize()
+    os.environ.pop("GAVIKO_HIP_ATTN_VAR")
+    raw = wsp[so + 16: so + 16 + 3 * 64].cpu().view(torch.int64).view(3, 4, 8)[:, :, :6]
+    names = ["finish_prev", "dK dV + dS write", "drain vmcnt(0)", "poll + barrier", "signal, request, tile switch", "dQ + next scores"]
+    for wg in range(3):
+        for w in range(4):
+            tot = raw[wg, w].sum().item()
+            print(f"wg {wg} wave {w}: " + "  ".join(f"{n} {raw[wg, w, k].item() / 24:.0f}" for k, n in enumerate(names)) + f"  | per sub-block {tot / 24:.0f} clocks (100 MHz ticks x ?)")

@@ -18,9 +18,12 @@ def run():
     dout[:B * T] = torch.randn(B * T, inner, device=dev).bfloat16()
     lse, delta = torch.empty(B * H * T, device=dev), torch.empty(B * H * T, device=dev)
     dqkv = ops.act_zeros(B * T, 3 * inner, torch.bfloat16, dev)
+    ops.qkv_prescale(qkv, B * T, H, 0.125)
+    wsp = ops.attention_bwd_workspace(B, T, H, dev)
     for _ in range(6):
-        ops.attention_fwd(qkv, out, lse, B, T, H, 0.125)
-        ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, 0.125)
+        ops.attention_fwd(qkv, out, lse, B, T, H, 0.125, q_prescaled=True)
+        ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, 0.125, q_prescaled=True)                 # two passes
+        ops.attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, 0.125, q_prescaled=True, ws=wsp)         # one pass
     torch.cuda.synchronize()
 
 
