@@ -398,7 +398,10 @@ __device__ __forceinline__ int ds_unit(int keyl, int g, int h) {
 }
 
 // VAR (measurement build only; results wrong unless 0): bit 0 = no waiting / no running-sum loads, bit 1 = no running-sum stores,
-// bit 2 = no dQ product at all, bit 3 = write-through stores whatever the successor's XCD, bit 4 = no polling (sums loaded whatever their state)
+// bit 2 = no dQ product at all, bit 3 = write-through stores whatever the successor's XCD, bit 4 = no polling (sums loaded whatever their
+// state), bit 5 = dQ product kept but nothing loaded or stored, bit 6 = shader-clock totals of the loop's phases, bit 7 = barrier without
+// a drain of the vector-memory queue
+// QT = queries per STEP (one staged tile, one barrier, one hand-off): 64 = two 32-query sub-blocks
 template <int QT, int VAR>
 __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                              const float* __restrict__ delta, bf16* __restrict__ dqkv, float* dq_acc, int* prog,
@@ -407,11 +410,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const bf16* __re
   constexpr int kTileQ = QT * 128;                // bytes of a [QT][64] bf16 tile
   constexpr int kBuf = 2 * kTileQ + 2 * 128 * 4;  // Q tile | dO tile | lse 128 f32 | delta 128 f32
   constexpr int kDS = 128 * 64;                   // one dS^T image: [128 keys][32 queries] bf16
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][kBuf] | [2][kDS] | start tiles of the key blocks (int [256])
-  char* const sDSbase = smem + 2 * kBuf;      // (the two images first hold the K tile, once)
-  int* const stab = (int*)(sDSbase + 2 * kDS);
+  constexpr int kImg = NSB * kDS;                 // the images of one step
+  static_assert(2 * kImg >= 128 * 128, "the dS^T images first hold the K tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][kBuf] | [2][NSB][kDS] | start tiles of the key blocks (int [256])
+  char* const sDSbase = smem + 2 * kBuf;      // (the images first hold the K tile, once)
+  int* const stab = (int*)(sDSbase + 2 * kImg);
   const int nkb = (T + 127) / 128, nqt = (T + QT - 1) / QT;
-  const int nsv = (T + 31) / 32;                   // 32-query sub-blocks that hold rows of the sequence
   int bh, kblk;
   xcd_group_block(blockIdx.x, nkb, gridDim.x / nkb, bh, kblk);   // all key blocks of a (batch, head) on one XCD, consecutive in its dispatch order
   const int b = bh / H, head = bh - b * H, k0 = kblk * 128;
@@ -442,10 +446,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const bf16* __re
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, nB * T * ld_qkv * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)d_o, 0, nB * T * ld_o * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(wave < 2 ? lse : delta), 0, nB * H * T * 4, 0x00020000);
-  const int nsub = nqt * NSB;                      // sub-block slots of a (batch, head): one running-sum slab and one progress word each
-  const __amdgpu_buffer_rsrc_t racc = __builtin_amdgcn_make_buffer_rsrc((void*)(dq_acc + (size_t)bh * nsub * 2048), 0, nsub * 8192, 0x00020000);
-  float* const accb = dq_acc + (size_t)bh * nsub * 2048;
-  int* const progb = prog + (size_t)bh * nsub * 32;     // one progress word per 128-byte line: polls and advances of 432 workgroups spread over the memory channels
+  // per (batch, head): one running-sum slab (NSB x 8 KB) and one progress word (on a 128-byte line of its own) per step
+  const __amdgpu_buffer_rsrc_t racc = __builtin_amdgcn_make_buffer_rsrc((void*)(dq_acc + (size_t)bh * nqt * NSB * 2048), 0, nqt * NSB * 8192, 0x00020000);
+  float* const accb = dq_acc + (size_t)bh * nqt * NSB * 2048;
+  int* const progb = prog + (size_t)bh * nqt * 32;
   const int rsub = lane >> 3, slot = lane & 7;
   int voq[NSB], vod[NSB];
 #pragma unroll
@@ -461,31 +465,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const bf16* __re
     char* sQ = smem + buf * kBuf;
     char* sD = sQ + kTileQ;
     char* sL = sD + kTileQ;
-    const bool last = qt == nqt - 1;
     const int soq = qt * QT * ld_qkv * 2, sod = qt * QT * ld_o * 2, sol = qt * QT * 4;
 #pragma unroll
     for (int r = 0; r < NSB; ++r) {
-      const int over = last ? max(qt * QT + r * 32 + wave * 8 + rsub - (T - 1), 0) : 0;
+      const int over = max(qt * QT + r * 32 + wave * 8 + rsub - (T - 1), 0);          // rows past the sequence: copies of the last row (masked below)
       const int vq = voq[r] - over * ld_qkv * 2, vd = vod[r] - over * ld_o * 2;
       lds_dma16(rq, sQ + (r * 32 + wave * 8) * 128, vq, soq);
       lds_dma16(rd, sD + (r * 32 + wave * 8) * 128, vd, sod);
     }
-    const int overl = last ? max(qt * QT + lrow - (T - 1), 0) : 0;
-    const int vl = vol - overl * 4;
-    lds_dma4(rl, sL + (wave >> 1) * 512 + (wave & 1) * 256, vl, sol);
+    const int overl = max(qt * QT + lrow - (T - 1), 0);
+    lds_dma4(rl, sL + (wave >> 1) * 512 + (wave & 1) * 256, vol - overl * 4, sol);
   };
 
   const int start = (kblk * nqt) / nkb;            // first tile of this workgroup's cyclic sweep
   if ((int)threadIdx.x < nkb) stab[threadIdx.x] = ((int)threadIdx.x * nqt) / nkb;     // every member's (one division each, here, instead of nkb per tile)
-  // ---- prologue: the K tile of the workgroup through LDS (once), first query tile
+  // ---- prologue: the K tile of the workgroup through LDS (once), the first two query tiles
   GVK_LOADS_LANDED();
-  {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {                  // 128 key rows x 128 B into the (not yet used) dS^T images, rows past the sequence = copies of the last key
-      const int row = r * 32 + wave * 8 + rsub;
-      const int rowc = min(k0 + row, T - 1);
-      lds_dma16(rq, sDSbase + (r * 32 + wave * 8) * 128, ((b * T + rowc) * ld_qkv + inner + head * 64 + ((slot ^ attn_swz(row)) << 3)) * 2, 0);
-    }
+  for (int r = 0; r < 4; ++r) {                    // 128 key rows x 128 B into the (not yet used) dS^T images, rows past the sequence = copies of the last key
+    const int row = r * 32 + wave * 8 + rsub;
+    const int rowc = min(k0 + row, T - 1);
+    lds_dma16(rq, sDSbase + (r * 32 + wave * 8) * 128, ((b * T + rowc) * ld_qkv + inner + head * 64 + ((slot ^ attn_swz(row)) << 3)) * 2, 0);
   }
   stage(0, start);
   GVK_DMA_DRAIN();
@@ -526,10 +526,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const bf16* __re
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) dsr[qh][rd] = ds_unit(8 * G + 4 * rd + tq, 2 * qh + (tp >> 1), tp & 1);
 
-  // ---- the sweep.  One iteration = one 32-query sub-block from barrier to barrier, software-pipelined over THREE sub-blocks so that no
-  // global latency and no dependent MFMA chain sits alone on a wave's critical path:
-  //     [n-1: add the predecessor's sum (requested one iteration ago), store]   dK, dV of n; dS^T(n) -> image   [drain, poll n, barrier]
-  //     [word of n-1 advanced]  [sum of n requested]  [poll word of n+1 requested]   dQ(n) product  ||  S, dP, exp of n+1 (one basic block)
+  // ---- the sweep.  One iteration = one STEP of QT queries from barrier to barrier, software-pipelined so that no global latency and no
+  // dependent MFMA chain sits alone on a wave's critical path:
+  //     dK, dV of sub-block 0 (its scores came with the previous step); scores, dK, dV of the others; dS^T -> images   [drain, poll, barrier]
+  //     [word of the previous step advanced]  [this step's sum and the next step's poll word requested]
+  //     dQ products of the step  ||  S, dP of the next step's first sub-block (one basic block)   [add the sum, pass it on]   exponentials
   // position of this workgroup in a tile's summation chain = members that reach the tile at an earlier step; its successor = the next one
   auto chain = [&](int qt, int& pos, int& succ) {
     int mine = qt - start;
@@ -574,105 +575,117 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const bf16* __re
       dp[r] = pr * dp[r];
     }
   };
+  // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key];  dS^T -> the sub-block's image
+  auto grads = [&](int buf, int sub, char* sDS) {
+    const char* sQ = smem + buf * kBuf + sub * 32 * 128;
+    const char* sD = sQ + kTileQ;
+#pragma unroll
+    for (int sk = 0; sk < 2; ++sk) {
+      bf16x8 pf, dsf;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) { pf[jj] = (bf16)s[8 * sk + jj]; dsf[jj] = (bf16)dp[8 * sk + jj]; }
+      const u32x4 dsw = __builtin_bit_cast(u32x4, dsf);
+      *(u32x2*)(sDS + ds_unit(keyl, 2 * sk, hh)) = u32x2{dsw[0], dsw[1]};
+      *(u32x2*)(sDS + ds_unit(keyl, 2 * sk + 1, hh)) = u32x2{dsw[2], dsw[3]};
+      const int q0r = 16 * sk + 4 * (g >> 1);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
+        const int ra = q0r + tq, rb = q0r + 8 + tq;
+        const int oa = ra * 128 + ((chunk ^ attn_swz(ra)) << 4) + (tp & 1) * 8;
+        const int ob = rb * 128 + ((chunk ^ attn_swz(rb)) << 4) + (tp & 1) * 8;
+        const bf16x4 da0 = lds_read_tr16(sD + oa), da1 = lds_read_tr16(sD + ob);
+        const bf16x4 qa0 = lds_read_tr16(sQ + oa), qa1 = lds_read_tr16(sQ + ob);
+        const bf16x8 dof = {da0[0], da0[1], da0[2], da0[3], da1[0], da1[1], da1[2], da1[3]};
+        const bf16x8 qf = {qa0[0], qa0[1], qa0[2], qa0[3], qa1[0], qa1[1], qa1[2], qa1[3]};
+        dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dvt[db], 0, 0, 0);
+        dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, dsf, dkt[db], 0, 0, 0);
+      }
+    }
+  };
 
   int pend_word = -1, pend_val = 0;                // progress word to advance behind the next barrier
-  // a sub-block's share of dQ: add the predecessor's sum (requested behind the barrier, consumed here a whole product later), pass it on
-  auto finish = [&](f32x4 (&hdq)[2], const u32x4 (&hld)[2], int gsub, int q0, int ppos, bool add, bool last, bool plain) {
-    const int aoff = gsub * 8192 + wave * 2048 + lane * 16;
+  // a step's share of dQ (NSB sub-blocks x 2 query halves of this wave's 16-d slab): add the predecessor's sum (requested behind the
+  // barrier, consumed here a whole product later), pass it on
+  auto finish = [&](f32x4 (&hdq)[NSB][2], const u32x4 (&hld)[NSB][2], int qt, int ppos, bool add, bool last, bool plain) {
+    const int aoff = qt * NSB * 8192 + wave * 2048 + lane * 16;
     {   // (a select, not a branch: the requested sum is always consumed, so its registers are never overwritten while in flight -- the
         //  compiler answers that hazard with a full s_waitcnt vmcnt(0), which would also wait for the stores below)
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      hdq[0] += add ? __builtin_bit_cast(f32x4, hld[0]) : z;
-      hdq[1] += add ? __builtin_bit_cast(f32x4, hld[1]) : z;
+#pragma unroll
+      for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh) hdq[sb][qh] += add ? __builtin_bit_cast(f32x4, hld[sb][qh]) : z;
     }
     if (last) {
 #pragma unroll
-      for (int qh = 0; qh < 2; ++qh) {
-        const int q = q0 + 16 * qh + li;
-        const bf16x4 o = {(bf16)(hdq[qh][0] * scale), (bf16)(hdq[qh][1] * scale), (bf16)(hdq[qh][2] * scale), (bf16)(hdq[qh][3] * scale)};
-        if (q < T) *(bf16x4*)(dqkv + ((size_t)b * T + q) * ld_qkv + head * 64 + 16 * wave + 4 * G) = o;
-      }
+      for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh) {
+          const int q = qt * QT + sb * 32 + 16 * qh + li;
+          const bf16x4 o = {(bf16)(hdq[sb][qh][0] * scale), (bf16)(hdq[sb][qh][1] * scale), (bf16)(hdq[sb][qh][2] * scale), (bf16)(hdq[sb][qh][3] * scale)};
+          if (q < T) *(bf16x4*)(dqkv + ((size_t)b * T + q) * ld_qkv + head * 64 + 16 * wave + 4 * G) = o;
+        }
     } else if (plain) {
       // the successor runs on this XCD: plain stores leave the sum in the shared L2, where its L1-bypassing loads find it (a write-through
-      // store would drop the lines from the L2 and send every one of those loads to the fabric: 228 MB per launch)
+      // store would drop the lines from the L2 and send every one of those loads to the fabric)
 #pragma unroll
-      for (int qh = 0; qh < 2; ++qh) *(f32x4*)((char*)accb + aoff + qh * 1024) = hdq[qh];
+      for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh) *(f32x4*)((char*)accb + aoff + sb * 8192 + qh * 1024) = hdq[sb][qh];
     } else {
 #pragma unroll
-      for (int qh = 0; qh < 2; ++qh) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hdq[qh]), racc, aoff + qh * 1024, 0, 16);   // aux 16 = sc1
+      for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hdq[sb][qh]), racc, aoff + sb * 8192 + qh * 1024, 0, 16);   // aux 16 = sc1
     }
-    pend_word = gsub;
-    pend_val = (last || (VAR & 7) != 0) ? 0 : ppos + 1;      // (the timing ablations never leave a progress word set)
+    pend_word = qt;
+    pend_val = (last || (VAR & 39) != 0) ? 0 : ppos + 1;      // (the timing ablations never leave a progress word set)
   };
 
-  // current sub-block
-  int gcur = start * NSB;                          // slot index: tile * NSB + sub (slots of the last tile past the sequence are never visited)
-  int qt = start, sub = 0, buf = 0;
-  int pos, succ;
+  int qt = start, pos, succ;
   chain(qt, pos, succ);
   if constexpr ((VAR & 1) != 0) pos = 0;
-  int tv = 0;                                      // tiles visited so far (the first two are requested before the loop)
   // every member's XCD + 1, lane k2 = member k2 (0: had not started when this was read, a few microseconds into the kernel -> write-through
   // towards it).  Read ONCE: a load inside the loop whose result is carried around it makes the compiler drain the queue (WAW on the
   // carried register) in every iteration.
   const int xall = __hip_atomic_load((GVK_GLOBAL int*)(xrow + min(lane, nkb - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __builtin_amdgcn_s_waitcnt(0x0F70);              // (vmcnt(0), visible to the compiler: otherwise its wait for xall lands inside the loop)
-  int xs = succ >= 0 ? __builtin_amdgcn_readlane(xall, succ & 63) : 0;      // the successor's (key blocks past 64: unknown)
-  if (succ >= 64) xs = 0;
-  int pv = 0;                                      // progress word of the current sub-block (wave 0 only), requested one iteration ahead
+  int xs = succ >= 0 && succ < 64 ? __builtin_amdgcn_readlane(xall, succ & 63) : 0;      // the successor's (key blocks past 64: unknown)
+  int pv = 0;                                      // progress word of the current step (wave 0 only), requested one step ahead
   if (nqt > 1) stage(1, start + 1 < nqt ? start + 1 : 0);
   scores(0, 0, start * QT);
   soft();
   int par = 0;
-  [[maybe_unused]] unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;     // VAR bit 6: shader-clock totals of the loop's phases (wave 0 of a few workgroups)
+  [[maybe_unused]] unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;     // VAR bit 6: shader-clock totals of the loop's phases (a few workgroups)
 #define GVK_PH(k)                                                             \
   if constexpr ((VAR & 64) != 0) {                                            \
     const unsigned long long tnow = __builtin_amdgcn_s_memtime();             \
-    if (i >= 4 && i < 28) ph[k] += tnow - tprev;                              \
+    if (j >= 2 && j < nqt - 2) ph[k] += tnow - tprev;                         \
     tprev = tnow;                                                             \
   }
-  for (int i = 0; i < nsv; ++i) {
-    const int qrow0 = qt * QT + sub * 32;
+  for (int j = 0; j < nqt; ++j) {
+    const int buf = j & 1;
     const bool lastm = (VAR & 2) ? true : pos == nkb - 1;
-    char* sDS = sDSbase + par * kDS;
+    char* sDS = sDSbase + par * kImg;
     GVK_PH(5)
-    {
-      const char* sQ = smem + buf * kBuf + sub * 32 * 128;
-      const char* sD = sQ + kTileQ;
-      // dV^T[d][key] += dO^T[d][q] . P[q][key] ;  dK^T[d][key] += Q^T[d][q] . dS[q][key];  dS^T -> the image
+    grads(buf, 0, sDS);
 #pragma unroll
-      for (int sk = 0; sk < 2; ++sk) {
-        bf16x8 pf, dsf;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) { pf[jj] = (bf16)s[8 * sk + jj]; dsf[jj] = (bf16)dp[8 * sk + jj]; }
-        const u32x4 dsw = __builtin_bit_cast(u32x4, dsf);
-        *(u32x2*)(sDS + ds_unit(keyl, 2 * sk, hh)) = u32x2{dsw[0], dsw[1]};
-        *(u32x2*)(sDS + ds_unit(keyl, 2 * sk + 1, hh)) = u32x2{dsw[2], dsw[3]};
-        const int q0r = 16 * sk + 4 * (g >> 1);
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const int chunk = db * 4 + 2 * (g & 1) + (tp >> 1);
-          const int ra = q0r + tq, rb = q0r + 8 + tq;
-          const int oa = ra * 128 + ((chunk ^ attn_swz(ra)) << 4) + (tp & 1) * 8;
-          const int ob = rb * 128 + ((chunk ^ attn_swz(rb)) << 4) + (tp & 1) * 8;
-          const bf16x4 da0 = lds_read_tr16(sD + oa), da1 = lds_read_tr16(sD + ob);
-          const bf16x4 qa0 = lds_read_tr16(sQ + oa), qa1 = lds_read_tr16(sQ + ob);
-          const bf16x8 dof = {da0[0], da0[1], da0[2], da0[3], da1[0], da1[1], da1[2], da1[3]};
-          const bf16x8 qf = {qa0[0], qa0[1], qa0[2], qa0[3], qa1[0], qa1[1], qa1[2], qa1[3]};
-          dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pf, dvt[db], 0, 0, 0);
-          dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, dsf, dkt[db], 0, 0, 0);
-        }
-      }
+    for (int sb = 1; sb < NSB; ++sb) {
+      scores(buf, sb, qt * QT + sb * 32);
+      soft();
+      grads(buf, sb, sDS + sb * kDS);
     }
     GVK_PH(1)
-    // drain: this wave's stores of the previous sub-block have been acknowledged, the poll word and the next tile's rows have arrived
+    // drain: this wave's stores of the previous step have been acknowledged, the poll word and the next tile's rows have arrived
     if constexpr ((VAR & 128) == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv) : : "memory");
     GVK_PH(2)
     if constexpr ((VAR & 16) == 0) {
       if (wave == 0 && pos > 0 && pv != pos) {     // (rare) the predecessor's sum is not complete yet: wave 0 waits in front of the barrier for all
         for (unsigned spins = 0;; ++spins) {
           __builtin_amdgcn_s_sleep(4);
-          pv = __hip_atomic_load((GVK_GLOBAL int*)(progb + gcur * 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pv = __hip_atomic_load((GVK_GLOBAL int*)(progb + qt * 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (pv == pos) break;
           if (spins > (1u << 16)) { if (lane == 0) atomicAdd(status, 1); break; }     // (never seen: bounded so that a broken chain ends the launch)
         }
@@ -691,59 +704,65 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const bf16* __re
     if (pend_word >= 0 && threadIdx.x == 0)
       __hip_atomic_store((GVK_GLOBAL int*)(progb + pend_word * 32), pend_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     pend_word = -1;
-    // this sub-block's place in its chain; the predecessor's sum is requested here and added behind the products below
-    const int h_gsub = gcur, h_q0 = qrow0, h_pos = pos;
+    // this step's place in its chain; the predecessor's sum is requested here and added behind the products below
+    const int h_qt = qt, h_pos = pos;
     const bool h_last = lastm, h_add = pos > 0, h_plain = (VAR & 8) == 0 && xs == my_xcc + 1;
-    f32x4 hdq[2];
-    u32x4 hld[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+    f32x4 hdq[NSB][2];
+    u32x4 hld[NSB][2];
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+      for (int qh = 0; qh < 2; ++qh) hld[sb][qh] = u32x4{0u, 0u, 0u, 0u};
     if constexpr ((VAR & 37) == 0) {               // (unconditional: a load under a branch would leave registers in flight on the other path)
-      const int aoff = gcur * 8192 + wave * 2048 + lane * 16;
-      hld[0] = __builtin_amdgcn_raw_buffer_load_b128(racc, aoff, 0, 16);              // aux 16 = sc1: past this CU's L1, served by the L2
-      hld[1] = __builtin_amdgcn_raw_buffer_load_b128(racc, aoff + 1024, 0, 16);
+      const int aoff = qt * NSB * 8192 + wave * 2048 + lane * 16;
+#pragma unroll
+      for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh)
+          hld[sb][qh] = __builtin_amdgcn_raw_buffer_load_b128(racc, aoff + sb * 8192 + qh * 1024, 0, 16);     // aux 16 = sc1: past this CU's L1, served by the L2
     }
-    // the next sub-block (cyclic over the nsv valid ones); a new tile: its successor tile is requested into the buffer just left
-    int gn = gcur + 1, qtn = qt, subn = sub + 1, bufn = buf;
-    if (subn == NSB || qt * QT + subn * 32 >= T) {
-      subn = 0;
-      qtn = qt + 1 < nqt ? qt + 1 : 0;
-      gn = qtn * NSB;
-      bufn = buf ^ 1;
-      if (i + 1 < nsv) {
-        ++tv;
-        if (tv + 1 < nqt) stage(buf, qtn + 1 < nqt ? qtn + 1 : 0);       // the tile after the one being entered, into the buffer just left
-        chain(qtn, pos, succ);
-        if constexpr ((VAR & 1) != 0) pos = 0;
-        xs = succ >= 0 && succ < 64 ? __builtin_amdgcn_readlane(xall, succ & 63) : 0;
-      }
+    // the next step's tile (cyclic); the tile after it is requested into the buffer just left
+    int qtn = qt + 1 < nqt ? qt + 1 : 0;
+    if (j + 1 < nqt) {
+      if (j + 2 < nqt) stage(buf, qtn + 1 < nqt ? qtn + 1 : 0);
+      chain(qtn, pos, succ);
+      if constexpr ((VAR & 1) != 0) pos = 0;
+      xs = succ >= 0 && succ < 64 ? __builtin_amdgcn_readlane(xall, succ & 63) : 0;
+    } else {
+      qtn = qt;                                    // (last step: the scores below are recomputed and unused)
     }
-    if (i + 1 >= nsv) { gn = gcur; qtn = qt; subn = sub; bufn = buf; }    // (last iteration: the scores below are recomputed and unused)
+    const int bufn = j + 1 < nqt ? buf ^ 1 : buf;
     if constexpr ((VAR & 16) == 0) {
-      if (wave == 0) asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(pv) : "v"(0), "s"(progb + gn * 32) : "memory");
+      if (wave == 0) asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(pv) : "v"(0), "s"(progb + qtn * 32) : "memory");
     }
     GVK_PH(4)
-    // dQ^T[16 d of this wave][32 q] of THIS sub-block over the workgroup's 128 keys, in one block with the scores of the NEXT one
-    hdq[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    hdq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr ((VAR & 4) == 0) {
+    // dQ^T[16 d of this wave][QT q] of THIS step over the workgroup's 128 keys, in one block with the first scores of the NEXT one
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+    for (int sb = 0; sb < NSB; ++sb) {
+      hdq[sb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      hdq[sb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr ((VAR & 4) == 0) {
 #pragma unroll
-        for (int qh = 0; qh < 2; ++qh) {
-          const bf16x4 b0 = lds_read_tr16(sDS + kk * 2048 + dsr[qh][0]), b1 = lds_read_tr16(sDS + kk * 2048 + dsr[qh][1]);
-          const bf16x8 bb = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-          hdq[qh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[kk], bb, hdq[qh], 0, 0, 0);
-        }
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int qh = 0; qh < 2; ++qh) {
+            const char* im = sDS + sb * kDS + kk * 2048;
+            const bf16x4 b0 = lds_read_tr16(im + dsr[qh][0]), b1 = lds_read_tr16(im + dsr[qh][1]);
+            const bf16x8 bb = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            hdq[sb][qh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[kk], bb, hdq[sb][qh], 0, 0, 0);
+          }
+      }
     }
-    scores(bufn, subn, qtn * QT + subn * 32);
+    scores(bufn, 0, qtn * QT);
     GVK_PH(0)
-    // between the two halves of the next sub-block's scores: the requested sum has had the products above to arrive, the stores have the
-    // exponentials and the dK / dV products below to be acknowledged before the drain in front of the next barrier
-    if constexpr ((VAR & 4) == 0 && (VAR & 32) == 0) finish(hdq, hld, h_gsub, h_q0, h_pos, h_add, h_last, h_plain);
-    soft();
+    // between the two halves of the next scores: the requested sum has had the products above to arrive, the stores have the exponentials
+    // and the next step's dK / dV products to be acknowledged before the drain in front of its barrier
+    if constexpr ((VAR & 4) == 0 && (VAR & 32) == 0) finish(hdq, hld, h_qt, h_pos, h_add, h_last, h_plain);
     if constexpr ((VAR & 32) != 0) {               // (dQ product kept alive, nothing loaded or stored)
-      if (hdq[0][0] + hdq[1][3] == 123.456f) atomicAdd(status + 3, 1);
+      if (hdq[0][0][0] + hdq[NSB - 1][1][3] == 123.456f) atomicAdd(status + 3, 1);
     }
-    gcur = gn; qt = qtn; sub = subn; buf = bufn;
+    soft();
+    qt = qtn;
     par ^= 1;
   }
 #undef GVK_PH
@@ -814,7 +833,7 @@ extern "C" int gvk_attention_bwd_bf16_dropout(const void* qkv, const void* out, 
 // dQ sums: cap slabs of 8 KB].
 // The layout follows from the workspace SIZE alone (cap = slabs it can hold), never from T: a model whose layers run different sequence
 // lengths through one workspace (deep VPT) then keeps its progress words in one place, where every launch leaves them zero.
-static constexpr int kFusedQT = 96;                 // staging tile of the query sweep (sub-blocks past the sequence are skipped, so its padding costs nothing)
+static constexpr int kFusedQT = 64;                 // queries per step of the sweep: one staged tile, one barrier, one hand-off (two 32-query sub-blocks)
 static size_t fused_slabs(int B, int T, int H) { return (size_t)B * H * ((T + kFusedQT - 1) / kFusedQT) * (kFusedQT / 32); }
 static size_t fused_ws_cap(size_t ws_bytes) { return ws_bytes < 1024 ? 0 : (ws_bytes - 1024) / (8192 + 128 + 4); }
 static size_t fused_status_off(size_t ws_bytes) { return (fused_ws_cap(ws_bytes) * 132 + 255) / 256 * 256; }
@@ -840,7 +859,7 @@ extern "C" int gvk_attention_bwd_bf16_fused(const void* qkv, const void* out, co
   const size_t nsub = (size_t)((T + kFusedQT - 1) / kFusedQT) * (kFusedQT / 32);
   GVK_REQUIRE(nsub * 8192 < ((size_t)1 << 31) && (T + 127) / 128 <= 256, "gvk_attention_bwd_bf16_fused: sequence too long (32-bit slab offsets, 256 key blocks)");
   hipStream_t s = (hipStream_t)stream;
-  constexpr unsigned lds = 2 * (2 * kFusedQT * 128 + 2 * 128 * 4) + 2 * 128 * 64 + 1024;
+  constexpr unsigned lds = 2 * (2 * kFusedQT * 128 + 2 * 128 * 4) + 2 * (kFusedQT / 32) * 128 * 64 + 1024;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_fused_kernel<kFusedQT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

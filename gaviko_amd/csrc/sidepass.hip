@@ -24,26 +24,11 @@
 
 namespace gvk {
 
-// Streaming accesses of the [M][C] tensors (read or written once per launch).  -DGVK_SIDE_NT=1 marks them non-temporal, to keep the
-// 12 MB a pass moves from evicting the backbone kernels' operands from the per-XCD L2: measured 660 vs 681 volumes/s -- worse (the next
-// side kernel re-reads the same rows from L2 / the MALL a few tens of microseconds later), so the plain form is the default.
-#ifndef GVK_SIDE_NT
-#define GVK_SIDE_NT 0
-#endif
-__device__ __forceinline__ f32x4 ld_stream(const float* p) {
-#if GVK_SIDE_NT
-  return __builtin_nontemporal_load((const f32x4*)p);
-#else
-  return *(const f32x4*)p;
-#endif
-}
-__device__ __forceinline__ void st_stream(float* p, const f32x4 v) {
-#if GVK_SIDE_NT
-  __builtin_nontemporal_store(v, (f32x4*)p);
-#else
-  *(f32x4*)p = v;
-#endif
-}
+// Streaming accesses of the [M][C] tensors (read or written once per launch): plain loads and stores.  Marking them non-temporal, to keep
+// the 12 MB a pass moves from evicting the backbone kernels' operands from the per-XCD L2, was measured worse (660 vs 681 volumes/s, round
+// 2: the next side kernel re-reads the same rows from L2 / the MALL a few tens of microseconds later); that variant is not in the source.
+__device__ __forceinline__ f32x4 ld_stream(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ void st_stream(float* p, const f32x4 v) { *(f32x4*)p = v; }
 
 
 namespace {

@@ -23,7 +23,7 @@ struct WinArgs {
   int B, D, H, W, kd, kh, kw;
   float scale;
   unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;
-  int kv_side;        // window_mfma.hip backward: -1 = both sides in one launch (first half of the grid = query side), 0 / 1 = one side
+  int kv_side;        // window_mfma.hip backward: 0 = the query side (dq, delta), 1 = the key side (dk, dv)
 };
 
 struct Win {   // forward window of a query / reverse window of a key, per axis [lo, lo+n)

@@ -118,19 +118,13 @@ __device__ __forceinline__ void block_range(int dfirst, int dlast, int below, in
 // by run-time values, ~50 VALU instructions per iteration.  (2) The key side of the backward no longer reads the query side's delta:
 // delta_i = dctx_i . ctx_i comes from the rows it loads anyway, and the four (lse, delta) a lane needs are lane shuffles of its own
 // row's values instead of eight more loads -- the two backward kernels are independent launches.  Together: 740 -> 747 volumes/s.
-// Measured on the same box and NOT adopted (compile-time switches below, one box, three interleaved runs each):
-//   * GVK_WIN_MERGE=1, both backward sides in ONE launch of 504 workgroups: the kernels' summed time drops from 70 to 37 us per layer
-//     and the STEP gets 2 % slower (729 vs 747) -- twice the waves resident beside the flash-attention backward on the main stream;
-//   * GVK_WIN_RING=3 / 2, partner blocks prefetched three / two ahead instead of one (all loads unconditional with clamped indices so
-//     that vmcnt is counted exactly): 741 vs 747 -- 146 registers instead of ~100 cost more than the hidden L2 latency returns.
+// Measured on the same box and NOT adopted (round 4, three interleaved runs each; the variants are no longer in the source):
+//   * both backward sides in ONE launch of 504 workgroups: the kernels' summed time drops from 70 to 37 us per layer and the STEP gets
+//     2 % slower (729 vs 747) -- twice the waves resident beside the flash-attention backward on the main stream;
+//   * partner blocks prefetched three / two ahead instead of one (all loads unconditional with clamped indices so that vmcnt is counted
+//     exactly): 741 vs 747 -- 146 registers instead of ~100 cost more than the hidden L2 latency returns.
 // Once more: what the backbone pays for is the side kernels' resident registers x time, not their duration.
-#ifndef GVK_WIN_RING
-#define GVK_WIN_RING 1
-#endif
-#ifndef GVK_WIN_MERGE
-#define GVK_WIN_MERGE 0
-#endif
-constexpr int kRing = GVK_WIN_RING;
+constexpr int kRing = 1;                // partner blocks in flight ahead of the one being multiplied
 
 __device__ __forceinline__ int pack_tok(const Tok& t) { return t.d | (t.h << 10) | (t.w << 20); }
 __device__ __forceinline__ Tok unpack_tok(int v) { Tok t; t.d = v & 1023; t.h = (v >> 10) & 1023; t.w = v >> 20; return t; }
@@ -404,18 +398,16 @@ __device__ __forceinline__ void win_bwd_kv_body(const WinArgs& p, const int* tok
   }
 }
 
-// kv_side = 0 / 1: one side per launch (default);  -1: ONE launch, workgroups [0, B * nblk) = the query side (dq, delta),
-// [B * nblk, 2 B * nblk) = the key side (dk, dv) -- they share nothing
+// kv_side = 0: the query side (dq, delta);  1: the key side (dk, dv) -- one launch each, they share nothing
 __global__ __launch_bounds__(64 * kSplit) void win_mfma_bwd_kernel(WinArgs p) {
   extern __shared__ __attribute__((aligned(16))) int tokc[];
   __shared__ float sm_o[kSplit][2][kL][16];
   if (p.drop_thresh != 0u && p.seed_ptr != nullptr) p.seed += *p.seed_ptr;
   const int N = p.D * p.H * p.W, nblk = (N + 15) >> 4;
   fill_tok_table(tokc, N, p.H, p.W, 64 * kSplit);
-  const int side = p.kv_side >= 0 ? p.kv_side : ((int)blockIdx.x >= p.B * nblk ? 1 : 0);
-  const int id = p.kv_side >= 0 ? (int)blockIdx.x : (int)blockIdx.x - side * p.B * nblk;
+  const int id = (int)blockIdx.x;
   const int b = id / nblk, blk = id - b * nblk;
-  if (side == 0) win_bwd_q_body(p, tokc, (float (*)[kL][16])sm_o, b, blk);
+  if (p.kv_side == 0) win_bwd_q_body(p, tokc, (float (*)[kL][16])sm_o, b, blk);
   else win_bwd_kv_body(p, tokc, sm_o, b, blk);
 }
 
@@ -438,17 +430,11 @@ int launch_win_mfma_bwd(const WinArgs& a, int L, hipStream_t s) {
   if (L != kL || !mfma_enabled()) return 1;
   const int N = a.D * a.H * a.W;
   if (a.D > 1023 || a.H > 1023 || a.W > 1023 || N > 12288) return 1;
-#if GVK_WIN_MERGE
-  WinArgs m = a;
-  m.kv_side = -1;
-  GVK_LAUNCH(win_mfma_bwd_kernel, dim3(2 * a.B * ((N + 15) / 16)), dim3(64 * kSplit), ((N + 15) & ~15) * 4, s, m);
-#else
-  WinArgs m = a;
+  WinArgs m = a;                        // one launch per side: the query side (dq, delta), then the key side (dk, dv)
   m.kv_side = 0;
   GVK_LAUNCH(win_mfma_bwd_kernel, dim3(a.B * ((N + 15) / 16)), dim3(64 * kSplit), ((N + 15) & ~15) * 4, s, m);
   m.kv_side = 1;
   GVK_LAUNCH(win_mfma_bwd_kernel, dim3(a.B * ((N + 15) / 16)), dim3(64 * kSplit), ((N + 15) & ~15) * 4, s, m);
-#endif
   return check_launch("window_attn_bwd (mfma)");
 }
 

@@ -133,6 +133,9 @@ class Engine(GavikoPaths, PeftPaths):
         # GPA projections of backbone rows ride along in the backbone's LayerNorm kernels (gvk_layernorm_*_proj)
         self._fuse_proj = (kind == "gaviko" and not self.fp32 and ops.rowproj_supported(self.Lat, dim)
                            and L.diag_env("GAVIKO_HIP_FUSE_PROJ", "1") != "0")
+        # backward only: dcomb = dG . W_up inside the LayerNorm-1 backward on the main stream ("main"), or by the GPA stream's own projection
+        # kernel in front of its backward core ("gpa": one more 12.7 MB read there, a plain LayerNorm backward here)
+        self._proj_bwd_main = self._fuse_proj and L.diag_env("GAVIKO_HIP_PROJ_BWD", "main") != "gpa"
         self._fuse_local = kind == "gaviko" and ops.side_tile_supported(self.Lat, dim)
         self._fuse_bnd = self._fuse_local and L.diag_env("GAVIKO_HIP_FUSE_BOUNDARY", "1") != "0"
         self._fuse_next = self._fuse_local and L.diag_env("GAVIKO_HIP_FUSE_NEXT", "1") != "0"
@@ -990,7 +993,7 @@ class Engine(GavikoPaths, PeftPaths):
             if gaviko:
                 with torch.cuda.stream(gpa):
                     # dcomb = dGout . W_up was produced by the LayerNorm backward that wrote dGout, except for the top layer
-                    self._gpa_bwd_core(ws, sv, gv, i, dGout, M, B, par, project=not (self._fuse_proj and i < self.depth - 1))
+                    self._gpa_bwd_core(ws, sv, gv, i, dGout, M, B, par, project=not (self._proj_bwd_main and i < self.depth - 1))
                     dz_ready = self._ev_record(gpa)
                     self._gpa_bwd_params(ws, sv, gv, i, dGout, M, B, par)
                     self._bucket_mark("gpa", i)                              # prompt_projs.{i // share} gradients final once the lowest layer using it is done
@@ -1086,7 +1089,7 @@ class Engine(GavikoPaths, PeftPaths):
                 # dGout off the critical path.  The buffer being overwritten was last read by layer i+1's parameter kernels, which
                 # precede this layer's dz_ready in the GPA stream -- and the main stream has already waited for that above.
                 dGnext = ws["dGb"] if dGout is ws["dG"][0] else ws["dG"][0]
-                if self._fuse_proj and i > 0:
+                if self._proj_bwd_main and i > 0:
                     pre_lo, _ = self._gpa_names(i - 1)
                     ops.layernorm_bwd_proj(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGnext, dres=dGin,
                                            dx16=ws["dG16"], w=d(pre_lo + ".proj_up.weight"), y=ws["bw"]["dcomb"], w_layout=1, L_=self.Lat)
