@@ -423,6 +423,36 @@ def main():
     gf = GF_PER_VOLUME.get((args.method, args.backbone))
     if gf:
         out["mfma_roofline_frac_whole_step"] = round(vps / world * gf / 1e3 / peak, 4)
+    if eng0.prune_dead_rows:
+        # Rows nobody reads are not computed (engine.py: prune_dead_rows; results bit-identical, tests/test_model_gpu.py::test_pruned_rows_are_dead):
+        # the last layer's MLP forward + backward on the rows the head pools, the first layer's qkv dgrad + LayerNorm-1 backward on the
+        # prompt rows.  The flops those rows would have cost are part of BASELINE's algorithmic count but are NOT executed: the fraction of
+        # the roofline by executed flops is reported beside the algorithmic one, and the same K steps are timed once more with every row
+        # computed (`value_all_rows`) so that both rates come from this run.
+        Tt, Cc, mlp_, dep = eng0.T, eng0.C, eng0.mlp, eng0.depth
+        skipped = 2.0 * (Tt - 64) * Cc * (4 * mlp_ + 3 * Cc) / 1e9      # fc1 + fc2 fwd, fc2 + fc1 dgrad (last layer); qkv dgrad (first layer), 64-row panels kept
+        out["dead_row_pruning"] = {"on": True, "gf_not_executed_per_volume": round(skipped, 2)}
+        if gf:
+            out["dead_row_pruning"]["mfma_roofline_frac_executed_flops"] = round(vps / world * (gf - skipped) / 1e3 / peak, 4)
+        eng0.set_prune(False)
+        for _ in range(max(3, min(args.warmup, 6))):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        dt1 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt1], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt1 = t.item()
+        out["dead_row_pruning"]["value_all_rows"] = round(world * B * args.steps / dt1, 3)
+        out["dead_row_pruning"]["ms_per_step_all_rows"] = round(1e3 * dt1 / args.steps, 4)
+        eng0.set_prune(True)
+        for _ in range(3):
+            step()
+        sync()
 
     if not args.no_roofline:
         # (every rank runs this pass -- its steps contain the gradient all-reduce -- but only rank 0 reports)

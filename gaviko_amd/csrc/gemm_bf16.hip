@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs p) {
     tile_m = wg / p.nbn;
     tile_n = wg - tile_m * p.nbn;
   }
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * p.m_stride, n0 = tile_n * BN;      // (m_stride = BM except for strided row panels)
 
   const int lane = lane_id();
   const int wave = wave_id();
@@ -236,6 +236,13 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   p.nbm = (a.M + BM - 1) / BM;
   p.nbn = a.N / BN;
   p.a_rows = (a.M + 127) / 128 * 128;
+  p.m_stride = BM;
+  if (a.m_stride > 0) {                                  // strided row panels (gvk_gemm_desc.m_panels): nbm was set by the caller
+    if (a.m_stride < BM || (long)(a.nbm - 1) * a.m_stride + BM > p.a_rows)
+      return set_error(-2, "gvk_gemm_nt_bf16: %d row panels of %d rows at stride %d do not fit %d (padded) rows", a.nbm, BM, a.m_stride, p.a_rows);
+    p.nbm = a.nbm;
+    p.m_stride = a.m_stride;
+  }
   {
     // row panels per group ~ (tiles per XCD) / (column tiles), within 1..8: N = 768 at M = 4132 -> 198 tiles, 24.75 per XCD, 6 columns -> 4
     const int per_xcd = (p.nbm * p.nbn) >> 3;
@@ -264,6 +271,10 @@ static long wide_lo() {
 
 template <int EPI>
 static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
+  if (a.m_stride > 0) {                                  // strided row panels: a few short tiles, latency-bound -- 64 x 128 with three stages
+    if (tile == 0) tile = (a.N % 128 == 0 && a.drop_thresh == 0u) ? 4064128 : 64064;       // (four stages: these launches are bound by the L2 round trip of a k-step)
+    if (tile == 8256256 || tile == 7256256 || tile == 256256) return set_error(-2, "gvk_gemm_nt_bf16: strided row panels run on the 4-wave tiles only");
+  }
   if (tile == 0) {
     const int bn = (a.N % 128 == 0) ? 128 : 64;
     // fill the 256 CUs: fall back to 64-row tiles when 128-row tiles give < ~1.5 workgroups per CU
@@ -325,6 +336,7 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     case 7256256: return launch_gemm8p(a, EPI, 1, stream);      // ... issued inside the MFMA clusters (2546 vs 2426 cycles per k-tile)
     case 3128128: return launch_gemm<128, 128, EPI, false, 3>(a, stream);
     case 3064128: return launch_gemm<64, 128, EPI, false, 3>(a, stream);     // 64 x 128 with three stages (A/B switch GAVIKO_HIP_GEMM_N768=3064)
+    case 4064128: return launch_gemm<64, 128, EPI, false, 4>(a, stream);     // ... four stages: the strided row-panel launches (a few tiles, 12-49 k-steps each)
     case 3096128: return launch_gemm<96, 128, EPI, false, 3>(a, stream);     // 96 x 128 with three stages (M = 2066, N = 1024: 176 tiles in one round)
     case 256256:
       if constexpr (EPI == GVK_EPI_STORE_BF16 || EPI == GVK_EPI_BIAS_GELU_BF16 || EPI == GVK_EPI_GELU_BWD_BF16) return launch_gemm<256, 256, EPI, false, 2, 8>(a, stream);
@@ -372,6 +384,9 @@ extern "C" int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream) {
   GVK_REQUIRE(d->stat_part == nullptr || (d->epilogue == GVK_EPI_BIAS_RES_F32_BF16 && d->N % 128 == 0 && (d->tile == 0 || d->tile % 1000 == 128)),
               "gvk_gemm_nt_bf16: stat_part needs the BIAS_RES_F32_BF16 epilogue on 128-column tiles (64-column groups)");
   a.stat_part = d->stat_part; a.stat_pivot = d->stat_pivot;
+  GVK_REQUIRE((d->m_panels == 0 && d->m_stride == 0) || (d->m_panels > 0 && d->m_stride > 0 && d->epilogue != GVK_EPI_PATCH_F32),
+              "gvk_gemm_nt_bf16: m_panels=%d / m_stride=%d: both positive (or both 0), not with the PATCH epilogue", d->m_panels, d->m_stride);
+  a.m_stride = d->m_stride; a.nbm = d->m_panels;
   hipStream_t s = (hipStream_t)stream;
   switch (d->epilogue) {
     case GVK_EPI_STORE_BF16:

@@ -24,6 +24,7 @@ struct GemmArgs {
   int group_m;                                           // row panels per rasterisation group (4-wave kernel; set by launch_gemm)
   int xcd_panels;                                        // > 0: panel-major tile order inside each XCD's run (launch_gemm: one-round launches)
   int a_rows;                                            // rows the A buffer really has (M padded to 128): the 256-row tile clamps to it
+  int m_stride;                                          // first row of row tile t = t * m_stride (launch_gemm: the tile's rows, or gvk_gemm_desc.m_stride)
   // DROP instantiations only (nn.Dropout behind a Linear of the unfrozen-backbone methods): mask index m * N + n
   unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;
   // STORE_BF16 only: columns n < scale_cols leave as (acc + bias) * col_scale (the q block of a qkv projection, pre-scaled for the attention kernels)

@@ -140,9 +140,10 @@ __global__ __launch_bounds__(256) void ln_fwd_fix_kernel(float* __restrict__ x, 
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
-                                                     float* __restrict__ dx, bf16* __restrict__ dx16, int M, int C) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                     float* __restrict__ dx, bf16* __restrict__ dx16, int M, int C, int rpg, int gstride) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  if (rpg > 0) row = (row / rpg) * gstride + row % rpg;       // a row subset: the first rpg rows of every group of gstride rows (M = groups * rpg)
   const int lane = lane_id();
   const float mean = mean_i[row], rstd = rstd_i[row];
   f32x4 xh[kMaxChunks], dh[kMaxChunks];
@@ -253,8 +254,22 @@ extern "C" int gvk_layernorm_bwd(const float* dy, const float* x, const float* m
   GVK_REQUIRE(dy && x && mean && rstd && gamma && dx, "gvk_layernorm_bwd: null pointer");
   GVK_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 256 * kMaxChunks, "gvk_layernorm_bwd: C=%d must be a multiple of 4 and <= 1024", C);
   GVK_LAUNCH(ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dres, dx,
-                     (bf16*)dx_bf16, M, C);
+                     (bf16*)dx_bf16, M, C, 0, 0);
   return check_launch("layernorm_bwd");
+}
+
+extern "C" int gvk_layernorm_bwd_rows(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                      const float* dres, float* dx, void* dx_bf16, int groups, int rows_per_group, int group_stride, int C,
+                                      void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(dy && x && mean && rstd && gamma && dx, "gvk_layernorm_bwd_rows: null pointer");
+  GVK_REQUIRE(groups > 0 && rows_per_group > 0 && group_stride >= rows_per_group, "gvk_layernorm_bwd_rows: groups=%d rows_per_group=%d group_stride=%d",
+              groups, rows_per_group, group_stride);
+  GVK_REQUIRE(C > 0 && C % 4 == 0 && C <= 256 * kMaxChunks, "gvk_layernorm_bwd_rows: C=%d must be a multiple of 4 and <= 1024", C);
+  const int M = groups * rows_per_group;
+  GVK_LAUNCH(ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dres, dx,
+                     (bf16*)dx_bf16, M, C, rows_per_group, group_stride);
+  return check_launch("layernorm_bwd_rows");
 }
 
 // ---- LayerNorm with a fused rank-L projection of the rows it holds: the row-per-wave projection kernel of rowwise.hip run

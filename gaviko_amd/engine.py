@@ -136,6 +136,14 @@ class Engine(GavikoPaths, PeftPaths):
         # backward only: dcomb = dG . W_up inside the LayerNorm-1 backward on the main stream ("main"), or by the GPA stream's own projection
         # kernel in front of its backward core ("gpa": one more 12.7 MB read there, a plain LayerNorm backward here)
         self._proj_bwd_main = self._fuse_proj and L.diag_env("GAVIKO_HIP_PROJ_BWD", "main") != "gpa"
+        # Rows nobody consumes are not computed (round 5).  With a frozen backbone the loss reads the LAST layer's output only at the rows
+        # the head pools (prompts + CLS, gaviko.py:316), so that layer's MLP -- a row-wise function -- runs on those rows in the forward, and
+        # its backward (fc2 / fc1 dgrad, LayerNorm 2) on the same rows: every other row of the incoming gradient is an exact zero.  At the
+        # other end only the P prompt rows of the FIRST layer's input carry a trainable tensor (patch embedding, cls token and position
+        # embedding are frozen: gaviko.py:540-548), so its qkv dgrad and LayerNorm-1 backward run on those rows.  Logits and every gradient
+        # are bit-identical to the full computation (tests/test_model_gpu.py::test_pruned_rows_are_dead); GAVIKO_HIP_PRUNE=0 computes
+        # everything (the golden taps of the last layer's far rows need that).
+        self.prune_dead_rows = kind == "gaviko" and not self.fp32 and os.environ.get("GAVIKO_HIP_PRUNE", "1") != "0"
         self._fuse_local = kind == "gaviko" and ops.side_tile_supported(self.Lat, dim)
         self._fuse_bnd = self._fuse_local and L.diag_env("GAVIKO_HIP_FUSE_BOUNDARY", "1") != "0"
         self._fuse_next = self._fuse_local and L.diag_env("GAVIKO_HIP_FUSE_NEXT", "1") != "0"
@@ -181,6 +189,9 @@ class Engine(GavikoPaths, PeftPaths):
         N, K = w.shape[0], int(kw.get("K") or w.shape[1])
         ka = int(alg_k) if alg_k is not None else K
         key = f"gemm_nt_{'f32' if self.fp32 else 'bf16'}[{_EPI_NAMES[kw['epilogue']]}] M={M} N={N} K={K}"
+        if kw.get("m_panels"):                               # strided row panels: 64-row tiles at the first rows of every sample
+            M = 64 * kw["m_panels"]
+            key += f" panels={kw['m_panels']}x64"
         cur = torch.cuda.current_stream()
         e0 = self._ev_record(cur)
         ops.gemm_nt(a, w, M, out0, **kw)
@@ -699,8 +710,11 @@ class Engine(GavikoPaths, PeftPaths):
             fold_next = bool(up_in_fc2 and self._fold_on and i + 1 < self.depth and _on("noside") and not _FIX_IN_LN)
             # fc2 carries proj_up of the PLAIN latents of every row (ready right behind the LayerNorm); the GPA has the two GEMMs' time
             # to finish, and only the P prompt rows it replaces are fixed up afterwards
+            # the last layer's output is read at the pooled rows only (frozen backbone, no dropout behind fc2): its MLP runs on those rows
+            last_rows = (self._panels(B, self._pool_rows()[0] + self._pool_rows()[1])
+                         if (gaviko and i + 1 == self.depth and up_in_fc2 and not self._keep_inputs and sv["bdrop"] <= 0) else None)
             self._mlp_block_fwd(ws, i, si, ws["G1"][si], gout, Mi, train, sv["bdrop"],
-                                up_in_fc2=up_in_fc2, stats_out=fold_next)
+                                up_in_fc2=up_in_fc2, stats_out=fold_next, panels=last_rows)
             if self.kind == "adaptformer":
                 self._adapter_fwd_up(ws, i, si, gout, Mi)
             if self.kind == "dvpt":
@@ -813,14 +827,21 @@ class Engine(GavikoPaths, PeftPaths):
         else:
             ops.layernorm_fwd(g1, d(m + ".net.0.weight"), d(m + ".net.0.bias"), M, C, y16=ws["xn"], mean=st[2], rstd=st[3])
 
-    def _mlp_block_fwd(self, ws, i, si, g1, gout, M, train, pdrop=0.0, up_in_fc2=False, stats_out=False):
+    def _panels(self, B, rows):
+        """gemm_nt kwargs that restrict a launch to the first `rows` rows of every sample (64-row tiles at stride T), or {}."""
+        if not self.prune_dead_rows or rows > 64 or self.T < 64:
+            return {}
+        return dict(m_panels=B, m_stride=self.T)
+
+    def _mlp_block_fwd(self, ws, i, si, g1, gout, M, train, pdrop=0.0, up_in_fc2=False, stats_out=False, panels=None):
         nm, w, d, C = self.names, self._w16, self._d, self.C
         m = nm.mlp(i)
+        pk = panels or {}
         if self._keep_inputs:
             ops.copy_(ws["sav"]["xn2"][si], ws["xn"])
         self._gemm(ws["xn"], w[f"fc1{i}"], M, ws["pre"][si] if train else None, epilogue=ops.EPI_BIAS_GELU_BF16, out1=ws["act"],
                     bias=d(m + ".net.1.bias"),           # inference keeps no pre-activation (out0 = NULL)
-                    ldo=self.ldx, drop_p=pdrop, seed=SEED_LAYER + 8 * i + 2, seed_ptr=ws["seed"])
+                    ldo=self.ldx, drop_p=pdrop, seed=SEED_LAYER + 8 * i + 2, seed_ptr=ws["seed"], **pk)
         if self._keep_inputs:
             ops.copy_(ws["sav"]["act"][si], ws["act"])
         so = (dict(epilogue=ops.EPI_BIAS_RES_F32_BF16, out1=ws["xg16"], stat_part=ws["spart"], stat_pivot=ws["stat"][si][2]) if stats_out     # pivot = mean of the residual row (LN2)
@@ -828,7 +849,7 @@ class Engine(GavikoPaths, PeftPaths):
         self._gemm(ws["act"], w[f"fc2{i}"], M, gout, bias=d(m + ".net.4.bias"), res=g1,
                    K=self.ldx if up_in_fc2 else self.mlp,      # the GPA latents ride this GEMM as 64 extra K columns (self._fuse_up)
                    alg_k=self.mlp + self.Lat if up_in_fc2 else None,
-                   drop_p=pdrop, seed=SEED_LAYER + 8 * i + 3, seed_ptr=ws["seed"], **so)
+                   drop_p=pdrop, seed=SEED_LAYER + 8 * i + 3, seed_ptr=ws["seed"], **so, **pk)
 
     # ------------------------------------------------------------------ backward
     def trainable_names(self) -> List[str]:
@@ -850,6 +871,14 @@ class Engine(GavikoPaths, PeftPaths):
         if k != self.bucket_layers:
             self.bucket_layers = k
             self._flat_grad = None
+            self._graphs.clear()
+            self._calls.clear()
+
+    def set_prune(self, on: bool) -> None:
+        """Dead-row pruning on / off (see prune_dead_rows in __init__).  Recorded plans hold the launch lists, so they are dropped."""
+        on = bool(on) and self.kind == "gaviko" and not self.fp32
+        if on != self.prune_dead_rows:
+            self.prune_dead_rows = on
             self._graphs.clear()
             self._calls.clear()
 
@@ -1014,14 +1043,18 @@ class Engine(GavikoPaths, PeftPaths):
             if ssf:                                                          # fc2 + ssf_2: dy = dGout, y = G[i+1] - G1[i]
                 # (behind a live dropout the stored difference is kept / (1 - p): masked gradient, y_mul = 1 - p)
                 self._ssf_linear_grad(ws, gv, m, 2, dy_ff, ws["G"][i + 1], M, C, y1=ws["G1"][i], y_mul=1.0 - pd_)
+            # top layer, frozen backbone: the incoming gradient is an exact zero outside the rows the head pools -- the MLP's backward (row-wise)
+            # runs on those rows; the rest of dG1 is zeroed in one memset instead of being computed as LN'(0) + 0
+            top = (self._panels(B, self._pool_rows()[0] + self._pool_rows()[1])
+                   if (gaviko and first and i == self.depth - 1 and not bb and pd_ <= 0 and not sv["wgrad"]) else {})
             self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i], ldaux=self.ldx,
-                       drop_p=pd_, seed=SEED_LAYER + 8 * i + 2, seed_ptr=ws["seed"])
+                       drop_p=pd_, seed=SEED_LAYER + 8 * i + 2, seed_ptr=ws["seed"], **top)
             if ssf:                                                          # fc1 + ssf_1: dy = d(pre-activation), y = saved pre-activation
                 self._ssf_linear_grad(ws, gv, m, 1, ws["dpre"], ws["pre"][i], M, self.mlp)
             if bb:                                                           # fc1: db = colsum(dpre), dW = dpre^T . LN2(G1)
                 self._bb_linear_grads(ws, gv, bb, m + ".net.1", ws["dpre"], ws["dpre"], ws["sav"]["xn2"][i] if sv["wgrad"] else None, M, self.mlp, C)
             self._mark(f"b{i}:fc2d") if False else None
-            self._gemm(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
+            self._gemm(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32, **top)
             self._mark(f"b{i}:fc1d")
             if bb:
                 self._bb_ln_grads(ws, gv, bb, m + ".net.0", ws["dx32"], ws["G1"][i], st[2], st[3], M)
@@ -1037,6 +1070,10 @@ class Engine(GavikoPaths, PeftPaths):
                 gpre, _ = self._gpa_names(i)
                 ops.layernorm_bwd_up(ws["dx32"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), M, C, dx=dGin, dres=dGout, dx16=ws["dG16"],
                                      lat=ws["bw"]["dzx"], w=d(gpre + ".proj_down.0.weight"), L_=self.Lat, w_layout=1)
+            elif top:
+                ops.memset_zero(dGin)
+                ops.layernorm_bwd_rows(ws["dx32"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), B, self._pool_rows()[0] + self._pool_rows()[1],
+                                       T, C, dx=dGin, dres=dGout)
             else:
                 ops.layernorm_bwd(ws["dx32"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), M, C, dx=dGin, dres=dGout,
                                   dx16=None if (gaviko or adapter or dvpt) else ws["dG16"])
@@ -1078,7 +1115,10 @@ class Engine(GavikoPaths, PeftPaths):
                 self._ssf_linear_grad(ws, gv, a, 1, ws["dqkv"], ws["qkv"][i], M, 3 * C, **uq)
             if bb:                                                           # to_qkv (bias-free): dW = dqkv^T . LN1(G)
                 self._bb_linear_grads(ws, gv, bb, a + ".to_qkv", None, ws["dqkv"], ws["sav"]["xn1"][i] if sv["wgrad"] else None, M, 3 * C, C)
-            self._gemm(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32)
+            # bottom layer, frozen backbone: of this layer's INPUT gradient only the P prompt rows of every sample are read (prompt_embeddings and
+            # their position embedding; patch embedding, cls token and pos_embedding carry none) -- qkv dgrad and LayerNorm 1 on those rows
+            bot = (self._panels(B, self.P) if (gaviko and last and i == 0 and not bb and pd_ <= 0 and not sv["wgrad"] and self.P > 0) else {})
+            self._gemm(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32, **bot)
             if bb:
                 self._bb_ln_grads(ws, gv, bb, a + ".norm", ws["dx32"], ws["G"][i], st[0], st[1], M)
             if ssf:                                                          # LN1 + ssf_0
@@ -1093,6 +1133,8 @@ class Engine(GavikoPaths, PeftPaths):
                     pre_lo, _ = self._gpa_names(i - 1)
                     ops.layernorm_bwd_proj(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGnext, dres=dGin,
                                            dx16=ws["dG16"], w=d(pre_lo + ".proj_up.weight"), y=ws["bw"]["dcomb"], w_layout=1, L_=self.Lat)
+                elif bot:
+                    ops.layernorm_bwd_rows(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), B, self.P, T, C, dx=dGnext, dres=dGin)
                 else:
                     ops.layernorm_bwd(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGnext, dres=dGin,
                                       dx16=ws["dG16"])

@@ -48,6 +48,7 @@ class GemmDesc(C.Structure):
         ("tile", C.c_int32), ("drop_p", C.c_float), ("seed", C.c_uint64),
         ("scale_cols", C.c_int32), ("col_scale", C.c_float),
         ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p), ("ln_c1", C.c_void_p), ("stat_part", C.c_void_p), ("stat_pivot", C.c_void_p),
+        ("m_panels", C.c_int32), ("m_stride", C.c_int32),
     ]
 
 
@@ -115,6 +116,7 @@ SIGNATURES = {
     "gvk_patchify_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gvk_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "gvk_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "gvk_layernorm_bwd_rows": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gvk_layernorm_bwd_affine": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gvk_attention_fwd_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "gvk_qkv_prescale_bf16": [_P, _I, _I, _I, _F, _P],

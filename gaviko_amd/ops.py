@@ -41,9 +41,11 @@ def _chk(t, dtype, what, min_elems=0):
 
 def gemm_nt(a, w, M, out0, *, epilogue, out1=None, bias=None, res=None, aux=None, pos=None,
             lda=None, ldo=None, ldres=None, ldaux=None, rows_in=0, rows_out=0, row_off=0, tile=0, N=None, K=None,
-            drop_p=0.0, seed=0, seed_ptr=None, scale_cols=0, col_scale=1.0, ln_mean=None, ln_rstd=None, ln_c1=None, stat_part=None, stat_pivot=None):
+            drop_p=0.0, seed=0, seed_ptr=None, scale_cols=0, col_scale=1.0, ln_mean=None, ln_rstd=None, ln_c1=None, stat_part=None, stat_pivot=None,
+            m_panels=0, m_stride=0):
     """Y[M,N] = A[M,K] . W[N,K]^T with a fused epilogue.  The operand dtype picks the kernel: bf16 -> gvk_gemm_nt_bf16 (MFMA
-    bf16, fp32 accumulate), fp32 -> gvk_gemm_nt_f32 (every 16-bit slot of the epilogue table then carries fp32)."""
+    bf16, fp32 accumulate), fp32 -> gvk_gemm_nt_f32 (every 16-bit slot of the epilogue table then carries fp32).
+    m_panels / m_stride (bf16): only the row tiles starting at rows 0, m_stride, 2 m_stride, ... are computed (gvk_gemm_desc)."""
     adt = a.dtype
     if adt not in (torch.bfloat16, torch.float32):
         raise L.GavikoHipError(f"gemm A: expected bf16 or fp32 operands, got {adt}")
@@ -66,7 +68,7 @@ def gemm_nt(a, w, M, out0, *, epilogue, out1=None, bias=None, res=None, aux=None
                    L.ptr(seed_ptr) if (seed_ptr is not None and drop_p > 0) else None,
                    M, N, K, lda, ldw, ldo, (N if ldres is None else ldres), (N if ldaux is None else ldaux),
                    epilogue, rows_in, rows_out, row_off, tile, float(drop_p), int(seed), int(scale_cols), float(col_scale),
-                   L.ptr(ln_mean), L.ptr(ln_rstd), L.ptr(ln_c1), L.ptr(stat_part), L.ptr(stat_pivot))
+                   L.ptr(ln_mean), L.ptr(ln_rstd), L.ptr(ln_c1), L.ptr(stat_part), L.ptr(stat_pivot), int(m_panels), int(m_stride))
     _chk(ln_mean, torch.float32, "gemm ln_mean", M)
     _chk(ln_rstd, torch.float32, "gemm ln_rstd", M)
     _chk(ln_c1, torch.float32, "gemm ln_c1", N)
@@ -322,6 +324,21 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, M, C_, *, dx, dres=None, dx16=None):
     _chk(gamma, torch.float32, "ln_bwd gamma", C_)
     L.check(L.load().gvk_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dres), L.ptr(dx),
                                        L.ptr(dx16), M, C_, L.stream_ptr()), "gvk_layernorm_bwd")
+
+
+def layernorm_bwd_rows(dy, x, mean, rstd, gamma, groups, rows_per_group, group_stride, C_, *, dx, dres=None, dx16=None):
+    """layernorm_bwd for the first `rows_per_group` rows of every group of `group_stride` rows (every sample's leading tokens); the other
+    rows of dx / dx16 are left as they are."""
+    M = (groups - 1) * group_stride + rows_per_group
+    for t, n in ((dy, "dy"), (x, "x"), (dx, "dx")):
+        _chk(t, torch.float32, "ln_bwd_rows " + n, M * C_)
+    _chk(dres, torch.float32, "ln_bwd_rows dres", M * C_)
+    _chk(dx16, torch.bfloat16, "ln_bwd_rows dx16", M * C_)
+    _chk(mean, torch.float32, "ln_bwd_rows mean", M)
+    _chk(rstd, torch.float32, "ln_bwd_rows rstd", M)
+    _chk(gamma, torch.float32, "ln_bwd_rows gamma", C_)
+    L.check(L.load().gvk_layernorm_bwd_rows(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dres), L.ptr(dx), L.ptr(dx16),
+                                            groups, rows_per_group, group_stride, C_, L.stream_ptr()), "gvk_layernorm_bwd_rows")
 
 
 def layernorm_bwd_affine(dy, x, mean, rstd, dgamma, dbeta, scratch, M, C_, accumulate=False):

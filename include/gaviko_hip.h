@@ -107,6 +107,13 @@ typedef struct gvk_gemm_desc {
      E[x^2] - mean^2 form does.  stat_pivot NULL = pivot 0 */
   float* stat_part;
   const float* stat_pivot;
+  /* Row PANELS at a stride (bf16 entry point; 0 = off): the launch covers m_panels row tiles whose first rows are 0, m_stride, 2 m_stride, ...
+     (the first rows of every sample of a [B][T][.] token tensor: m_stride = T) instead of the contiguous rows 0 .. M-1; M stays the
+     number of rows the operands have (rows >= M are not stored).  Only rows of the panels are read and written.  What it is for: a
+     product whose other rows are never consumed -- the last layer's MLP when the head pools the first rows of every sample
+     (gaviko.py:316), the first layer's qkv dgrad when only the prompt rows of the input carry a trainable tensor.  Tile: one of the
+     4-wave kernels (tile = 0 picks 64 x 128 with three stages), m_stride >= the tile's rows, (m_panels - 1) * m_stride + tile rows <= the padded M */
+  int32_t m_panels, m_stride;
 } gvk_gemm_desc;
 int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream);
 /* number of 64-column groups gvk_gemm_desc.stat_part is indexed by for an N-column output */
@@ -164,6 +171,10 @@ int gvk_layernorm_fwd_fix(float* x, const float* gamma, const float* beta, void*
 /* bwd (input gradient only -- frozen affine): dx = dres + LN'(dy); dres may be NULL; dx_bf16 (optional) = bf16 copy. */
 int gvk_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                       const float* dres, float* dx, void* dx_bf16, int M, int C, void* stream);
+/* the same for a row SUBSET: rows g * group_stride + r, r < rows_per_group, g < groups, of every operand (the first rows of every sample);
+ * the other rows are neither read nor written */
+int gvk_layernorm_bwd_rows(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                           const float* dres, float* dx, void* dx_bf16, int groups, int rows_per_group, int group_stride, int C, void* stream);
 /* affine gradients of a trainable LayerNorm: dgamma[c] += sum_m dy*xhat, dbeta[c] += sum_m dy (accumulate=0 overwrites).
  * scratch: f32 [2*64*C]. */
 int gvk_layernorm_bwd_affine(const float* dy, const float* x, const float* mean, const float* rstd, float* dgamma,

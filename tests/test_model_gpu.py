@@ -97,6 +97,7 @@ def test_gaviko_forward_backward_vs_golden(dev, name, backbone, B, extra):
     from gaviko_amd.utils import synth
     g = golden(name)
     m, cfg = build("gaviko", backbone, extra, dev)
+    m._engine().set_prune(False)          # every row of every layer is compared below (the product skips rows nobody reads: test_pruned_rows_are_dead)
     x = torch.from_numpy(synth.volumes(0, B)).to(dev)
     y = torch.from_numpy(synth.labels(0, B)).to(dev)
     logits = m(x)
@@ -513,3 +514,36 @@ def test_unfrozen_gaviko_vit_b_eval_forward_after_an_optimizer_step(dev):
         if prev is not None:
             assert (got - prev).abs().max().item() > 1e-4, "the second update must change the eval logits"
         prev = got
+
+
+@pytest.mark.parametrize("backbone,B,extra", [("vit-t16", 2, dict(GAVIKO)), ("vit-b16", 4, dict(GAVIKO)), ("vit-t16", 3, dict(GAVIKO, num_prompts=8, share_factor=2))])
+def test_pruned_rows_are_dead(dev, backbone, B, extra):
+    """Round 5: with a frozen backbone the engine does not compute rows nobody reads -- the last layer's MLP (forward, and the fc2 / fc1
+    dgrads + LayerNorm 2 of its backward) runs on the rows the head pools, the first layer's qkv dgrad + LayerNorm 1 backward on the
+    prompt rows.  Those rows' values are what the full computation gives and every other consumer sees the same bits: logits, loss and
+    EVERY trainable gradient must be identical to a run with pruning off -- eagerly and from replayed plans -- and the last layer's
+    output must agree on the pooled rows."""
+    from gaviko_amd.utils import synth
+    x = torch.from_numpy(synth.volumes(0, B)).to(dev)
+    y = torch.from_numpy(synth.labels(0, B)).to(dev)
+    out = {}
+    for prune in (False, True):
+        m, cfg = build("gaviko", backbone, extra, dev)
+        eng = m._engine()
+        eng.set_prune(prune)
+        assert eng.prune_dead_rows == prune
+        for _ in range(4):                                            # past the warm-up: the last steps replay recorded plans
+            m.zero_grad(set_to_none=True)
+            logits = m(x)
+            loss = torch.nn.functional.cross_entropy(logits, y)
+            loss.backward()
+        torch.cuda.synchronize()
+        named = dict(m.named_parameters())
+        P = eng.P
+        fin = eng._ws["G"][eng.depth][: B * eng.T].view(B, eng.T, -1)[:, : P + 1].clone()
+        out[prune] = (logits.detach().clone(), loss.detach().clone(), {n: named[n].grad.clone() for n in eng.trainable_names()}, fin)
+    a, b = out[False], out[True]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[3], b[3])
+    bad = [n for n in a[2] if not torch.equal(a[2][n], b[2][n])]
+    assert not bad, bad[:5]

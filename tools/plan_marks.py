@@ -11,8 +11,9 @@ from gaviko_amd import lib as L
 from gaviko_amd.utils import synth
 
 dev = torch.device("cuda:0")
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-model = bench.build(sys.argv[2] if len(sys.argv) > 2 else "vit-b16", dev)      # plan_marks.py [B [backbone]]
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+B = int(_pos[0]) if len(_pos) > 0 else 4
+model = bench.build(_pos[1] if len(_pos) > 1 else "vit-b16", dev)      # plan_marks.py [B [backbone]]
 x = torch.from_numpy(synth.volumes(0, B)).to(dev); y = torch.from_numpy(synth.labels(0, B)).to(dev)
 def step():
     for p in model.parameters(): p.grad = None
@@ -31,3 +32,7 @@ for pid, (tag, marks) in eng.plan_marks.items():
     print(f"plan {pid} ({tag}): {total:.0f} us between first and last mark")
     for k, v in agg.items():
         print(f"   {k:22s} n={len(v):3d} avg {sum(v) / len(v):7.1f} us  min {min(v):7.1f} max {max(v):7.1f}")
+    if "--per-layer" in sys.argv:                # every interval of the plan in order (layer numbers kept): where a single layer differs
+        for (n0, e0), (n1, e1) in zip(marks, marks[1:]):
+            L.check(lib.gvk_plan_event_elapsed(pid, e0, e1, ctypes.byref(ms)), "elapsed")
+            print(f"      {n0:14s} -> {n1:14s} {ms.value * 1e3:7.1f} us")
