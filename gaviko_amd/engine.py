@@ -189,14 +189,15 @@ class Engine(GavikoPaths, PeftPaths):
         N, K = w.shape[0], int(kw.get("K") or w.shape[1])
         ka = int(alg_k) if alg_k is not None else K
         key = f"gemm_nt_{'f32' if self.fp32 else 'bf16'}[{_EPI_NAMES[kw['epilogue']]}] M={M} N={N} K={K}"
+        mrows = M
         if kw.get("m_panels"):                               # strided row panels: 64-row tiles at the first rows of every sample
-            M = 64 * kw["m_panels"]
+            mrows = 64 * kw["m_panels"]
             key += f" panels={kw['m_panels']}x64"
         cur = torch.cuda.current_stream()
         e0 = self._ev_record(cur)
         ops.gemm_nt(a, w, M, out0, **kw)
         e1 = self._ev_record(cur)
-        self._gemm_marks.append((key, 2.0 * M * N * ka, [M, N, K], None, e0, e1))
+        self._gemm_marks.append((key, 2.0 * mrows * N * ka, [mrows, N, K], None, e0, e1))
 
     def collect_gemm_marks(self, acc=None):
         """After a sync: add the event-pair durations of the last replay of every instrumented plan to `acc`
