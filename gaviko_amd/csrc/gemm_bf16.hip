@@ -27,9 +27,14 @@ __device__ __forceinline__ int swz_chunk(int row) {
 // NS = LDS stages.  2: the tuned default (two workgroups per CU hide each other's stalls).  3: for the shapes that run ONE workgroup
 // per CU (128 x 128 tiles of the N = 768 GEMMs: 198 tiles) -- there a third tile in flight is what hides the L2 round trip.
 // NW = waves per workgroup: 4 (2 x 2 over the tile) or 8 (4 x 2: the 256 x 256 tile of the wide shapes, 64 x 128 per wave).
-template <int BM, int BN, int EPI, int BK = 64, bool DROP = false, int NS = 2, int NW = 4>
+// SPLITK (strided row panels only): a handful of 64-row tiles with 12 - 49 k-tiles each runs at the latency of ONE workgroup's k loop
+// (0.6 - 0.75 us per k-tile: 36 us for K = 3072 on 24 of 256 CUs); cut into pieces over idle CUs the loop is ~6 k-tiles long.  The
+// pieces' partial tiles are summed in piece order by the last arriver (write-through stores, drained, agent-scope ticket, acquire:
+// the hand-off of paramgrad.hip), so the result does not depend on which workgroup that is.
+template <int BM, int BN, int EPI, int BK = 64, bool DROP = false, int NS = 2, int NW = 4, bool SPLITK = false>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs p) {
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert(!SPLITK || (NS >= 3 && NW == 4 && !DROP), "split-K is built on the multi-stage 4-wave loop");
   static_assert(BK == 64, "the interleaved weight-row mapping is built for 128-byte tile rows");
   static_assert(NS >= 2 && NS <= 4, "2..4 LDS stages");
   constexpr int WM = BM / (NW / 2), WN = BN / 2;
@@ -43,7 +48,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs p) {
   // XCD-aware bijective remap: blocks b, b+8, ... share an XCD (own L2); give each XCD a contiguous run of tiles.
   const int nwg = p.nbm * p.nbn;
   int wg;
-  {
+  [[maybe_unused]] int piece = 0;
+  if constexpr (SPLITK) {                                  // consecutive blocks = the pieces of one tile
+    wg = blockIdx.x / p.ksplit;
+    piece = blockIdx.x - wg * p.ksplit;
+  } else {
     const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
@@ -78,6 +87,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs p) {
 
   const bf16* __restrict__ Ag = p.A + (size_t)m0 * p.lda;
   const bf16* __restrict__ Wg = p.W + (size_t)n0 * p.ldw;
+  if constexpr (SPLITK) {                                  // this piece's k range starts at k-tile piece * kt_per
+    Ag += (size_t)piece * p.kt_per * BK;
+    Wg += (size_t)piece * p.kt_per * BK;
+  }
 
   auto stage = [&](int buf, int kt) {
     char* sA = smem + buf * STAGE;
@@ -106,7 +119,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nt = p.K / BK;
+  int nt = p.K / BK;
+  if constexpr (SPLITK) nt = min(p.kt_per, nt - piece * p.kt_per);
   if constexpr (BK == 64) {
     // Software-pipelined main loop.  Fragments of the next 32-wide k sub-step are read from LDS while the 16 MFMAs of the
     // current one run, so no MFMA ever waits on an LDS read it was issued behind; the single barrier per tile sits between
@@ -218,16 +232,54 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs p) {
 #undef GVK_MMA
   }
 
+  if constexpr (SPLITK) {
+    // partial tile -> memory (write-through), ticket, and the last arriver of the tile sums the pieces in piece order
+    const int tile_id = tile_m * p.nbn + tile_n;
+    constexpr int kPiece = NW * MT * NT * 64 * 4;          // floats of one partial tile
+    float* const base = p.sk_part + ((size_t)tile_id * p.ksplit) * kPiece;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, p.ksplit * kPiece * 4, 0x00020000);
+    const int off = ((wave * MT * NT) * 64 + lane) * 16;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs, (piece * kPiece) * 4 + off + (i * NT + j) * 1024, 0, 16);   // aux 16 = sc1
+    int* const s_last = (int*)smem;                        // (the tiles are dead; a static __shared__ word would shift the dynamic region off its 16-byte alignment)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains its write-through stores ...
+    __syncthreads();                                       // ... before the one lane that signals for all of them
+    if (threadIdx.x == 0) {
+      const int t = __hip_atomic_fetch_add(p.sk_tick + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (t == p.ksplit - 1) ? 1 : 0;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // drop this CU's stale lines before any wave of it reads a partial
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(p.sk_tick + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this stream
+      }
+      *s_last = last;
+    }
+    __syncthreads();
+    if (!*s_last) return;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int pc = 0; pc < p.ksplit; ++pc) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] += *(const f32x4*)((const char*)base + (size_t)pc * kPiece * 4 + off + (i * NT + j) * 1024);
+    }
+  }
   gemm_epilogue<EPI, DROP, MT, NT>(p, acc, m0 + wm * WM, n0 + wn * WN, l15, lq);
 }
 
-template <int BM, int BN, int EPI, bool DROP = false, int NS = 2, int NW = 4>
+template <int BM, int BN, int EPI, bool DROP = false, int NS = 2, int NW = 4, bool SPLITK = false>
 static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
   constexpr int BK = 64;
   constexpr int lds = NS * (BM + BN) * BK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, EPI, BK, DROP, NS, NW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, EPI, BK, DROP, NS, NW, SPLITK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(-3, "hipFuncSetAttribute(gemm %dx%d): %s", BM, BN, hipGetErrorString(e));
     attr_set = true;
@@ -258,7 +310,24 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     static const int mode = diag_env("GAVIKO_HIP_GEMM_XCD_PANELS") ? atoi(diag_env("GAVIKO_HIP_GEMM_XCD_PANELS")) : 1;     // A/B switch
     if (mode != 0 && NS >= 3 && grid <= 256) p.xcd_panels = 1;
   }
-  GVK_LAUNCH((gemm_nt_kernel<BM, BN, EPI, BK, DROP, NS, NW>), dim3(grid), dim3(64 * NW), lds, stream, p);
+  if constexpr (SPLITK) {
+    // pieces of at least two k-tiles, as many as keep the launch within one round of the chip
+    const int nt = a.K / BK;
+    int s = 256 / (grid > 0 ? grid : 1);
+    s = s < 1 ? 1 : s > 8 ? 8 : s;
+    if (s > nt / 2) s = nt / 2 > 0 ? nt / 2 : 1;
+    p.kt_per = (nt + s - 1) / s;
+    p.ksplit = (nt + p.kt_per - 1) / p.kt_per;
+    constexpr size_t kPiece = (size_t)NW * (BM / (NW / 2) / 16) * (BN / 2 / 16) * 64 * 4 * 4;      // bytes of one partial tile
+    const size_t need = 1024 + (size_t)grid * p.ksplit * kPiece;
+    if (a.sk_part == nullptr || a.sk_bytes < need || grid > 256)
+      return set_error(-2, "gvk_gemm_nt_bf16: split-K workspace of %zu bytes needed (%zu given; at most 256 tiles)", need, a.sk_bytes);
+    p.sk_tick = (int*)a.sk_part;                           // [256 ticket words | partial tiles]
+    p.sk_part = (float*)((char*)a.sk_part + 1024);
+    GVK_LAUNCH((gemm_nt_kernel<BM, BN, EPI, BK, DROP, NS, NW, SPLITK>), dim3(grid * p.ksplit), dim3(64 * NW), lds, stream, p);
+    return check_launch("gemm_nt_bf16 (split-K panels)");
+  }
+  GVK_LAUNCH((gemm_nt_kernel<BM, BN, EPI, BK, DROP, NS, NW, SPLITK>), dim3(grid), dim3(64 * NW), lds, stream, p);
   return check_launch("gemm_nt_bf16");
 }
 
@@ -336,7 +405,9 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
     case 7256256: return launch_gemm8p(a, EPI, 1, stream);      // ... issued inside the MFMA clusters (2546 vs 2426 cycles per k-tile)
     case 3128128: return launch_gemm<128, 128, EPI, false, 3>(a, stream);
     case 3064128: return launch_gemm<64, 128, EPI, false, 3>(a, stream);     // 64 x 128 with three stages (A/B switch GAVIKO_HIP_GEMM_N768=3064)
-    case 4064128: return launch_gemm<64, 128, EPI, false, 4>(a, stream);     // ... four stages: the strided row-panel launches (a few tiles, 12-49 k-steps each)
+    case 4064128:                                                            // ... four stages: the strided row-panel launches (a few tiles, 12-49 k-steps each),
+      if (a.sk_part != nullptr) return launch_gemm<64, 128, EPI, false, 4, 4, true>(a, stream);      // their k loops cut into pieces when a workspace is given
+      return launch_gemm<64, 128, EPI, false, 4>(a, stream);
     case 3096128: return launch_gemm<96, 128, EPI, false, 3>(a, stream);     // 96 x 128 with three stages (M = 2066, N = 1024: 176 tiles in one round)
     case 256256:
       if constexpr (EPI == GVK_EPI_STORE_BF16 || EPI == GVK_EPI_BIAS_GELU_BF16 || EPI == GVK_EPI_GELU_BWD_BF16) return launch_gemm<256, 256, EPI, false, 2, 8>(a, stream);
@@ -387,6 +458,8 @@ extern "C" int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream) {
   GVK_REQUIRE((d->m_panels == 0 && d->m_stride == 0) || (d->m_panels > 0 && d->m_stride > 0 && d->epilogue != GVK_EPI_PATCH_F32),
               "gvk_gemm_nt_bf16: m_panels=%d / m_stride=%d: both positive (or both 0), not with the PATCH epilogue", d->m_panels, d->m_stride);
   a.m_stride = d->m_stride; a.nbm = d->m_panels;
+  GVK_REQUIRE(d->splitk_ws == nullptr || (d->m_panels > 0 && ((uintptr_t)d->splitk_ws & 255) == 0), "gvk_gemm_nt_bf16: splitk_ws goes with strided row panels (256-byte aligned)");
+  a.sk_part = (float*)d->splitk_ws; a.sk_bytes = d->splitk_ws_bytes;
   hipStream_t s = (hipStream_t)stream;
   switch (d->epilogue) {
     case GVK_EPI_STORE_BF16:

@@ -25,6 +25,13 @@ struct GemmArgs {
   int xcd_panels;                                        // > 0: panel-major tile order inside each XCD's run (launch_gemm: one-round launches)
   int a_rows;                                            // rows the A buffer really has (M padded to 128): the 256-row tile clamps to it
   int m_stride;                                          // first row of row tile t = t * m_stride (launch_gemm: the tile's rows, or gvk_gemm_desc.m_stride)
+  // SPLITK instantiations only (strided row panels): the K loop of a tile is cut into `ksplit` consecutive pieces of `kt_per` k-tiles, one
+  // workgroup each; partial tiles meet in `sk_part` (f32, [tile][piece][wave][register][lane][4]) and the workgroup that arrives last at
+  // the tile's ticket word sums them in piece order and runs the epilogue
+  int ksplit, kt_per;
+  float* sk_part;
+  int* sk_tick;
+  size_t sk_bytes;                                       // (host side: bytes behind gvk_gemm_desc.splitk_ws)
   // DROP instantiations only (nn.Dropout behind a Linear of the unfrozen-backbone methods): mask index m * N + n
   unsigned long long seed; const unsigned long long* seed_ptr; unsigned int drop_thresh; float inv_keep;
   // STORE_BF16 only: columns n < scale_cols leave as (acc + bias) * col_scale (the q block of a qkv projection, pre-scaled for the attention kernels)

@@ -38,6 +38,9 @@ GEMM_MARKS = None
 # the bf16 attention backward as ONE pass (csrc/attention_bwd.hip::attn_bwd_fused_kernel, round 5): built, bit-compatible, and 5 % slower
 # than the two passes at T = 1033 -- the two-pass kernels stay the path; GAVIKO_HIP_ATTN_BWD=fused (measurement build) is the A/B
 _ATTN_FUSED = L.diag_env("GAVIKO_HIP_ATTN_BWD", "2pass") == "fused"
+# the K loops of the strided-panel GEMMs (dead-row pruning) cut into pieces over idle CUs (gvk_gemm_desc.splitk_ws): +0.4 % on the step, but the
+# sum of partial sums is no longer the bit pattern the full-size GEMM produces -- off, so that pruning stays bit-identical (measurement build: =1)
+_PANEL_SPLITK = L.diag_env("GAVIKO_HIP_PANEL_SPLITK", "0") == "1"
 
 
 # classes whose backbone tensors can train (engine_peft.py `_bb_*`): the plain ViT (`fft` / `bitfit`); every class that freezes by default, with freeze_vit=False
@@ -832,7 +835,13 @@ class Engine(GavikoPaths, PeftPaths):
         """gemm_nt kwargs that restrict a launch to the first `rows` rows of every sample (64-row tiles at stride T), or {}."""
         if not self.prune_dead_rows or rows > 64 or self.T < 64:
             return {}
-        return dict(m_panels=B, m_stride=self.T)
+        kw = dict(m_panels=B, m_stride=self.T)
+        if _PANEL_SPLITK:
+            ws = self._ws
+            if "gemm_ws" not in ws:                          # 256 ticket words + up to 256 partial tiles of 32 KiB
+                ws["gemm_ws"] = torch.zeros((1024 + 256 * 32768) // 4, dtype=torch.int32, device=ws["logits"].device)
+            kw["splitk_ws"] = ws["gemm_ws"]
+        return kw
 
     def _mlp_block_fwd(self, ws, i, si, g1, gout, M, train, pdrop=0.0, up_in_fc2=False, stats_out=False, panels=None):
         nm, w, d, C = self.names, self._w16, self._d, self.C

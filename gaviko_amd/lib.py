@@ -48,7 +48,7 @@ class GemmDesc(C.Structure):
         ("tile", C.c_int32), ("drop_p", C.c_float), ("seed", C.c_uint64),
         ("scale_cols", C.c_int32), ("col_scale", C.c_float),
         ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p), ("ln_c1", C.c_void_p), ("stat_part", C.c_void_p), ("stat_pivot", C.c_void_p),
-        ("m_panels", C.c_int32), ("m_stride", C.c_int32),
+        ("m_panels", C.c_int32), ("m_stride", C.c_int32), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_uint64),
     ]
 
 

@@ -114,6 +114,11 @@ typedef struct gvk_gemm_desc {
      (gaviko.py:316), the first layer's qkv dgrad when only the prompt rows of the input carry a trainable tensor.  Tile: one of the
      4-wave kernels (tile = 0 picks 64 x 128 with three stages), m_stride >= the tile's rows, (m_panels - 1) * m_stride + tile rows <= the padded M */
   int32_t m_panels, m_stride;
+  /* with m_panels: cut every tile's K loop into pieces over otherwise idle CUs (a few 64-row tiles run at the latency of one workgroup's
+     loop); the pieces are summed in a fixed order by the workgroup that arrives last (no float atomics, bitwise reproducible).
+     splitk_ws: 256-byte aligned device memory, >= 1 KiB + tiles * 8 * 32 KiB, its first KiB ZERO at allocation (ticket words, left zero);
+     launches that share it must be ordered by their stream.  NULL = one workgroup per tile */
+  void* splitk_ws; uint64_t splitk_ws_bytes;
 } gvk_gemm_desc;
 int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream);
 /* number of 64-column groups gvk_gemm_desc.stat_part is indexed by for an N-column output */

@@ -483,3 +483,41 @@ def test_gemm_eight_phase_kernel(dev, M, N, K, tile8):
     ops.gemm_nt(A, W, M, o, epilogue=ops.EPI_STORE_F32, tile=tile8)
     assert (o[:M] - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
 
+
+
+def test_gemm_strided_row_panels_and_split_k(dev):
+    """gvk_gemm_desc.m_panels / m_stride: only the 64-row tiles at rows 0, T, 2T, ... are computed (the first rows of every sample) -- those
+    rows must be bit-identical to the full launch on the same 4-wave tile, every other row of the output untouched; with a split-K
+    workspace the K loop of every tile is cut into pieces summed in a fixed order: equal to the unsplit rows within fp32 accumulation
+    noise, bitwise repeatable, ticket words back at zero."""
+    from gaviko_amd import ops
+    B, T, N, K = 4, 1033, 768, 3072
+    M = B * T
+    g = torch.Generator().manual_seed(3)
+    a = ops.act_zeros(M, K, torch.bfloat16, dev)
+    a[:M] = (torch.randn(M, K, generator=g) * 0.5).bfloat16().to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().to(dev)
+    full = torch.zeros(M, N, device=dev)
+    ops.gemm_nt(a, w, M, full, epilogue=ops.EPI_STORE_F32, tile=3064128)
+    part = torch.full((M, N), 7.0, device=dev)
+    ops.gemm_nt(a, w, M, part, epilogue=ops.EPI_STORE_F32, m_panels=B, m_stride=T)
+    torch.cuda.synchronize()
+    rows = torch.cat([torch.arange(b * T, b * T + 64) for b in range(B)]).to(dev)
+    mask = torch.zeros(M, dtype=torch.bool, device=dev)
+    mask[rows] = True
+    assert torch.equal(part[mask], full[mask])
+    assert bool((part[~mask] == 7.0).all())
+    ws = torch.zeros((1024 + 256 * 32768) // 4, dtype=torch.int32, device=dev)
+    outs = []
+    for _ in range(3):
+        o = torch.full((M, N), 7.0, device=dev)
+        ops.gemm_nt(a, w, M, o, epilogue=ops.EPI_STORE_F32, m_panels=B, m_stride=T, splitk_ws=ws)
+        torch.cuda.synchronize()
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and int(ws[:256].abs().max()) == 0
+    assert bool((outs[0][~mask] == 7.0).all())
+    ref = a[:M].float()[rows] @ w.float().t()
+    assert (outs[0][mask] - ref).abs().max().item() < 2e-5 * ref.abs().max().item() * (K ** 0.5)
+    assert (outs[0][mask] - full[mask]).abs().max().item() < 1e-5 * full[mask].abs().max().item()
+    with pytest.raises(Exception, match="row panels"):
+        ops.gemm_nt(a, w, M, part, epilogue=ops.EPI_STORE_F32, m_panels=B + 2, m_stride=T)
