@@ -53,15 +53,38 @@ def clusters(reads, writes):
     return out
 
 
+def kernel_family(kernel_name):
+    """Which launches a GEMM instantiation serves: 'wide' = the eight-phase / 256 x 256 kernels (N >= 2304 shapes), 'panels' = the
+    four-stage 64 x 128 tile of the strided row-panel launches (dead-row pruning), 'tile' = every other 4-wave tile."""
+    import re
+    if kernel_name.startswith("gemm8p_kernel") or re.match(r"gemm_nt_kernel<256, 256,", kernel_name):
+        return "wide"
+    if re.match(r"gemm_nt_kernel<64, 128, \d+, 64, false, 4, 4", kernel_name):
+        return "panels"
+    return "tile"
+
+
+def class_family(class_name, shape):
+    """The same split on bench.py's side (engine.py / gemm_bf16.hip::dispatch_tile): classes named '... panels=BxR' are panel launches;
+    N % 256 == 0 shapes with 140..256 tiles of 256 x 256 run on the eight-phase kernel."""
+    if "panels=" in class_name:
+        return "panels"
+    M, N, K = shape
+    t256 = ((M + 255) // 256) * (N // 256) if N % 256 == 0 else 0
+    return "wide" if 140 <= t256 <= 256 else "tile"
+
+
 def attach_shapes(kernels, shapes_doc, epi_of, alg_bytes, epi_names):
     """Give every cluster of a GEMM instantiation the [M, N, K] (and class name) it was measured on: the workload's classes with that
-    epilogue, in ascending algorithmic bytes, against the clusters in ascending traffic -- only when the counts agree and no cluster
-    moved fewer bytes than its shape needs (then the pairing cannot be right and the clusters stay unlabelled)."""
+    epilogue AND kernel family, in ascending algorithmic bytes, against the clusters in ascending traffic -- only when the counts agree
+    and no cluster moved fewer bytes than its shape needs (then the pairing cannot be right and the clusters stay unlabelled)."""
     for k, v in kernels.items():
         epi = epi_of(k)
         if epi is None or epi not in epi_names:
             continue
-        cand = sorted((c for c in shapes_doc["classes"] if c.startswith(f"gemm_nt_bf16[{epi_names[epi]}]")),
+        fam = kernel_family(k)
+        cand = sorted((c for c in shapes_doc["classes"] if c.startswith(f"gemm_nt_bf16[{epi_names[epi]}]")
+                       and class_family(c, shapes_doc["classes"][c]) == fam),
                       key=lambda c: alg_bytes(epi, shapes_doc["classes"][c]))
         cl = v.get("clusters") or []
         if not cand or len(cand) != len(cl):
