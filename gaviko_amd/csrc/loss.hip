@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs p) {
     if (!ign && am == t) correct += 1.f;
     if (ign) {
       for (int k = 0; k < K; ++k) dx[k] = 0.f;
+      if (p.reduction == 2) p.loss[b] = 0.f;             // 'none': an ignored row's loss is masked to zero (focal_loss.py:108)
       continue;
     }
     wsum += w;
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs p) {
       float s = 0.f;
       for (int k = 0; k < K; ++k) s += expf(x[k] - m);
       lsum += w * (logf(s) + m - x[t]);
+      if (p.reduction == 2) p.loss[b] = w * (logf(s) + m - x[t]);
       for (int k = 0; k < K; ++k) dx[k] = w * (expf(x[k] - m) / s - (k == t ? 1.f : 0.f));
       continue;
     }
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs p) {
     const float om = 1.f - pt, nll = -logf(p.eps + pt);
     const float fg = powf(om, p.gamma);
     lsum += w * fg * nll;
+    if (p.reduction == 2) p.loss[b] = w * fg * nll;       // 'none' (focal_loss.py:118): the per-sample vector, dlogits = its rows' own gradients
     // dl/dpt = -gamma (1-pt)^(gamma-1) nll - (1-pt)^gamma / (eps + pt)
     const float dpt = w * (-p.gamma * powf(om, p.gamma - 1.f) * nll - fg / (p.eps + pt));
     // through softmax 2 and clamp 2: g1_j = dpt * pt * (delta_tj - p2_j) * [lo <= p1_j <= hi];  dot = sum_j g1_j p1_j
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs p) {
     for (int k = 0; k < K; ++k) dx[k] /= den;
   }
   if (tid == 0) {
-    p.loss[0] = loss;
+    if (p.reduction != 2) p.loss[0] = loss;
     if (p.meter != nullptr) {                              // train.py:327-328: running_loss += loss * B; num_acc += correct
       p.meter[0] += loss * (float)p.B;
       p.meter[1] += red[2][0];
@@ -122,7 +125,7 @@ extern "C" int gvk_loss_fwd_bwd(const gvk_loss_desc* d, void* stream) {
   GVK_REQUIRE(d && d->logits && d->target && d->loss && d->dlogits, "gvk_loss_fwd_bwd: null pointer");
   GVK_REQUIRE(d->B > 0 && d->K > 1 && d->K <= 4096, "gvk_loss_fwd_bwd: B=%d K=%d (K = 1, the sigmoid branch, is not built)", d->B, d->K);
   GVK_REQUIRE(d->kind == GVK_LOSS_CE || d->kind == GVK_LOSS_FOCAL, "gvk_loss_fwd_bwd: unknown kind %d", d->kind);
-  GVK_REQUIRE(d->reduction == 0 || d->reduction == 1, "gvk_loss_fwd_bwd: reduction must be 0 (mean) or 1 (sum)");
+  GVK_REQUIRE(d->reduction >= 0 && d->reduction <= 2, "gvk_loss_fwd_bwd: reduction must be 0 (mean), 1 (sum) or 2 (none: loss receives B values)");
   LossArgs a{d->logits, (const long long*)d->target, d->weights, d->loss, d->dlogits, d->meter, d->B, d->K, d->kind, d->reduction,
              d->gamma, d->eps, 1.f - d->eps, (long long)d->ignore_index};
   GVK_LAUNCH(loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);

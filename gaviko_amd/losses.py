@@ -40,18 +40,22 @@ class _LossFn(torch.autograd.Function):
         x = logits.detach()
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()
-        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        none = mod.reduction == "none"
+        loss = torch.empty(x.shape[0] if none else 1, dtype=torch.float32, device=x.device)
         dlogits = torch.empty_like(x)
         ops.loss_fwd_bwd(x, target.contiguous().view(-1), loss, dlogits, mod._kind, gamma=float(mod._gamma), eps=float(mod.eps),
                          ignore_index=int(mod.ignore_index), weights=mod._weights_on(x.device), meter=mod.meter.buf if mod.meter is not None else None,
                          reduction=mod.reduction)
         ctx.save_for_backward(dlogits)
         ctx.in_dtype = logits.dtype
-        return loss[0]
+        ctx.none = none
+        return loss if none else loss[0]
 
     @staticmethod
     def backward(ctx, grad_out):
         (dlogits,) = ctx.saved_tensors
+        if ctx.none:                                     # reduction='none': row i of dlogits is d loss_i / d logits_i
+            return (dlogits * grad_out.reshape(-1, 1)).to(ctx.in_dtype), None, None
         return (dlogits * grad_out).to(ctx.in_dtype), None, None
 
 
@@ -88,8 +92,6 @@ class FocalLoss(_FusedLoss):
         super().__init__()
         if reduction not in ["mean", "none", "sum"]:
             raise NotImplementedError("Reduction {} not implemented.".format(reduction))
-        if reduction == "none":
-            raise NotImplementedError("reduction='none' is not built (train.py:177 uses the default 'mean')")
         assert weights is None or isinstance(weights, Tensor), "weights should be of type Tensor or None, but {} given".format(type(weights))
         self.dtype = torch.float16 if fp16 else torch.float32
         self.reduction = reduction
@@ -105,8 +107,8 @@ class CrossEntropyLoss(_FusedLoss):
 
     def __init__(self, weight: Optional[Tensor] = None, ignore_index: int = -100, reduction: str = "mean") -> None:
         super().__init__()
-        if reduction not in ("mean", "sum"):
-            raise NotImplementedError("reduction='none' is not built")
+        if reduction not in ("mean", "sum", "none"):
+            raise NotImplementedError("Reduction {} not implemented.".format(reduction))
         self.weights = weight
         self.ignore_index = ignore_index
         self.reduction = reduction

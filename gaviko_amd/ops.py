@@ -824,7 +824,7 @@ def loss_fwd_bwd(logits, target, loss, dlogits, kind, gamma=0.0, eps=1e-16, igno
     B, K = logits.shape
     if target.dtype != torch.int64 or not target.is_contiguous() or target.numel() != B:
         raise ValueError("loss target must be a contiguous int64 [B] tensor")
-    _chk(loss, torch.float32, "loss out", 1)
+    _chk(loss, torch.float32, "loss out", B if reduction == "none" else 1)
     _chk(dlogits, torch.float32, "loss dlogits", B * K)
     if weights is not None:
         _chk(weights, torch.float32, "loss weights", K)
@@ -832,7 +832,7 @@ def loss_fwd_bwd(logits, target, loss, dlogits, kind, gamma=0.0, eps=1e-16, igno
         _chk(meter, torch.float32, "loss meter", 3)
     d = L.LossDesc(logits=L.ptr(logits), target=L.ptr(target), weights=L.ptr(weights) if weights is not None else None,
                    loss=L.ptr(loss), dlogits=L.ptr(dlogits), meter=L.ptr(meter) if meter is not None else None,
-                   B=B, K=K, kind=kind, reduction={"mean": 0, "sum": 1}[reduction], gamma=gamma, eps=eps, ignore_index=ignore_index)
+                   B=B, K=K, kind=kind, reduction={"mean": 0, "sum": 1, "none": 2}[reduction], gamma=gamma, eps=eps, ignore_index=ignore_index)
     L.check(L.load().gvk_loss_fwd_bwd(C.byref(d), L.stream_ptr()), "gvk_loss_fwd_bwd")
 
 

@@ -548,7 +548,7 @@ enum { GVK_LOSS_CE = 0, GVK_LOSS_FOCAL = 1 };
 typedef struct gvk_loss_desc {
   const float* logits; const void* target; const float* weights;
   float* loss; float* dlogits; float* meter;
-  int32_t B, K, kind, reduction;           /* reduction 0 = 'mean', 1 = 'sum' */
+  int32_t B, K, kind, reduction;           /* reduction 0 = 'mean', 1 = 'sum', 2 = 'none' (loss then receives the B per-sample values, dlogits each row's own gradient) */
   float gamma, eps;
   int64_t ignore_index;
 } gvk_loss_desc;

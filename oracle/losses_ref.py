@@ -10,7 +10,7 @@ def focal_loss(logits: torch.Tensor, target: torch.Tensor, gamma: float = 1.2, e
     """FocalLoss.forward as it actually executes (losses/focal_loss.py:84-115): the live
     _process_preds (84-91) clamps to [eps, 1-eps] THEN softmaxes, and forward calls it twice (94, 102);
     pt = prob of the target class (0 on ignored rows, 77-83); loss_i = w_i (1-pt)^gamma * -log(eps+pt), zero on ignored rows (107);
-    w_i = weights[target_i] or 1 (54-58); 'mean' divides by the weight sum of the rows that are not ignored (112-118)."""
+    w_i = weights[target_i] or 1 (54-58); 'mean' divides by the weight sum of the rows that are not ignored (112-116); 'none' returns the vector (117-118)."""
     x = torch.softmax(torch.clamp(logits, eps, 1 - eps), dim=-1)
     x = torch.softmax(torch.clamp(x, eps, 1 - eps), dim=-1)
     mask = target.view(-1) == ignore_index
@@ -21,6 +21,8 @@ def focal_loss(logits: torch.Tensor, target: torch.Tensor, gamma: float = 1.2, e
     loss = w * (1 - pt) ** gamma * nll
     if reduction == "sum":
         return loss.sum()
+    if reduction == "none":                                   # focal_loss.py:117-118: the per-sample vector (ignored rows: 0)
+        return loss
     return loss.sum() / ((~mask) * w).sum()
 
 

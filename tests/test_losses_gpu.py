@@ -91,8 +91,40 @@ def test_focal_loss_vs_oracle_random(dev):
 def test_loss_rejects_what_is_not_built(dev):
     from gaviko_amd.losses import FocalLoss
     with pytest.raises(NotImplementedError):
-        FocalLoss(gamma=1.2, reduction="none")
-    with pytest.raises(NotImplementedError):
         FocalLoss(gamma=1.2, reduction="median")
     with pytest.raises(NotImplementedError):
         FocalLoss(gamma=1.2)(torch.zeros(4, device=dev), torch.zeros(4, dtype=torch.int64, device=dev))
+
+
+@pytest.mark.parametrize("kind", ["focal", "ce"])
+def test_loss_reduction_none_vs_oracle(dev, kind):
+    """reduction='none' (focal_loss.py:40,117-118 accepts it): the per-sample vector, ignored rows zero, and the backward of an arbitrary
+    per-sample upstream gradient -- against the oracle (itself checked against the reference class in tests/test_oracle_vs_golden.py)."""
+    from gaviko_amd.losses import CrossEntropyLoss, FocalLoss
+    gen = torch.Generator().manual_seed(11)
+    x = torch.rand(40, 5, generator=gen) * 1.6 - 0.3
+    y = torch.randint(0, 5, (40,), generator=gen)
+    y[3] = y[17] = -100
+    w = torch.tensor([0.5, 1.0, 2.0, 1.5, 0.25])
+    up = torch.rand(40, generator=gen) + 0.5
+    xo = x.clone().requires_grad_(True)
+    lo = (oracle.focal_loss(xo, y, gamma=1.2, weights=w, reduction="none") if kind == "focal"
+          else oracle.cross_entropy(xo, y, weight=w, reduction="none"))
+    (lo * up).sum().backward()
+    xg = x.to(dev).requires_grad_(True)
+    crit = FocalLoss(gamma=1.2, weights=w, reduction="none") if kind == "focal" else CrossEntropyLoss(weight=w, reduction="none")
+    lg = crit(xg, y.to(dev))
+    assert lg.shape == (40,) and float(lg[3]) == 0.0 and float(lg[17]) == 0.0
+    (lg * up.to(dev)).sum().backward()
+    assert (lg.detach().cpu() - lo.detach()).abs().max().item() < 5e-6
+    assert (xg.grad.cpu() - xo.grad).abs().max().item() < 5e-6
+
+
+def test_focal_loss_reduction_none_matches_reference_fixture(dev):
+    from gaviko_amd.losses import FocalLoss
+    g = np.load(os.path.join(GOLD, "focal_loss_weighted.npz"))
+    lg = torch.from_numpy(g["logits"]).to(dev).requires_grad_(True)
+    vec = FocalLoss(gamma=1.2, weights=torch.from_numpy(g["weights"]), reduction="none")(lg, torch.from_numpy(g["target"]).to(dev))
+    (vec * torch.from_numpy(g["up"]).to(dev)).sum().backward()
+    assert np.abs(vec.detach().cpu().numpy() - g["loss_none"]).max() < 2e-6
+    assert np.abs(lg.grad.cpu().numpy() - g["grad_none"]).max() < 5e-6

@@ -92,6 +92,18 @@ def test_focal_loss_weights_and_ignored_rows_match_reference_fixture(red):
     assert (lg.grad.numpy()[g["target"] == -100] == 0).all()
 
 
+def test_focal_loss_reduction_none_fixture():
+    """reduction='none' of the reference class (focal_loss.py:40,117-118): per-sample vector (ignored rows 0) and the gradient of its
+    `up`-weighted sum."""
+    g = golden("focal_loss_weighted")
+    lg = torch.from_numpy(g["logits"]).requires_grad_(True)
+    vec = oracle.focal_loss(lg, torch.from_numpy(g["target"]), weights=torch.from_numpy(g["weights"]), reduction="none")
+    (vec * torch.from_numpy(g["up"])).sum().backward()
+    assert vec.shape == (16,) and np.abs(vec.detach().numpy() - g["loss_none"]).max() < 1e-6
+    assert (vec.detach().numpy()[g["target"] == -100] == 0).all()
+    assert np.abs(lg.grad.numpy() - g["grad_none"]).max() < 1e-6
+
+
 @pytest.mark.parametrize("lk", [(6, 6, 6), (3, 6, 6), (3, 3, 3)])
 def test_window_mask_matches_reference_mask(lk):
     g = golden(f"mwsa_mask_{lk[0]}{lk[1]}{lk[2]}")

@@ -301,6 +301,12 @@ def focal_case(mods, outdir):
         loss.backward()
         out["loss_" + red], out["grad_" + red] = np.float32(loss.item()), lg2.grad.numpy()
         print("focal_loss weighted/ignored", red, loss.item())
+    # reduction='none' (focal_loss.py:40,117-118): the per-sample vector and the gradient of its plain sum weighted by `up`
+    up = torch.from_numpy(synth.symmetric("focal.up", (16,), 0.5)) + 1.0
+    lg3 = lg.detach().clone().requires_grad_(True)
+    vec = mods["fl"].FocalLoss(gamma=1.2, weights=w, reduction="none")(lg3, y2)
+    (vec * up).sum().backward()
+    out["up"], out["loss_none"], out["grad_none"] = up.numpy(), vec.detach().numpy(), lg3.grad.numpy()
     np.savez_compressed(os.path.join(outdir, "focal_loss_weighted.npz"), **out)
 
 
