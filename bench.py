@@ -200,9 +200,15 @@ def pin_rank_cpus(local_rank: int, local_world: int):
     if local_world <= 1 or not hasattr(os, "sched_setaffinity") or os.environ.get("GAVIKO_BENCH_NO_PIN") == "1":
         return None
     from gaviko_amd.utils import cputopo
-    table, how = cputopo.rank_cpu_table(local_world)
-    mine = table[local_rank % len(table)]
-    os.sched_setaffinity(0, mine)
+    try:
+        table, how = cputopo.rank_cpu_table(local_world)
+        mine = table[local_rank % len(table)]
+        os.sched_setaffinity(0, mine)
+    except Exception as e:                                   # an unreadable / unexpected sysfs must never cost the run: equal runs of logical ids
+        cpus = sorted(os.sched_getaffinity(0))
+        k = max(1, len(cpus) // local_world)
+        mine, how = cpus[(local_rank * k) % len(cpus):][:k] or cpus[:1], f"logical ids (topology lookup failed: {type(e).__name__}: {e})"
+        os.sched_setaffinity(0, mine)
     print(f"bench.py: rank {local_rank}/{local_world} pinned to {len(mine)} CPU(s) {cputopo_ranges(mine)} [{how}]", file=sys.stderr, flush=True)
     return mine
 
