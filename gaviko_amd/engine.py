@@ -1178,7 +1178,8 @@ class Engine(GavikoPaths, PeftPaths):
                 ops.to_operand(dGout, ws["dG16"], self.adt)
         if gaviko:
             if last:                                                         # (the deferred step crosses segment boundaries like layer boundaries)
-                self._mwsa_flush(ws, B, loc)
+                # frozen embedding: the local stream's INPUT gradient (layer 0's deferred last step) has no reader -- conv / pos_embedding carry none
+                self._mwsa_flush(ws, B, loc, dead=self.prune_dead_rows and lo == 0 and not sv.get("bb"))
             self._wait(None, "gpa")
             self._wait(None, "loc")
         if last and sv.get("bb"):

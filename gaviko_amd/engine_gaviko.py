@@ -177,11 +177,12 @@ class GavikoPaths:
             self._mwsa_pending = i
             self._bucket_mark("loc", i)
 
-    def _mwsa_flush(self, ws, B, loc):
-        """End of a backward plan: the deferred last step of the lowest layer of the sweep."""
+    def _mwsa_flush(self, ws, B, loc, dead=False):
+        """End of a backward plan: the deferred last step of the lowest layer of the sweep (dead: nobody reads its result -- skipped)."""
         if self._mwsa_pending is not None:
-            with torch.cuda.stream(loc):
-                self._mwsa_final(ws, self._mwsa_pending, B)
+            if not dead:
+                with torch.cuda.stream(loc):
+                    self._mwsa_final(ws, self._mwsa_pending, B)
             self._mwsa_pending = None
 
     def _mwsa_final(self, ws, j, B):
