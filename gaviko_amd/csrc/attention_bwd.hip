@@ -32,7 +32,7 @@ template <int QT, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                             const float* __restrict__ lse, const float* __restrict__ delta,
                                                             bf16* __restrict__ dqkv, int T, int H, int ld_qkv, int ld_o, float dk_scale,
-                                                            AttnDrop dr) {
+                                                            AttnDrop dr, int need_rows) {
   constexpr int NSB = QT / 32;
   constexpr int kTileQ = QT * 128;                // bytes of a [QT][64] bf16 tile
   constexpr int kBuf = 2 * kTileQ + 2 * 128 * 4;  // Q tile | dO tile | lse 128 f32 | delta 128 f32
@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16* __res
   int bh, kblk;
   xcd_group_block(blockIdx.x, (T + 127) / 128, gridDim.x / ((T + 127) / 128), bh, kblk);   // all key blocks of a (batch, head) on one XCD
   const int b = bh / H, head = bh - b * H, k0 = kblk * 128;
+  if (k0 >= need_rows) return;                     // (gvk_attention_bwd_bf16_rows: dk, dv of the first need_rows tokens only -- the whole workgroup leaves)
   const int lane = lane_id(), wave = wave_id();
   const int r31 = lane & 31, hh = lane >> 5;
   const int inner = H * 64;
@@ -216,7 +217,7 @@ template <int KB, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o_fwd, const bf16* __restrict__ d_o,
                                                           const float* __restrict__ lse, float* __restrict__ delta,
                                                           bf16* __restrict__ dqkv, int T, int H, int ld_qkv, int ld_o, float scale,
-                                                          AttnDrop dr) {
+                                                          AttnDrop dr, int need_rows) {
   constexpr int NKB = KB / 32;
   constexpr int kTileBytes = KB * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][K tile | V tile]
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
   }
   del = half_sum(del);                                    // the two half-waves hold the two halves of the 64-wide row
   if (hh == 0 && q < T) delta[((size_t)b * H + head) * T + q] = del;
+  if (q0 >= need_rows) return;                            // (gvk_attention_bwd_bf16_rows: delta of every row, dq of the first need_rows tokens only)
   [[maybe_unused]] unsigned int akey = 0u, qoff = 0u;
   if constexpr (DROP) {
     akey = attn_key(dr.seed + *dr.seed_ptr, b * H + head);
@@ -785,7 +787,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused_kernel(const bf16* __re
 
 template <int KB, bool DROP>
 static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B, int T, int H,
-                           int ld_qkv, int ld_out, float scale, AttnDrop dr, hipStream_t s) {
+                           int ld_qkv, int ld_out, float scale, AttnDrop dr, hipStream_t s, int need_rows = 1 << 30) {
   const float dk_scale = 0.69314718055994530942f;      // dK = scale . dS^T.Q = dS^T.Q' / log2(e)
   const dim3 grid(((T + 127) / 128) * H * B);
   constexpr unsigned lds_kv = 2 * (2 * KB * 128 + 2 * 128 * 4), lds_q = 2 * 2 * KB * 128;
@@ -797,11 +799,11 @@ static int launch_attn_bwd(const void* qkv, const void* out, const void* dout, c
     attr = true;
   }
   GVK_LAUNCH((attn_bwd_dq_kernel<KB, DROP>), grid, dim3(256), lds_q, s, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, T, H,
-             ld_qkv, ld_out, scale, dr);
+             ld_qkv, ld_out, scale, dr, need_rows);
   int rc = check_launch("attention_bwd/dq");
   if (rc) return rc;
   GVK_LAUNCH((attn_bwd_dkdv_kernel<KB, DROP>), grid, dim3(256), lds_kv, s, (const bf16*)qkv, (const bf16*)dout, lse, (const float*)delta, (bf16*)dqkv, T, H,
-             ld_qkv, ld_out, dk_scale, dr);
+             ld_qkv, ld_out, dk_scale, dr, need_rows);
   return check_launch("attention_bwd/dkdv");
 }
 
@@ -891,6 +893,20 @@ extern "C" int gvk_attention_bwd_bf16_fused(const void* qkv, const void* out, co
   GVK_FUSED(0);
 #undef GVK_FUSED
   return check_launch("attention_bwd/fused");
+}
+
+extern "C" int gvk_attention_bwd_bf16_rows(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
+                                           int T, int H, int ld_qkv, int ld_out, float scale, int need_rows, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(qkv && out && dout && lse && delta && dqkv, "gvk_attention_bwd_bf16_rows: null pointer");
+  GVK_REQUIRE(B > 0 && T > 0 && H > 0 && need_rows > 0, "gvk_attention_bwd_bf16_rows: empty shape");
+  GVK_REQUIRE(ld_qkv >= 3 * H * 64 && ld_qkv % 8 == 0 && ld_out >= H * 64 && ld_out % 8 == 0,
+              "gvk_attention_bwd_bf16_rows: head dim is fixed at 64; ld_qkv=%d ld_out=%d inconsistent with H=%d", ld_qkv, ld_out, H);
+  GVK_REQUIRE((int64_t)B * T * ld_qkv * 2 < (int64_t)1 << 31, "gvk_attention_bwd_bf16_rows: the qkv tensor must stay below 2 GiB (32-bit buffer offsets)");
+  const AttnDrop dr{0, nullptr, 0u, 1.f};
+  const int kb = ((T + 95) / 96 * 96 < (T + 127) / 128 * 128) ? 96 : 128;        // the same tile choice as gvk_attention_bwd_bf16: the same bits
+  return kb == 96 ? launch_attn_bwd<96, false>(qkv, out, dout, lse, delta, dqkv, B, T, H, ld_qkv, ld_out, scale, dr, (hipStream_t)stream, need_rows)
+                  : launch_attn_bwd<128, false>(qkv, out, dout, lse, delta, dqkv, B, T, H, ld_qkv, ld_out, scale, dr, (hipStream_t)stream, need_rows);
 }
 
 extern "C" int gvk_attention_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,

@@ -1113,8 +1113,11 @@ class Engine(GavikoPaths, PeftPaths):
                 self._bb_linear_grads(ws, gv, bb, a + ".to_out.0", dy_at, ws["dG16"], ws["ctx"][i], M, C, C)
             self._gemm(ws["dG16"], w[f"out{i}_t"], M, ws["dctx"], epilogue=ops.EPI_STORE_BF16)
             self._mark(f"b{i}:outd")
+            # (bottom layer of a frozen backbone: only dq / dk / dv of the prompt rows are read -- by the row-panel qkv dgrad below)
+            rows0 = self.P if (gaviko and last and i == 0 and not bb and pd_ <= 0 and not sv["wgrad"] and self._panels(B, self.P)) else None
             ops.attention_bwd(ws["qkv"][i], ws["ctx"][i], ws["dctx"], ws["lse"][i], ws["delta"], ws["dqkv"], B, T, self.heads, 64 ** -0.5,
-                              drop_p=pd_, seed=SEED_LAYER + 8 * i, seed_ptr=ws["seed"], q_prescaled=True, ws=ws.get("attn_ws") if _ATTN_FUSED else None)
+                              drop_p=pd_, seed=SEED_LAYER + 8 * i, seed_ptr=ws["seed"], q_prescaled=True,
+                              ws=ws.get("attn_ws") if (_ATTN_FUSED and rows0 is None) else None, need_rows=rows0)
             self._mark(f"b{i}:attnb")
             if gaviko and shift:
                 self._mwsa_chain_bwd(ws, sv, gv, i, par, B, loc, self._ev_record(torch.cuda.current_stream()))

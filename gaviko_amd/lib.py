@@ -122,6 +122,7 @@ SIGNATURES = {
     "gvk_qkv_prescale_bf16": [_P, _I, _I, _I, _F, _P],
     "gvk_prompt_up_fix_stats": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "gvk_attention_bwd_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "gvk_attention_bwd_bf16_rows": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "gvk_attention_bwd_bf16_fused": [_P, _P, _P, _P, _P, _P, _P, C.c_size_t, _I, _I, _I, _I, _I, _F, _P],
     "gvk_attention_fwd_f32_dropout": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P, _P],
     "gvk_attention_bwd_f32_dropout": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, C.c_uint64, _P, _P],

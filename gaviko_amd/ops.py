@@ -574,9 +574,9 @@ def attention_bwd_timeouts(ws) -> int:
     return int(ws[int(L.load().gvk_attention_bwd_status_offset(ws.numel() * 4)) // 4].item())
 
 
-def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, scale, drop_p=0.0, seed=0, seed_ptr=None, q_prescaled=False, ws=None):
+def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, scale, drop_p=0.0, seed=0, seed_ptr=None, q_prescaled=False, ws=None, need_rows=None):
     """ws (attention_bwd_workspace): run the one-pass kernel (five products, ordered dQ hand-off); without it, or with attention
-    dropout, the two-pass kernels."""
+    dropout, the two-pass kernels.  need_rows (bf16, no dropout): gradients of the first need_rows tokens of every sample only."""
     inner = H * 64
     if qkv.dtype == torch.float32:
         for t, n, k in ((qkv, "qkv", 3), (out, "out", 1), (dout, "dout", 1), (dqkv, "dqkv", 3)):
@@ -599,6 +599,10 @@ def attention_bwd(qkv, out, dout, lse, delta, dqkv, B, T, H, scale, drop_p=0.0, 
         L.check(L.load().gvk_attention_bwd_bf16_dropout(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), B, T, H,
                                                         3 * inner, inner, scale, float(drop_p), int(seed), L.ptr(seed_ptr), L.stream_ptr()),
                 "gvk_attention_bwd_bf16_dropout")
+        return
+    if need_rows is not None:
+        L.check(L.load().gvk_attention_bwd_bf16_rows(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), B, T, H,
+                                                     3 * inner, inner, scale, int(need_rows), L.stream_ptr()), "gvk_attention_bwd_bf16_rows")
         return
     if ws is not None:
         _chk(ws, torch.int32, "attn_bwd ws", (int(L.load().gvk_attention_bwd_ws_bytes(B, T, H)) + 3) // 4)

@@ -238,6 +238,11 @@ size_t gvk_attention_bwd_ws_bytes(int B, int T, int H);
 size_t gvk_attention_bwd_status_offset(size_t ws_bytes);
 int gvk_attention_bwd_bf16_fused(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, void* ws,
                                  size_t ws_bytes, int B, int T, int H, int ld_qkv, int ld_out, float scale, void* stream);
+/* gvk_attention_bwd_bf16 when only the FIRST need_rows tokens of every sample carry a consumer (the bottom layer of a frozen backbone: of its
+ * input only the prompt rows hold a trainable tensor, gaviko.py:540-548): dq, dk, dv of tokens < need_rows (rounded up to 128) are written --
+ * the very bits the full call writes there -- the other rows of dqkv are left untouched; delta is complete. */
+int gvk_attention_bwd_bf16_rows(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                                int B, int T, int H, int ld_qkv, int ld_out, float scale, int need_rows, void* stream);
 /* the same with nn.Dropout(drop_p) on the attention probabilities (vision_transformer.py:52,68 -- live in training for the methods
  * that do not freeze the backbone): softmax statistics of the undropped scores, out = (P * mask / (1 - drop_p)) . V; the backward
  * regenerates mask(seed + *seed_ptr; b*H + head, query, key).  drop_p = 0 is the plain call. */

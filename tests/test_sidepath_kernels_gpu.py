@@ -680,3 +680,29 @@ def test_param_grads_hand_off_beside_a_stream_that_dirties_the_caches(dev):
     torch.cuda.synchronize()
     assert all(torch.equal(o, quiet) for o in outs)
     assert int(tick.abs().max()) == 0
+
+
+def test_attention_bwd_first_rows_only(dev):
+    """gvk_attention_bwd_bf16_rows: dq, dk, dv of the first need_rows tokens of every sample (rounded up to the 128-row blocks) carry the
+    very bits of the full call, every other row of dqkv is left untouched, delta is complete."""
+    from gaviko_amd import ops
+    B, T, H = 2, 1033, 3
+    inner = H * 64
+    qkv = ops.act_zeros(B * T, 3 * inner, torch.bfloat16, dev)
+    qkv[: B * T] = _rand((B * T, 3 * inner), 71, 1.0).bfloat16().to(dev)
+    ops.qkv_prescale(qkv, B * T, H, 0.125)
+    O = ops.act_zeros(B * T, inner, torch.bfloat16, dev)
+    lse = torch.zeros((B, H, T), device=dev)
+    ops.attention_fwd(qkv, O, lse, B, T, H, 0.125, q_prescaled=True)
+    DO = ops.act_zeros(B * T, inner, torch.bfloat16, dev)
+    DO[: B * T] = _rand((B * T, inner), 72, 1.0).bfloat16().to(dev)
+    full, part = ops.act_zeros(B * T, 3 * inner, torch.bfloat16, dev), ops.act_zeros(B * T, 3 * inner, torch.bfloat16, dev)
+    part.fill_(3.0)
+    d_full, d_part = torch.zeros((B, H, T), device=dev), torch.zeros((B, H, T), device=dev)
+    ops.attention_bwd(qkv, O, DO, lse, d_full, full, B, T, H, 0.125, q_prescaled=True)
+    ops.attention_bwd(qkv, O, DO, lse, d_part, part, B, T, H, 0.125, q_prescaled=True, need_rows=32)
+    torch.cuda.synchronize()
+    assert torch.equal(d_full, d_part)
+    f, p = full[: B * T].view(B, T, -1), part[: B * T].view(B, T, -1)
+    assert torch.equal(f[:, :128], p[:, :128])
+    assert bool((p[:, 128:] == 3.0).all())
