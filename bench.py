@@ -146,7 +146,7 @@ def gemm_alg_bytes(epi: int, shape):
 
 def gemm_kernel_epilogue(kernel_name: str):
     """Epilogue id of a GEMM kernel instantiation as rocprofv3 prints it, or None for other kernels."""
-    m = re.match(r"gemm_nt_kernel<\d+, \d+, (\d+), \d+(, false)?(, \d+)*>", kernel_name) or re.match(r"gemm8p_kernel<(\d+), \d+>", kernel_name)
+    m = re.match(r"gemm_nt_kernel<\d+, \d+, (\d+)(, (\d+|true|false))*>", kernel_name) or re.match(r"gemm8p_kernel<(\d+), \d+>", kernel_name)
     return int(m.group(1)) if m else None
 
 

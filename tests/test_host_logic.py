@@ -227,6 +227,10 @@ def test_pmc_traffic_is_attached_only_to_the_shape_it_was_measured_on(tmp_path):
     kname = "gemm_nt_kernel<128, 128, 5, 64, false, 3, 4>(GemmArgs)"
     assert bench.gemm_kernel_epilogue(kname) == 5 and bench.gemm_kernel_epilogue("gemm8p_kernel<2, 0>(GemmArgs)") == 2
     assert bench.gemm_kernel_epilogue("param_grads_kernel<2>(PgArgs)") is None
+    # the instantiation as the current build prints it (trailing split-K flag), and the panel tile
+    assert bench.gemm_kernel_epilogue("gemm_nt_kernel<128, 128, 6, 64, false, 3, 4, false>(GemmArgs)") == 6
+    assert bench.gemm_kernel_epilogue("gemm_nt_kernel<64, 128, 4, 64, false, 4, 4, true>(GemmArgs)") == 4
+    assert mod.kernel_family("gemm_nt_kernel<64, 128, 4, 64, false, 4, 4, false>(GemmArgs)") == "panels"
     kernels = {kname: {"launches": 144, "clusters": [{"launches": 72, "total_bytes": 63526960}, {"launches": 72, "total_bytes": 80435275}]},
                "param_grads_kernel<2>(PgArgs)": {"launches": 144, "clusters": [{"launches": 144, "total_bytes": 49017128}]}}
     cfg2 = {"workload": {"backbone": "vit-b16", "method": "gaviko", "batch": 4, "precision": "bf16"},
