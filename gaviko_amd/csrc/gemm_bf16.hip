@@ -34,7 +34,7 @@ __device__ __forceinline__ int swz_chunk(int row) {
 template <int BM, int BN, int EPI, int BK = 64, bool DROP = false, int NS = 2, int NW = 4, bool SPLITK = false>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs p) {
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-  static_assert(!SPLITK || (NS >= 3 && NW == 4 && !DROP), "split-K is built on the multi-stage 4-wave loop");
+  static_assert(!SPLITK || (NW == 4 && !DROP), "split-K is built on the 4-wave loops");
   static_assert(BK == 64, "the interleaved weight-row mapping is built for 128-byte tile rows");
   static_assert(NS >= 2 && NS <= 4, "2..4 LDS stages");
   constexpr int WM = BM / (NW / 2), WN = BN / 2;
@@ -49,9 +49,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs p) {
   const int nwg = p.nbm * p.nbn;
   int wg;
   [[maybe_unused]] int piece = 0;
-  if constexpr (SPLITK) {                                  // consecutive blocks = the pieces of one tile
-    wg = blockIdx.x / p.ksplit;
-    piece = blockIdx.x - wg * p.ksplit;
+  if constexpr (SPLITK) {                                  // the same remap over (tile, piece) units: the pieces of a tile are neighbours in an XCD's run
+    const int nu = nwg * p.ksplit;
+    const int bid = blockIdx.x, xcd = bid & 7, q = nu >> 3, r = nu & 7;
+    const int u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    wg = u / p.ksplit;
+    piece = u - wg * p.ksplit;
   } else {
     const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -259,15 +262,24 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs p) {
     }
     __syncthreads();
     if (!*s_last) return;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int pc = 0; pc < p.ksplit; ++pc) {
+    if (p.ksplit == 2) {
+      // two pieces: own accumulators + the other piece's partial -- a + b is the same bits in either order, so who arrives last does not matter
+      const int pc = piece ^ 1;
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] += *(const f32x4*)((const char*)base + (size_t)pc * kPiece * 4 + off + (i * NT + j) * 1024);
+    } else {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int pc = 0; pc < p.ksplit; ++pc) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] += *(const f32x4*)((const char*)base + (size_t)pc * kPiece * 4 + off + (i * NT + j) * 1024);
+      }
     }
   }
   gemm_epilogue<EPI, DROP, MT, NT>(p, acc, m0 + wm * WM, n0 + wn * WN, l15, lq);
@@ -315,6 +327,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     const int nt = a.K / BK;
     int s = 256 / (grid > 0 ? grid : 1);
     s = s < 1 ? 1 : s > 8 ? 8 : s;
+    if (a.ksplit > 0) s = a.ksplit;                        // the caller's piece count (gvk_gemm_desc.ksplit)
     if (s > nt / 2) s = nt / 2 > 0 ? nt / 2 : 1;
     p.kt_per = (nt + s - 1) / s;
     p.ksplit = (nt + p.kt_per - 1) / p.kt_per;
@@ -403,6 +416,9 @@ static int dispatch_tile(const GemmArgs& a, int tile, hipStream_t stream) {
   switch (tile) {
     case 8256256: return launch_gemm8p(a, EPI, 0, stream);      // eight-phase kernel, LDS-DMA issued in the load sections (default)
     case 7256256: return launch_gemm8p(a, EPI, 1, stream);      // ... issued inside the MFMA clusters (2546 vs 2426 cycles per k-tile)
+    case 2128128:                                                            // 128 x 128, two stages, every tile's K loop cut into pieces (two workgroups share a CU)
+      if (a.sk_part == nullptr) return set_error(-2, "gvk_gemm_nt_bf16: tile 2128128 needs splitk_ws");
+      return launch_gemm<128, 128, EPI, false, 2, 4, true>(a, stream);
     case 3128128: return launch_gemm<128, 128, EPI, false, 3>(a, stream);
     case 3064128: return launch_gemm<64, 128, EPI, false, 3>(a, stream);     // 64 x 128 with three stages (A/B switch GAVIKO_HIP_GEMM_N768=3064)
     case 4064128:                                                            // ... four stages: the strided row-panel launches (a few tiles, 12-49 k-steps each),
@@ -458,8 +474,10 @@ extern "C" int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream) {
   GVK_REQUIRE((d->m_panels == 0 && d->m_stride == 0) || (d->m_panels > 0 && d->m_stride > 0 && d->epilogue != GVK_EPI_PATCH_F32),
               "gvk_gemm_nt_bf16: m_panels=%d / m_stride=%d: both positive (or both 0), not with the PATCH epilogue", d->m_panels, d->m_stride);
   a.m_stride = d->m_stride; a.nbm = d->m_panels;
-  GVK_REQUIRE(d->splitk_ws == nullptr || (d->m_panels > 0 && ((uintptr_t)d->splitk_ws & 255) == 0), "gvk_gemm_nt_bf16: splitk_ws goes with strided row panels (256-byte aligned)");
-  a.sk_part = (float*)d->splitk_ws; a.sk_bytes = d->splitk_ws_bytes;
+  GVK_REQUIRE(d->splitk_ws == nullptr || ((d->m_panels > 0 || d->tile == 2128128) && ((uintptr_t)d->splitk_ws & 255) == 0),
+              "gvk_gemm_nt_bf16: splitk_ws goes with strided row panels or tile 2128128 (256-byte aligned)");
+  GVK_REQUIRE(d->ksplit >= 0 && d->ksplit <= 8 && (d->ksplit == 0 || d->splitk_ws != nullptr), "gvk_gemm_nt_bf16: ksplit=%d: 0 (auto) .. 8, with splitk_ws", d->ksplit);
+  a.sk_part = (float*)d->splitk_ws; a.sk_bytes = d->splitk_ws_bytes; a.ksplit = d->ksplit;
   hipStream_t s = (hipStream_t)stream;
   switch (d->epilogue) {
     case GVK_EPI_STORE_BF16:

@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256) void ln_fwd_fix_kernel(float* __restrict__ x, 
 }
 
 // dx = dres + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <bool DY16>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const float* __restrict__ gamma, const float* __restrict__ dres,
                                                      float* __restrict__ dx, bf16* __restrict__ dx16, int M, int C, int rpg, int gstride) {
@@ -153,7 +154,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     const int c = k * 256 + lane * 4;
     if (c < C) {
       const f32x4 xv = *(const f32x4*)(x + (size_t)row * C + c);
-      const f32x4 dv = *(const f32x4*)(dy + (size_t)row * C + c);
+      f32x4 dv;
+      if constexpr (DY16) {                                  // the gradient as a dgrad GEMM stored it (bf16)
+        const bf16x4 h = *(const bf16x4*)((const bf16*)dy_ + (size_t)row * C + c);
+        dv = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+      } else {
+        dv = *(const f32x4*)((const float*)dy_ + (size_t)row * C + c);
+      }
       const f32x4 g = *(const f32x4*)(gamma + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -253,7 +260,7 @@ extern "C" int gvk_layernorm_bwd(const float* dy, const float* x, const float* m
   using namespace gvk;
   GVK_REQUIRE(dy && x && mean && rstd && gamma && dx, "gvk_layernorm_bwd: null pointer");
   GVK_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && C <= 256 * kMaxChunks, "gvk_layernorm_bwd: C=%d must be a multiple of 4 and <= 1024", C);
-  GVK_LAUNCH(ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dres, dx,
+  GVK_LAUNCH(ln_bwd_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const void*)dy, x, mean, rstd, gamma, dres, dx,
                      (bf16*)dx_bf16, M, C, 0, 0);
   return check_launch("layernorm_bwd");
 }
@@ -267,7 +274,7 @@ extern "C" int gvk_layernorm_bwd_rows(const float* dy, const float* x, const flo
               groups, rows_per_group, group_stride);
   GVK_REQUIRE(C > 0 && C % 4 == 0 && C <= 256 * kMaxChunks, "gvk_layernorm_bwd_rows: C=%d must be a multiple of 4 and <= 1024", C);
   const int M = groups * rows_per_group;
-  GVK_LAUNCH(ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, gamma, dres, dx,
+  GVK_LAUNCH(ln_bwd_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const void*)dy, x, mean, rstd, gamma, dres, dx,
                      (bf16*)dx_bf16, M, C, rows_per_group, group_stride);
   return check_launch("layernorm_bwd_rows");
 }
@@ -316,6 +323,31 @@ extern "C" int gvk_layernorm_bwd_proj(const float* dy, const float* x, const flo
   a.mode = 2; a.x = x; a.dy = dy; a.mean_in = mean; a.rstd_in = rstd; a.ln_g = gamma; a.dres = dres; a.dx = dx; a.dx16 = (bf16*)dx_bf16;
   a.M = M; a.C = C; a.eps = 1e-5f; a.inv_keep = 1.f;
   return launch_proj(a, proj, (hipStream_t)stream, "gvk_layernorm_bwd_proj");
+}
+
+// The three backward forms above with the output gradient in bf16 (what the dgrad GEMM in front stores: half the bytes on both sides)
+extern "C" int gvk_layernorm_bwd_dy16(const gvk_ln_bwd_dy16_desc* d, void* stream) {
+  using namespace gvk;
+  GVK_REQUIRE(d && d->dy_bf16 && d->x && d->mean && d->rstd && d->gamma && d->dx, "gvk_layernorm_bwd_dy16: null pointer");
+  const int C = d->C;
+  GVK_REQUIRE(d->M > 0 && C > 0 && C % 4 == 0 && C <= 256 * kMaxChunks, "gvk_layernorm_bwd_dy16: C=%d must be a multiple of 4 and <= 1024", C);
+  if (d->proj != nullptr) {
+    GVK_REQUIRE(d->rows_per_group == 0, "gvk_layernorm_bwd_dy16: the projection form covers all rows");
+    if (int rc = check_proj(d->proj, C, "gvk_layernorm_bwd_dy16")) return rc;
+    DownArgs a{};
+    a.mode = 2; a.x = d->x; a.dy16 = (const bf16*)d->dy_bf16; a.mean_in = d->mean; a.rstd_in = d->rstd; a.ln_g = d->gamma; a.dres = d->dres; a.dx = d->dx;
+    a.dx16 = (bf16*)d->dx_bf16; a.M = d->M; a.C = C; a.eps = 1e-5f; a.inv_keep = 1.f;
+    return launch_proj(a, d->proj, (hipStream_t)stream, "gvk_layernorm_bwd_dy16");
+  }
+  int M = d->M, rpg = 0, gs = 0;
+  if (d->rows_per_group > 0) {
+    GVK_REQUIRE(d->groups > 0 && d->group_stride >= d->rows_per_group && (long)(d->groups - 1) * d->group_stride + d->rows_per_group <= d->M,
+                "gvk_layernorm_bwd_dy16: groups=%d rows_per_group=%d group_stride=%d do not fit M=%d", d->groups, d->rows_per_group, d->group_stride, d->M);
+    M = d->groups * d->rows_per_group; rpg = d->rows_per_group; gs = d->group_stride;
+  }
+  GVK_LAUNCH(ln_bwd_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, d->dy_bf16, d->x, d->mean, d->rstd, d->gamma, d->dres, d->dx,
+             (bf16*)d->dx_bf16, M, C, rpg, gs);
+  return check_launch("layernorm_bwd_dy16");
 }
 
 // LayerNorm backward of the MLP block fused with GPA's rank-L scatter (gaviko.py:155: dG1 += dzx . W_d): one pass over the row

@@ -128,7 +128,13 @@ __device__ __forceinline__ void row_down_pass(const DownArgs& p, float* Wc, floa
         const int c = k * 256 + lane * 4;
         dh[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < C) {
-          const f32x4 dv = *(const f32x4*)(p.dy + (size_t)rows[r] * C + c);
+          f32x4 dv;
+          if (p.dy16 != nullptr) {
+            const bf16x4 h = *(const bf16x4*)(p.dy16 + (size_t)rows[r] * C + c);
+            dv = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+          } else {
+            dv = *(const f32x4*)(p.dy + (size_t)rows[r] * C + c);
+          }
           const f32x4 g = *(const f32x4*)(p.ln_g + c);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {

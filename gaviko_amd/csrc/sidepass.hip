@@ -658,6 +658,7 @@ int launch_side_down(const DownArgs& a, int L, hipStream_t s) {
   const int ngw = groups_per_wave(a.C);
   if (!side_enabled() || L != kSL || ngw == 0 || a.mode < 0 || a.mode > 2 || (a.w2 != nullptr && a.L2 > 64)) return 1;
   if (a.mode != 0 && (a.w2 != nullptr || a.drop_thresh != 0u)) return 1;
+  if (a.dy16 != nullptr) return 1;                                  // bf16 gradient input: the row-per-wave kernel
   // A/B switch, see DESIGN.md section 7b: '1' = both LayerNorm modes on the tile kernels, 'f' = the forward one (MODE 1), 'b' = the backward one
   static const char ln_sel = diag_env("GAVIKO_HIP_SIDE_LN") != nullptr ? diag_env("GAVIKO_HIP_SIDE_LN")[0] : 'f';
   if (a.mode == 1 && !(ln_sel == '1' || ln_sel == 'f')) return 1;

@@ -765,17 +765,40 @@ __global__ __launch_bounds__(256) void prompt_fix_stats_kernel(const float* __re
   __shared__ float red[8];
   const int b = blockIdx.x / P, pi = blockIdx.x - b * P;
   const size_t row = (size_t)b * T + pi;
+  // every load of the block goes out before the first use: the row's own columns and the weight rows (w [C][L], L floats contiguous per
+  // column: float4 pieces when L % 4 == 0) do not depend on the latent difference
+  float x[4] = {0.f, 0.f, 0.f, 0.f};                            // C <= 1024: up to four columns per thread
+  f32x4 wv[4][5];                                               // L <= 20 in float4 pieces (the wider / odd widths take the scalar loop below)
+  const bool vec = (L & 3) == 0 && L <= 20;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = threadIdx.x + 256 * u;
+    if (c < C) {
+      x[u] = out[row * C + c];
+      if (vec) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) wv[u][q] = 4 * q < L ? *(const f32x4*)(w + (size_t)c * L + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
   if ((int)threadIdx.x < L) dl[threadIdx.x] = enh[((size_t)b * P + pi) * L + threadIdx.x] - lat[row * L + threadIdx.x];
   __syncthreads();
-  float x[4] = {0.f, 0.f, 0.f, 0.f};                            // C <= 1024: up to four columns per thread
   float s1 = 0.f;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int c = threadIdx.x + 256 * u;
     if (c < C) {
       float a = 0.f;
-      for (int l = 0; l < L; ++l) a = __builtin_fmaf(dl[l], w[(size_t)c * L + l], a);
-      x[u] = out[row * C + c] + a;
+      if (vec) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (4 * q + e < L) a = __builtin_fmaf(dl[4 * q + e], wv[u][q][e], a);      // same order as the scalar loop: l ascending
+      } else {
+        for (int l = 0; l < L; ++l) a = __builtin_fmaf(dl[l], w[(size_t)c * L + l], a);
+      }
+      x[u] += a;
       out[row * C + c] = x[u];
       out16[row * C + c] = (bf16)x[u];
       s1 += x[u];

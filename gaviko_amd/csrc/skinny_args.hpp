@@ -23,6 +23,7 @@ struct DownArgs {
   int tile_off;                                            // sidepass.hip: first 16-row tile of this launch (chunked launches, GAVIKO_HIP_SIDE_CHUNKS)
   bf16* ysplit; int ysplit_ld, ysplit_col;                // row-per-wave kernel: split-bf16 copy [hi | lo | hi] of y into spare K columns of a GEMM operand
   const float* dy; const float* mean_in; const float* rstd_in; const float* dres; float* dx; bf16* dx16;
+  const bf16* dy16;                                        // mode 2: the LayerNorm output gradient as bf16 (then dy is NULL): what a dgrad GEMM stores
 };
 
 struct UpArgs {

@@ -147,6 +147,9 @@ class Engine(GavikoPaths, PeftPaths):
         # are bit-identical to the full computation (tests/test_model_gpu.py::test_pruned_rows_are_dead); GAVIKO_HIP_PRUNE=0 computes
         # everything (the golden taps of the last layer's far rows need that).
         self.prune_dead_rows = kind == "gaviko" and not self.fp32 and os.environ.get("GAVIKO_HIP_PRUNE", "1") != "0"
+        # frozen backbone: the fc1 / qkv dgrad GEMMs hand the LayerNorm backward its input gradient in bf16 (half the bytes on both sides; the other
+        # operands of that chain -- dpre, dqkv, the dgrad operands -- are bf16 already)
+        self._dy16 = kind == "gaviko" and not self.fp32 and L.diag_env("GAVIKO_HIP_DY16", "1") != "0"
         self._fuse_local = kind == "gaviko" and ops.side_tile_supported(self.Lat, dim)
         self._fuse_bnd = self._fuse_local and L.diag_env("GAVIKO_HIP_FUSE_BOUNDARY", "1") != "0"
         self._fuse_next = self._fuse_local and L.diag_env("GAVIKO_HIP_FUSE_NEXT", "1") != "0"
@@ -401,6 +404,8 @@ class Engine(GavikoPaths, PeftPaths):
             ws["dG16"] = z(M, C, bf16)
             ws["dpre"] = z(M, self.mlp, bf16)
             ws["dx32"] = z(M, C, f32)
+            if self._dy16:
+                ws["dx16b"] = z(M, C, bf16)
             ws["dctx"] = z(M, C, bf16)
             ws["dqkv"] = z(M, 3 * C, bf16)
             ws["delta"] = torch.zeros((B, self.heads, T), device=device)
@@ -1064,15 +1069,19 @@ class Engine(GavikoPaths, PeftPaths):
             if bb:                                                           # fc1: db = colsum(dpre), dW = dpre^T . LN2(G1)
                 self._bb_linear_grads(ws, gv, bb, m + ".net.1", ws["dpre"], ws["dpre"], ws["sav"]["xn2"][i] if sv["wgrad"] else None, M, self.mlp, C)
             self._mark(f"b{i}:fc2d") if False else None
-            self._gemm(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32, **top)
+            fuse_scatter = (gaviko and self._fuse_local and not self.fp32 and "noside" not in _ABLATE
+                            and L.diag_env("GAVIKO_HIP_FUSE_SCATTER", "0") == "1")     # measured: 651 vs 676 volumes/s -- off (DESIGN.md section 7)
+            dy16 = bool(self._dy16 and not bb and not sv["wgrad"] and not fuse_scatter)
+            if dy16:
+                self._gemm(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx16b"], epilogue=ops.EPI_STORE_BF16, **top)
+            else:
+                self._gemm(ws["dpre"], w[f"fc1{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32, **top)
             self._mark(f"b{i}:fc1d")
             if bb:
                 self._bb_ln_grads(ws, gv, bb, m + ".net.0", ws["dx32"], ws["G1"][i], st[2], st[3], M)
             if ssf:                                                          # LN2 + ssf_0
                 self._ssf_ln_grad(ws, gv, m, ".net.0", ws["dx32"], ws["G1"][i], st[2], st[3], M)
             adapter = self.kind == "adaptformer"
-            fuse_scatter = (gaviko and self._fuse_local and not self.fp32 and "noside" not in _ABLATE
-                            and L.diag_env("GAVIKO_HIP_FUSE_SCATTER", "0") == "1")     # measured: 651 vs 676 volumes/s -- off (DESIGN.md section 7)
             if fuse_scatter:
                 # dG1 = dGout + LN'(dx32) + dzx . W_d (+ the bf16 operand of the out-proj dgrad) in ONE pass: the GPA core of this layer
                 # (started at the top of the layer on its own stream) has long finished when the two MLP dgrad GEMMs are through
@@ -1082,8 +1091,14 @@ class Engine(GavikoPaths, PeftPaths):
                                      lat=ws["bw"]["dzx"], w=d(gpre + ".proj_down.0.weight"), L_=self.Lat, w_layout=1)
             elif top:
                 ops.memset_zero(dGin)
-                ops.layernorm_bwd_rows(ws["dx32"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), B, self._pool_rows()[0] + self._pool_rows()[1],
-                                       T, C, dx=dGin, dres=dGout)
+                if dy16:
+                    ops.layernorm_bwd_dy16(ws["dx16b"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), M, C, dx=dGin, dres=dGout,
+                                           rows=(B, self._pool_rows()[0] + self._pool_rows()[1], T))
+                else:
+                    ops.layernorm_bwd_rows(ws["dx32"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), B, self._pool_rows()[0] + self._pool_rows()[1],
+                                           T, C, dx=dGin, dres=dGout)
+            elif dy16:
+                ops.layernorm_bwd_dy16(ws["dx16b"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), M, C, dx=dGin, dres=dGout)
             else:
                 ops.layernorm_bwd(ws["dx32"], ws["G1"][i], st[2], st[3], d(m + ".net.0.weight"), M, C, dx=dGin, dres=dGout,
                                   dx16=None if (gaviko or adapter or dvpt) else ws["dG16"])
@@ -1131,7 +1146,10 @@ class Engine(GavikoPaths, PeftPaths):
             # bottom layer, frozen backbone: of this layer's INPUT gradient only the P prompt rows of every sample are read (prompt_embeddings and
             # their position embedding; patch embedding, cls token and pos_embedding carry none) -- qkv dgrad and LayerNorm 1 on those rows
             bot = (self._panels(B, self.P) if (gaviko and last and i == 0 and not bb and pd_ <= 0 and not sv["wgrad"] and self.P > 0) else {})
-            self._gemm(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32, **bot)
+            if dy16:
+                self._gemm(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx16b"], epilogue=ops.EPI_STORE_BF16, **bot)
+            else:
+                self._gemm(ws["dqkv"], w[f"qkv{i}_t"], M, ws["dx32"], epilogue=ops.EPI_STORE_F32, **bot)
             if bb:
                 self._bb_ln_grads(ws, gv, bb, a + ".norm", ws["dx32"], ws["G"][i], st[0], st[1], M)
             if ssf:                                                          # LN1 + ssf_0
@@ -1142,7 +1160,17 @@ class Engine(GavikoPaths, PeftPaths):
                 # dGout off the critical path.  The buffer being overwritten was last read by layer i+1's parameter kernels, which
                 # precede this layer's dz_ready in the GPA stream -- and the main stream has already waited for that above.
                 dGnext = ws["dGb"] if dGout is ws["dG"][0] else ws["dG"][0]
-                if self._proj_bwd_main and i > 0:
+                if dy16:
+                    g1 = d(a + ".norm.weight")
+                    if self._proj_bwd_main and i > 0:
+                        pre_lo, _ = self._gpa_names(i - 1)
+                        ops.layernorm_bwd_dy16(ws["dx16b"], ws["G"][i], st[0], st[1], g1, M, C, dx=dGnext, dres=dGin, dx16=ws["dG16"],
+                                               proj=dict(w=d(pre_lo + ".proj_up.weight"), y=ws["bw"]["dcomb"], w_layout=1, L_=self.Lat))
+                    elif bot:
+                        ops.layernorm_bwd_dy16(ws["dx16b"], ws["G"][i], st[0], st[1], g1, M, C, dx=dGnext, dres=dGin, rows=(B, self.P, T))
+                    else:
+                        ops.layernorm_bwd_dy16(ws["dx16b"], ws["G"][i], st[0], st[1], g1, M, C, dx=dGnext, dres=dGin, dx16=ws["dG16"])
+                elif self._proj_bwd_main and i > 0:
                     pre_lo, _ = self._gpa_names(i - 1)
                     ops.layernorm_bwd_proj(ws["dx32"], ws["G"][i], st[0], st[1], d(a + ".norm.weight"), M, C, dx=dGnext, dres=dGin,
                                            dx16=ws["dG16"], w=d(pre_lo + ".proj_up.weight"), y=ws["bw"]["dcomb"], w_layout=1, L_=self.Lat)

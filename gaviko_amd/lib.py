@@ -26,7 +26,7 @@ if os.environ.get("GPU_MAX_HW_QUEUES") is None:
     except Exception:
         pass
 
-ABI_VERSION = 10                                  # gvk_abi_version() of the library these declarations describe
+ABI_VERSION = 11                                  # gvk_abi_version() of the library these declarations describe
 # GAVIKO_HIP_DIAG=1 (tools/ only): load the measurement build libgaviko_hip_diag.so (`python -m gaviko_amd.build --diag`) -- the product
 # library ignores every A/B switch of the kernel sources and exports no diagnostics (include/gaviko_hip_diag.h)
 DIAG = os.environ.get("GAVIKO_HIP_DIAG", "0") == "1"
@@ -49,6 +49,7 @@ class GemmDesc(C.Structure):
         ("scale_cols", C.c_int32), ("col_scale", C.c_float),
         ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p), ("ln_c1", C.c_void_p), ("stat_part", C.c_void_p), ("stat_pivot", C.c_void_p),
         ("m_panels", C.c_int32), ("m_stride", C.c_int32), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_uint64),
+        ("ksplit", C.c_int32),
     ]
 
 
@@ -86,6 +87,8 @@ AdamDesc = _struct("AdamDesc", ["ptr_tab", "blk_tab", "grad", "m", "v", "norm_sq
 LossDesc = _struct("LossDesc", ["logits", "target", "weights", "loss", "dlogits", "meter"], ["B", "K", "kind", "reduction"], ["gamma", "eps"], i64=["ignore_index"])
 DropoutDesc = _struct("DropoutDesc", ["x", "out32", "out16", "seed_ptr"], ["M", "N", "ld", "rows_in", "rows_out", "row_off"], ["drop_p"], ["seed"])
 RowProjDesc = _struct("RowProjDesc", ["w", "bias", "y", "z", "y_split"], ["L", "w_layout", "act", "ld_split", "col_split"])
+LnBwdDy16Desc = _struct("LnBwdDy16Desc", ["dy_bf16", "x", "mean", "rstd", "gamma", "dres", "dx", "dx_bf16", "proj"],
+                        ["M", "C", "groups", "rows_per_group", "group_stride"])
 ReduceJob = _struct("ReduceJob", ["a", "b", "out", "a2"], ["M", "J", "L", "accumulate", "M2"])
 PgradOuter = _struct("PgradOuter", ["narrow", "wide", "narrow2", "wide2", "lat_override", "mean", "rstd", "out", "colsum",
                                     "aff_w", "aff_gamma", "aff_beta", "aff_dgamma", "aff_dbeta", "aff_dbias"],
@@ -149,6 +152,7 @@ SIGNATURES = {
     "gvk_cast_bf16_f32_strided": [_P, _P, _I, _I, _I, _P],
     "gvk_lora_merge_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "gvk_layernorm_fwd_proj": [_P, _P, _P, _P, _P, _P, _I, _I, _F, C.POINTER(RowProjDesc), _P],
+    "gvk_layernorm_bwd_dy16": [C.POINTER(LnBwdDy16Desc), _P],
     "gvk_layernorm_bwd_proj": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, C.POINTER(RowProjDesc), _P],
     "gvk_layernorm_bwd_up": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gvk_ssf_fold_weight": [_P, _P, _P, _P, _I, _I, _I, _P],

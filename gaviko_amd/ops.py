@@ -42,7 +42,7 @@ def _chk(t, dtype, what, min_elems=0):
 def gemm_nt(a, w, M, out0, *, epilogue, out1=None, bias=None, res=None, aux=None, pos=None,
             lda=None, ldo=None, ldres=None, ldaux=None, rows_in=0, rows_out=0, row_off=0, tile=0, N=None, K=None,
             drop_p=0.0, seed=0, seed_ptr=None, scale_cols=0, col_scale=1.0, ln_mean=None, ln_rstd=None, ln_c1=None, stat_part=None, stat_pivot=None,
-            m_panels=0, m_stride=0, splitk_ws=None):
+            m_panels=0, m_stride=0, splitk_ws=None, ksplit=0):
     """Y[M,N] = A[M,K] . W[N,K]^T with a fused epilogue.  The operand dtype picks the kernel: bf16 -> gvk_gemm_nt_bf16 (MFMA
     bf16, fp32 accumulate), fp32 -> gvk_gemm_nt_f32 (every 16-bit slot of the epilogue table then carries fp32).
     m_panels / m_stride (bf16): only the row tiles starting at rows 0, m_stride, 2 m_stride, ... are computed (gvk_gemm_desc)."""
@@ -69,7 +69,7 @@ def gemm_nt(a, w, M, out0, *, epilogue, out1=None, bias=None, res=None, aux=None
                    M, N, K, lda, ldw, ldo, (N if ldres is None else ldres), (N if ldaux is None else ldaux),
                    epilogue, rows_in, rows_out, row_off, tile, float(drop_p), int(seed), int(scale_cols), float(col_scale),
                    L.ptr(ln_mean), L.ptr(ln_rstd), L.ptr(ln_c1), L.ptr(stat_part), L.ptr(stat_pivot), int(m_panels), int(m_stride),
-                   L.ptr(splitk_ws), 0 if splitk_ws is None else splitk_ws.numel() * splitk_ws.element_size())
+                   L.ptr(splitk_ws), 0 if splitk_ws is None else splitk_ws.numel() * splitk_ws.element_size(), int(ksplit))
     _chk(ln_mean, torch.float32, "gemm ln_mean", M)
     _chk(ln_rstd, torch.float32, "gemm ln_rstd", M)
     _chk(ln_c1, torch.float32, "gemm ln_c1", N)
@@ -325,6 +325,26 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, M, C_, *, dx, dres=None, dx16=None):
     _chk(gamma, torch.float32, "ln_bwd gamma", C_)
     L.check(L.load().gvk_layernorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dres), L.ptr(dx),
                                        L.ptr(dx16), M, C_, L.stream_ptr()), "gvk_layernorm_bwd")
+
+
+def layernorm_bwd_dy16(dy16, x, mean, rstd, gamma, M, C_, *, dx, dres=None, dx16=None, rows=None, proj=None):
+    """LayerNorm backward with the output gradient in bf16 (gvk_layernorm_bwd_dy16).  rows = (groups, rows_per_group, group_stride) restricts it
+    to the leading rows of every group; proj = dict(w=, y=, L_=, w_layout=) adds the rank-L projection of dx (as layernorm_bwd_proj)."""
+    _chk(dy16, torch.bfloat16, "ln_bwd_dy16 dy", M * C_)
+    for t, n in ((x, "x"), (dx, "dx")):
+        _chk(t, torch.float32, "ln_bwd_dy16 " + n, M * C_)
+    _chk(dres, torch.float32, "ln_bwd_dy16 dres", M * C_)
+    _chk(dx16, torch.bfloat16, "ln_bwd_dy16 dx16", M * C_)
+    _chk(mean, torch.float32, "ln_bwd_dy16 mean", M)
+    _chk(rstd, torch.float32, "ln_bwd_dy16 rstd", M)
+    _chk(gamma, torch.float32, "ln_bwd_dy16 gamma", C_)
+    g, rpg, gs = rows if rows is not None else (0, 0, 0)
+    pj = None
+    if proj is not None:
+        pj = _rowproj(M, C_, proj["w"], proj["y"], None, None, proj.get("L_", ROWPROJ_L), proj.get("w_layout", 1), 0)
+    d = L.LnBwdDy16Desc(L.ptr(dy16), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dres), L.ptr(dx), L.ptr(dx16),
+                        C.cast(C.pointer(pj), C.c_void_p) if pj is not None else None, M, C_, int(g), int(rpg), int(gs))
+    L.check(L.load().gvk_layernorm_bwd_dy16(C.byref(d), L.stream_ptr()), "gvk_layernorm_bwd_dy16")
 
 
 def layernorm_bwd_rows(dy, x, mean, rstd, gamma, groups, rows_per_group, group_stride, C_, *, dx, dres=None, dx16=None):

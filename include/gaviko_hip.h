@@ -22,7 +22,7 @@ extern "C" {
 const char* gvk_last_error(void);
 /* returns 950 when the code object loaded on the current device is gfx950, else <0 */
 int gvk_device_check(void);
-int gvk_abi_version(void);   /* 10 */
+int gvk_abi_version(void);   /* 11 */
 
 /* ------------------------------------------------------------------ launch plans
  * The reference drives its step from the Python interpreter (train.py:296-319: one autograd node per op).  Here one
@@ -119,6 +119,10 @@ typedef struct gvk_gemm_desc {
      splitk_ws: 256-byte aligned device memory, >= 1 KiB + tiles * 8 * 32 KiB, its first KiB ZERO at allocation (ticket words, left zero);
      launches that share it must be ordered by their stream.  NULL = one workgroup per tile */
   void* splitk_ws; uint64_t splitk_ws_bytes;
+  /* pieces per tile (2..8) when splitk_ws is given; 0 = as many as keep the launch within one round of the chip.  Also: tile = 2128128 runs a
+     FULL launch (no panels) of <= 256 tiles of 128 x 128 this way -- two pieces of a K >= 2304 loop on two workgroups that share a CU
+     (measured: no faster than one three-stage workgroup per tile; the engine does not use it) */
+  int32_t ksplit;
 } gvk_gemm_desc;
 int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream);
 /* number of 64-column groups gvk_gemm_desc.stat_part is indexed by for an N-column output */
@@ -203,6 +207,16 @@ int gvk_layernorm_fwd_proj(const float* x, const float* gamma, const float* beta
                            int M, int C, float eps, const gvk_rowproj_desc* proj, void* stream);
 int gvk_layernorm_bwd_proj(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                            const float* dres, float* dx, void* dx_bf16, int M, int C, const gvk_rowproj_desc* proj, void* stream);
+/* gvk_layernorm_bwd / _rows / _bwd_proj with the output gradient dy in bf16 [M][C] -- the form a dgrad GEMM with the STORE_BF16 epilogue
+ * leaves it in (fc1 / qkv dgrad of a frozen backbone: half the bytes written by the GEMM and read here).  rows_per_group = 0: all M rows;
+ * otherwise rows g * group_stride + r, r < rows_per_group, g < groups (then proj must be NULL).  proj != NULL: as gvk_layernorm_bwd_proj. */
+typedef struct gvk_ln_bwd_dy16_desc {
+  const void* dy_bf16; const float* x; const float* mean; const float* rstd; const float* gamma; const float* dres;
+  float* dx; void* dx_bf16;
+  const gvk_rowproj_desc* proj;
+  int32_t M, C, groups, rows_per_group, group_stride;
+} gvk_ln_bwd_dy16_desc;
+int gvk_layernorm_bwd_dy16(const gvk_ln_bwd_dy16_desc* d, void* stream);
 /* LayerNorm backward fused with a rank-L update of the same rows:  dx = dres + LN'(dy; x, mean, rstd, gamma) + lat . W^T  (+ bf16 copy).
  * Replaces gvk_layernorm_bwd followed by gvk_skinny_up(accumulate) on the backbone stream: the autograd of gaviko.py:304 (the MLP block's
  * LayerNorm) and of gaviko.py:155 (GPA's proj_down of the global tokens: dG1 += dzx . W_d) in one pass.  lat f32 [M][L]; w_layout 0: W [C][L],

@@ -521,3 +521,18 @@ def test_gemm_strided_row_panels_and_split_k(dev):
     assert (outs[0][mask] - full[mask]).abs().max().item() < 1e-5 * full[mask].abs().max().item()
     with pytest.raises(Exception, match="row panels"):
         ops.gemm_nt(a, w, M, part, epilogue=ops.EPI_STORE_F32, m_panels=B + 2, m_stride=T)
+    # a FULL launch in two pieces per tile (tile 2128128: 396 workgroups, two per CU): close to the unsplit product, bitwise repeatable, and
+    # the row panels cut the same way (ksplit = 2) carry the same bits as its rows
+    ws2 = torch.zeros((1024 + 256 * 2 * 65536) // 4, dtype=torch.int32, device=dev)
+    f2 = []
+    for _ in range(3):
+        o = torch.zeros(M, N, device=dev)
+        ops.gemm_nt(a, w, M, o, epilogue=ops.EPI_STORE_F32, tile=2128128, splitk_ws=ws2, ksplit=2)
+        torch.cuda.synchronize()
+        f2.append(o)
+    assert torch.equal(f2[0], f2[1]) and torch.equal(f2[0], f2[2]) and int(ws2[:256].abs().max()) == 0
+    assert (f2[0] - full).abs().max().item() < 1e-5 * full.abs().max().item()
+    p2 = torch.full((M, N), 7.0, device=dev)
+    ops.gemm_nt(a, w, M, p2, epilogue=ops.EPI_STORE_F32, m_panels=B, m_stride=T, splitk_ws=ws, ksplit=2)
+    torch.cuda.synchronize()
+    assert torch.equal(p2[mask], f2[0][mask]) and bool((p2[~mask] == 7.0).all())

@@ -405,6 +405,39 @@ def test_layernorm_bwd_with_fused_projection(dev, M, C):
     assert torch.allclose(y, (dx.double() @ wup.double()).float(), atol=3e-5, rtol=1e-5)
 
 
+def test_layernorm_bwd_with_bf16_gradient_input(dev):
+    """gvk_layernorm_bwd_dy16: the three backward forms (all rows / the leading rows of every sample / with the rank-L projection) reading the
+    output gradient as bf16 -- the same numbers as the fp32-input kernels fed the upcast values (bit-equal for the two plain forms: one kernel)."""
+    from gaviko_amd import ops
+    B, T, C, L_, P = 4, 1033, 768, 20, 32
+    M = B * T
+    g_ = torch.Generator(device=dev).manual_seed(11)
+    rnd = lambda *sh: torch.randn(*sh, device=dev, generator=g_)
+    x, dres = rnd(M, C), rnd(M, C)
+    dy16 = rnd(M, C).bfloat16()
+    dy = dy16.float()
+    g = 1 + 0.2 * rnd(C)
+    wup = rnd(C, L_) * C ** -0.5
+    mean, rstd = x.mean(-1).contiguous(), (x.var(-1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    a, b = torch.empty(M, C, device=dev), torch.empty(M, C, device=dev)
+    a16, b16 = (torch.empty(M, C, dtype=torch.bfloat16, device=dev) for _ in range(2))
+    ops.layernorm_bwd_dy16(dy16, x, mean, rstd, g, M, C, dx=a, dres=dres, dx16=a16)
+    ops.layernorm_bwd(dy, x, mean, rstd, g, M, C, dx=b, dres=dres, dx16=b16)
+    assert torch.equal(a, b) and torch.equal(a16, b16)
+    a.fill_(7.0); b.fill_(7.0)
+    ops.layernorm_bwd_dy16(dy16, x, mean, rstd, g, M, C, dx=a, dres=dres, rows=(B, P, T))
+    ops.layernorm_bwd_rows(dy, x, mean, rstd, g, B, P, T, C, dx=b, dres=dres)
+    assert torch.equal(a, b)
+    assert bool((a[P:T] == 7.0).all()) and bool((a[T:T + P] != 7.0).any())
+    ya, yb = torch.empty(M, L_, device=dev), torch.empty(M, L_, device=dev)
+    ops.layernorm_bwd_dy16(dy16, x, mean, rstd, g, M, C, dx=a, dres=dres, dx16=a16, proj=dict(w=wup, y=ya, w_layout=1, L_=L_))
+    ops.layernorm_bwd_proj(dy, x, mean, rstd, g, M, C, dx=b, dres=dres, dx16=b16, w=wup, y=yb, w_layout=1)
+    assert (a - b).abs().max().item() <= 4e-6 * b.abs().max().item()
+    assert torch.allclose(ya, yb, atol=3e-5, rtol=1e-5)
+    with pytest.raises(ops.L.GavikoHipError, match="all rows"):
+        ops.layernorm_bwd_dy16(dy16, x, mean, rstd, g, M, C, dx=a, rows=(B, P, T), proj=dict(w=wup, y=ya, w_layout=1, L_=L_))
+
+
 def test_fused_projection_rejects_other_latent_widths(dev):
     from gaviko_amd import ops
     rnd = lambda *sh, device: torch.randn(*sh, device=device)

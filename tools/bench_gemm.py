@@ -24,8 +24,10 @@ for name, N, K, epi in shapes:
     res = ops.act_zeros(M, N, torch.float32, dev)
     aux = ops.act_zeros(M, N, torch.bfloat16, dev); aux.normal_()
     line = f"{name:10s} N={N:5d} K={K:5d} "
+    skws = torch.zeros((1024 + 256 * 2 * 65536) // 4, dtype=torch.int32, device=dev)      # tile 2128128: two pieces of 64 KiB per tile
     for t in tiles:
         kw = dict(epilogue=epi, tile=t)
+        if t == 2128128: kw.update(splitk_ws=skws, ksplit=int(os.environ.get("KSPLIT", "2")))
         if epi == ops.EPI_BIAS_RES_F32: kw.update(bias=bias, res=res)
         if epi == ops.EPI_BIAS_GELU_BF16: kw.update(bias=bias, out1=out1)
         if epi == ops.EPI_GELU_BWD_BF16: kw.update(aux=aux)
