@@ -154,12 +154,11 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
     if (sl == 0 && oi < no) pg_store4_wt(part + slab * 64 + oi, (lds[oi] + lds[64 + oi]) + (lds[128 + oi] + lds[192 + oi]));
     if (!pg_arrive_last(p.tickets + jb.tick0 + chunk, jb.nslab, &s_flag)) return;
     if (threadIdx.x < no) {
-      float a4[4] = {0.f, 0.f, 0.f, 0.f};
+      float a4[4] = {0.f, 0.f, 0.f, 0.f}, pv[kPgRedSlabs];
 #pragma unroll
-      for (int s = 0; s < kPgRedSlabs; s += 4) {
+      for (int s = 0; s < kPgRedSlabs; ++s) pv[s] = part[min(s, jb.nslab - 1) * 64 + threadIdx.x];      // every slab's partial requested at once
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a4[u] += (s + u < jb.nslab) ? part[(s + u) * 64 + threadIdx.x] : 0.f;
-      }
+      for (int s = 0; s < kPgRedSlabs; ++s) a4[s & 3] += (s < jb.nslab) ? pv[s] : 0.f;
       const float t = (a4[0] + a4[1]) + (a4[2] + a4[3]);
       float* dst = jb.out + o0 + threadIdx.x;
       *dst = jb.accumulate ? *dst + t : t;
@@ -275,14 +274,22 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
   }
   {
     const int nch = (nr + kPgCh - 1) / kPgCh;
-    f32x4 xa[kPgKS], xb[kPgKS], na[kNP], nb[kNP];
-    float mua = 0.f, rsa = 0.f, mub = 0.f, rsb = 0.f;
-    load(xa, na, mua, rsa, 0);
-    for (int ch = 0; ch < nch; ch += 2) {
-      load(xb, nb, mub, rsb, ch + 1);
-      compute(xa, na, mua, rsa, 0, ch);
-      load(xa, na, mua, rsa, ch + 2);
-      compute(xb, nb, mub, rsb, 1, ch + 1);
+    // four register buffers: three chunks' loads (12 KiB of wide rows per wave) stay in flight behind the chunk being multiplied -- the
+    // launch is a few chunks long per wave, so what it costs is round trips, not bytes (two buffers: 1.2 us per chunk)
+    f32x4 x0[kPgKS], x1[kPgKS], x2[kPgKS], x3[kPgKS], n0[kNP], n1[kNP], n2[kNP], n3[kNP];
+    float mu0 = 0.f, rs0 = 0.f, mu1 = 0.f, rs1 = 0.f, mu2 = 0.f, rs2 = 0.f, mu3 = 0.f, rs3 = 0.f;
+    load(x0, n0, mu0, rs0, 0);
+    load(x1, n1, mu1, rs1, 1);
+    load(x2, n2, mu2, rs2, 2);
+    for (int ch = 0; ch < nch; ch += 4) {
+      load(x3, n3, mu3, rs3, ch + 3);
+      compute(x0, n0, mu0, rs0, 0, ch);
+      load(x0, n0, mu0, rs0, ch + 4);
+      compute(x1, n1, mu1, rs1, 1, ch + 1);
+      load(x1, n1, mu1, rs1, ch + 5);
+      compute(x2, n2, mu2, rs2, 0, ch + 2);
+      load(x2, n2, mu2, rs2, ch + 6);
+      compute(x3, n3, mu3, rs3, 1, ch + 3);
     }
   }
   if (J.aff_w != nullptr && lane < NW) sw[wave][lane] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
@@ -321,16 +328,39 @@ __global__ __launch_bounds__(256) void param_grads_kernel(PgArgs p) {
   static_assert(kLdsFloats >= 30 * 64, "the affine epilogue stages [L + 2][64] floats");
   float (*qt)[64] = (float (*)[64])lds;                       // affine epilogue: the summed tile [L + 1][64] and S behind it
   const int ngran = (L + 1) * 16 + ((J.aff_w != nullptr) ? NW / 4 : 0);     // float4 granules: the tile (+ the S row)
-  for (int g = threadIdx.x; g < ngran; g += 256) {
-    f32x4 a4[4];
+  // The partials come from memory (they were stored write-through): up to 16 row ranges x both granules of a thread are requested before the
+  // first is consumed (clamped, unconditional loads; one round trip instead of nsg / 4 dependent ones).  Same association as a plain
+  // four-way interleaved sum over the ranges: a4[s & 3] += partial[s], in range order.
+  f32x4 vsum[2];
+  {
+    f32x4 a4[2][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) a4[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < J.nsg; s += 4) {
+    for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (s + u < J.nsg) a4[u] += *(const f32x4*)(tile0 + (size_t)(s + u) * stride + 4 * g);
+      for (int u = 0; u < 4; ++u) a4[gi][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < J.nsg; s0 += 16) {
+      f32x4 pb[2][16];
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi) {
+        const int g = min((int)threadIdx.x + 256 * gi, ngran - 1);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) pb[gi][u] = *(const f32x4*)(tile0 + (size_t)min(s0 + u, J.nsg - 1) * stride + 4 * g);
+      }
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (s0 + u < J.nsg) a4[gi][u & 3] += pb[gi][u];
     }
-    const f32x4 v = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) vsum[gi] = (a4[gi][0] + a4[gi][1]) + (a4[gi][2] + a4[gi][3]);
+  }
+  static_assert((28 + 1) * 16 + 8 <= 512, "two granules per thread cover the tile");
+#pragma unroll
+  for (int gi = 0; gi < 2; ++gi) {
+    const int g = threadIdx.x + 256 * gi;
+    if (g >= ngran) continue;
+    const f32x4 v = vsum[gi];
     const int l = g >> 4, cc = ct * 64 + 4 * (g & 15);
     if (J.aff_w != nullptr) {
       *(f32x4*)(&qt[0][0] + 4 * g) = v;                        // rows 0..L-1 = Q, row L = column sum (unused), row L+1.. = S
