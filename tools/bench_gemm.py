@@ -11,6 +11,8 @@ shapes = [("qkv", 2304, 768, ops.EPI_STORE_BF16), ("out", 768, 768, ops.EPI_BIAS
           ("fc2", 768, 3072, ops.EPI_BIAS_RES_F32), ("fc2_dgrad", 3072, 768, ops.EPI_GELU_BWD_BF16), ("fc1_dgrad", 768, 3072, ops.EPI_STORE_F32),
           ("out_dgrad", 768, 768, ops.EPI_STORE_BF16), ("qkv_dgrad", 768, 2304, ops.EPI_STORE_F32),
           ("fc1_plain16", 3072, 768, ops.EPI_STORE_BF16), ("fc1_plain32", 3072, 768, ops.EPI_STORE_F32), ("big", 4096, 4096, ops.EPI_STORE_BF16)]
+if os.environ.get("SHAPES"):          # SHAPES="fc2:1024:4096:1,fc1d:1024:4096:0" -> (name, N, K, epilogue id)
+    shapes = [(n, int(N), int(K), int(e)) for n, N, K, e in (x.split(":") for x in os.environ["SHAPES"].split(","))]
 if os.environ.get("ONLY"):
     shapes = [s for s in shapes if s[0] in os.environ["ONLY"].split(",")]
 tiles = [int(t) for t in os.environ["TILES"].split(",")] if os.environ.get("TILES") else [128128, 128064, 64128, 64064]
