@@ -100,6 +100,18 @@ __device__ __forceinline__ float gelu_fast_grad(float x) {
   const float erfv = copysignf(__builtin_fmaf(-as_poly(t), e, 1.0f), x);
   return __builtin_fmaf(x * 0.39894228040143267794f, e, __builtin_fmaf(0.5f, erfv, 0.5f));
 }
+// GELU(x) and GELU'(x) together: one reciprocal, one exponential, one polynomial (the forward GEMM epilogue that also leaves the derivative)
+__device__ __forceinline__ void gelu_fast_both(float x, float& y, float& dy) {
+  // erf exactly as gelu_fast / erf_fast take it (the activation must not depend on whether the derivative is wanted); its exponential
+  // e = exp(-x^2 / 2) is the density's
+  const float z = x * 0.70710678118654752440f, ax = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(ax * ax * -1.44269504088896340736f);
+  const float erfv = copysignf(__builtin_fmaf(-as_poly(t), e, 1.0f), z);
+  const float h = 0.5f * x;
+  y = __builtin_fmaf(h, erfv, h);
+  dy = __builtin_fmaf(x * 0.39894228040143267794f, e, __builtin_fmaf(0.5f, erfv, 0.5f));
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float quick_gelu(float x) { return x * sigmoidf_(1.702f * x); }
 __device__ __forceinline__ float quick_gelu_grad(float x) {

@@ -478,6 +478,9 @@ extern "C" int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream) {
               "gvk_gemm_nt_bf16: splitk_ws goes with strided row panels or tile 2128128 (256-byte aligned)");
   GVK_REQUIRE(d->ksplit >= 0 && d->ksplit <= 8 && (d->ksplit == 0 || d->splitk_ws != nullptr), "gvk_gemm_nt_bf16: ksplit=%d: 0 (auto) .. 8, with splitk_ws", d->ksplit);
   a.sk_part = (float*)d->splitk_ws; a.sk_bytes = d->splitk_ws_bytes; a.ksplit = d->ksplit;
+  GVK_REQUIRE(d->aux_is_grad == 0 || (d->drop_p == 0.f && ((d->epilogue == GVK_EPI_BIAS_GELU_BF16 && d->out0) || d->epilogue == GVK_EPI_GELU_BWD_BF16)),
+              "gvk_gemm_nt_bf16: aux_is_grad goes with BIAS_GELU_BF16 (out0 set) / GELU_BWD_BF16 and no dropout");
+  a.aux_grad = d->aux_is_grad;
   hipStream_t s = (hipStream_t)stream;
   switch (d->epilogue) {
     case GVK_EPI_STORE_BF16:

@@ -43,6 +43,8 @@ struct GemmArgs {
   // stat_part[(column group)][m] (float2; group = column / (16 * NT)); a later kernel turns the groups of a row into mean / rstd
   float* stat_part;
   const float* stat_pivot;                               // the partials are sums of (x - stat_pivot[m]) and its square (nullptr: pivot 0)
+  // BIAS_GELU_BF16: out0 = GELU'(pre) instead of pre;  GELU_BWD_BF16: aux holds that derivative (gvk_gemm_desc.aux_is_grad)
+  int aux_grad;
 };
 
 // LDS swizzles (applied to the 16-byte chunk index of a 128-byte tile row; conflict-free for the ds_read_b128 lane groups)
@@ -166,9 +168,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
             for (int e = 0; e < 8; ++e) { const float dv = v[e] - cur.pv; ps1 += dv; ps2 = __builtin_fmaf(dv, dv, ps2); }
           }
         } else if constexpr (EPI == GVK_EPI_BIAS_GELU_BF16) {
-          if (p.out0 != nullptr) store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
+          if (p.aux_grad != 0) {                             // out0 = GELU'(pre): what the fc2 dgrad multiplies by, from the exponential GELU needs anyway
+            bf16x8 g8;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+            for (int e = 0; e < 8; ++e) {
+              float y, dy;
+              gelu_fast_both(v[e], y, dy);
+              v[e] = y;
+              g8[e] = (bf16)dy;
+            }
+            *(bf16x8*)((bf16*)p.out0 + (size_t)m * p.ldo + n) = g8;
+          } else {
+            if (p.out0 != nullptr) store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_fast(v[e]);
+          }
           if constexpr (DROP) drop8();                       // out1 = dropout(GELU(pre)): vision_transformer.py:32-33
           store_bf16((bf16*)p.out1 + (size_t)m * p.ldo + n);
         } else if constexpr (kPos) {
@@ -179,7 +193,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
         } else if constexpr (EPI == GVK_EPI_GELU_BWD_BF16) {
           if constexpr (DROP) drop8();                       // gradient through that dropout, same mask
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= gelu_fast_grad((float)cur.a8[jp][e]);
+          for (int e = 0; e < 8; ++e) v[e] *= p.aux_grad != 0 ? (float)cur.a8[jp][e] : gelu_fast_grad((float)cur.a8[jp][e]);
           store_bf16((bf16*)p.out0 + (size_t)m * p.ldo + n);
         } else if constexpr (EPI == GVK_EPI_STORE_F32) {
           store_f32((float*)p.out0 + (size_t)m * p.ldo + n);

@@ -148,6 +148,7 @@ extern "C" int gvk_gemm_nt_f32(const gvk_gemm_desc* d, void* stream) {
   GVK_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gvk_gemm_nt_f32: empty shape");
   GVK_REQUIRE(d->scale_cols == 0, "gvk_gemm_nt_f32: scale_cols is a bf16-path option (the fp32 attention kernels take the raw q block)");
   GVK_REQUIRE(d->m_panels == 0 && d->m_stride == 0 && d->splitk_ws == nullptr, "gvk_gemm_nt_f32: strided row panels are a bf16-path option");
+  GVK_REQUIRE(d->aux_is_grad == 0, "gvk_gemm_nt_f32: aux_is_grad is a bf16-path option");
   GVK_REQUIRE(d->ln_mean == nullptr && d->stat_part == nullptr, "gvk_gemm_nt_f32: the LayerNorm fold / row-statistic partials are bf16-path options");
   GVK_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f && (d->drop_p == 0.f || d->seed_ptr != nullptr), "gvk_gemm_nt_f32: drop_p in [0,1) and a seed word");
   GVK_REQUIRE(d->drop_p == 0.f || d->epilogue == GVK_EPI_BIAS_RES_F32 || d->epilogue == GVK_EPI_BIAS_GELU_BF16 || d->epilogue == GVK_EPI_GELU_BWD_BF16,

@@ -241,7 +241,7 @@ extern "C" int gvk_scale_f32(float* x, float alpha, long n, void* stream) {
 }
 
 extern "C" const char* gvk_last_error(void) { return gvk::g_err; }
-extern "C" int gvk_abi_version(void) { return 11; }
+extern "C" int gvk_abi_version(void) { return 12; }
 
 extern "C" int gvk_device_check(void) {
   int dev = 0;

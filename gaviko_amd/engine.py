@@ -150,6 +150,9 @@ class Engine(GavikoPaths, PeftPaths):
         # frozen backbone: the fc1 / qkv dgrad GEMMs hand the LayerNorm backward its input gradient in bf16 (half the bytes on both sides; the other
         # operands of that chain -- dpre, dqkv, the dgrad operands -- are bf16 already)
         self._dy16 = kind == "gaviko" and not self.fp32 and L.diag_env("GAVIKO_HIP_DY16", "1") != "0"
+        # ... and fc1's forward epilogue leaves GELU'(pre) instead of pre (it has the exponential in hand and VALU to spare behind its two output
+        # streams); the fc2 dgrad epilogue then multiplies instead of evaluating the derivative (isolated: 33.7 -> 30.3 us with a free derivative)
+        self._gelu_grad = kind == "gaviko" and not self.fp32 and L.diag_env("GAVIKO_HIP_GELU_GRAD", "1") != "0"
         self._fuse_local = kind == "gaviko" and ops.side_tile_supported(self.Lat, dim)
         self._fuse_bnd = self._fuse_local and L.diag_env("GAVIKO_HIP_FUSE_BOUNDARY", "1") != "0"
         self._fuse_next = self._fuse_local and L.diag_env("GAVIKO_HIP_FUSE_NEXT", "1") != "0"
@@ -185,6 +188,7 @@ class Engine(GavikoPaths, PeftPaths):
         self._flat_names = None
         self.bucket_layers = 4              # layout of the flat gradient buffer: completion groups of this many layers (set_bucket_layers)
         self._saved = None
+        self._pre_is_grad = False
 
     def _gemm(self, a, w, M, out0, alg_k=None, **kw):
         """One NT GEMM launch.  alg_k: the ALGORITHMIC contraction length when the operand carries padding columns (fc2 with the
@@ -596,6 +600,7 @@ class Engine(GavikoPaths, PeftPaths):
             self._bb_buffers(ws, B, img.device, sv["wgrad"])
         key = (B, train, sv["attn_drop"], sv["proj_drop"], len(bb), sv["wgrad"], sv["bdrop"], sv["edrop"], sv["pdrop"])
         self._keep_inputs = bool(sv["wgrad"])
+        sv["pre_is_grad"] = self._pre_is_grad = bool(train and self._gelu_grad and not self._keep_inputs and sv["bdrop"] <= 0 and not bb)
         self._fold_on = (not self._keep_inputs) and self._ensure_fold()      # ONE place decides: operands are current whenever the fold is taken
         self._run("fwd", key, lambda: self._forward_impl(ws, sv))
         self._saved = sv if train else None
@@ -854,9 +859,10 @@ class Engine(GavikoPaths, PeftPaths):
         pk = panels or {}
         if self._keep_inputs:
             ops.copy_(ws["sav"]["xn2"][si], ws["xn"])
+        gg = bool(train and self._pre_is_grad)               # decided once per step in forward(); the backward reads ws["pre"] accordingly
         self._gemm(ws["xn"], w[f"fc1{i}"], M, ws["pre"][si] if train else None, epilogue=ops.EPI_BIAS_GELU_BF16, out1=ws["act"],
                     bias=d(m + ".net.1.bias"),           # inference keeps no pre-activation (out0 = NULL)
-                    ldo=self.ldx, drop_p=pdrop, seed=SEED_LAYER + 8 * i + 2, seed_ptr=ws["seed"], **pk)
+                    ldo=self.ldx, drop_p=pdrop, seed=SEED_LAYER + 8 * i + 2, seed_ptr=ws["seed"], aux_is_grad=int(gg), **pk)
         if self._keep_inputs:
             ops.copy_(ws["sav"]["act"][si], ws["act"])
         so = (dict(epilogue=ops.EPI_BIAS_RES_F32_BF16, out1=ws["xg16"], stat_part=ws["spart"], stat_pivot=ws["stat"][si][2]) if stats_out     # pivot = mean of the residual row (LN2)
@@ -1063,7 +1069,7 @@ class Engine(GavikoPaths, PeftPaths):
             top = (self._panels(B, self._pool_rows()[0] + self._pool_rows()[1])
                    if (gaviko and first and i == self.depth - 1 and not bb and pd_ <= 0 and not sv["wgrad"]) else {})
             self._gemm(ws["dG16"], w[f"fc2{i}_t"], M, ws["dpre"], epilogue=ops.EPI_GELU_BWD_BF16, aux=ws["pre"][i], ldaux=self.ldx,
-                       drop_p=pd_, seed=SEED_LAYER + 8 * i + 2, seed_ptr=ws["seed"], **top)
+                       drop_p=pd_, seed=SEED_LAYER + 8 * i + 2, seed_ptr=ws["seed"], aux_is_grad=int(sv.get("pre_is_grad", False)), **top)
             if ssf:                                                          # fc1 + ssf_1: dy = d(pre-activation), y = saved pre-activation
                 self._ssf_linear_grad(ws, gv, m, 1, ws["dpre"], ws["pre"][i], M, self.mlp)
             if bb:                                                           # fc1: db = colsum(dpre), dW = dpre^T . LN2(G1)

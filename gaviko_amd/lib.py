@@ -26,7 +26,7 @@ if os.environ.get("GPU_MAX_HW_QUEUES") is None:
     except Exception:
         pass
 
-ABI_VERSION = 11                                  # gvk_abi_version() of the library these declarations describe
+ABI_VERSION = 12                                  # gvk_abi_version() of the library these declarations describe
 # GAVIKO_HIP_DIAG=1 (tools/ only): load the measurement build libgaviko_hip_diag.so (`python -m gaviko_amd.build --diag`) -- the product
 # library ignores every A/B switch of the kernel sources and exports no diagnostics (include/gaviko_hip_diag.h)
 DIAG = os.environ.get("GAVIKO_HIP_DIAG", "0") == "1"
@@ -49,7 +49,7 @@ class GemmDesc(C.Structure):
         ("scale_cols", C.c_int32), ("col_scale", C.c_float),
         ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p), ("ln_c1", C.c_void_p), ("stat_part", C.c_void_p), ("stat_pivot", C.c_void_p),
         ("m_panels", C.c_int32), ("m_stride", C.c_int32), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_uint64),
-        ("ksplit", C.c_int32),
+        ("ksplit", C.c_int32), ("aux_is_grad", C.c_int32),
     ]
 
 

@@ -42,7 +42,7 @@ def _chk(t, dtype, what, min_elems=0):
 def gemm_nt(a, w, M, out0, *, epilogue, out1=None, bias=None, res=None, aux=None, pos=None,
             lda=None, ldo=None, ldres=None, ldaux=None, rows_in=0, rows_out=0, row_off=0, tile=0, N=None, K=None,
             drop_p=0.0, seed=0, seed_ptr=None, scale_cols=0, col_scale=1.0, ln_mean=None, ln_rstd=None, ln_c1=None, stat_part=None, stat_pivot=None,
-            m_panels=0, m_stride=0, splitk_ws=None, ksplit=0):
+            m_panels=0, m_stride=0, splitk_ws=None, ksplit=0, aux_is_grad=0):
     """Y[M,N] = A[M,K] . W[N,K]^T with a fused epilogue.  The operand dtype picks the kernel: bf16 -> gvk_gemm_nt_bf16 (MFMA
     bf16, fp32 accumulate), fp32 -> gvk_gemm_nt_f32 (every 16-bit slot of the epilogue table then carries fp32).
     m_panels / m_stride (bf16): only the row tiles starting at rows 0, m_stride, 2 m_stride, ... are computed (gvk_gemm_desc)."""
@@ -69,7 +69,7 @@ def gemm_nt(a, w, M, out0, *, epilogue, out1=None, bias=None, res=None, aux=None
                    M, N, K, lda, ldw, ldo, (N if ldres is None else ldres), (N if ldaux is None else ldaux),
                    epilogue, rows_in, rows_out, row_off, tile, float(drop_p), int(seed), int(scale_cols), float(col_scale),
                    L.ptr(ln_mean), L.ptr(ln_rstd), L.ptr(ln_c1), L.ptr(stat_part), L.ptr(stat_pivot), int(m_panels), int(m_stride),
-                   L.ptr(splitk_ws), 0 if splitk_ws is None else splitk_ws.numel() * splitk_ws.element_size(), int(ksplit))
+                   L.ptr(splitk_ws), 0 if splitk_ws is None else splitk_ws.numel() * splitk_ws.element_size(), int(ksplit), int(aux_is_grad))
     _chk(ln_mean, torch.float32, "gemm ln_mean", M)
     _chk(ln_rstd, torch.float32, "gemm ln_rstd", M)
     _chk(ln_c1, torch.float32, "gemm ln_c1", N)

@@ -22,7 +22,7 @@ extern "C" {
 const char* gvk_last_error(void);
 /* returns 950 when the code object loaded on the current device is gfx950, else <0 */
 int gvk_device_check(void);
-int gvk_abi_version(void);   /* 11 */
+int gvk_abi_version(void);   /* 12 */
 
 /* ------------------------------------------------------------------ launch plans
  * The reference drives its step from the Python interpreter (train.py:296-319: one autograd node per op).  Here one
@@ -123,6 +123,10 @@ typedef struct gvk_gemm_desc {
      FULL launch (no panels) of <= 256 tiles of 128 x 128 this way -- two pieces of a K >= 2304 loop on two workgroups that share a CU
      (measured: no faster than one three-stage workgroup per tile; the engine does not use it) */
   int32_t ksplit;
+  /* (bf16 entry point, no dropout) the GELU derivative is computed ONCE, where its exponential is computed anyway: with aux_is_grad = 1
+     GVK_EPI_BIAS_GELU_BF16 stores out0 = bf16 GELU'(acc + bias) instead of the pre-activation, and GVK_EPI_GELU_BWD_BF16 reads aux as that
+     derivative (out0 = acc * aux).  A caller sets it on both GEMMs of an MLP (vision_transformer.py:31-34 and its autograd) or on neither */
+  int32_t aux_is_grad;
 } gvk_gemm_desc;
 int gvk_gemm_nt_bf16(const gvk_gemm_desc* d, void* stream);
 /* number of 64-column groups gvk_gemm_desc.stat_part is indexed by for an N-column output */

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(set(decls)):
         assert hasattr(l, name), f"{name} declared in gaviko_hip.h but not exported by libgaviko_hip.so"
         assert name in bound, f"{name} has no ctypes signature in gaviko_amd/lib.py"
-    assert l.gvk_abi_version() == lib.ABI_VERSION == 11
+    assert l.gvk_abi_version() == lib.ABI_VERSION == 12
 
 
 def test_ctypes_structs_match_header_field_order():

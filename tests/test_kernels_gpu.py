@@ -485,6 +485,35 @@ def test_gemm_eight_phase_kernel(dev, M, N, K, tile8):
 
 
 
+def test_gemm_gelu_derivative_stored_by_the_forward(dev):
+    """gvk_gemm_desc.aux_is_grad: the forward GEMM's epilogue leaves bf16 GELU'(pre) (beside GELU(pre)), the dgrad GEMM multiplies by it --
+    the same dgrad as evaluating the derivative from the stored pre-activation, to bf16 rounding of the factor; both tile families."""
+    from gaviko_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, C, H = 4132, 768, 3072
+    x = ops.act_zeros(M, C, torch.bfloat16, dev); x[:M] = torch.randn(M, C, generator=g).bfloat16().to(dev)
+    w1 = (torch.randn(H, C, generator=g) * C ** -0.5).bfloat16().to(dev)
+    b1 = (torch.randn(H, generator=g) * 0.1).to(dev)
+    dy = ops.act_zeros(M, C, torch.bfloat16, dev); dy[:M] = torch.randn(M, C, generator=g).bfloat16().to(dev)
+    w2t = (torch.randn(H, C, generator=g) * C ** -0.5).bfloat16().to(dev)            # fc2 weight transposed: dgrad as an NT GEMM
+    for tile in (0, 3128128):
+        pre, gp, act, act2 = (ops.act_zeros(M, H, torch.bfloat16, dev) for _ in range(4))
+        ops.gemm_nt(x, w1, M, pre, epilogue=ops.EPI_BIAS_GELU_BF16, out1=act, bias=b1, tile=tile)
+        ops.gemm_nt(x, w1, M, gp, epilogue=ops.EPI_BIAS_GELU_BF16, out1=act2, bias=b1, tile=tile, aux_is_grad=1)
+        assert torch.equal(act[:M], act2[:M])                                        # the activation itself does not change
+        h = (x[:M].float() @ w1.float().t() + b1).double()
+        ref = 0.5 * (1 + torch.erf(h / 2 ** 0.5)) + h * torch.exp(-0.5 * h * h) / (2 * torch.pi) ** 0.5
+        assert (gp[:M].double() - ref).abs().max().item() < 6e-3                     # bf16 rounding of a value in [-0.13, 1.13] (+ the bf16 operands)
+        d0, d1 = ops.act_zeros(M, H, torch.bfloat16, dev), ops.act_zeros(M, H, torch.bfloat16, dev)
+        ops.gemm_nt(dy, w2t, M, d0, epilogue=ops.EPI_GELU_BWD_BF16, aux=pre, tile=tile)
+        ops.gemm_nt(dy, w2t, M, d1, epilogue=ops.EPI_GELU_BWD_BF16, aux=gp, tile=tile, aux_is_grad=1)
+        torch.cuda.synchronize()
+        err = (d0[:M].float() - d1[:M].float()).abs().max().item()
+        assert err < 3e-2 * d0[:M].float().abs().max().item(), err
+    with pytest.raises(Exception, match="aux_is_grad"):
+        ops.gemm_nt(x, w1, M, pre, epilogue=ops.EPI_STORE_BF16, aux_is_grad=1)
+
+
 def test_gemm_strided_row_panels_and_split_k(dev):
     """gvk_gemm_desc.m_panels / m_stride: only the 64-row tiles at rows 0, T, 2T, ... are computed (the first rows of every sample) -- those
     rows must be bit-identical to the full launch on the same 4-wave tile, every other row of the output untouched; with a split-K
