@@ -151,7 +151,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16* __res
             dp[r] = pr * (dp[r] * mm - dlr);
           } else {
             s[r] = pr;
-            dp[r] = pr * dp[r];
+          }
+        }
+        if constexpr (!DROP) {
+          // dS = P * dP' as explicit even-aligned pairs (v_pk_mul_f32), P first written in place: left to the SLP vectorizer, the dQ pass's
+          // form `exp2(s) * dp` was paired across registers hipcc had allocated one off an even boundary -- 36 v_mov + 24 v_alignbit /
+          // v_perm per 96-key tile to realign them, a quarter of that loop's vector instructions (203 -> 128 per tile and wave)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            typedef float f32x2_ __attribute__((ext_vector_type(2)));
+            const f32x2_ pp = {s[r], s[r + 1]}, dd = {dp[r], dp[r + 1]};
+            const f32x2_ o = pp * dd;
+            dp[r] = o[0]; dp[r + 1] = o[1];
           }
         }
       };
@@ -316,7 +327,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
             const int key = kt * KB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             dpv = dpv * attn_drop_scale(akey, qoff + (unsigned int)key, dr.thresh, dr.inv_keep) - del;
           }
-          st[r] = __builtin_amdgcn_exp2f(st[r]) * dpv;
+          if constexpr (DROP) st[r] = __builtin_amdgcn_exp2f(st[r]) * dpv;
+          else st[r] = __builtin_amdgcn_exp2f(st[r]);
+        }
+        if constexpr (!DROP) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            typedef float f32x2_ __attribute__((ext_vector_type(2)));
+            const f32x2_ pp = {st[r], st[r + 1]}, dd = {dpt[r], dpt[r + 1]};
+            const f32x2_ o = pp * dd;
+            st[r] = o[0]; st[r + 1] = o[1];
+          }
         }
       };
       auto grads = [&](int kb, const f32x16& st) {
