@@ -46,9 +46,11 @@ def gemm_labels(M, C, mlp, ldx):
         (r"gemm8p_kernel<2,", r".*", f"fc1 fwd        M={M} N={mlp} K={C}"),
         (r"gemm_nt_kernel<\d+, \d+, [16],", r"gemm8p_kernel<2,", f"fc2 fwd (+GPA up-projection)  M={M} N={C} K={ldx} (algorithmic K {mlp}+20)"),
         (r"gemm8p_kernel<4,", r".*", f"fc2 dgrad      M={M} N={mlp} K={C}"),
-        (r"gemm_nt_kernel<\d+, \d+, 5,", r"gemm8p_kernel<4,", f"fc1 dgrad      M={M} N={C} K={mlp}"),
+        # (epilogue 5 = fp32 store; 0 = bf16 store since round 5 hands the LayerNorm backward a bf16 gradient: the predecessor tells the sites apart;
+        #  the panel launches of the pruned top / bottom layers follow another 64 x 128 panel GEMM or the dK/dV pass)
+        (r"gemm_nt_kernel<\d+, \d+, [05],", r"gemm8p_kernel<4,|gemm_nt_kernel<64, 128, 4,", f"fc1 dgrad      M={M} N={C} K={mlp}"),
+        (r"gemm_nt_kernel<\d+, \d+, [05],", r"attn_bwd", f"qkv dgrad      M={M} N={C} K={3 * C}"),
         (r"gemm_nt_kernel<\d+, \d+, 0,", r".*", f"out-proj dgrad M={M} N={C} K={C}"),
-        (r"gemm_nt_kernel<\d+, \d+, 5,", r"attn_bwd", f"qkv dgrad      M={M} N={C} K={3 * C}"),
         (r"gemm_nt_kernel<\d+, \d+, 3,", r"patchify", f"patch embed    M={M // 1033 * 1000 if M % 1033 == 0 else '?'} N={C} K=3072"),
     ]
 
